@@ -1,0 +1,123 @@
+/* libsoccdpt_hip.so — C ABI of the MI355X-native SOccDPT_V3 forward path.
+ *
+ * The reference has no FFI layer: its "operator API" is nn.Module.forward
+ * (SURVEY.md §8b).  This header is the boundary a host binding replaces it
+ * with; each entry point cites the reference interface it stands in for
+ * (paths relative to /root/reference/SOccDPT).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions
+ *  - plain C types only; `stream` is a hipStream_t passed as void*.
+ *  - every pointer named dev_* / documented "device" is a device pointer owned
+ *    by the caller (PyTorch allocates; the library borrows for the call and
+ *    never frees).  No hidden allocation or synchronisation in *_forward /
+ *    stage calls: all launches go to `stream`.
+ *  - return value 0 = ok; non-zero = error, text via soccdpt_last_error().
+ *  - a handle is bound to the device current at soccdpt_create and is not
+ *    thread-safe; one handle per rank.
+ */
+#ifndef SOCCDPT_HIP_H
+#define SOCCDPT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SOCCDPT_ABI_VERSION 1
+
+/* backbone ids: model/loader.py:65-77 (model_type switch), model/blocks.py:59-78 */
+#define SOCCDPT_BACKBONE_SWIN2T16_256 0 /* dpt_swin2_tiny_256 */
+#define SOCCDPT_BACKBONE_SWIN2B24_384 1 /* dpt_swin2_base_384 */
+
+/* dtype codes for soccdpt_bind_weight */
+#define SOCCDPT_DTYPE_F32 0
+
+/* arithmetic of the encoder/decoder GEMMs and convolutions */
+#define SOCCDPT_PREC_BF16 0   /* bf16 MFMA operands, fp32 accumulate */
+#define SOCCDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMAs per product: ~fp32 */
+
+/* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
+typedef struct soccdpt_config {
+    int32_t abi_version;  /* SOCCDPT_ABI_VERSION */
+    int32_t backbone;     /* SOCCDPT_BACKBONE_* */
+    int32_t num_classes;  /* model/SOccDPT.py:139 (must be 3: :347-349 reshapes xyz with it) */
+    int32_t features;     /* 256 (model/SOccDPT.py:183) */
+    int32_t sigmoid;      /* 1: nn.Sigmoid, 0: ScaledTanh (model/SOccDPT.py:655-658) */
+    int32_t compute_occ;  /* model/SOccDPT.py:152 */
+    int32_t precision;    /* SOCCDPT_PREC_* */
+    int32_t cam_width;    /* Camera.width  (model/SOccDPT.py:227) */
+    int32_t cam_height;   /* Camera.height (model/SOccDPT.py:228) */
+    float fx, fy, cx, cy; /* model/SOccDPT.py:222-225, cast to f32 */
+    int32_t grid[3];      /* grid_size (model/SOccDPT.py:145) */
+    float occupancy_shape[3]; /* grid_size/scale as f32 (model/SOccDPT.py:175-181) */
+    float pc_scale[3];    /* model/SOccDPT.py:148 */
+    float pc_shift[3];    /* model/SOccDPT.py:149 */
+    float rot[27];        /* Ra, Rb, Rc row-major f32, built on the host exactly as
+                             rotate_points does (model/SOccDPT.py:74-111) */
+} soccdpt_config;
+
+/* ---- lifetime: replaces SOccDPT_V3.__init__ / load_model (model/loader.py:13-138) ---- */
+int soccdpt_create(const soccdpt_config* cfg, void** handle);
+void soccdpt_destroy(void* handle);
+const char* soccdpt_last_error(void* handle); /* handle may be NULL: last create error */
+int soccdpt_abi_version(void);
+
+/* ---- weights: replaces BaseModel.load_net -> load_state_dict (model/base_model.py:5-37) ----
+ * `key` is the reference's state-dict key, e.g.
+ * "depth_net.pretrained.model.layers.0.blocks.0.attn.qkv.weight",
+ * "depth_net.scratch.refinenet1.resConfUnit1.conv1.weight", "seg_head.1.running_var".
+ * Unknown keys return non-zero (the host prints them like load_state_dict(strict=False)). */
+int soccdpt_bind_weight(void* handle, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim);
+int soccdpt_num_weights(void* handle);                     /* tensors the path consumes */
+const char* soccdpt_weight_key(void* handle, int index);   /* their keys, for the host to iterate */
+
+/* Bytes of caller-provided device memory for the re-laid-out (bf16, tap-major,
+ * BN-folded, CPB-table) weights, and of per-forward scratch for batch B. */
+size_t soccdpt_prepared_bytes(void* handle);
+size_t soccdpt_workspace_bytes(void* handle, int B);
+
+/* Fold BN, convert/re-lay weights, build CPB bias tables.  Call after all binds and
+ * again whenever bound weight values change.  `prepared` stays in use by forward. */
+int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, void* stream);
+
+/* ---- the hot path: replaces SOccDPT_V3.forward (model/SOccDPT.py:681-685) ----
+ * x        [B,3,S,S] f32 NCHW (S = 256 / 384 by backbone)
+ * inv_up   [B,Hc,Wc] f32              clamped camera-resolution inverse depth (:270-290)
+ * seg_up   [B,C,Hc,Wc] f32            nearest-upsampled class probabilities (:278-282)
+ * points   [B,Hc,Wc,3] f32            un-rotated camera-frame points incl. the 3-pixel quirk (:301-353)
+ * occ      [B,gx,gy,gz,C] f32 or NULL union-over-batch binary grid in every row (:374-463)
+ * occ_bits (gx*gy*gz*C+31)/32 words   packed union grid of THIS call's frames (always written
+ *                                     when compute_occ; the multi-GPU exchange moves only this) */
+int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, float* dev_seg_up, float* dev_points,
+                    float* dev_occ, uint32_t* dev_occ_bits, void* dev_workspace, size_t workspace_bytes, void* stream);
+
+/* ---- stage-level entry points (parity tests, multi-GPU composition) ---- */
+
+/* Encoder + decoder + heads: DPTDepthModel.forward + seg_head (model/dpt.py:142-232,
+ * model/SOccDPT.py:660-674,682-683).  inv256 [B,S,S] f32, seg256 [B,C,S,S] f32. */
+int soccdpt_network(void* handle, const float* dev_x, int B, float* dev_inv256, float* dev_seg256, void* dev_workspace,
+                    size_t workspace_bytes, void* stream);
+
+/* SOccDPT.get_semantic_occupancy + rotate_points + points_to_occupancy_grid index pass
+ * (model/SOccDPT.py:264-463) fused into one kernel.  in_h/in_w: network output size.
+ * ORs into dev_occ_bits (cleared first when clear_bits != 0; pass NULL to skip voxelisation). */
+int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, int B, int in_h, int in_w,
+                    float* dev_inv_up, float* dev_seg_up, float* dev_points, uint32_t* dev_occ_bits, int clear_bits,
+                    void* stream);
+
+/* dst |= src[0] | ... | src[n_sets-1]  (each set = soccdpt_occ_words() words). */
+int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src_bits, int n_sets, void* stream);
+/* packed bits -> dense f32 rows, identical in every batch row (model/SOccDPT.py:449-455). */
+int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream);
+size_t soccdpt_occ_words(void* handle);
+
+/* Name and accumulated launch count of the kernels issued by the last forward (diagnostics). */
+int soccdpt_last_launch_count(void* handle);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOCCDPT_HIP_H */

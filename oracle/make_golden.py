@@ -42,26 +42,7 @@ from soccdpt_amd.utils.synth import synth_state_dict, synth_input, write_synth_c
 GOLD = os.path.join(REPO, "tests", "golden")
 
 
-# -- seeded inputs shared with the tests (tests/golden_inputs.py re-creates them) --
-def proj_inputs(seed: int = 1234, B: int = 2, S: int = 256):
-    g = torch.Generator().manual_seed(seed)
-    lo = torch.rand((B, 1, 16, 16), generator=g) * 0.29 + 0.005
-    inv = torch.nn.functional.interpolate(lo, size=(S, S), mode="bilinear", align_corners=False)[:, 0]
-    inv = inv + torch.randn((B, S, S), generator=g) * 0.002
-    inv[:, 5, 7] = 0.0           # clamp path (-> 1e-8 -> depth 1e8)
-    inv[:, 9, 11:14] = -0.5      # negative -> clamp
-    inv[0, 100, 50] = float("nan")
-    inv[1, 33, 200] = float("inf")
-    inv[1, 34, 200] = 1e-12
-    logits = torch.randn((B, 3, S, S), generator=g) * 6.0
-    seg = 0.5 * torch.tanh(logits) + 0.5   # ScaledTanh -> exact zeros for logits << 0
-    return inv.contiguous(), seg.contiguous()
-
-
-def decoder_features(seed: int = 77, B: int = 1):
-    g = torch.Generator().manual_seed(seed)
-    shapes = [(96, 64), (192, 32), (384, 16), (768, 8)]
-    return [torch.randn((B, c, r, r), generator=g) for c, r in shapes]
+from tests.golden_inputs import proj_inputs, decoder_features  # noqa: E402
 
 
 def sha(t: torch.Tensor) -> str:

@@ -1,0 +1,133 @@
+// extern "C" surface of libsoccdpt_hip.so (see include/soccdpt_hip.h).
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <string>
+
+#include "internal.h"
+
+using namespace soccdpt;
+
+static std::string g_create_error;
+
+static int fail(Handle* h, const std::string& msg) {
+    if (h) h->err = msg; else g_create_error = msg;
+    return 1;
+}
+
+extern "C" {
+
+int soccdpt_abi_version(void) { return SOCCDPT_ABI_VERSION; }
+
+int soccdpt_create(const soccdpt_config* cfg, void** handle) {
+    if (!cfg || !handle) return fail(nullptr, "soccdpt_create: null argument");
+    if (cfg->abi_version != SOCCDPT_ABI_VERSION) return fail(nullptr, "soccdpt_create: abi_version mismatch");
+    if (cfg->num_classes != 3) return fail(nullptr, "soccdpt_create: num_classes must be 3 (model/SOccDPT.py:347-349)");
+    if (cfg->features != 256) return fail(nullptr, "soccdpt_create: features must be 256");
+    if (cfg->cam_width <= 0 || cfg->cam_height <= 0) return fail(nullptr, "soccdpt_create: bad camera size");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
+    Handle* h = new Handle();
+    h->cfg = *cfg;
+    (void)hipGetDevice(&h->device);
+    std::string err;
+    if (model_init(*h, err)) {
+        delete h;
+        return fail(nullptr, err);
+    }
+    *handle = h;
+    return 0;
+}
+
+void soccdpt_destroy(void* handle) { delete static_cast<Handle*>(handle); }
+
+const char* soccdpt_last_error(void* handle) {
+    return handle ? static_cast<Handle*>(handle)->err.c_str() : g_create_error.c_str();
+}
+
+int soccdpt_bind_weight(void* handle, const char* key, const void* dev_ptr, int dtype, const int64_t* shape, int ndim) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !key || !dev_ptr) return fail(h, "soccdpt_bind_weight: null argument");
+    if (dtype != SOCCDPT_DTYPE_F32) return fail(h, std::string("soccdpt_bind_weight: only f32 tensors are accepted: ") + key);
+    return model_bind(*h, key, dev_ptr, shape, ndim, h->err);
+}
+
+int soccdpt_num_weights(void* handle) { return (int)static_cast<Handle*>(handle)->weights.size(); }
+const char* soccdpt_weight_key(void* handle, int index) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (index < 0 || index >= (int)h->weights.size()) return nullptr;
+    return h->weights[index].key.c_str();
+}
+
+size_t soccdpt_prepared_bytes(void* handle) { return static_cast<Handle*>(handle)->prepared_bytes; }
+size_t soccdpt_workspace_bytes(void* handle, int B) { return model_workspace_bytes(*static_cast<Handle*>(handle), B); }
+
+int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    return model_prepare(*h, dev_prepared, prepared_bytes, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_network(void* handle, const float* dev_x, int B, float* dev_inv256, float* dev_seg256, void* dev_workspace,
+                    size_t workspace_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    return model_network(*h, dev_x, B, dev_inv256, dev_seg256, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, int B, int in_h, int in_w, float* dev_inv_up,
+                    float* dev_seg_up, float* dev_points, uint32_t* dev_occ_bits, int clear_bits, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (!dev_inv || !dev_seg) return fail(h, "soccdpt_project: null input");
+    return launch_project(h->cfg, dev_inv, dev_seg, B, in_h, in_w, dev_inv_up, dev_seg_up, dev_points, dev_occ_bits, clear_bits,
+                          (hipStream_t)stream, h->err);
+}
+
+size_t soccdpt_occ_words(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    const size_t ncell = (size_t)h->cfg.grid[0] * h->cfg.grid[1] * h->cfg.grid[2] * h->cfg.num_classes;
+    return (ncell + 31) / 32;
+}
+
+int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src_bits, int n_sets, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (n_sets <= 0) return 0;
+    return launch_occ_or(h->cfg, dev_dst_bits, dev_src_bits, n_sets, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (B <= 0) return fail(h, "soccdpt_occ_expand: empty batch");
+    return launch_occ_expand(h->cfg, dev_bits, B, dev_occ, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, float* dev_seg_up, float* dev_points,
+                    float* dev_occ, uint32_t* dev_occ_bits, void* dev_workspace, size_t workspace_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (B <= 0) return fail(h, "soccdpt_forward: empty batch");
+    const int S = h->img;
+    // the network outputs live at the head of the workspace
+    float* inv = static_cast<float*>(dev_workspace);
+    float* seg = inv + (size_t)B * S * S;
+    const size_t head = (size_t)B * S * S * (1 + h->cfg.num_classes) * sizeof(float);
+    if (workspace_bytes < head) return fail(h, "soccdpt_forward: workspace too small");
+    int rc = model_network(*h, dev_x, B, inv, seg, static_cast<char*>(dev_workspace) + head, workspace_bytes - head,
+                           (hipStream_t)stream, h->err);
+    if (rc) return rc;
+    const bool occ_on = h->cfg.compute_occ != 0;
+    if (occ_on && !dev_occ_bits) return fail(h, "soccdpt_forward: compute_occ needs dev_occ_bits");
+    rc = launch_project(h->cfg, inv, seg, B, S, S, dev_inv_up, dev_seg_up, dev_points, occ_on ? dev_occ_bits : nullptr, 1,
+                        (hipStream_t)stream, h->err);
+    if (rc) return rc;
+    if (occ_on && dev_occ) rc = launch_occ_expand(h->cfg, dev_occ_bits, B, dev_occ, (hipStream_t)stream, h->err);
+    return rc;
+}
+
+int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
+
+}  // extern "C"

@@ -1,0 +1,71 @@
+// Internal declarations shared by the translation units of libsoccdpt_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/soccdpt_hip.h"
+
+namespace soccdpt {
+
+// Swin-V2 geometry (timm swinv2_* as created by /root/reference/SOccDPT/model/backbones/swin2.py:15-30;
+// hooks from /root/reference/SOccDPT/model/dpt.py:67-72).
+struct Arch {
+    int img = 256, patch = 4, embed = 96, window = 16;
+    int depths[4] = {2, 2, 6, 2};
+    int heads[4] = {3, 6, 12, 24};
+    int pretrained_window[4] = {0, 0, 0, 0};
+    int hooks[4] = {1, 1, 5, 1};
+    int grid() const { return img / patch; }
+    int dim(int s) const { return embed << s; }
+    int res(int s) const { return grid() >> s; }
+    int ws(int s) const { return res(s) < window ? res(s) : window; }
+    int shift(int s, int j) const { return (j % 2 == 0 || res(s) <= window) ? 0 : window / 2; }
+};
+
+struct WeightSlot {
+    std::string key;
+    std::vector<int64_t> shape;
+    const float* ptr = nullptr;
+    size_t numel() const {
+        size_t n = 1;
+        for (auto d : shape) n *= (size_t)d;
+        return n;
+    }
+};
+
+struct Prepared;  // model.cpp
+
+struct Handle {
+    soccdpt_config cfg;
+    int device = 0;
+    int img = 256;
+    Arch arch;
+    std::string err;
+    std::vector<WeightSlot> weights;
+    std::unordered_map<std::string, int> index;
+    size_t prepared_bytes = 0;
+    Prepared* prep = nullptr;
+    bool is_prepared = false;
+    int launches = 0;
+    ~Handle();
+};
+
+// model.cpp
+int model_init(Handle& h, std::string& err);
+int model_bind(Handle& h, const char* key, const void* ptr, const int64_t* shape, int ndim, std::string& err);
+size_t model_workspace_bytes(Handle& h, int B);
+int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t stream, std::string& err);
+int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t stream,
+                  std::string& err);
+
+// projection.hip
+int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg, int B, int in_h, int in_w, float* inv_up,
+                   float* seg_up, float* points, uint32_t* occ_bits, int clear_bits, hipStream_t stream, std::string& err);
+int launch_occ_expand(const soccdpt_config& cfg, const uint32_t* bits, int B, float* occ, hipStream_t stream, std::string& err);
+int launch_occ_or(const soccdpt_config& cfg, uint32_t* dst, const uint32_t* src, int nsets, hipStream_t stream, std::string& err);
+
+}  // namespace soccdpt

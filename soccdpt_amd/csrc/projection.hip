@@ -1,0 +1,293 @@
+// Fused projection + voxelisation for gfx950 (HBM-bound, integer/index work bit-exact).
+//
+// One pass per camera pixel replaces the ~20 ATen launches of
+//   SOccDPT.get_semantic_occupancy   /root/reference/SOccDPT/model/SOccDPT.py:264-372
+//   rotate_points                    /root/reference/SOccDPT/model/SOccDPT.py:60-130
+//   points_to_occupancy_grid         /root/reference/SOccDPT/model/SOccDPT.py:374-463
+// bicubic-sample inverse depth, nearest-sample class probabilities, clamp, reciprocal,
+// back-project, write inv_up / seg_up / points, rotate in registers, voxel index, bounds
+// test, OR into a bit-packed union grid.  A second kernel expands bits -> f32 rows.
+//
+// Float contract (matches PyTorch's CPU kernels bit-for-bit, see oracle/projection_ref.c):
+// this TU is compiled with -ffp-contract=off; every fused multiply-add that the CPU
+// build performs is written with fmaf, every other op rounds to f32 separately, all
+// divisions are IEEE.
+//
+// Algorithmic HBM bytes per frame: read (1+C)*h*w*4, write Hc*Wc*4*(1+C+3)
+// + one occupancy row gx*gy*gz*C*4.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "internal.h"
+
+namespace soccdpt {
+
+__device__ __forceinline__ float cc1(float x) {
+    float t = fmaf(1.25f, x, -2.25f);
+    return (t * x) * x + 1.0f;
+}
+__device__ __forceinline__ float cc2(float x) {
+    float t = fmaf(-0.75f, x, 3.75f);
+    t = fmaf(t, x, -6.0f);
+    return t * x + 3.0f;
+}
+
+struct Taps {
+    int idx[4];
+    float w[4];
+};
+
+__device__ __forceinline__ Taps cubic_taps(int dst, int in, float scale) {
+    Taps tp;
+    float real = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    int ii = (int)floorf(real);
+    if (ii > in - 1) ii = in - 1;
+    float t = real - (float)ii;
+    t = t < 0.0f ? 0.0f : t;
+    t = t > 1.0f ? 1.0f : t;
+    tp.w[0] = cc2(t + 1.0f);
+    tp.w[1] = cc1(t);
+    float u = 1.0f - t;
+    tp.w[2] = cc1(u);
+    tp.w[3] = cc2(u + 1.0f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int k = ii + j - 1;
+        k = k < 0 ? 0 : k;
+        k = k > in - 1 ? in - 1 : k;
+        tp.idx[j] = k;
+    }
+    return tp;
+}
+
+__device__ __forceinline__ float dot4(float v0, float v1, float v2, float v3, const float* w) {
+    return fmaf(v3, w[3], fmaf(v2, w[2], fmaf(v0, w[0], v1 * w[1])));
+}
+
+__device__ __forceinline__ int nearest_src(int dst, int in, float scale) {
+    int s = (int)floorf((float)dst * scale);
+    return s > in - 1 ? in - 1 : s;
+}
+
+__device__ __forceinline__ void rot3(const float p[3], const float* R, float o[3]) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[j] = fmaf(p[2], R[6 + j], fmaf(p[1], R[3 + j], p[0] * R[j]));
+}
+
+struct ProjParams {
+    const float* inv;   // [B,h,w]
+    const float* seg;   // [B,C,h,w]
+    float* inv_up;      // [B,Hc,Wc]
+    float* seg_up;      // [B,C,Hc,Wc]
+    float* points;      // [B,Hc,Wc,3]
+    uint32_t* occ_bits; // packed union grid or nullptr
+    int B, h, w, Hc, Wc;
+    float fx, fy, cx, cy;
+    float pc_scale[3], pc_shift[3];
+    float rot[27];
+    float occ_shape[3];
+    int grid[3];
+};
+
+// One thread = VEC consecutive pixels of one camera row (VEC = 4: 16-byte stores).
+template <int C, int VEC>
+__global__ __launch_bounds__(256) void project_kernel(ProjParams P) {
+    const int quads_per_row = P.Wc / VEC;
+    const long long total = (long long)P.B * P.Hc * quads_per_row;
+    const float sy = (float)P.h / (float)P.Hc;
+    const float sx = (float)P.w / (float)P.Wc;
+    const size_t npix = (size_t)P.Hc * P.Wc;
+    for (long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long long)gridDim.x * blockDim.x) {
+        const int qx = (int)(q % quads_per_row);
+        const long long ru = q / quads_per_row;
+        const int u = (int)(ru % P.Hc);
+        const int b = (int)(ru / P.Hc);
+        const int v0 = qx * VEC;
+        const float* src = P.inv + (size_t)b * P.h * P.w;
+        const Taps ty = cubic_taps(u, P.h, sy);
+        const int su = nearest_src(u, P.h, sy);
+        const float* r0 = src + (size_t)ty.idx[0] * P.w;
+        const float* r1 = src + (size_t)ty.idx[1] * P.w;
+        const float* r2 = src + (size_t)ty.idx[2] * P.w;
+        const float* r3 = src + (size_t)ty.idx[3] * P.w;
+        const float yterm = (float)u - P.cy;
+
+        float iv[VEC], sem[C][VEC], pt[VEC][3];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            const int v = v0 + e;
+            const Taps tx = cubic_taps(v, P.w, sx);
+            float t0 = dot4(r0[tx.idx[0]], r0[tx.idx[1]], r0[tx.idx[2]], r0[tx.idx[3]], tx.w);
+            float t1 = dot4(r1[tx.idx[0]], r1[tx.idx[1]], r1[tx.idx[2]], r1[tx.idx[3]], tx.w);
+            float t2 = dot4(r2[tx.idx[0]], r2[tx.idx[1]], r2[tx.idx[2]], r2[tx.idx[3]], tx.w);
+            float t3 = dot4(r3[tx.idx[0]], r3[tx.idx[1]], r3[tx.idx[2]], r3[tx.idx[3]], tx.w);
+            float val = dot4(t0, t1, t2, t3, ty.w);
+            if (val < 1e-8f) val = 1e-8f;  // NaN compares false and stays NaN
+            float d = 1.0f / val;
+            if (isinf(d) || isnan(d)) d = __builtin_inff();
+            iv[e] = val;
+            const int sv = nearest_src(v, P.w, sx);
+#pragma unroll
+            for (int c = 0; c < C; ++c) sem[c][e] = P.seg[(((size_t)b * C + c) * P.h + su) * P.w + sv];
+            float p[3];
+            p[0] = (((float)v - P.cx) * d) / P.fx;
+            p[1] = (yterm * d) / P.fy;
+            p[2] = d;
+            const size_t n = (size_t)u * P.Wc + v;
+            if (n < 3) {  // the reference scales/shifts flat pixels 0,1,2 of each image
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[k] = p[k] * P.pc_scale[n] + P.pc_shift[n];
+            }
+            pt[e][0] = p[0];
+            pt[e][1] = p[1];
+            pt[e][2] = p[2];
+
+            if (P.occ_bits) {
+                float a[3], bq[3], cq[3];
+                rot3(p, P.rot, a);
+                rot3(a, P.rot + 9, bq);
+                rot3(bq, P.rot + 18, cq);
+                const bool fin = isfinite(cq[0]) && isfinite(cq[1]) && isfinite(cq[2]);
+                const float fi = (cq[0] / P.occ_shape[0]) * (float)P.grid[0];
+                const float fj = (cq[1] / P.occ_shape[1]) * (float)P.grid[1];
+                const float fk = (cq[2] / P.occ_shape[2]) * (float)P.grid[2];
+                // trunc-toward-zero as the reference's .type(int64); window test in float first so the
+                // integer conversion is always in range
+                const bool inr = fin && fi > -1.0f && fi < 65536.0f && fj > -1.0f && fj < 65536.0f && fk > -1.0f && fk < 65536.0f;
+                if (inr) {
+                    const int i = (int)fi, j = (int)fj, k = (int)fk;
+                    if (0 < i && i < P.grid[0] && 0 < j && j < P.grid[1] && 0 < k && k < P.grid[2]) {
+                        const uint32_t base = (uint32_t)(((i * P.grid[1] + j) * P.grid[2] + k) * C);
+#pragma unroll
+                        for (int c = 0; c < C; ++c) {
+                            if (sem[c][e] != 0.0f) {
+                                const uint32_t bit = base + c;
+                                const uint32_t m = 1u << (bit & 31);
+                                uint32_t* wp = P.occ_bits + (bit >> 5);
+                                // idempotent OR: a stale read only costs a redundant atomic
+                                if (!(__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m)) atomicOr(wp, m);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // ---- stores (16 B per lane where VEC == 4) ----
+        const size_t n0 = (size_t)u * P.Wc + v0;
+        if constexpr (VEC == 4) {
+            if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
+            if (P.seg_up) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    *reinterpret_cast<float4*>(P.seg_up + ((size_t)b * C + c) * npix + n0) =
+                        make_float4(sem[c][0], sem[c][1], sem[c][2], sem[c][3]);
+            }
+            if (P.points) {
+                float4* o = reinterpret_cast<float4*>(P.points + ((size_t)b * npix + n0) * 3);
+                o[0] = make_float4(pt[0][0], pt[0][1], pt[0][2], pt[1][0]);
+                o[1] = make_float4(pt[1][1], pt[1][2], pt[2][0], pt[2][1]);
+                o[2] = make_float4(pt[2][2], pt[3][0], pt[3][1], pt[3][2]);
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                if (P.inv_up) P.inv_up[(size_t)b * npix + n0 + e] = iv[e];
+                if (P.seg_up) {
+#pragma unroll
+                    for (int c = 0; c < C; ++c) P.seg_up[((size_t)b * C + c) * npix + n0 + e] = sem[c][e];
+                }
+                if (P.points) {
+                    float* o = P.points + ((size_t)b * npix + n0 + e) * 3;
+                    o[0] = pt[e][0];
+                    o[1] = pt[e][1];
+                    o[2] = pt[e][2];
+                }
+            }
+        }
+    }
+}
+
+// bits -> f32, every batch row gets the same union grid.  One thread = 4 consecutive cells.
+__global__ __launch_bounds__(256) void occ_expand_kernel(const uint32_t* __restrict__ bits, float* __restrict__ occ, size_t ncell, int B) {
+    const size_t nq = ncell / 4;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < nq; q += (size_t)gridDim.x * blockDim.x) {
+        const size_t n = q * 4;
+        const uint32_t wv = bits[n >> 5] >> (n & 31);
+        const float4 val = make_float4((float)(wv & 1u), (float)((wv >> 1) & 1u), (float)((wv >> 2) & 1u), (float)((wv >> 3) & 1u));
+        for (int b = 0; b < B; ++b) *reinterpret_cast<float4*>(occ + (size_t)b * ncell + n) = val;
+    }
+}
+
+__global__ __launch_bounds__(256) void occ_or_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t nwords, int nsets) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t v = dst[i];
+        for (int s = 0; s < nsets; ++s) v |= src[(size_t)s * nwords + i];
+        dst[i] = v;
+    }
+}
+
+int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg, int B, int in_h, int in_w, float* inv_up,
+                   float* seg_up, float* points, uint32_t* occ_bits, int clear_bits, hipStream_t stream, std::string& err) {
+    if (cfg.num_classes != 3) {
+        err = "projection kernel is instantiated for num_classes == 3 (the reference reshapes xyz with num_classes)";
+        return 1;
+    }
+    if (B <= 0 || in_h <= 0 || in_w <= 0) {
+        err = "soccdpt_project: empty input";
+        return 1;
+    }
+    const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
+    if (ncell >= (1ull << 31) || cfg.grid[0] > 65535 || cfg.grid[1] > 65535 || cfg.grid[2] > 65535) {
+        err = "occupancy grid too large for 32-bit cell indices";
+        return 1;
+    }
+    ProjParams P;
+    P.inv = inv; P.seg = seg; P.inv_up = inv_up; P.seg_up = seg_up; P.points = points; P.occ_bits = occ_bits;
+    P.B = B; P.h = in_h; P.w = in_w; P.Hc = cfg.cam_height; P.Wc = cfg.cam_width;
+    P.fx = cfg.fx; P.fy = cfg.fy; P.cx = cfg.cx; P.cy = cfg.cy;
+    for (int i = 0; i < 3; ++i) {
+        P.pc_scale[i] = cfg.pc_scale[i];
+        P.pc_shift[i] = cfg.pc_shift[i];
+        P.occ_shape[i] = cfg.occupancy_shape[i];
+        P.grid[i] = cfg.grid[i];
+    }
+    for (int i = 0; i < 27; ++i) P.rot[i] = cfg.rot[i];
+    if (occ_bits && clear_bits) {
+        hipError_t e = hipMemsetAsync(occ_bits, 0, ((ncell + 31) / 32) * sizeof(uint32_t), stream);
+        if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    }
+    const bool vec4 = (P.Wc % 4 == 0);
+    const long long total = (long long)B * P.Hc * (vec4 ? P.Wc / 4 : P.Wc);
+    long long blocks = (total + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
+    if (vec4)
+        hipLaunchKernelGGL((project_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
+    else
+        hipLaunchKernelGGL((project_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+int launch_occ_expand(const soccdpt_config& cfg, const uint32_t* bits, int B, float* occ, hipStream_t stream, std::string& err) {
+    const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
+    if (ncell % 32 != 0) { err = "occupancy cell count must be a multiple of 32"; return 1; }
+    size_t blocks = (ncell / 4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    hipLaunchKernelGGL(occ_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, occ, ncell, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+int launch_occ_or(const soccdpt_config& cfg, uint32_t* dst, const uint32_t* src, int nsets, hipStream_t stream, std::string& err) {
+    const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
+    const size_t nwords = (ncell + 31) / 32;
+    size_t blocks = (nwords + 255) / 256;
+    hipLaunchKernelGGL(occ_or_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, nwords, nsets);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+}  // namespace soccdpt

@@ -1,0 +1,251 @@
+"""ctypes binding of libsoccdpt_hip.so (include/soccdpt_hip.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  If the
+shared object is missing or a call fails, this module raises.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsoccdpt_hip.so")
+
+ABI_VERSION = 1
+BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1}
+PREC_BF16 = 0
+PREC_BF16X3 = 1
+
+
+class SoccdptConfig(ctypes.Structure):
+    _fields_ = [
+        ("abi_version", ctypes.c_int32),
+        ("backbone", ctypes.c_int32),
+        ("num_classes", ctypes.c_int32),
+        ("features", ctypes.c_int32),
+        ("sigmoid", ctypes.c_int32),
+        ("compute_occ", ctypes.c_int32),
+        ("precision", ctypes.c_int32),
+        ("cam_width", ctypes.c_int32),
+        ("cam_height", ctypes.c_int32),
+        ("fx", ctypes.c_float), ("fy", ctypes.c_float), ("cx", ctypes.c_float), ("cy", ctypes.c_float),
+        ("grid", ctypes.c_int32 * 3),
+        ("occupancy_shape", ctypes.c_float * 3),
+        ("pc_scale", ctypes.c_float * 3),
+        ("pc_shift", ctypes.c_float * 3),
+        ("rot", ctypes.c_float * 27),
+    ]
+
+
+_lib = None
+
+
+def load_library() -> ctypes.CDLL:
+    """Load libsoccdpt_hip.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(make -C soccdpt_amd/csrc).  The SOccDPT MI355X path has no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, ci, cs = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
+    L.soccdpt_abi_version.restype = ci
+    L.soccdpt_create.argtypes = [ctypes.POINTER(SoccdptConfig), ctypes.POINTER(vp)]
+    L.soccdpt_create.restype = ci
+    L.soccdpt_destroy.argtypes = [vp]
+    L.soccdpt_destroy.restype = None
+    L.soccdpt_last_error.argtypes = [vp]
+    L.soccdpt_last_error.restype = ctypes.c_char_p
+    L.soccdpt_bind_weight.argtypes = [vp, ctypes.c_char_p, vp, ci, ctypes.POINTER(ctypes.c_int64), ci]
+    L.soccdpt_bind_weight.restype = ci
+    L.soccdpt_num_weights.argtypes = [vp]
+    L.soccdpt_num_weights.restype = ci
+    L.soccdpt_weight_key.argtypes = [vp, ci]
+    L.soccdpt_weight_key.restype = ctypes.c_char_p
+    L.soccdpt_prepared_bytes.argtypes = [vp]
+    L.soccdpt_prepared_bytes.restype = cs
+    L.soccdpt_workspace_bytes.argtypes = [vp, ci]
+    L.soccdpt_workspace_bytes.restype = cs
+    L.soccdpt_prepare.argtypes = [vp, vp, cs, vp]
+    L.soccdpt_prepare.restype = ci
+    L.soccdpt_forward.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, cs, vp]
+    L.soccdpt_forward.restype = ci
+    L.soccdpt_network.argtypes = [vp, vp, ci, vp, vp, vp, cs, vp]
+    L.soccdpt_network.restype = ci
+    L.soccdpt_project.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
+    L.soccdpt_project.restype = ci
+    L.soccdpt_occ_or.argtypes = [vp, vp, vp, ci, vp]
+    L.soccdpt_occ_or.restype = ci
+    L.soccdpt_occ_expand.argtypes = [vp, vp, ci, vp, vp]
+    L.soccdpt_occ_expand.restype = ci
+    L.soccdpt_occ_words.argtypes = [vp]
+    L.soccdpt_occ_words.restype = cs
+    L.soccdpt_last_launch_count.argtypes = [vp]
+    L.soccdpt_last_launch_count.restype = ci
+    if L.soccdpt_abi_version() != ABI_VERSION:
+        raise RuntimeError("libsoccdpt_hip.so ABI version mismatch; rebuild the library")
+    _lib = L
+    return L
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    assert t.is_contiguous(), "device tensors handed to libsoccdpt_hip must be contiguous"
+    return t.data_ptr()
+
+
+def _stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def host_rotation_matrices(angles: Sequence[float]) -> np.ndarray:
+    """Ra, Rb, Rc as 27 f32 values, computed on the host CPU with the same torch ops
+    as rotate_points (/root/reference/SOccDPT/model/SOccDPT.py:74-111)."""
+    a, b, c = [torch.deg2rad(torch.tensor(float(v), dtype=torch.float32)) for v in angles]
+    ra = torch.tensor([[1, 0, 0], [0, torch.cos(a), -torch.sin(a)], [0, torch.sin(a), torch.cos(a)]], dtype=torch.float32)
+    rb = torch.tensor([[torch.cos(b), 0, torch.sin(b)], [0, 1, 0], [-torch.sin(b), 0, torch.cos(b)]], dtype=torch.float32)
+    rc = torch.tensor([[torch.cos(c), -torch.sin(c), 0], [torch.sin(c), torch.cos(c), 0], [0, 0, 1]], dtype=torch.float32)
+    return torch.cat([ra.reshape(-1), rb.reshape(-1), rc.reshape(-1)]).numpy().astype(np.float32)
+
+
+def make_config(backbone: str, num_classes: int, features: int, sigmoid: bool, compute_occ: bool,
+                cam_width: int, cam_height: int, fx: float, fy: float, cx: float, cy: float,
+                grid_size, occupancy_shape, pc_scale, pc_shift, correction_angle,
+                precision: int = PREC_BF16) -> SoccdptConfig:
+    if backbone not in BACKBONE_IDS:
+        raise AssertionError(f"Backbone '{backbone}' not implemented on the MI355X path")
+    cfg = SoccdptConfig()
+    cfg.abi_version = ABI_VERSION
+    cfg.backbone = BACKBONE_IDS[backbone]
+    cfg.num_classes = int(num_classes)
+    cfg.features = int(features)
+    cfg.sigmoid = 1 if sigmoid else 0
+    cfg.compute_occ = 1 if compute_occ else 0
+    cfg.precision = int(precision)
+    cfg.cam_width = int(cam_width)
+    cfg.cam_height = int(cam_height)
+    cfg.fx, cfg.fy, cfg.cx, cfg.cy = [float(np.float32(v)) for v in (fx, fy, cx, cy)]
+    for i in range(3):
+        cfg.grid[i] = int(grid_size[i])
+        cfg.occupancy_shape[i] = float(np.float32(occupancy_shape[i]))
+        cfg.pc_scale[i] = float(np.float32(pc_scale[i]))
+        cfg.pc_shift[i] = float(np.float32(pc_shift[i]))
+    rot = host_rotation_matrices(correction_angle)
+    for i in range(27):
+        cfg.rot[i] = float(rot[i])
+    return cfg
+
+
+class Engine:
+    """One handle of libsoccdpt_hip.so bound to one GPU (one per rank)."""
+
+    def __init__(self, cfg: SoccdptConfig, device: torch.device):
+        if not torch.cuda.is_available():
+            raise RuntimeError("soccdpt_amd needs a ROCm GPU (MI355X); there is no CPU fallback")
+        self.L = load_library()
+        self.cfg = cfg
+        self.device = torch.device(device)
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            rc = self.L.soccdpt_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc != 0:
+            raise RuntimeError("soccdpt_create failed: " + self.L.soccdpt_last_error(None).decode())
+        self._prepared: Optional[torch.Tensor] = None
+        self._workspace: Optional[torch.Tensor] = None
+        self._bound = {}
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.soccdpt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.L.soccdpt_last_error(self._h).decode()}")
+
+    # ---- weights ----
+    def weight_keys(self):
+        n = self.L.soccdpt_num_weights(self._h)
+        return [self.L.soccdpt_weight_key(self._h, i).decode() for i in range(n)]
+
+    def bind(self, key: str, t: torch.Tensor) -> bool:
+        """Bind one device tensor under its state-dict key; False if the key is not consumed."""
+        assert t.device.type == "cuda" and t.dtype == torch.float32 and t.is_contiguous(), key
+        shape = (ctypes.c_int64 * t.dim())(*t.shape)
+        rc = self.L.soccdpt_bind_weight(self._h, key.encode(), t.data_ptr(), 0, shape, t.dim())
+        if rc == 2:
+            return False
+        self._check(rc, "soccdpt_bind_weight")
+        self._bound[key] = t  # keep alive
+        return True
+
+    def prepare(self):
+        nbytes = self.L.soccdpt_prepared_bytes(self._h)
+        if self._prepared is None or self._prepared.numel() < nbytes:
+            self._prepared = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_prepare(self._h, self._prepared.data_ptr(), nbytes, _stream_ptr(self.device)),
+                        "soccdpt_prepare")
+
+    def workspace(self, B: int) -> torch.Tensor:
+        nbytes = self.L.soccdpt_workspace_bytes(self._h, B)
+        if self._workspace is None or self._workspace.numel() < nbytes:
+            # zero-filled: halo borders of the padded NHWC activations stay zero for ever
+            self._workspace = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self._workspace_B = B
+        elif self._workspace_B != B:
+            self._workspace.zero_()  # the layout (and so the halo positions) depends on B
+            self._workspace_B = B
+        return self._workspace
+
+    def occ_words(self) -> int:
+        return int(self.L.soccdpt_occ_words(self._h))
+
+    # ---- stage-level calls ----
+    def project(self, inv: torch.Tensor, seg: torch.Tensor, inv_up, seg_up, points, occ_bits, clear_bits: bool = True):
+        B, h, w = inv.shape
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_project(self._h, _ptr(inv), _ptr(seg), B, h, w, _ptr(inv_up), _ptr(seg_up),
+                                               _ptr(points), _ptr(occ_bits), 1 if clear_bits else 0,
+                                               _stream_ptr(self.device)), "soccdpt_project")
+
+    def occ_or(self, dst_bits: torch.Tensor, src_bits: torch.Tensor, n_sets: int):
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_occ_or(self._h, _ptr(dst_bits), _ptr(src_bits), n_sets, _stream_ptr(self.device)),
+                        "soccdpt_occ_or")
+
+    def occ_expand(self, bits: torch.Tensor, B: int, occ: torch.Tensor):
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_occ_expand(self._h, _ptr(bits), B, _ptr(occ), _stream_ptr(self.device)),
+                        "soccdpt_occ_expand")
+
+    def network(self, x: torch.Tensor, inv256: torch.Tensor, seg256: torch.Tensor):
+        B = x.shape[0]
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_network(self._h, _ptr(x), B, _ptr(inv256), _ptr(seg256), ws.data_ptr(), ws.numel(),
+                                               _stream_ptr(self.device)), "soccdpt_network")
+
+    def forward(self, x: torch.Tensor, inv_up, seg_up, points, occ, occ_bits):
+        B = x.shape[0]
+        ws = self.workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_forward(self._h, _ptr(x), B, _ptr(inv_up), _ptr(seg_up), _ptr(points), _ptr(occ),
+                                               _ptr(occ_bits), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
+                        "soccdpt_forward")
+
+    def launch_count(self) -> int:
+        return int(self.L.soccdpt_last_launch_count(self._h))

@@ -1,0 +1,25 @@
+"""Seeded inputs of the golden fixtures (shared by oracle/make_golden.py and the tests).
+Only outputs are stored in tests/golden/*.npz; inputs are regenerated from these seeds."""
+import torch
+
+
+def proj_inputs(seed: int = 1234, B: int = 2, S: int = 256):
+    """inv[B,S,S] in ~[0.005,0.3] with zeros / negatives / NaN / inf / tiny values, and
+    ScaledTanh class probabilities with exact zeros (SURVEY.md §8c fixture 1)."""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand((B, 1, 16, 16), generator=g) * 0.29 + 0.005
+    inv = torch.nn.functional.interpolate(lo, size=(S, S), mode="bilinear", align_corners=False)[:, 0]
+    inv = inv + torch.randn((B, S, S), generator=g) * 0.002
+    inv[:, 5, 7] = 0.0           # clamp path (-> 1e-8 -> depth 1e8)
+    inv[:, 9, 11:14] = -0.5      # negative -> clamp
+    inv[0, 100, 50] = float("nan")
+    inv[B - 1, 33, 200] = float("inf")
+    inv[B - 1, 34, 200] = 1e-12
+    logits = torch.randn((B, 3, S, S), generator=g) * 6.0
+    seg = 0.5 * torch.tanh(logits) + 0.5   # ScaledTanh -> exact zeros for logits << 0
+    return inv.contiguous(), seg.contiguous()
+
+
+def decoder_features(seed: int = 77, B: int = 1, dims=(96, 192, 384, 768), res=(64, 32, 16, 8)):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn((B, c, r, r), generator=g) for c, r in zip(dims, res)]
