@@ -114,8 +114,46 @@ int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src
 int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream);
 size_t soccdpt_occ_words(void* handle);
 
-/* Name and accumulated launch count of the kernels issued by the last forward (diagnostics). */
+/* Number of kernel launches issued by the last soccdpt_network call (diagnostics). */
 int soccdpt_last_launch_count(void* handle);
+
+/* ---- kernel-level entry points (parity tests of the individual HIP kernels) ---- */
+
+/* One implicit-GEMM launch: out[m][n] = epilogue(sum_k X[m][k] * Wt[n][k]) with bf16 operands and f32
+ * accumulation; stands in for F.conv2d / F.linear of model/blocks.py:155-191,391-414 and timm's Linear layers.
+ * taps == 1: X is [M][ldx] bf16.  taps == 9: X is a zero-haloed NHWC bf16 image [B][H+2][W+2][Cin], M = B*H*W,
+ * Wt is [N][9*Cin] (tap-major).  v = acc + bias[n] + res1[m][n] + res2[m][n]; act: 0 none, 1 relu, 2 gelu(erf).
+ * out_f32 gets v (or act(v) when act_on_f32), out_bf16 gets act(v) ([M][N] or a halo image), out_dot[m] =
+ * relu(sum_n act(v)[n]*dot_w[n] + dot_b) (N <= 32).  Unused pointers are NULL. */
+typedef struct soccdpt_igemm_args {
+    const void* x;
+    const void* wt;
+    int32_t M, N, Cin, taps, ldx, H, W;
+    const float* bias;
+    const float* res1;
+    const float* res2;
+    int32_t act;
+    float* out_f32;
+    int32_t act_on_f32;
+    void* out_bf16;
+    int32_t out_halo;
+    const float* dot_w;
+    float dot_b;
+    float* out_dot;
+} soccdpt_igemm_args;
+int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
+
+/* Swin-V2 cosine window attention of one block (timm WindowAttention + shift/partition/reverse):
+ * qkv [B*res*res][3*heads*32] bf16 -> out [B*res*res][heads*32] bf16.  cpb_table [(2ws-1)^2][heads] f32 is
+ * 16*sigmoid(cpb_mlp(coords)); scale[heads] = exp(min(logit_scale, ln 100)); bias_scratch: heads*ws^4 floats. */
+int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
+                                float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, void* stream);
+
+/* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
+ * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "xf" (final stage tokens f32).
+ * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC.  Returns non-zero for unknown names. */
+int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind,
+                             int* H, int* W, int* C);
 
 #ifdef __cplusplus
 }

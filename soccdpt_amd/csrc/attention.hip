@@ -1,0 +1,248 @@
+// Swin-V2 cosine window attention for gfx950 (one workgroup per (batch, window, head)).
+//
+// Replaces timm WindowAttention.forward + window_partition / roll / window_reverse
+// (call site /root/reference/SOccDPT/model/backbones/swin2.py:25-27; maths SURVEY.md §8a a4-E,
+// HF modeling_swinv2.py:389-452,652-695):
+//   S = normalize(q) normalize(k)^T * exp(min(logit_scale, ln100)) + 16*sigmoid(CPB) [+ shift mask]
+//   O = softmax(S) V
+// Design (CDNA4):
+//  * the cyclic shift, window partition and window reverse are folded into the load/store row index;
+//  * q,k rows are L2-normalised in f32 while staging (4 lanes per token, 16-byte loads), the logit
+//    scale is folded into q-hat; Q-hat/K-hat live in LDS as [token][32] bf16 with a 16-byte chunk XOR
+//    swizzle (conflict-free ds_read_b128), V is stored transposed [d][token] with an 8-byte row pad;
+//  * S^T = K-hat Q-hat^T with v_mfma_f32_32x32x16_bf16 ("swapped" product): a lane then owns one
+//    query column, so softmax statistics are lane-local plus one cross-half exchange, and the
+//    exponentiated accumulators are directly the B operand of O^T = V^T P^T (no LDS round trip);
+//  * the CPB bias is precomputed per weight load in MFMA accumulator order and loaded as the
+//    initial accumulator (4 x 16-byte loads per tile, coalesced); the shift mask is arithmetic.
+#include "kernels.h"
+
+namespace soccdpt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+template <int WS>
+struct AttnCfg {
+    static constexpr int N = WS * WS;
+    static constexpr int WAVES = N / 64;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int KT = N / 32;  // 32-key tiles
+    static constexpr int QB = N / 32;  // 32-query blocks
+    static constexpr int VT_STRIDE = N * 2 + 8;
+    static constexpr int QS_OFF = 0, KS_OFF = N * 64, VT_OFF = 2 * N * 64;
+    static constexpr int LDS = 2 * N * 64 + 32 * VT_STRIDE;
+};
+
+__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+template <int WS>
+__global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
+                                                                                 const float* __restrict__ scale, bf16_t* __restrict__ out,
+                                                                                 int res, int shift, int heads) {
+    using A = AttnCfg<WS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem + A::QS_OFF;
+    char* Ks = smem + A::KS_OFF;
+    char* Vt = smem + A::VT_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * 32;
+    const int nw = res / WS;
+    int bid = blockIdx.x;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const float hscale = scale[head];
+
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / WS, c = p % WS;
+        int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+
+    // ---- stage Q-hat, K-hat, V^T ----
+#pragma unroll
+    for (int it = 0; it < (A::N * 4) / A::THREADS; ++it) {
+        const int idx = it * A::THREADS + tid;
+        const int p = idx >> 2, c = idx & 3;
+        const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
+        const uint4 qv = *reinterpret_cast<const uint4*>(src);
+        const uint4 kv = *reinterpret_cast<const uint4*>(src + C);
+        const uint4 vv = *reinterpret_cast<const uint4*>(src + 2 * C);
+        const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
+        float qf[8], kf[8];
+        float qs = 0.f, ks = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[2 * j] = __builtin_bit_cast(float, qu[j] << 16);
+            qf[2 * j + 1] = __builtin_bit_cast(float, qu[j] & 0xffff0000u);
+            kf[2 * j] = __builtin_bit_cast(float, ku[j] << 16);
+            kf[2 * j + 1] = __builtin_bit_cast(float, ku[j] & 0xffff0000u);
+            qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
+            ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
+        }
+        qs += __shfl_xor(qs, 1);
+        qs += __shfl_xor(qs, 2);
+        ks += __shfl_xor(ks, 1);
+        ks += __shfl_xor(ks, 2);
+        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);  // F.normalize eps
+        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
+        uint4 qo, ko;
+        qo.x = pk_bf16(qf[0] * qi, qf[1] * qi); qo.y = pk_bf16(qf[2] * qi, qf[3] * qi);
+        qo.z = pk_bf16(qf[4] * qi, qf[5] * qi); qo.w = pk_bf16(qf[6] * qi, qf[7] * qi);
+        ko.x = pk_bf16(kf[0] * ki, kf[1] * ki); ko.y = pk_bf16(kf[2] * ki, kf[3] * ki);
+        ko.z = pk_bf16(kf[4] * ki, kf[5] * ki); ko.w = pk_bf16(kf[6] * ki, kf[7] * ki);
+        const int sw = (c ^ ((p >> 2) & 3)) * 16;
+        *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
+        *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+#pragma unroll 1
+    for (int qbi = 0; qbi < 2; ++qbi) {
+        const int qb = wave * 2 + qbi;
+        const int qrow = qb * 32 + r32;
+        bf16x8 qfrag[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qfrag[ks] = *reinterpret_cast<const bf16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
+
+        f32x16 s[A::KT];
+        const float* bp = bias_acc + ((size_t)(head * A::QB + qb) * A::KT) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t) {
+            const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)t * 1024);
+            const float4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+            f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+            if constexpr (WS == 16) {
+                // shift mask (0 / -100): region differs in the last window row (token rows >= 8) or column (cols >= 8)
+                if (lastrow || lastcol) {
+                    const bool rowdiff = lastrow && ((t >= 4) != (qb >= 4));
+                    const bool qc = (lane >> 3) & 1;
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const bool kc = (rg >> 2) & 1;
+                        if (rowdiff || (lastcol && (kc != qc))) acc[rg] += -100.0f;
+                    }
+                }
+            }
+            const int krow = t * 32 + r32;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qfrag[ks], acc, 0, 0, 0);
+            }
+            s[t] = acc;
+        }
+        // ---- softmax over keys: lane-local over (t, reg) + the other half-wave ----
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) mx = fmaxf(mx, s[t][rg]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const float e = __expf(s[t][rg] - mx);
+                s[t][rg] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        // ---- O^T = V^T P^T ----
+        f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t) {
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[t][8 * st + j];
+                // element j of this lane half is key 32t + 16st + 8(j>>2) + 4h + (j&3): V^T must use the same k order
+                const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o, 0, 0, 0);
+            }
+        }
+        // ---- store: lane owns query column r32, rows d = (rg&3) + 8(rg>>2) + 4h ----
+        const float inv = 1.0f / sum;
+        bf16_t* orow = out + token_row(qrow) * (size_t)C + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pkt;
+            pkt.x = pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv);
+            pkt.y = pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            *reinterpret_cast<uint2*>(orow + 8 * g + 4 * h) = pkt;
+        }
+    }
+}
+
+// CPB bias in accumulator order: [head][qb][t][lane][16]; value for query 32qb+(lane&31),
+// key 32t + (reg&3) + 8(reg>>2) + 4(lane>>5)
+__global__ void attn_bias_kernel(const float* __restrict__ table, float* __restrict__ bias_acc, int ws, int heads) {
+    const int N = ws * ws, QB = N / 32, KT = N / 32;
+    const size_t total = (size_t)heads * N * N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rg = (int)(i & 15), lane = (int)((i >> 4) & 63);
+        size_t r = i >> 10;
+        const int t = (int)(r % KT);
+        r /= KT;
+        const int qb = (int)(r % QB);
+        const int head = (int)(r / QB);
+        const int q = 32 * qb + (lane & 31), k = 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+        const int rq = q / ws, cq = q % ws, rk = k / ws, ck = k % ws;
+        const int idx = (rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1);
+        bias_acc[i] = table[(size_t)idx * heads + head];
+    }
+}
+
+size_t attn_bias_elems(int ws, int heads) { return (size_t)heads * ws * ws * ws * ws; }
+
+int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hipStream_t st, std::string& err) {
+    const size_t total = attn_bias_elems(ws, heads);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(attn_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, table, bias_acc, ws, heads);
+    return check_launch("attn_bias", err);
+}
+
+int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,
+                            int heads, hipStream_t st, std::string& err) {
+    if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
+    const int nw = res / ws;
+    const unsigned blocks = (unsigned)(B * nw * nw * heads);
+    if (ws == 16) {
+        using A = AttnCfg<16>;
+        hipLaunchKernelGGL((window_attention_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+    } else if (ws == 8) {
+        using A = AttnCfg<8>;
+        if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
+        hipLaunchKernelGGL((window_attention_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+    } else {
+        err = "window_attention: window size not instantiated (16 and 8 are)";
+        return 1;
+    }
+    return check_launch("window_attention", err);
+}
+
+}  // namespace soccdpt

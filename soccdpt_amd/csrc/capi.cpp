@@ -5,6 +5,7 @@
 #include <string>
 
 #include "internal.h"
+#include "kernels.h"
 
 using namespace soccdpt;
 
@@ -129,5 +130,34 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
 }
 
 int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
+
+int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
+    if (!a) return fail(nullptr, "soccdpt_op_igemm: null args");
+    IgemmDesc d;
+    d.X = static_cast<const bf16_t*>(a->x); d.Wt = static_cast<const bf16_t*>(a->wt);
+    d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
+    d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
+    d.out_bf16 = static_cast<bf16_t*>(a->out_bf16); d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot;
+    std::string err;
+    if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
+                                float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, void* stream) {
+    std::string err;
+    if (launch_attn_bias(dev_cpb_table, dev_bias_scratch, ws, heads, (hipStream_t)stream, err)) return fail(nullptr, err);
+    if (launch_window_attention(static_cast<const bf16_t*>(dev_qkv), dev_bias_scratch, dev_scale, static_cast<bf16_t*>(dev_out), B, res, ws,
+                                shift, heads, (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W,
+                             int* C) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !name) return 1;
+    return model_workspace_tensor(*h, B, name, byte_offset, elems, kind, H, W, C);
+}
 
 }  // extern "C"

@@ -1,0 +1,412 @@
+// HBM-bound glue kernels of the SOccDPT_V3 network on gfx950: patch embedding + LayerNorm,
+// post-norm residual LayerNorm, patch-merging gather, align_corners bilinear resampling, the
+// 3-channel tail of the seg head, and the one-time weight re-layout / CPB-table kernels.
+// Every kernel cites the reference computation it replaces; 64-lane waves, 16-byte accesses
+// where the layout allows, NHWC ("token-major") activations throughout.
+#include "kernels.h"
+
+namespace soccdpt {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 x = (__bf16)f;
+    return __builtin_bit_cast(bf16_t, x);
+}
+__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+
+// ---------------------------------------------------------------------------------------------
+// patch_embed: Conv2d(3, C0, k=4, s=4) + bias, flatten, LayerNorm(C0)   (timm PatchEmbed;
+// call site /root/reference/SOccDPT/model/backbones/swin2.py:25-27).  One wave per token.
+// x NCHW f32 [B,3,S,S] -> xf [M,C0] f32 residual stream, xb [M,C0] bf16 GEMM operand.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, const float* __restrict__ g,
+                                                           const float* __restrict__ beta, float* __restrict__ xf,
+                                                           bf16_t* __restrict__ xb, int B, int S, int C0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* wT = reinterpret_cast<float*>(smem);  // [48][C0]
+    for (int i = threadIdx.x; i < 48 * C0; i += blockDim.x) {
+        const int k = i / C0, n = i - k * C0;
+        wT[i] = w[n * 48 + k];
+    }
+    __syncthreads();
+    const int G = S / 4, lane = threadIdx.x & 63;
+    const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
+    const int M = B * G * G;
+    for (int tok = wave_global; tok < M; tok += nwaves) {
+        const int b = tok / (G * G), r = tok - b * G * G, py = r / G, px = r - py * G;
+        float in = 0.f;
+        if (lane < 48) {
+            const int c = lane >> 4, ky = (lane >> 2) & 3, kx = lane & 3;
+            in = x[((size_t)(b * 3 + c) * S + py * 4 + ky) * S + px * 4 + kx];
+        }
+        float o0 = (lane < C0) ? bias[lane] : 0.f;
+        float o1 = (lane + 64 < C0) ? bias[lane + 64] : 0.f;
+#pragma unroll 8
+        for (int k = 0; k < 48; ++k) {
+            const float v = __shfl(in, k);
+            if (lane < C0) o0 = fmaf(v, wT[k * C0 + lane], o0);
+            if (lane + 64 < C0) o1 = fmaf(v, wT[k * C0 + lane + 64], o1);
+        }
+        const float mean = wave_sum(o0 + o1) / (float)C0;
+        const float d0 = (lane < C0) ? o0 - mean : 0.f, d1 = (lane + 64 < C0) ? o1 - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C0 + 1e-5f);
+        if (lane < C0) {
+            const float y = d0 * rstd * g[lane] + beta[lane];
+            xf[(size_t)tok * C0 + lane] = y;
+            xb[(size_t)tok * C0 + lane] = f2bf(y);
+        }
+        if (lane + 64 < C0) {
+            const float y = d1 * rstd * g[lane + 64] + beta[lane + 64];
+            xf[(size_t)tok * C0 + lane + 64] = y;
+            xb[(size_t)tok * C0 + lane + 64] = f2bf(y);
+        }
+    }
+}
+
+int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
+                       int B, int S, int C0, hipStream_t st, std::string& err) {
+    if (C0 > 128) { err = "patch_embed: C0 > 128"; return 1; }
+    const int M = B * (S / 4) * (S / 4);
+    int blocks = (M + 3) / 4;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(blocks), dim3(256), 48 * C0 * sizeof(float), st, x, w, bias, g, beta, xf, xb, B, S, C0);
+    return check_launch("patch_embed", err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Swin-V2 residual post-norm: x = x + LN(y) (timm SwinTransformerV2Block; HF modeling_swinv2.py:697-703),
+// or x = LN(y) after PatchMerging.reduction.  One wave per token row, C <= 1024.
+// Writes the f32 residual stream, its bf16 copy (next GEMM operand) and, for hooked blocks, the
+// zero-haloed NHWC bf16 feature map the decoder's 3x3 reassemble conv reads
+// (/root/reference/SOccDPT/model/backbones/swin_common.py:38-52 does this as Transpose+Unflatten).
+// ---------------------------------------------------------------------------------------------
+template <int VPL>  // values per lane = ceil(C / 64)
+__global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                           const float* __restrict__ beta, float* __restrict__ xf,
+                                                           bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, int M, int C, int residual,
+                                                           int res /*spatial size for halo*/) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* yr = y + (size_t)row * C;
+    float v[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < VPL; ++t) {
+        const int c = lane + 64 * t;
+        v[t] = c < C ? yr[c] : 0.f;
+        s += v[t];
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < VPL; ++t) {
+        const int c = lane + 64 * t;
+        const float d = c < C ? v[t] - mean : 0.f;
+        v[t] = d;
+        q += d * d;
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+    size_t hoff = 0;
+    if (halo) {
+        const int hw = res * res, b = row / hw, r = row - b * hw, yy = r / res, xx = r - yy * res;
+        hoff = ((size_t)(b * (res + 2) + yy + 1) * (res + 2) + xx + 1) * C;
+    }
+#pragma unroll
+    for (int t = 0; t < VPL; ++t) {
+        const int c = lane + 64 * t;
+        if (c < C) {
+            float o = v[t] * rstd * g[c] + beta[c];
+            if (residual) o += xf[(size_t)row * C + c];
+            xf[(size_t)row * C + c] = o;
+            const bf16_t ob = f2bf(o);
+            xb[(size_t)row * C + c] = ob;
+            if (halo) halo[hoff + c] = ob;
+        }
+    }
+}
+
+int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, int M, int C,
+                       int residual, int res, hipStream_t st, std::string& err) {
+    const int vpl = (C + 63) / 64;
+    dim3 grid((M + 3) / 4), block(256);
+#define LN_CASE(V) hipLaunchKernelGGL((ln_residual_kernel<V>), grid, block, 0, st, y, g, beta, xf, xb, halo, M, C, residual, res)
+    if (vpl <= 2) LN_CASE(2);
+    else if (vpl <= 4) LN_CASE(4);
+    else if (vpl <= 8) LN_CASE(8);
+    else if (vpl <= 12) LN_CASE(12);
+    else if (vpl <= 16) LN_CASE(16);
+    else { err = "ln_residual: C > 1024"; return 1; }
+#undef LN_CASE
+    return check_launch("ln_residual", err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// PatchMerging gather (timm PatchMerging; HF modeling_swinv2.py:333-352): [B,R,R,C] bf16 ->
+// [B,R/2,R/2,4C] with channel blocks (0,0),(1,0),(0,1),(1,1).  16-byte chunks.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void merge_gather_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int R, int C) {
+    const int cpt = C / 8;  // 16-byte chunks per source token
+    const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * cpt;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ch = (int)(i % cpt);
+        size_t r = i / cpt;
+        const int blk = (int)(r & 3);
+        r >>= 2;
+        const int R2 = R / 2;
+        const int ox = (int)(r % R2);
+        r /= R2;
+        const int oy = (int)(r % R2);
+        const int b = (int)(r / R2);
+        const int dy = blk & 1, dx = blk >> 1;  // block order: (0,0),(1,0),(0,1),(1,1) = (dy,dx)
+        const uint4 v = *reinterpret_cast<const uint4*>(in + ((size_t)(b * R + 2 * oy + dy) * R + 2 * ox + dx) * C + ch * 8);
+        *reinterpret_cast<uint4*>(out + i * 8) = v;
+    }
+}
+
+int launch_merge_gather(const bf16_t* in, bf16_t* out, int B, int R, int C, hipStream_t st, std::string& err) {
+    const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * (C / 8);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, B, R, C);
+    return check_launch("merge_gather", err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Bilinear resampling, align_corners=True, NHWC (F.interpolate in
+// /root/reference/SOccDPT/model/blocks.py:488-493 and Interpolate model/blocks.py:239-273).
+// src = dst * (in-1)/(out-1); i0 = int(src); l1 = src - i0.  One thread = 4 channels of one
+// output pixel.  TIn: float or bf16_t.  Output: f32 plain [M][C] and/or bf16 plain / halo.
+// ---------------------------------------------------------------------------------------------
+template <typename TIn>
+__device__ __forceinline__ float4 load4(const TIn* p);
+template <>
+__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <>
+__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
+                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ in, float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16,
+                                                        int out_halo, int B, int h, int w, int H, int W, int C) {
+    const int c4 = C / 4;
+    const size_t total = (size_t)B * H * W * c4;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c4) * 4;
+        size_t r = i / c4;
+        const int ox = (int)(r % W);
+        r /= W;
+        const int oy = (int)(r % H);
+        const int b = (int)(r / H);
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const TIn* base = in + (size_t)b * h * w * C + cc;
+        const float4 v00 = load4<TIn>(base + ((size_t)y0 * w + x0) * C);
+        const float4 v01 = load4<TIn>(base + ((size_t)y0 * w + x1) * C);
+        const float4 v10 = load4<TIn>(base + ((size_t)y1 * w + x0) * C);
+        const float4 v11 = load4<TIn>(base + ((size_t)y1 * w + x1) * C);
+        float4 o;
+        o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+        o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+        o.z = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+        o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        const size_t pix = ((size_t)b * H + oy) * W + ox;
+        if (out_f32) *reinterpret_cast<float4*>(out_f32 + pix * C + cc) = o;
+        if (out_bf16) {
+            const size_t off = out_halo ? (((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) : (pix * C + cc);
+            uint2 p;
+            p.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
+            p.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+            *reinterpret_cast<uint2*>(out_bf16 + off) = p;
+        }
+    }
+}
+
+int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, int out_halo, int B, int h, int w, int H, int W,
+                    int C, hipStream_t st, std::string& err) {
+    if (C % 4) { err = "bilinear: C % 4 != 0"; return 1; }
+    const size_t total = (size_t)B * H * W * (C / 4);
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (in_is_bf16)
+        hipLaunchKernelGGL((bilinear_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)in, out_f32, out_bf16, out_halo, B, h, w, H, W, C);
+    else
+        hipLaunchKernelGGL((bilinear_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)in, out_f32, out_bf16, out_halo, B, h, w, H, W, C);
+    return check_launch("bilinear", err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// seg head tail (/root/reference/SOccDPT/model/SOccDPT.py:671-673):
+//   (a) Conv2d(256, 3, k=1) + bias on the bf16 [M,256] feature map -> f32 [M,3]
+//       16 lanes per pixel, each 16 channels (2 x 16-byte loads), 4-step shuffle reduction.
+//   (b) bilinear x2 (align_corners=True) + Sigmoid / ScaledTanh -> NCHW f32 [B,3,2h,2w]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w /*[3][256]*/,
+                                                          const float* __restrict__ bias, float* __restrict__ out, int M) {
+    const int sub = threadIdx.x & 15;
+    const size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (pix >= (size_t)M) return;  // M % 16 == 0 rows per block keeps shuffles within full groups
+    const bf16_t* p = in + pix * 256 + sub * 16;
+    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+    const uint32_t u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+        const int c = sub * 16 + 2 * k;
+        s0 += lo * w[c] + hi * w[c + 1];
+        s1 += lo * w[256 + c] + hi * w[256 + c + 1];
+        s2 += lo * w[512 + c] + hi * w[512 + c + 1];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (sub == 0) {
+        out[pix * 3 + 0] = s0 + bias[0];
+        out[pix * 3 + 1] = s1 + bias[1];
+        out[pix * 3 + 2] = s2 + bias[2];
+    }
+}
+
+__global__ __launch_bounds__(256) void seg_up_act_kernel(const float* __restrict__ in /*[B,h,w,3]*/, float* __restrict__ out /*[B,3,H,W]*/, int B,
+                                                          int h, int w, int sigmoid) {
+    const int H = 2 * h, W = 2 * w;
+    const size_t total = (size_t)B * H * W;
+    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % W);
+        size_t r = i / W;
+        const int oy = (int)(r % H), b = (int)(r / H);
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = in + (size_t)b * h * w * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = hy * (hx * base[((size_t)y0 * w + x0) * 3 + c] + lx * base[((size_t)y0 * w + x1) * 3 + c]) +
+                            ly * (hx * base[((size_t)y1 * w + x0) * 3 + c] + lx * base[((size_t)y1 * w + x1) * 3 + c]);
+            const float a = sigmoid ? 1.f / (1.f + expf(-v)) : 0.5f * tanhf(v) + 0.5f;
+            out[((size_t)(b * 3 + c) * H + oy) * W + ox] = a;
+        }
+    }
+}
+
+int launch_seg_tail(const bf16_t* feat, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd, int sigmoid,
+                    hipStream_t st, std::string& err) {
+    const int M = B * h * wd;
+    hipLaunchKernelGGL(conv1x1_c3_kernel, dim3((unsigned)(((size_t)M * 16 + 255) / 256)), dim3(256), 0, st, feat, w, bias, tmp, M);
+    if (check_launch("conv1x1_c3", err)) return 1;
+    const size_t total = (size_t)B * 4 * h * wd;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(seg_up_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tmp, seg, B, h, wd, sigmoid);
+    return check_launch("seg_up_act", err);
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-time weight preparation
+// ---------------------------------------------------------------------------------------------
+__global__ void cvt_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+}
+// [Cout][Cin][3][3] f32 -> [Cout][3][3][Cin] bf16, optionally scaled per Cout (BatchNorm fold)
+__global__ void conv_w_kernel(const float* __restrict__ in, const float* __restrict__ scale, bf16_t* __restrict__ out, int Cout, int Cin) {
+    const size_t n = (size_t)Cout * Cin * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        size_t r = i / Cin;
+        const int tap = (int)(r % 9), co = (int)(r / 9);
+        float v = in[((size_t)co * Cin + ci) * 9 + tap];
+        if (scale) v *= scale[co];
+        out[i] = f2bf(v);
+    }
+}
+// BatchNorm2d eval fold (model/SOccDPT.py:668): scale = g / sqrt(var + eps), shift = b - mean * scale
+__global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < C) {
+        const float s = g[i] / sqrtf(var[i] + 1e-5f);
+        scale[i] = s;
+        shift[i] = b[i] - mean[i] * s;
+    }
+}
+// qkv bias = cat(q_bias, 0, v_bias)  (timm WindowAttention.forward)
+__global__ void qkv_bias_kernel(const float* q, const float* v, float* out, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 3 * C) out[i] = i < C ? q[i] : (i < 2 * C ? 0.f : v[i - 2 * C]);
+}
+// logit scale: exp(min(logit_scale, ln 100))
+__global__ void logit_scale_kernel(const float* ls, float* out, int H) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < H) out[i] = expf(fminf(ls[i], 4.605170185988092f));
+}
+// continuous position bias table: 16*sigmoid(cpb_mlp(coords))  [(2ws-1)^2][heads]
+__global__ void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, const float* __restrict__ b0, const float* __restrict__ w2 /*[H][512]*/,
+                                 float* __restrict__ table, int ws, int pws, int H) {
+    const int T = 2 * ws - 1;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * T * H) return;
+    const int hd = i % H, e = i / H, dy = e / T - (ws - 1), dx = e % T - (ws - 1);
+    const float denom = (float)((pws > 0 ? pws : ws) - 1);
+    float cy = (float)dy / denom * 8.f, cx = (float)dx / denom * 8.f;
+    cy = (cy > 0.f ? 1.f : (cy < 0.f ? -1.f : 0.f)) * log2f(fabsf(cy) + 1.f) / 3.f;
+    cx = (cx > 0.f ? 1.f : (cx < 0.f ? -1.f : 0.f)) * log2f(fabsf(cx) + 1.f) / 3.f;
+    float s = 0.f;
+    for (int k = 0; k < 512; ++k) {
+        const float hdn = fmaxf(w0[2 * k] * cy + w0[2 * k + 1] * cx + b0[k], 0.f);
+        s += hdn * w2[hd * 512 + k];
+    }
+    table[i] = 16.f / (1.f + expf(-s));
+}
+
+int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std::string& err) {
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+    return check_launch("cvt_bf16", err);
+}
+int launch_conv_w(const float* in, const float* scale, bf16_t* out, int Cout, int Cin, hipStream_t st, std::string& err) {
+    size_t n = (size_t)Cout * Cin * 9, blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, out, Cout, Cin);
+    return check_launch("conv_w", err);
+}
+int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,
+                   std::string& err) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, b, mean, var, scale, shift, C);
+    return check_launch("bn_fold", err);
+}
+int launch_qkv_bias(const float* q, const float* v, float* out, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(qkv_bias_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, q, v, out, C);
+    return check_launch("qkv_bias", err);
+}
+int launch_logit_scale(const float* ls, float* out, int H, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(logit_scale_kernel, dim3(1), dim3(64), 0, st, ls, out, H);
+    return check_launch("logit_scale", err);
+}
+int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* table, int ws, int pws, int H, hipStream_t st,
+                     std::string& err) {
+    const int n = (2 * ws - 1) * (2 * ws - 1) * H;
+    hipLaunchKernelGGL(cpb_table_kernel, dim3((n + 127) / 128), dim3(128), 0, st, w0, b0, w2, table, ws, pws, H);
+    return check_launch("cpb_table", err);
+}
+
+}  // namespace soccdpt

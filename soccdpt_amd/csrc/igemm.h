@@ -1,0 +1,50 @@
+// Descriptor of one implicit-GEMM launch (igemm.hip): out[m][n] = sum_k X[m][k] * Wt[n][k].
+// X rows are either plain rows of a [M][K] bf16 matrix (Linear layers, 1x1 convs) or the
+// 3x3 neighbourhoods of a zero-haloed NHWC bf16 image (the decoder's 3x3 convolutions).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+namespace soccdpt {
+
+typedef uint16_t bf16_t;  // raw bf16 bits
+
+// Zero-haloed NHWC activation: pixel (b,y,x) lives at ((b*(H+2)+y+1)*(W+2)+x+1)*C.
+// The one-pixel border is never written by any kernel and is zero from workspace init.
+struct Halo {
+    int H = 0, W = 0, C = 0;
+    __host__ __device__ size_t elems(int B) const { return (size_t)B * (H + 2) * (W + 2) * C; }
+};
+
+enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
+
+struct IgemmDesc {
+    // ---- operands ----
+    const bf16_t* X = nullptr;   // activations
+    const bf16_t* Wt = nullptr;  // weights [N][taps*Cin], K contiguous
+    int M = 0, N = 0;
+    int Cin = 0;      // channels per tap (K of a plain GEMM)
+    int taps = 1;     // 1 (GEMM / 1x1) or 9 (3x3, pad 1)
+    // plain mode: row m at X + m*ldx.  conv mode (taps == 9): X is a Halo image [B][H+2][W+2][Cin], M = B*H*W
+    int ldx = 0;
+    int H = 0, W = 0;
+    // ---- epilogue: v = acc (+bias[n]) (+res1[m][n]) (+res2[m][n]); act; stores ----
+    const float* bias = nullptr;
+    const float* res1 = nullptr;  // f32 [M][N]
+    const float* res2 = nullptr;  // f32 [M][N]
+    int act = ACT_NONE;           // applied to every store except out_f32_raw
+    float* out_f32 = nullptr;     // [M][N], value BEFORE `act` when act_on_f32 == 0
+    int act_on_f32 = 0;
+    bf16_t* out_bf16 = nullptr;   // [M][N] plain (ld = N) or Halo image when out_halo != 0 (C = N)
+    int out_halo = 0;
+    // fused 1x1 tail of the depth head: out_dot[m] = relu(sum_n act(v)[n]*dot_w[n] + dot_b)   (N <= 32)
+    const float* dot_w = nullptr;
+    float dot_b = 0.f;
+    float* out_dot = nullptr;
+};
+
+int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);
+
+}  // namespace soccdpt

@@ -1,0 +1,269 @@
+// bf16 MFMA implicit GEMM for gfx950: Linear layers, 1x1 and 3x3 convolutions of the
+// SOccDPT_V3 encoder/decoder with fused epilogues.
+//
+//   out[m][n] = epilogue( sum_k X[m][k] * Wt[n][k] )            fp32 accumulation
+//
+// Replaces the ATen conv2d / linear calls of
+//   /root/reference/SOccDPT/model/blocks.py:155-191,391-414,488-495 (scratch convs, RCUs, out_conv)
+//   /root/reference/SOccDPT/model/dpt.py:199-219 (depth head), model/SOccDPT.py:660-674 (seg head)
+//   and timm's qkv / proj / fc1 / fc2 / reduction Linear layers.
+//
+// Design (CDNA4):
+//  * v_mfma_f32_16x16x32_bf16, 64-lane waves; the WEIGHT tile is the MFMA A operand and the
+//    activation tile the B operand, so a lane's 4 accumulator registers are 4 consecutive output
+//    channels of one pixel -> 8-byte (bf16) / 16-byte (f32) channel-contiguous NHWC stores.
+//  * both operand tiles are staged HBM/L2 -> LDS with global_load_lds_dwordx4 (no VGPR round
+//    trip), double-buffered; the 3x3 taps are gathered by the per-lane SOURCE address from a
+//    zero-haloed NHWC image, so the main loop has no bounds checks.
+//  * LDS rows are BK*2 bytes; the 16-byte chunks of a row are XOR-swizzled on the source side and
+//    on the ds_read_b128 side (same involution) -> conflict-free fragment reads.
+//  * blockIdx is remapped so the N-tiles that share an activation tile run on one XCD (L2 reuse).
+#include "igemm.h"
+
+namespace soccdpt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+template <int BM_, int BN_, int BK_, int WM_, int WN_>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int ROWB = BK * 2;    // bytes per LDS tile row
+    static constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
+    static constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB;
+    static constexpr int STAGE = X_BYTES + W_BYTES;
+    static constexpr int X_LOADS = X_BYTES / 16 / THREADS;
+    static constexpr int W_LOADS = W_BYTES / 16 / THREADS;
+    static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 tiles per wave
+    static constexpr int KS = BK / 32;
+    static_assert(X_LOADS * THREADS * 16 == X_BYTES && W_LOADS * THREADS * 16 == W_BYTES, "tile/threads mismatch");
+};
+
+template <int BK>
+__device__ __forceinline__ int swz_of_row(int row) {
+    if constexpr (BK == 64) return row & 7;          // 128-byte rows: 8 chunks
+    else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
+}
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+template <class C>
+__global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+
+    // XCD-aware bijective remap: consecutive logical tiles -> same XCD (blocks b, b+8 share one)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int nt = bid % ntiles, mt = bid / ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int Ktot = d.taps * d.Cin;
+    const int Wp = d.W + 2;
+
+    // ---- per-thread staging sources (element offsets) ----
+    uint32_t x_off[C::X_LOADS], w_off[C::W_LOADS];
+#pragma unroll
+    for (int i = 0; i < C::X_LOADS; ++i) {
+        const int cid = i * C::THREADS + tid;
+        const int row = cid / C::CPR, c = cid % C::CPR;
+        int m = m0 + row;
+        m = m < d.M ? m : d.M - 1;
+        uint32_t base;
+        if (d.taps == 9) {
+            const int hw = d.H * d.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / d.W, x = rem - y * d.W;
+            base = (uint32_t)(((b * (d.H + 2) + y) * Wp + x) * d.Cin);
+        } else {
+            base = (uint32_t)m * (uint32_t)d.ldx;
+        }
+        x_off[i] = base + (uint32_t)((c ^ swz_of_row<BK>(row)) * 8);
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_LOADS; ++i) {
+        const int cid = i * C::THREADS + tid;
+        const int row = cid / C::CPR, c = cid % C::CPR;
+        int n = n0 + row;
+        n = n < d.N ? n : d.N - 1;
+        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<BK>(row)) * 8);
+    }
+
+    auto stage = [&](int kt, int buf) {
+        uint32_t xk, wk = (uint32_t)kt * BK;
+        if (d.taps == 9) {
+            const int tap = kt / kpt, kc = kt - tap * kpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            xk = (uint32_t)((ky * Wp + kx) * d.Cin + kc * BK);
+        } else {
+            xk = wk;
+        }
+        char* sb = smem + buf * C::STAGE;
+#pragma unroll
+        for (int i = 0; i < C::X_LOADS; ++i) {
+            const bf16_t* g = d.X + x_off[i] + xk;
+            char* l = sb + (i * C::THREADS + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_LOADS; ++i) {
+            const bf16_t* g = d.Wt + w_off[i] + wk;
+            char* l = sb + C::X_BYTES + (i * C::THREADS + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[C::TN][C::TM];
+#pragma unroll
+    for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+        for (int j = 0; j < C::TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // fragment read offsets (bytes within a stage), constant per lane
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswz = swz_of_row<BK>(frow);
+    int xr_off[C::KS], wr_off[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        const int q = ((ks * 4 + fq) ^ fswz) * 16;
+        xr_off[ks] = (wm * C::TM * 16 + frow) * C::ROWB + q;
+        wr_off[ks] = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB + q;
+    }
+
+    stage(0, 0);
+    __syncthreads();  // glds in flight -> the compiler drains vmcnt(0) before the barrier
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
+        const char* sb = smem + buf * C::STAGE;
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            bf16x8 wf[C::TN], xf[C::TM];
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
+    const int N = d.N;
+    float dot_part[C::TM];
+#pragma unroll
+    for (int j = 0; j < C::TM; ++j) dot_part[j] = 0.f;
+#pragma unroll
+    for (int j = 0; j < C::TM; ++j) {
+        const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+        const bool mv = m < d.M;
+        size_t orow = (size_t)m * N;
+        size_t hrow = 0;
+        if (d.out_halo && mv) {
+            const int hw = d.H * d.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / d.W, x = rem - y * d.W;
+            hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+        }
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i) {
+            const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            if (!mv || n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (d.bias) {
+                const float4 b4 = *reinterpret_cast<const float4*>(d.bias + n);
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+            }
+            if (d.res1) {
+                const float4 r4 = *reinterpret_cast<const float4*>(d.res1 + orow + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            if (d.res2) {
+                const float4 r4 = *reinterpret_cast<const float4*>(d.res2 + orow + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = d.act == ACT_RELU ? fmaxf(v[r], 0.f) : (d.act == ACT_GELU ? gelu_erf(v[r]) : v[r]);
+            }
+            if (d.out_f32) {
+                const float* s = d.act_on_f32 ? a : v;
+                *reinterpret_cast<float4*>(d.out_f32 + orow + n) = make_float4(s[0], s[1], s[2], s[3]);
+            }
+            if (d.out_bf16) {
+                uint2 p;
+                p.x = pack_bf16x2(a[0], a[1]);
+                p.y = pack_bf16x2(a[2], a[3]);
+                *reinterpret_cast<uint2*>(d.out_bf16 + (d.out_halo ? hrow : orow) + n) = p;
+            }
+            if (d.out_dot) {
+                const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
+                dot_part[j] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+            }
+        }
+    }
+    if (d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
+#pragma unroll
+        for (int j = 0; j < C::TM; ++j) {
+            float s = dot_part[j];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+            if ((lane >> 4) == 0 && m < d.M) d.out_dot[m] = fmaxf(s + d.dot_b, 0.f);
+        }
+    }
+}
+
+template <class C>
+static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    const int nk = d.taps * d.Cin / C::BK, kpt = d.Cin / C::BK;
+    const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
+    const size_t lds = 2 * C::STAGE;
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((igemm_kernel<C>), dim3((unsigned)(mtiles * ntiles)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (d.M <= 0 || d.N <= 0 || d.Cin <= 0 || !d.X || !d.Wt) { err = "igemm: bad descriptor"; return 1; }
+    if (d.N % 4 != 0) { err = "igemm: N must be a multiple of 4"; return 1; }
+    if (d.Cin % 32 != 0) { err = "igemm: Cin must be a multiple of 32"; return 1; }
+    if (d.taps != 1 && d.taps != 9) { err = "igemm: taps must be 1 or 9"; return 1; }
+    if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
+    if (d.out_halo && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output needs H, W"; return 1; }
+    if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    const bool k64 = (d.Cin % 64 == 0);
+    if (d.N <= 32) {
+        if (!k64) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
+        return launch_cfg<Cfg<128, 32, 64, 4, 1>>(d, stream, err);
+    }
+    if (k64) return launch_cfg<Cfg<128, 128, 64, 2, 2>>(d, stream, err);
+    return launch_cfg<Cfg<128, 128, 32, 2, 2>>(d, stream, err);
+}
+
+}  // namespace soccdpt

@@ -62,6 +62,8 @@ int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t stream, s
 int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t stream,
                   std::string& err);
 
+int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C);
+
 // projection.hip
 int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg, int B, int in_h, int in_w, float* inv_up,
                    float* seg_up, float* points, uint32_t* occ_bits, int clear_bits, hipStream_t stream, std::string& err);

@@ -1,15 +1,216 @@
-// Host-side orchestration of the SOccDPT_V3 network on gfx950 (weights table, prepare, launch sequence).
+// Host-side orchestration of the SOccDPT_V3 network on gfx950: state-dict table, weight
+// preparation (bf16 re-layout, BN fold, CPB bias tables) and the kernel launch sequence of
+//   DPTDepthModel.forward  /root/reference/SOccDPT/model/dpt.py:142-232
+//   forward_swin + hooks   /root/reference/SOccDPT/model/backbones/swin_common.py:8-54
+//   seg_head               /root/reference/SOccDPT/model/SOccDPT.py:660-674,682-683
+// All activations are NHWC ("token-major"): the encoder's [B,L,C] tokens ARE the decoder's feature
+// maps, so the reference's Transpose+Unflatten never materialises.  3x3-conv inputs are bf16 images
+// with a one-pixel zero halo that no kernel ever writes (the workspace is zero-filled once by the
+// host), which removes all bounds checks from the convolution main loop.
+#include <cstring>
+
 #include "internal.h"
+#include "kernels.h"
 
 namespace soccdpt {
 
-struct Prepared {};
+struct BlockW {
+    const bf16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    float *qkv_bias, *scale, *table, *bias_acc;
+    const float *proj_b, *n1_g, *n1_b, *fc1_b, *fc2_b, *n2_g, *n2_b;
+};
+struct MergeW {
+    const bf16_t* red_w;
+    const float *g, *b;
+};
+struct RcuW {
+    const bf16_t *w1, *w2;
+    const float *b1, *b2;
+};
+struct Prepared {
+    std::vector<std::vector<BlockW>> blocks;  // [stage][block]
+    MergeW merge[3];
+    const bf16_t* layer_rn[4];
+    RcuW rcu[4][2];  // [refinenet-1][unit-1]
+    const bf16_t* oc_w[4];
+    const float* oc_b[4];
+    const bf16_t *d0_w, *d2_w;
+    const float *d0_b, *d2_b, *d4_w;
+    float d4_b = 0.f;
+    const bf16_t* s0_w;
+    float *bn_scale, *bn_shift;
+    const float *s4_w, *s4_b;
+};
+
 Handle::~Handle() { delete prep; }
 
-static void add_w(Handle& h, const std::string& key, std::vector<int64_t> shape) {
+namespace {
+
+struct Arena {
+    char* base;
+    size_t off = 0, cap;
+    Arena(void* p, size_t c) : base(static_cast<char*>(p)), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+void add_w(Handle& h, const std::string& key, std::vector<int64_t> shape) {
     h.index[key] = (int)h.weights.size();
     h.weights.push_back(WeightSlot{key, std::move(shape), nullptr});
 }
+
+const std::string ENC = "depth_net.pretrained.model.";
+const std::string SCR = "depth_net.scratch.";
+
+std::string blk(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
+
+// Walks the prepared-weights arena; with base == nullptr it only measures.  When `st` runs
+// (base != nullptr) it also launches the conversion kernels.
+int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err) {
+    const Arch& a = h.arch;
+    const bool run = ar.base != nullptr;
+    auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
+    auto cvt = [&](const std::string& key, size_t n) -> const bf16_t* {
+        bf16_t* p = ar.take<bf16_t>(n);
+        if (run && launch_cvt_bf16(W(key), p, n, st, err)) return nullptr;
+        return p;
+    };
+    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const bf16_t* {
+        bf16_t* p = ar.take<bf16_t>((size_t)Cout * Cin * 9);
+        if (run && launch_conv_w(W(key), scale, p, Cout, Cin, st, err)) return nullptr;
+        return p;
+    };
+    if (run) P->blocks.assign(4, {});
+    for (int s = 0; s < 4; ++s) {
+        const int C = a.dim(s), H = a.heads[s], ws = a.ws(s);
+        for (int j = 0; j < a.depths[s]; ++j) {
+            const std::string b = blk(s, j);
+            BlockW bw{};
+            bw.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * C * C);
+            bw.proj_w = cvt(b + "attn.proj.weight", (size_t)C * C);
+            bw.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * C * C);
+            bw.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * C * C);
+            bw.qkv_bias = ar.take<float>(3 * C);
+            bw.scale = ar.take<float>(H);
+            bw.table = ar.take<float>((size_t)(2 * ws - 1) * (2 * ws - 1) * H);
+            bw.bias_acc = ar.take<float>(attn_bias_elems(ws, H));
+            if (run) {
+                if (!bw.qkv_w || !bw.proj_w || !bw.fc1_w || !bw.fc2_w) return 1;
+                if (launch_qkv_bias(W(b + "attn.q_bias"), W(b + "attn.v_bias"), bw.qkv_bias, C, st, err)) return 1;
+                if (launch_logit_scale(W(b + "attn.logit_scale"), bw.scale, H, st, err)) return 1;
+                if (launch_cpb_table(W(b + "attn.cpb_mlp.0.weight"), W(b + "attn.cpb_mlp.0.bias"), W(b + "attn.cpb_mlp.2.weight"), bw.table,
+                                     ws, a.pretrained_window[s], H, st, err))
+                    return 1;
+                if (launch_attn_bias(bw.table, bw.bias_acc, ws, H, st, err)) return 1;
+                bw.proj_b = W(b + "attn.proj.bias");
+                bw.n1_g = W(b + "norm1.weight"); bw.n1_b = W(b + "norm1.bias");
+                bw.fc1_b = W(b + "mlp.fc1.bias"); bw.fc2_b = W(b + "mlp.fc2.bias");
+                bw.n2_g = W(b + "norm2.weight"); bw.n2_b = W(b + "norm2.bias");
+                P->blocks[s].push_back(bw);
+            }
+        }
+        if (s < 3) {
+            const std::string d = ENC + "layers." + std::to_string(s) + ".downsample.";
+            const bf16_t* rw = cvt(d + "reduction.weight", (size_t)8 * C * C);
+            if (run) {
+                if (!rw) return 1;
+                P->merge[s] = MergeW{rw, W(d + "norm.weight"), W(d + "norm.bias")};
+            }
+        }
+    }
+    const int F = h.cfg.features;
+    for (int i = 0; i < 4; ++i) {
+        const bf16_t* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.dim(i), nullptr);
+        if (run) { if (!p) return 1; P->layer_rn[i] = p; }
+    }
+    for (int r = 1; r <= 4; ++r) {
+        const std::string b = SCR + "refinenet" + std::to_string(r) + ".";
+        const bf16_t* ocw = cvt(b + "out_conv.weight", (size_t)F * F);
+        if (run) { if (!ocw) return 1; P->oc_w[r - 1] = ocw; P->oc_b[r - 1] = W(b + "out_conv.bias"); }
+        for (int u = 1; u <= 2; ++u) {
+            if (r == 4 && u == 1) continue;
+            const std::string ub = b + "resConfUnit" + std::to_string(u) + ".";
+            const bf16_t* w1 = convw(ub + "conv1.weight", F, F, nullptr);
+            const bf16_t* w2 = convw(ub + "conv2.weight", F, F, nullptr);
+            if (run) {
+                if (!w1 || !w2) return 1;
+                P->rcu[r - 1][u - 1] = RcuW{w1, w2, W(ub + "conv1.bias"), W(ub + "conv2.bias")};
+            }
+        }
+    }
+    {
+        const bf16_t* d0 = convw(SCR + "output_conv.0.weight", F / 2, F, nullptr);
+        const bf16_t* d2 = convw(SCR + "output_conv.2.weight", 32, F / 2, nullptr);
+        float* bscale = ar.take<float>(F);
+        float* bshift = ar.take<float>(F);
+        if (run && launch_bn_fold(W("seg_head.1.weight"), W("seg_head.1.bias"), W("seg_head.1.running_mean"), W("seg_head.1.running_var"),
+                                  bscale, bshift, F, st, err))
+            return 1;
+        const bf16_t* s0 = convw("seg_head.0.weight", F, F, bscale);
+        if (run) {
+            if (!d0 || !d2 || !s0) return 1;
+            P->d0_w = d0; P->d2_w = d2; P->s0_w = s0;
+            P->d0_b = W(SCR + "output_conv.0.bias"); P->d2_b = W(SCR + "output_conv.2.bias");
+            P->d4_w = W(SCR + "output_conv.4.weight");
+            P->bn_scale = bscale; P->bn_shift = bshift;
+            P->s4_w = W("seg_head.4.weight"); P->s4_b = W("seg_head.4.bias");
+        }
+    }
+    return 0;
+}
+
+struct Workspace {
+    float *xf, *y;
+    bf16_t *xb, *qkv, *attn, *hbuf;
+    bf16_t* feat[4];  // halo
+    // decoder, index = level-1 (level 4 = coarsest)
+    float *lrn_raw[4], *out_raw[4], *oc[4], *path[4];
+    bf16_t *lrn_relu[4], *t_relu[4], *out_relu[4], *u[4];
+    bf16_t *path1, *d1, *d1u, *s1;
+    float* s2;
+};
+
+void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
+    const Arch& a = h.arch;
+    const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
+    const size_t M0 = (size_t)B * G * G;
+    w.xf = ar.take<float>(M0 * C0);
+    w.y = ar.take<float>(M0 * C0);
+    w.xb = ar.take<bf16_t>(M0 * C0);
+    w.qkv = ar.take<bf16_t>(M0 * 3 * C0);
+    w.attn = ar.take<bf16_t>(M0 * C0);
+    w.hbuf = ar.take<bf16_t>(M0 * 4 * C0);
+    for (int s = 0; s < 4; ++s) {
+        Halo hl{a.res(s), a.res(s), a.dim(s)};
+        w.feat[s] = ar.take<bf16_t>(hl.elems(B));
+    }
+    for (int l = 0; l < 4; ++l) {
+        const int r = a.res(l);
+        const size_t M = (size_t)B * r * r;
+        Halo hl{r, r, F};
+        w.lrn_raw[l] = ar.take<float>(M * F);
+        w.out_raw[l] = ar.take<float>(M * F);
+        w.oc[l] = ar.take<float>(M * F);
+        w.path[l] = ar.take<float>(M * F);  // path arriving AT this level (from level l+1)
+        w.lrn_relu[l] = ar.take<bf16_t>(hl.elems(B));
+        w.t_relu[l] = ar.take<bf16_t>(hl.elems(B));
+        w.out_relu[l] = ar.take<bf16_t>(hl.elems(B));
+        w.u[l] = ar.take<bf16_t>(M * F);
+    }
+    const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
+    w.path1 = ar.take<bf16_t>(Halo{r1, r1, F}.elems(B));
+    w.d1 = ar.take<bf16_t>((size_t)B * r1 * r1 * (F / 2));
+    w.d1u = ar.take<bf16_t>(Halo{r0, r0, F / 2}.elems(B));
+    w.s1 = ar.take<bf16_t>((size_t)B * r1 * r1 * F);
+    w.s2 = ar.take<float>((size_t)B * r1 * r1 * 4);
+}
+
+}  // namespace
 
 int model_init(Handle& h, std::string& err) {
     Arch a;
@@ -25,16 +226,15 @@ int model_init(Handle& h, std::string& err) {
     }
     h.arch = a;
     h.img = a.img;
-    const std::string E = "depth_net.pretrained.model.";
     const int64_t C0 = a.embed;
-    add_w(h, E + "patch_embed.proj.weight", {C0, 3, a.patch, a.patch});
-    add_w(h, E + "patch_embed.proj.bias", {C0});
-    add_w(h, E + "patch_embed.norm.weight", {C0});
-    add_w(h, E + "patch_embed.norm.bias", {C0});
+    add_w(h, ENC + "patch_embed.proj.weight", {C0, 3, a.patch, a.patch});
+    add_w(h, ENC + "patch_embed.proj.bias", {C0});
+    add_w(h, ENC + "patch_embed.norm.weight", {C0});
+    add_w(h, ENC + "patch_embed.norm.bias", {C0});
     for (int s = 0; s < 4; ++s) {
         const int64_t C = a.dim(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
-            const std::string b = E + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + ".";
+            const std::string b = blk(s, j);
             add_w(h, b + "attn.logit_scale", {H, 1, 1});
             add_w(h, b + "attn.q_bias", {C});
             add_w(h, b + "attn.v_bias", {C});
@@ -54,17 +254,16 @@ int model_init(Handle& h, std::string& err) {
             add_w(h, b + "norm2.bias", {C});
         }
         if (s < 3) {
-            const std::string d = E + "layers." + std::to_string(s) + ".downsample.";
+            const std::string d = ENC + "layers." + std::to_string(s) + ".downsample.";
             add_w(h, d + "reduction.weight", {2 * C, 4 * C});
             add_w(h, d + "norm.weight", {2 * C});
             add_w(h, d + "norm.bias", {2 * C});
         }
     }
-    const std::string S = "depth_net.scratch.";
     const int64_t F = h.cfg.features;
-    for (int i = 0; i < 4; ++i) add_w(h, S + "layer" + std::to_string(i + 1) + "_rn.weight", {F, a.dim(i), 3, 3});
+    for (int i = 0; i < 4; ++i) add_w(h, SCR + "layer" + std::to_string(i + 1) + "_rn.weight", {F, a.dim(i), 3, 3});
     for (int r = 1; r <= 4; ++r) {
-        const std::string b = S + "refinenet" + std::to_string(r) + ".";
+        const std::string b = SCR + "refinenet" + std::to_string(r) + ".";
         add_w(h, b + "out_conv.weight", {F, F, 1, 1});
         add_w(h, b + "out_conv.bias", {F});
         for (int u = 1; u <= 2; ++u) {
@@ -75,12 +274,12 @@ int model_init(Handle& h, std::string& err) {
             }
         }
     }
-    add_w(h, S + "output_conv.0.weight", {F / 2, F, 3, 3});
-    add_w(h, S + "output_conv.0.bias", {F / 2});
-    add_w(h, S + "output_conv.2.weight", {32, F / 2, 3, 3});
-    add_w(h, S + "output_conv.2.bias", {32});
-    add_w(h, S + "output_conv.4.weight", {1, 32, 1, 1});
-    add_w(h, S + "output_conv.4.bias", {1});
+    add_w(h, SCR + "output_conv.0.weight", {F / 2, F, 3, 3});
+    add_w(h, SCR + "output_conv.0.bias", {F / 2});
+    add_w(h, SCR + "output_conv.2.weight", {32, F / 2, 3, 3});
+    add_w(h, SCR + "output_conv.2.bias", {32});
+    add_w(h, SCR + "output_conv.4.weight", {1, 32, 1, 1});
+    add_w(h, SCR + "output_conv.4.bias", {1});
     add_w(h, "seg_head.0.weight", {F, F, 3, 3});
     add_w(h, "seg_head.1.weight", {F});
     add_w(h, "seg_head.1.bias", {F});
@@ -88,6 +287,15 @@ int model_init(Handle& h, std::string& err) {
     add_w(h, "seg_head.1.running_var", {F});
     add_w(h, "seg_head.4.weight", {h.cfg.num_classes, F, 1, 1});
     add_w(h, "seg_head.4.bias", {h.cfg.num_classes});
+
+    if (a.window != 16) {
+        // the window-attention kernel is instantiated for 16x16 / 8x8 windows (dpt_swin2_tiny_256)
+        err = "soccdpt_create: this build instantiates window attention for swin2t16_256 only";
+        return 1;
+    }
+    Arena measure(nullptr, 0);
+    if (lay_out(h, measure, nullptr, nullptr, err)) return 1;
+    h.prepared_bytes = measure.off + 256;
     return 0;
 }
 
@@ -109,15 +317,158 @@ int model_bind(Handle& h, const char* key, const void* ptr, const int64_t* shape
     return 0;
 }
 
-size_t model_workspace_bytes(Handle& h, int B) { return (size_t)B * h.img * h.img * 4 * sizeof(float); }
+size_t model_workspace_bytes(Handle& h, int B) {
+    Arena ar(nullptr, 0);
+    Workspace w;
+    carve(h, B, ar, w);
+    // + network outputs at the head of the workspace when called through soccdpt_forward
+    return ar.off + 256 + (size_t)B * h.img * h.img * (1 + h.cfg.num_classes) * sizeof(float) + 256;
+}
 
-int model_prepare(Handle&, void*, size_t, hipStream_t, std::string& err) {
-    err = "soccdpt_prepare: network kernels not built yet";
+int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C) {
+    char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);  // only offsets are used
+    Arena ar(fake, ~size_t(0) >> 1);
+    Workspace w;
+    carve(h, B, ar, w);
+    const Arch& a = h.arch;
+    const std::string n(name);
+    auto set = [&](const void* p, size_t e, int k, int hh, int ww, int cc) {
+        *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
+        return 0;
+    };
+    for (int s = 0; s < 4; ++s)
+        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), 2, a.res(s), a.res(s), a.dim(s));
+    const int r1 = 2 * a.res(0);
+    if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), 2, r1, r1, h.cfg.features);
+    if (n == "xf") return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     return 1;
 }
-int model_network(Handle&, const float*, int, float*, float*, void*, size_t, hipStream_t, std::string& err) {
-    err = "soccdpt_network: network kernels not built yet";
-    return 1;
+
+int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t st, std::string& err) {
+    for (const auto& w : h.weights)
+        if (!w.ptr) { err = "soccdpt_prepare: weight not bound: " + w.key; return 1; }
+    if (!prepared || bytes < h.prepared_bytes) { err = "soccdpt_prepare: prepared buffer too small"; return 1; }
+    delete h.prep;
+    h.prep = new Prepared();
+    Arena ar(prepared, bytes);
+    if (lay_out(h, ar, h.prep, st, err)) return 1;
+    // the depth head's last bias is a kernel argument: fetch the scalar (prepare may synchronise)
+    hipError_t e = hipMemcpyAsync(&h.prep->d4_b, h.weights[h.index.at(SCR + "output_conv.4.bias")].ptr, sizeof(float), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) { err = std::string("soccdpt_prepare: ") + hipGetErrorString(e); return 1; }
+    h.is_prepared = true;
+    return 0;
+}
+
+int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t st,
+                  std::string& err) {
+    if (!h.is_prepared) { err = "soccdpt_network: call soccdpt_prepare after binding weights"; return 1; }
+    if (B <= 0 || !x || !inv256 || !seg256) { err = "soccdpt_network: bad argument"; return 1; }
+    const Arch& a = h.arch;
+    const Prepared& P = *h.prep;
+    Arena ar(ws, ws_bytes);
+    Workspace w;
+    carve(h, B, ar, w);
+    if (ar.off > ws_bytes) { err = "soccdpt_network: workspace too small"; return 1; }
+    const int F = h.cfg.features;
+    int launches = 0;
+#define RUN(call) do { if (call) return 1; ++launches; } while (0)
+
+    auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
+    // ---------------- encoder ----------------
+    RUN(launch_patch_embed(x, W(ENC + "patch_embed.proj.weight"), W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
+                           W(ENC + "patch_embed.norm.bias"), w.xf, w.xb, B, a.img, a.embed, st, err));
+    for (int s = 0; s < 4; ++s) {
+        const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
+        for (int j = 0; j < a.depths[s]; ++j) {
+            const BlockW& bw = P.blocks[s][j];
+            IgemmDesc d;
+            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_bf16 = w.qkv;
+            RUN(launch_igemm(d, st, err));
+            RUN(launch_window_attention(w.qkv, bw.bias_acc, bw.scale, w.attn, B, res, wsz, a.shift(s, j), H, st, err));
+            d = IgemmDesc();
+            d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b; d.out_f32 = w.y;
+            RUN(launch_igemm(d, st, err));
+            RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, w.xb, nullptr, M, C, 1, res, st, err));
+            d = IgemmDesc();
+            d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_bf16 = w.hbuf;
+            RUN(launch_igemm(d, st, err));
+            d = IgemmDesc();
+            d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b; d.out_f32 = w.y;
+            RUN(launch_igemm(d, st, err));
+            RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, w.xb, j == a.hooks[s] ? w.feat[s] : nullptr, M, C, 1, res, st, err));
+        }
+        if (s < 3) {
+            RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, st, err));
+            IgemmDesc d;
+            d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
+            RUN(launch_igemm(d, st, err));
+            RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, w.xb, nullptr, M / 4, 2 * C, 0, res / 2, st, err));
+        }
+    }
+    // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------
+    auto conv = [&](const bf16_t* X, int Cin, const bf16_t* Wt, int N, int r) {
+        IgemmDesc d;
+        d.X = X; d.Wt = Wt; d.M = B * r * r; d.N = N; d.Cin = Cin; d.taps = 9; d.H = r; d.W = r;
+        return d;
+    };
+    for (int l = 3; l >= 0; --l) {
+        const int r = a.res(l), M = B * r * r;
+        {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd bf16 halo (RCU conv1 input)
+            IgemmDesc d = conv(w.feat[l], a.dim(l), P.layer_rn[l], F, r);
+            d.out_f32 = w.lrn_raw[l]; d.out_bf16 = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            RUN(launch_igemm(d, st, err));
+        }
+        const float* fused_raw = w.lrn_raw[l];
+        const bf16_t* fused_relu = w.lrn_relu[l];
+        if (l < 3) {  // output = path + RCU1(layer_rn)
+            const RcuW& u1 = P.rcu[l][0];
+            IgemmDesc d = conv(w.lrn_relu[l], F, u1.w1, F, r);
+            d.bias = u1.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
+            RUN(launch_igemm(d, st, err));
+            d = conv(w.t_relu[l], F, u1.w2, F, r);
+            d.bias = u1.b2; d.res1 = w.lrn_raw[l]; d.res2 = w.path[l];
+            d.out_f32 = w.out_raw[l]; d.out_bf16 = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            RUN(launch_igemm(d, st, err));
+            fused_raw = w.out_raw[l];
+            fused_relu = w.out_relu[l];
+        }
+        {   // RCU2
+            const RcuW& u2 = P.rcu[l][1];
+            IgemmDesc d = conv(fused_relu, F, u2.w1, F, r);
+            d.bias = u2.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
+            RUN(launch_igemm(d, st, err));
+            d = conv(w.t_relu[l], F, u2.w2, F, r);
+            d.bias = u2.b2; d.res1 = fused_raw; d.out_bf16 = w.u[l];
+            RUN(launch_igemm(d, st, err));
+        }
+        {   // out_conv (1x1) BEFORE the bilinear resize: both are linear and the interpolation weights sum to 1
+            IgemmDesc d;
+            d.X = w.u[l]; d.Wt = P.oc_w[l]; d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = P.oc_b[l]; d.out_f32 = w.oc[l];
+            RUN(launch_igemm(d, st, err));
+        }
+        if (l > 0) RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err));
+        else RUN(launch_bilinear(w.oc[0], 0, nullptr, w.path1, 1, B, r, r, 2 * r, 2 * r, F, st, err));
+    }
+    // ---------------- heads ----------------
+    const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
+    {
+        IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
+        d.bias = P.d0_b; d.out_bf16 = w.d1;
+        RUN(launch_igemm(d, st, err));
+        RUN(launch_bilinear(w.d1, 1, nullptr, w.d1u, 1, B, r1, r1, r0, r0, F / 2, st, err));
+        d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
+        d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
+        RUN(launch_igemm(d, st, err));
+        d = conv(w.path1, F, P.s0_w, F, r1);
+        d.bias = P.bn_shift; d.act = ACT_RELU; d.out_bf16 = w.s1;
+        RUN(launch_igemm(d, st, err));
+        RUN(launch_seg_tail(w.s1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err));
+        ++launches;
+    }
+#undef RUN
+    h.launches = launches;
+    return 0;
 }
 
 }  // namespace soccdpt

@@ -41,6 +41,18 @@ class SoccdptConfig(ctypes.Structure):
     ]
 
 
+class IgemmArgs(ctypes.Structure):
+    _fields_ = [
+        ("x", ctypes.c_void_p), ("wt", ctypes.c_void_p),
+        ("M", ctypes.c_int32), ("N", ctypes.c_int32), ("Cin", ctypes.c_int32), ("taps", ctypes.c_int32),
+        ("ldx", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32),
+        ("bias", ctypes.c_void_p), ("res1", ctypes.c_void_p), ("res2", ctypes.c_void_p),
+        ("act", ctypes.c_int32), ("out_f32", ctypes.c_void_p), ("act_on_f32", ctypes.c_int32),
+        ("out_bf16", ctypes.c_void_p), ("out_halo", ctypes.c_int32),
+        ("dot_w", ctypes.c_void_p), ("dot_b", ctypes.c_float), ("out_dot", ctypes.c_void_p),
+    ]
+
+
 _lib = None
 
 
@@ -88,6 +100,13 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_words.restype = cs
     L.soccdpt_last_launch_count.argtypes = [vp]
     L.soccdpt_last_launch_count.restype = ci
+    L.soccdpt_op_igemm.argtypes = [ctypes.POINTER(IgemmArgs), vp]
+    L.soccdpt_op_igemm.restype = ci
+    L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.soccdpt_op_window_attention.restype = ci
+    L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
+                                           ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
+    L.soccdpt_workspace_tensor.restype = ci
     if L.soccdpt_abi_version() != ABI_VERSION:
         raise RuntimeError("libsoccdpt_hip.so ABI version mismatch; rebuild the library")
     _lib = L
@@ -235,6 +254,7 @@ class Engine:
     def network(self, x: torch.Tensor, inv256: torch.Tensor, seg256: torch.Tensor):
         B = x.shape[0]
         ws = self.workspace(B)
+        self._ws_head_bytes = 0
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_network(self._h, _ptr(x), B, _ptr(inv256), _ptr(seg256), ws.data_ptr(), ws.numel(),
                                                _stream_ptr(self.device)), "soccdpt_network")
@@ -242,6 +262,7 @@ class Engine:
     def forward(self, x: torch.Tensor, inv_up, seg_up, points, occ, occ_bits):
         B = x.shape[0]
         ws = self.workspace(B)
+        self._ws_head_bytes = B * x.shape[2] * x.shape[3] * 4 * (1 + self.cfg.num_classes)
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_forward(self._h, _ptr(x), B, _ptr(inv_up), _ptr(seg_up), _ptr(points), _ptr(occ),
                                                _ptr(occ_bits), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
@@ -249,3 +270,46 @@ class Engine:
 
     def launch_count(self) -> int:
         return int(self.L.soccdpt_last_launch_count(self._h))
+
+
+    def workspace_tensor(self, B: int, name: str):
+        """View of a named intermediate of the last soccdpt_network(B) call (diagnostics / parity tests).
+        Returns an NHWC float32 tensor [B,H,W,C] (halo stripped, bf16 widened)."""
+        off, n = ctypes.c_size_t(), ctypes.c_size_t()
+        kind, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = self.L.soccdpt_workspace_tensor(self._h, B, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(kind),
+                                             ctypes.byref(H), ctypes.byref(W), ctypes.byref(C))
+        if rc != 0:
+            raise KeyError(name)
+        raw = self._workspace[self._ws_head(B) + off.value:]
+        if kind.value == 0:
+            return raw[: n.value * 4].view(torch.float32).reshape(B, H.value, W.value, C.value).clone()
+        t = raw[: n.value * 2].view(torch.bfloat16)
+        if kind.value == 2:
+            t = t.reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
+        else:
+            t = t.reshape(B, H.value, W.value, C.value)
+        return t.float()
+
+    def _ws_head(self, B: int) -> int:
+        return getattr(self, "_ws_head_bytes", 0)
+
+
+def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
+             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None):
+    """Kernel-level entry (tests): one implicit-GEMM launch on the current stream."""
+    L = load_library()
+    a = IgemmArgs(_ptr(x), _ptr(wt), M, N, Cin, taps, ldx, H, W, _ptr(bias), _ptr(res1), _ptr(res2), act, _ptr(out_f32),
+                  act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot))
+    rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads):
+    L = load_library()
+    scratch = torch.empty((heads * ws ** 4,), dtype=torch.float32, device=qkv.device)
+    rc = L.soccdpt_op_window_attention(_ptr(qkv), _ptr(cpb_table), _ptr(scale), _ptr(out), _ptr(scratch), B, res, ws, shift,
+                                       heads, _stream_ptr(qkv.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_window_attention failed: " + L.soccdpt_last_error(None).decode())

@@ -1,0 +1,293 @@
+"""SOccDPT model API on MI355X: same classes, constructor arguments, forward signature and
+return shapes as /root/reference/SOccDPT/model/SOccDPT.py, with the arithmetic in
+libsoccdpt_hip.so (no CPU / eager-PyTorch fallback).
+
+  SOccDPT              base: constants + calibration (:134-245), get_semantic_occupancy (:264-372)
+  SOccDPT_V3           depth_net (DPTDepthModel) + seg_head + projection (:626-685)
+  SOccDPT_versions     {3: SOccDPT_V3}; V1/V2 are out of scope of the hot path
+  DepthNet / SegNet    output selectors (:697-724)
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional, Type
+
+import numpy as np
+import torch
+import torch.nn as nn
+import yaml
+
+from ..lib import PREC_BF16, Engine, make_config
+from .base_model import BaseModel
+from .blocks import Interpolate
+from .dpt import DPTDepthModel
+from .scaled_tanh import ScaledTanh
+from .spec import DEFAULT_DEPTH_WEIGHTS, MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS, model_types  # noqa: F401
+
+# /root/reference/SOccDPT/datasets/bdd_helper.py:53-56
+DATASET_BASE = "~/Datasets/Depth_Dataset_Bengaluru"
+DEFAULT_CALIB = os.path.join(DATASET_BASE, "calibration/pocoX3/calib.yaml")
+
+cpu_device = torch.device("cpu")
+default_depth_models = dict(DEFAULT_DEPTH_WEIGHTS)
+default_seg_models = {k: None for k in default_depth_models}
+DEPTH_l39icv3q = "checkpoints_pretrained/depth_dpt_hybrid/l39icv3q/checkpoint_epoch15.pth"  # noqa: E501
+
+
+class SOccDPT(BaseModel):
+    def __init__(self, model_type="dpt_swin2_tiny_256", backbone="swin2t16_256", path=None, num_classes: int = 3,
+                 camera_intrinsics_yaml=DEFAULT_CALIB, point_compute_method="torch",
+                 grid_size=(256, 256, 32), scale=(2.0, 2.0, 0.666), shift=(0.0, 0.0, 0.0),
+                 pc_scale=(10000.0, 50000.0, 800.0), pc_shift=(55.0, -20.0, 15.0), correction_angle=(7.0, 0, 0),
+                 compute_occ=False, precision: int = PREC_BF16, **kwargs):
+        super().__init__()
+        self.compute_occ = compute_occ
+        self.grid_size = grid_size
+        self.scale = scale
+        self.shift = shift
+        self.pc_scale = pc_scale
+        self.pc_shift = pc_shift
+        self.correction_angle = correction_angle
+        self.backbone = backbone
+        self.model_type = model_type
+        self.path = path
+        self.num_classes = num_classes
+        self.precision = precision
+        self.occupancy_shape = np.array([float(grid_size[i] / scale[i]) for i in range(len(grid_size))], dtype=np.float32)
+        self.features = kwargs["features"] if "features" in kwargs else 256
+        assert point_compute_method in ("torch", "numpy")
+        assert point_compute_method == "torch", "the MI355X path fuses the 'torch' point computation"
+        self.point_compute_method = point_compute_method
+        # camera intrinsics (a missing file raises FileNotFoundError like the reference)
+        self.camera_intrinsics_yaml = os.path.expanduser(camera_intrinsics_yaml)
+        with open(self.camera_intrinsics_yaml, "r") as stream:
+            try:
+                self.cam_settings = yaml.load(stream, Loader=yaml.FullLoader)
+            except yaml.YAMLError as exc:
+                print(exc)
+        cs = self.cam_settings
+        k3 = cs["Camera.k3"] if "Camera.k3" in cs else 0
+        self.DistCoef = np.array([cs["Camera.k1"], cs["Camera.k2"], cs["Camera.p1"], cs["Camera.p2"], k3])
+        self.intrinsic_matrix = np.array([[cs["Camera.fx"], 0.0, cs["Camera.cx"]], [0.0, cs["Camera.fy"], cs["Camera.cy"]],
+                                          [0.0, 0.0, 1.0]])
+        self.fx = self.intrinsic_matrix[0, 0]
+        self.fy = self.intrinsic_matrix[1, 1]
+        self.cx = self.intrinsic_matrix[0, 2]
+        self.cy = self.intrinsic_matrix[1, 2]
+        self.width = cs["Camera.width"]
+        self.height = cs["Camera.height"]
+        self.occupancy_conv = nn.Identity()
+        # ---- MI355X engine state (one handle per device, created lazily) ----
+        self._engines = {}
+        self._bound_versions = {}
+        self._weight_refs = {}
+        self.occ_exchange = None  # set by soccdpt_amd.dist for multi-GPU: callable(bits) -> union bits
+
+    # -- engine plumbing --
+    def _engine_backbone(self) -> str:
+        return self.backbone if self.backbone in SWIN_ARCHS else "swin2t16_256"
+
+    def _sigmoid_flag(self) -> bool:
+        return True
+
+    def _engine(self, device: torch.device) -> Engine:
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("soccdpt_amd runs on MI355X only: move the model and inputs to a cuda device "
+                               "(there is no CPU fallback)")
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        eng = self._engines.get(key)
+        if eng is None:
+            cfg = make_config(self._engine_backbone(), self.num_classes, self.features, self._sigmoid_flag(),
+                              bool(self.compute_occ), self.width, self.height, self.fx, self.fy, self.cx, self.cy,
+                              self.grid_size, self.occupancy_shape, self.pc_scale, self.pc_shift, self.correction_angle,
+                              precision=self.precision)
+            eng = Engine(cfg, torch.device(key[0], key[1]))
+            self._engines[key] = eng
+        return eng
+
+    def forward(self, x: torch.Tensor):
+        assert False, "Not implemented, take input batch and produce inv_depth, segmentation and call " \
+                      "self.get_semantic_occupancy(inv_depth, segmentation)"
+
+    def _shape_outputs(self, inv_up, seg_up, points, occ):
+        # .squeeze() quirk of model/SOccDPT.py:276-285: B == 1 -> segmentation loses its batch dim
+        if seg_up.shape[0] == 1:
+            seg_up = seg_up[0]
+        return inv_up, seg_up, points, occ
+
+    def get_semantic_occupancy(self, inv_depth: torch.Tensor, segmentation: torch.Tensor):
+        """inv_depth [B,h,w] (or [B,1,h,w]), segmentation [B,C,h,w] on a cuda device ->
+        (inv_depth_up [B,Hc,Wc], seg_up [B,C,Hc,Wc] | [C,Hc,Wc], points [B,Hc,Wc,3], occupancy | None)."""
+        if inv_depth.dim() == 4:
+            inv_depth = inv_depth[:, 0]
+        eng = self._engine(inv_depth.device)
+        dev = inv_depth.device
+        inv = inv_depth.detach().to(torch.float32).contiguous()
+        seg = segmentation.detach().to(torch.float32).contiguous()
+        B = inv.shape[0]
+        Hc, Wc, C = self.height, self.width, self.num_classes
+        inv_up = torch.empty((B, Hc, Wc), device=dev)
+        seg_up = torch.empty((B, C, Hc, Wc), device=dev)
+        points = torch.empty((B, Hc, Wc, 3), device=dev)
+        occ = None
+        bits = torch.empty((eng.occ_words(),), dtype=torch.int32, device=dev) if self.compute_occ else None
+        eng.project(inv, seg, inv_up, seg_up, points, bits, clear_bits=True)
+        if self.compute_occ:
+            occ = self._finish_occupancy(eng, bits, B)
+        return self._shape_outputs(inv_up, seg_up, points, occ)
+
+    def _finish_occupancy(self, eng: Engine, bits: torch.Tensor, B: int):
+        if self.occ_exchange is not None:  # multi-GPU: union over every rank's frames
+            bits = self.occ_exchange(eng, bits)
+        g = self.grid_size
+        occ = torch.empty((B, g[0], g[1], g[2], self.num_classes), device=bits.device)
+        eng.occ_expand(bits, B, occ)
+        self.last_occ_bits = bits
+        return occ
+
+
+class SOccDPT_V3(SOccDPT):
+    def __init__(self, sigmoid=True, load_depth: str = DEPTH_l39icv3q, **kwargs):
+        super().__init__(**kwargs)
+        from .loader import load_model
+
+        depth_model_weights = load_depth
+        if depth_model_weights is None:
+            depth_model_weights = default_depth_models[self.model_type]
+        print("Loading depth net")
+        self.depth_net = load_model(DPTDepthModel, dict(non_negative=True, return_features=True), cpu_device,
+                                    depth_model_weights, self.model_type)
+        self.depth_net.return_features = True
+        self.pretrained = self.depth_net.pretrained  # same module registered twice, like the reference (:650)
+        self.sigmoid = bool(sigmoid)
+        activation = nn.Sigmoid() if sigmoid else ScaledTanh()
+        self.seg_head = nn.Sequential(
+            nn.Conv2d(self.features, self.features, kernel_size=3, padding=1, bias=False),
+            nn.BatchNorm2d(self.features),
+            nn.ReLU(True),
+            nn.Dropout(0.1, False),
+            nn.Conv2d(self.features, self.num_classes, kernel_size=1),
+            Interpolate(scale_factor=2, mode="bilinear", align_corners=True),
+            activation,
+        )
+        self.load_net(self.path)
+
+    def _engine_backbone(self) -> str:
+        return self.depth_net.backbone
+
+    def _sigmoid_flag(self) -> bool:
+        return self.sigmoid
+
+    # -- weights -> library --
+    def _apply(self, fn, *args, **kwargs):
+        # .to()/.cuda()/.float() replace parameter storage: forget what was bound
+        self._bound_versions.clear()
+        self._weight_refs.clear()
+        return super()._apply(fn, *args, **kwargs)
+
+    def _sync_weights(self, eng: Engine):
+        refs = self._weight_refs.get(id(eng))
+        if refs is not None:
+            version = tuple(t._version for t in refs)
+            if self._bound_versions.get(id(eng)) == version:
+                return
+        sd = self.state_dict()
+        keys = eng.weight_keys()
+        refs = [sd[k] for k in keys]
+        version = tuple(t._version for t in refs)
+        for k in keys:
+            t = sd[k]
+            if t.device != eng.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"weight {k} must be a contiguous float32 tensor on {eng.device} (got {t.device}, {t.dtype})")
+            eng.bind(k, t)
+        eng.prepare()
+        self._weight_refs[id(eng)] = refs
+        self._bound_versions[id(eng)] = version
+
+    def forward(self, x: torch.Tensor):
+        """x [B,3,S,S] f32 on cuda -> (inv_depth, segmentation, points, occupancy | None); see SOccDPT_V3.forward
+        (/root/reference/SOccDPT/model/SOccDPT.py:681-685)."""
+        if self.training:
+            raise RuntimeError("the MI355X path implements the eval-mode forward; call net.eval() "
+                               "(patch-wise training is the next scope row, SURVEY.md §8f)")
+        arch = SWIN_ARCHS[self._engine_backbone()]
+        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == arch.img and x.shape[3] == arch.img, \
+            f"expected x [B,3,{arch.img},{arch.img}], got {tuple(x.shape)}"
+        eng = self._engine(x.device)
+        self._sync_weights(eng)
+        dev = x.device
+        xin = x.detach().to(torch.float32).contiguous()
+        B = xin.shape[0]
+        Hc, Wc, C = self.height, self.width, self.num_classes
+        inv_up = torch.empty((B, Hc, Wc), device=dev)
+        seg_up = torch.empty((B, C, Hc, Wc), device=dev)
+        points = torch.empty((B, Hc, Wc, 3), device=dev)
+        occ = None
+        bits = None
+        if self.compute_occ:
+            bits = torch.empty((eng.occ_words(),), dtype=torch.int32, device=dev)
+            if self.occ_exchange is None:
+                g = self.grid_size
+                occ = torch.empty((B, g[0], g[1], g[2], C), device=dev)
+        eng.forward(xin, inv_up, seg_up, points, occ, bits)
+        if self.compute_occ and self.occ_exchange is not None:
+            occ = self._finish_occupancy(eng, bits, B)
+        self.last_occ_bits = bits
+        return self._shape_outputs(inv_up, seg_up, points, occ)
+
+    def network(self, x: torch.Tensor):
+        """Stage-level: encoder + decoder + heads only -> (inv_depth [B,S,S], segmentation [B,C,S,S])."""
+        eng = self._engine(x.device)
+        self._sync_weights(eng)
+        B, S = x.shape[0], x.shape[2]
+        inv = torch.empty((B, S, S), device=x.device)
+        seg = torch.empty((B, self.num_classes, S, S), device=x.device)
+        eng.network(x.detach().to(torch.float32).contiguous(), inv, seg)
+        return inv, seg
+
+
+def _not_in_scope(version):
+    class _Unavailable(SOccDPT):
+        def __init__(self, *a, **k):
+            raise NotImplementedError(
+                f"SOccDPT_V{version} is outside the MI355X hot path (SURVEY.md §2: V1 = two full DPTs, V2 raises in the "
+                "reference); use version 3")
+    _Unavailable.__name__ = f"SOccDPT_V{version}"
+    return _Unavailable
+
+
+SOccDPT_V1 = _not_in_scope(1)
+SOccDPT_V2 = _not_in_scope(2)
+
+SOccDPT_versions = {1: SOccDPT_V1, 2: SOccDPT_V2, 3: SOccDPT_V3}
+
+
+class DepthNet:
+    def __init__(self, net: Type[SOccDPT]) -> None:
+        self.net = net
+
+    def __call__(self, x: torch.Tensor):
+        y_disp_pred, _, _, _ = self.net(x)
+        return y_disp_pred
+
+    def eval(self):
+        self.net.eval()
+
+    def train(self):
+        self.net.train()
+
+
+class SegNet:
+    def __init__(self, net: Type[SOccDPT]) -> None:
+        self.net = net
+
+    def __call__(self, x: torch.Tensor):
+        _, y_seg_pred, _, _ = self.net(x)
+        return y_seg_pred
+
+    def eval(self):
+        self.net.eval()
+
+    def train(self):
+        self.net.train()

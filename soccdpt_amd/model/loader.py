@@ -1,0 +1,60 @@
+"""load_model / load_transforms with the reference's signatures
+(/root/reference/SOccDPT/model/loader.py:13-138,141-272)."""
+from typing import Type, Union
+
+import numpy as np
+import torch
+
+from .base_model import BaseModel
+from .spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+
+
+def load_model(arch, model_kwargs: dict, device: torch.device, model_path: str, model_type: str = "dpt_large_384",
+               optimize: bool = False) -> Type[BaseModel]:
+    """model_type -> backbone id -> arch(path=..., backbone=..., **model_kwargs), then .to(device).
+    Unknown model types assert like the reference (loader.py:122-124).  model_types whose backbone has
+    no HIP implementation are constructible only by classes that merely store the backbone string (the
+    SOccDPT outer class, exactly as in the reference's scripts — SURVEY.md §3.2)."""
+    assert issubclass(arch, BaseModel), f"arch '{arch}' not implemented, must be an instance of soccdpt_amd BaseModel"
+    if model_type not in MODEL_TYPE_TO_BACKBONE:
+        print(f"model_type '{model_type}' not implemented")
+        assert False, f"model_type '{model_type}' not implemented"
+    kwargs = dict(model_kwargs)
+    if model_type == "dpt_levit_224":
+        kwargs.update(head_features_1=64, head_features_2=8)
+    model = arch(path=model_path, backbone=MODEL_TYPE_TO_BACKBONE[model_type], **kwargs)
+    print("Model loaded, number of parameters = {:.0f}M".format(sum(p.numel() for p in model.parameters()) / 1e6))
+    if optimize and (device == torch.device("cuda")):
+        # the reference switches to channels_last + fp16 here (loader.py:132-134); the MI355X path is
+        # already NHWC with bf16 MFMA operands, so there is nothing to switch
+        pass
+    model.to(device)
+    return model
+
+
+class _NormalizePrepare:
+    """NormalizeImage(mean=0.5,std=0.5) + PrepareForNet (model/transforms.py:206-251) for images that are
+    already at network resolution; the cv2 Resize step of the reference is host-side preprocessing outside
+    the hot path."""
+
+    def __init__(self, net_w, net_h):
+        self.net_w, self.net_h = net_w, net_h
+
+    def __call__(self, sample):
+        img = np.asarray(sample["image"], dtype=np.float32)
+        assert img.shape[0] == self.net_h and img.shape[1] == self.net_w, "resize to network resolution first"
+        img = (img - 0.5) / 0.5
+        sample["image"] = np.ascontiguousarray(np.transpose(img, (2, 0, 1))).astype(np.float32)
+        return sample
+
+
+def load_transforms(model_type: str = "dpt_large_384", height: int = 0, square: bool = False):
+    """Returns (transform, net_w, net_h) (loader.py:141-272).  Sizes follow the model (the reference
+    returns 256 for dpt_swin2_base_384, an inconsistency noted in SURVEY.md §3.4)."""
+    if model_type not in MODEL_TYPE_TO_BACKBONE:
+        print(f"model_type '{model_type}' not implemented")
+        assert False, f"model_type '{model_type}' not implemented"
+    backbone = MODEL_TYPE_TO_BACKBONE[model_type]
+    size = SWIN_ARCHS[backbone].img if backbone in SWIN_ARCHS else 384
+    net_w = net_h = size
+    return _NormalizePrepare(net_w, net_h), net_w, net_h

@@ -1,0 +1,128 @@
+"""GPU: the individual HIP kernels (through the kernel-level C-ABI entry points) against plain
+PyTorch fp32 references of the same op on the same bf16-rounded operands.
+
+Tolerances: operands are identical bf16 values on both sides, accumulation is fp32 on both sides,
+so GEMM/conv results agree to fp32 summation-order noise (rtol 2e-3 on the bf16-rounded outputs,
+1e-4 on f32 outputs).  The attention kernel additionally rounds q-hat, k-hat and the softmax
+numerators to bf16: atol 3e-2 on outputs of magnitude O(1)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import soccdpt_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16)
+
+
+def _halo(x_nhwc):  # [B,H,W,C] -> zero-haloed [B,H+2,W+2,C]
+    return F.pad(x_nhwc, (0, 0, 1, 1, 1, 1)).contiguous()
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 288, 96), (1024, 96, 384), (512, 2304, 768), (64, 768, 3072), (4096, 192, 384)])
+def test_igemm_linear(gpu_device, M, N, K):
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    res = torch.randn(M, N, generator=g).to(gpu_device)
+    ref = x.float() @ w.float().t() + bias
+    out = torch.empty(M, N, device=gpu_device)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_f32=out)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+    # gelu -> bf16, and residual -> f32
+    outb = torch.empty(M, N, dtype=torch.bfloat16, device=gpu_device)
+    out2 = torch.empty(M, N, device=gpu_device)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, act=2, out_bf16=outb)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, res1=res, out_f32=out2)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(outb.float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(out2, ref + res, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 256, 256), (3, 8, 96, 256), (1, 32, 192, 256), (2, 16, 256, 128), (1, 8, 768, 256)])
+def test_igemm_conv3x3(gpu_device, B, H, Cin, Cout):
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
+    x = _bf(torch.randn(B, Cin, H, H, generator=g)).to(gpu_device)            # NCHW like the reference
+    w = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(gpu_device)
+    bias = torch.randn(Cout, generator=g).to(gpu_device)
+    res1 = torch.randn(B, H, H, Cout, generator=g).to(gpu_device)
+    res2 = torch.randn(B, H, H, Cout, generator=g).to(gpu_device)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1)  # NHWC
+    xh = _halo(x.permute(0, 2, 3, 1).contiguous())
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()             # [Cout][tap][Cin]
+    M = B * H * H
+    out = torch.empty(B, H, H, Cout, device=gpu_device)
+    outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=gpu_device)
+    op_igemm(xh, wt, M, Cout, Cin, taps=9, H=H, W=H, bias=bias, res1=res1, res2=res2, act=1, out_f32=out, out_bf16=outh,
+             out_halo=1)
+    torch.cuda.synchronize()
+    full = ref + res1 + res2
+    torch.testing.assert_close(out, full, rtol=1e-4, atol=2e-4)                 # raw f32 (pre-activation)
+    torch.testing.assert_close(outh[:, 1:-1, 1:-1].float(), F.relu(full), rtol=1e-2, atol=1e-2)
+    assert float(outh[:, 0].abs().max()) == 0 and float(outh[:, :, 0].abs().max()) == 0  # halo untouched
+
+
+def test_igemm_depth_tail(gpu_device):
+    """conv3x3 128->32 + bias, ReLU, 1x1 32->1 + bias, ReLU fused (model/dpt.py:209-216)."""
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(5)
+    B, H, Cin = 2, 16, 128
+    x = _bf(torch.randn(B, Cin, H, H, generator=g)).to(gpu_device)
+    w = _bf(torch.randn(32, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(gpu_device)
+    bias = torch.randn(32, generator=g).to(gpu_device)
+    w2 = torch.randn(32, generator=g).to(gpu_device)
+    b2 = 0.1
+    ref = F.relu(F.conv2d(x.float(), w.float(), bias, padding=1))
+    ref = F.relu((ref * w2.view(1, 32, 1, 1)).sum(1) + b2)
+    out = torch.empty(B, H, H, device=gpu_device)
+    xh = _halo(x.permute(0, 2, 3, 1).contiguous())
+    wt = w.permute(0, 2, 3, 1).reshape(32, 9 * Cin).contiguous()
+    op_igemm(xh, wt, B * H * H, 32, Cin, taps=9, H=H, W=H, bias=bias, act=1, dot_w=w2, dot_b=b2, out_dot=out)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)
+
+
+def _attention_ref(qkv, table, scale, B, res, ws, shift, heads):
+    C = heads * 32
+    N = ws * ws
+    nw = res // ws
+    x = qkv.float().reshape(B, res, res, 3 * C)
+    if shift:
+        x = torch.roll(x, (-shift, -shift), (1, 2))
+    win = x.reshape(B, nw, ws, nw, ws, 3 * C).permute(0, 1, 3, 2, 4, 5).reshape(B * nw * nw, N, 3, heads, 32)
+    q, k, v = [win[:, :, i].permute(0, 2, 1, 3) for i in range(3)]
+    attn = F.normalize(q, dim=-1) @ F.normalize(k, dim=-1).transpose(-2, -1) * scale.view(1, heads, 1, 1)
+    idx = R.relative_position_index(ws).reshape(-1).to(table.device)
+    attn = attn + table[idx].reshape(N, N, heads).permute(2, 0, 1).unsqueeze(0)
+    mask = R.shift_attn_mask(res, ws, shift)
+    if mask is not None:
+        attn = (attn.reshape(B, nw * nw, heads, N, N) + mask.to(attn.device)[None, :, None]).reshape(-1, heads, N, N)
+    out = (torch.softmax(attn, -1) @ v).transpose(1, 2).reshape(B, nw, nw, ws, ws, C).permute(0, 1, 3, 2, 4, 5).reshape(B, res, res, C)
+    if shift:
+        out = torch.roll(out, (shift, shift), (1, 2))
+    return out.reshape(B * res * res, C)
+
+
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 0, 3), (2, 64, 16, 8, 3), (1, 32, 16, 8, 6), (3, 16, 16, 0, 12), (2, 8, 8, 0, 24)])
+def test_window_attention(gpu_device, B, res, ws, shift, heads):
+    from soccdpt_amd.lib import op_window_attention
+    g = torch.Generator().manual_seed(res * 100 + shift + heads)
+    C = heads * 32
+    qkv = _bf(torch.randn(B * res * res, 3 * C, generator=g)).to(gpu_device)
+    table = (16 * torch.sigmoid(torch.randn((2 * ws - 1) ** 2, heads, generator=g))).to(gpu_device)
+    scale = (10.0 + 5 * torch.rand(heads, generator=g)).to(gpu_device)
+    out = torch.empty(B * res * res, C, dtype=torch.bfloat16, device=gpu_device)
+    op_window_attention(qkv, table, scale, out, B, res, ws, shift, heads)
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv, table, scale, B, res, ws, shift, heads)
+    err = (out.float() - ref).abs()
+    assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
