@@ -117,8 +117,8 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
     float* seg = inv + (size_t)B * S * S;
     const size_t head = (size_t)B * S * S * (1 + h->cfg.num_classes) * sizeof(float);
     if (workspace_bytes < head) return fail(h, "soccdpt_forward: workspace too small");
-    int rc = model_network(*h, dev_x, B, inv, seg, static_cast<char*>(dev_workspace) + head, workspace_bytes - head,
-                           (hipStream_t)stream, h->err);
+    // model_network carves its scratch behind the same head, so the halo images sit at the same place for every entry point
+    int rc = model_network(*h, dev_x, B, inv, seg, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
     if (rc) return rc;
     const bool occ_on = h->cfg.compute_occ != 0;
     if (occ_on && !dev_occ_bits) return fail(h, "soccdpt_forward: compute_occ needs dev_occ_bits");

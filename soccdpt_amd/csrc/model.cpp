@@ -179,6 +179,9 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const Arch& a = h.arch;
     const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
     const size_t M0 = (size_t)B * G * G;
+    // head: network outputs (inv [B,S,S], seg [B,C,S,S]) when called through soccdpt_forward.  Always reserved, so the
+    // zero-halo images occupy the same bytes whichever entry point runs (their borders must stay zero).
+    ar.take<float>((size_t)B * h.img * h.img * (1 + h.cfg.num_classes));
     w.xf = ar.take<float>(M0 * C0);
     w.y = ar.take<float>(M0 * C0);
     w.xb = ar.take<bf16_t>(M0 * C0);
@@ -321,8 +324,7 @@ size_t model_workspace_bytes(Handle& h, int B) {
     Arena ar(nullptr, 0);
     Workspace w;
     carve(h, B, ar, w);
-    // + network outputs at the head of the workspace when called through soccdpt_forward
-    return ar.off + 256 + (size_t)B * h.img * h.img * (1 + h.cfg.num_classes) * sizeof(float) + 256;
+    return ar.off + 256;
 }
 
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C) {

@@ -254,7 +254,6 @@ class Engine:
     def network(self, x: torch.Tensor, inv256: torch.Tensor, seg256: torch.Tensor):
         B = x.shape[0]
         ws = self.workspace(B)
-        self._ws_head_bytes = 0
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_network(self._h, _ptr(x), B, _ptr(inv256), _ptr(seg256), ws.data_ptr(), ws.numel(),
                                                _stream_ptr(self.device)), "soccdpt_network")
@@ -262,7 +261,6 @@ class Engine:
     def forward(self, x: torch.Tensor, inv_up, seg_up, points, occ, occ_bits):
         B = x.shape[0]
         ws = self.workspace(B)
-        self._ws_head_bytes = B * x.shape[2] * x.shape[3] * 4 * (1 + self.cfg.num_classes)
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_forward(self._h, _ptr(x), B, _ptr(inv_up), _ptr(seg_up), _ptr(points), _ptr(occ),
                                                _ptr(occ_bits), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
@@ -281,7 +279,7 @@ class Engine:
                                              ctypes.byref(H), ctypes.byref(W), ctypes.byref(C))
         if rc != 0:
             raise KeyError(name)
-        raw = self._workspace[self._ws_head(B) + off.value:]
+        raw = self._workspace[off.value:]
         if kind.value == 0:
             return raw[: n.value * 4].view(torch.float32).reshape(B, H.value, W.value, C.value).clone()
         t = raw[: n.value * 2].view(torch.bfloat16)
@@ -290,9 +288,6 @@ class Engine:
         else:
             t = t.reshape(B, H.value, W.value, C.value)
         return t.float()
-
-    def _ws_head(self, B: int) -> int:
-        return getattr(self, "_ws_head_bytes", 0)
 
 
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
