@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — frames/s of the full SOccDPT_V3 forward (depth + seg + points + occupancy) on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver launches it
+under torch.distributed.run, one rank per GPU (RCCL).  One "step" = one forward of one batch of
+synthetic 256x256 frames per rank (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
+
+Workload at N = 1: BASELINE.json configs[1] — SOccDPT_V3 dpt_swin2_tiny_256, bf16 MFMA operands,
+batch 8, compute_occ=True, eval mode, synthetic weights/inputs/camera.
+
+Extra objects:
+  roofline     dominant kernel family of the forward (by summed device time), timed live with HIP
+               events on the launch stream (soccdpt_profile_*): achieved = algorithmic FLOPs / time.
+  cpu_baseline the CPU oracle (oracle/soccdpt_ref.py, fp32 PyTorch-CPU restatement, kind "port")
+               timed on this host's cores on a bounded sample (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from soccdpt_amd import dist as sdist
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+
+    rank, local, world = sdist.init_from_env("nccl")
+    if world != max(args.gpus, 1):
+        if rank == 0:
+            print(f"[bench] note: --gpus {args.gpus} but WORLD_SIZE={world}; using WORLD_SIZE", file=sys.stderr)
+    dev = torch.device("cuda", local)
+    torch.cuda.set_device(dev)
+
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True)
+    sd = synth_state_dict(alias_pretrained=True)
+    net.load_state_dict(sd, strict=False)
+    net = net.eval().to(dev)
+    sdist.attach(net)
+
+    B = args.batch
+    x = synth_input(B, seed0=rank * B).to(dev)   # different frames per rank
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = net(x)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = net(x)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    frames = world * B * args.steps
+    fps = frames / elapsed
+
+    # ---- per-kernel timing with HIP events on the launch stream (separate, equally sized region) ----
+    eng = net._engine(dev)
+    prof_steps = max(3, min(args.steps, 10))
+    eng.profile_enable(True)
+    barrier()
+    t1 = time.perf_counter()
+    for _ in range(prof_steps):
+        out = net(x)
+    torch.cuda.synchronize()
+    elapsed_prof = time.perf_counter() - t1
+    stats = eng.profile_collect()
+    eng.profile_enable(False)
+
+    result = None
+    if rank == 0:
+        total_ms = sum(s["ms"] for s in stats.values())
+        fam, dom = max(stats.items(), key=lambda kv: kv[1]["ms"])
+        kernels = []
+        for name, s in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]):
+            k = dict(name=name, launches_per_step=s["launches"] / prof_steps, ms_per_step=round(s["ms"] / prof_steps, 4),
+                     share=round(s["ms"] / total_ms, 4))
+            if s["flops"] > 0:
+                k["tflops"] = round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2)
+            if s["bytes"] > 0:
+                k["gbs"] = round(s["bytes"] / (s["ms"] * 1e-3) / 1e9, 1)
+            kernels.append(k)
+        if dom["flops"] > 0:
+            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+            roofline = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                            frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+                            avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2),
+                            flops_per_step=dom["flops"] / prof_steps, launches_per_step=dom["launches"] / prof_steps)
+        else:
+            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
+            roofline = dict(bound="hbm", kernel=fam, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
+                            avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2))
+        result = {
+            "metric": "frames/sec SOccDPT_V3 swin2_tiny_256 @256px (depth+seg+points+occupancy forward)",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SOccDPT_V3 dpt_swin2_tiny_256 full forward, compute_occ=True, camera 1920x1080",
+                       "batch_per_gpu": B, "global_batch": B * world, "image": 256,
+                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
+            "roofline": roofline,
+            "kernels": kernels,
+            "device_ms_per_step": round(total_ms / prof_steps, 3),
+            "ms_per_step_with_events": round(elapsed_prof / prof_steps * 1e3, 3),
+            "launches_per_step": eng.launch_count() + 2,
+            "paper_hz": 47.0, "x_paper_hz": round(fps / 47.0, 2),
+        }
+
+    # ---- CPU baseline: the oracle on this host's cores, bounded sample, rank 0 at N = 1 only ----
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import soccdpt_ref as R
+        # the GPU box gives one GPU's share of the host: 16 cores (more threads only oversubscribe)
+        try:
+            avail = len(os.sched_getaffinity(0))
+        except AttributeError:
+            avail = os.cpu_count() or 1
+        cores = max(1, min(avail, 16))
+        torch.set_num_threads(cores)
+        nb = max(1, min(args.cpu_sample_frames, B))
+        xs = x[:nb].cpu()
+        sd_cpu = {k: v.cpu() for k, v in sd.items()}
+        R.soccdpt_v3_forward(sd_cpu, xs[:1], sigmoid=False)   # warm-up (allocator, oneDNN primitives)
+        reps, tcpu = 0, 0.0
+        while tcpu < 10.0 and reps < 6:
+            t2 = time.perf_counter()
+            R.soccdpt_v3_forward(sd_cpu, xs, sigmoid=False)
+            tcpu += time.perf_counter() - t2
+            reps += 1
+        result["cpu_baseline"] = {"value": round(nb * reps / tcpu, 3), "unit": "frames/s", "cores": cores, "kind": "port",
+                                  "sample": f"{reps} x batch {nb} of the same synthetic workload, fp32 PyTorch-CPU oracle "
+                                            f"(oracle/soccdpt_ref.py), {tcpu:.1f} s"}
+    if rank == 0:
+        print(json.dumps(result))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -117,6 +117,21 @@ size_t soccdpt_occ_words(void* handle);
 /* Number of kernel launches issued by the last soccdpt_network call (diagnostics). */
 int soccdpt_last_launch_count(void* handle);
 
+/* ---- per-kernel timing with HIP events on the caller's stream (bench.py roofline) ----
+ * While enabled, every kernel launch of soccdpt_network / soccdpt_project / soccdpt_occ_expand /
+ * soccdpt_forward is bracketed by a hipEvent pair on `stream`.  soccdpt_profile_collect synchronises the
+ * recorded events, aggregates per kernel family (sum of elapsed ms, launches, algorithmic FLOPs and
+ * algorithmic HBM bytes as defined in DESIGN.md) and resets the recording. */
+typedef struct soccdpt_kernel_stat {
+    char name[48];
+    int32_t launches;
+    double ms;     /* sum of per-launch durations */
+    double flops;  /* algorithmic: 2*M*N*K per GEMM/conv launch, 4*N*N*d per attention (window, head) */
+    double bytes;  /* algorithmic HBM bytes (HBM-bound kernels), 0 where not defined */
+} soccdpt_kernel_stat;
+int soccdpt_profile_enable(void* handle, int on);
+int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entries, int* n_entries);
+
 /* ---- kernel-level entry points (parity tests of the individual HIP kernels) ---- */
 
 /* One implicit-GEMM launch: out[m][n] = epilogue(sum_k X[m][k] * Wt[n][k]) with bf16 operands and f32

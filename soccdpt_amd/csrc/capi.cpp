@@ -11,6 +11,13 @@ using namespace soccdpt;
 
 static std::string g_create_error;
 
+// algorithmic HBM bytes of the projection kernel: inputs once + every requested output once
+static double project_bytes(const soccdpt_config& c, int B, int h, int w, const void* inv_up, const void* seg_up, const void* points) {
+    const double px = (double)c.cam_width * c.cam_height * B;
+    return (double)B * h * w * 4.0 * (1 + c.num_classes) + px * 4.0 * ((inv_up ? 1 : 0) + (seg_up ? c.num_classes : 0) + (points ? 3 : 0));
+}
+static double occ_cells(const soccdpt_config& c) { return (double)c.grid[0] * c.grid[1] * c.grid[2] * c.num_classes; }
+
 static int fail(Handle* h, const std::string& msg) {
     if (h) h->err = msg; else g_create_error = msg;
     return 1;
@@ -82,6 +89,7 @@ int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, in
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
     if (!dev_inv || !dev_seg) return fail(h, "soccdpt_project: null input");
+    ProfScope ps(h->prof, "project_voxelise", 0.0, project_bytes(h->cfg, B, in_h, in_w, dev_inv_up, dev_seg_up, dev_points), (hipStream_t)stream);
     return launch_project(h->cfg, dev_inv, dev_seg, B, in_h, in_w, dev_inv_up, dev_seg_up, dev_points, dev_occ_bits, clear_bits,
                           (hipStream_t)stream, h->err);
 }
@@ -103,6 +111,7 @@ int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
     if (B <= 0) return fail(h, "soccdpt_occ_expand: empty batch");
+    ProfScope ps(h->prof, "occ_expand", 0.0, occ_cells(h->cfg) * (4.0 * B + 0.125), (hipStream_t)stream);
     return launch_occ_expand(h->cfg, dev_bits, B, dev_occ, (hipStream_t)stream, h->err);
 }
 
@@ -122,14 +131,57 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
     if (rc) return rc;
     const bool occ_on = h->cfg.compute_occ != 0;
     if (occ_on && !dev_occ_bits) return fail(h, "soccdpt_forward: compute_occ needs dev_occ_bits");
-    rc = launch_project(h->cfg, inv, seg, B, S, S, dev_inv_up, dev_seg_up, dev_points, occ_on ? dev_occ_bits : nullptr, 1,
-                        (hipStream_t)stream, h->err);
+    {
+        ProfScope ps(h->prof, "project_voxelise", 0.0, project_bytes(h->cfg, B, S, S, dev_inv_up, dev_seg_up, dev_points), (hipStream_t)stream);
+        rc = launch_project(h->cfg, inv, seg, B, S, S, dev_inv_up, dev_seg_up, dev_points, occ_on ? dev_occ_bits : nullptr, 1,
+                            (hipStream_t)stream, h->err);
+    }
     if (rc) return rc;
-    if (occ_on && dev_occ) rc = launch_occ_expand(h->cfg, dev_occ_bits, B, dev_occ, (hipStream_t)stream, h->err);
+    if (occ_on && dev_occ) {
+        ProfScope ps(h->prof, "occ_expand", 0.0, occ_cells(h->cfg) * (4.0 * B + 0.125), (hipStream_t)stream);
+        rc = launch_occ_expand(h->cfg, dev_occ_bits, B, dev_occ, (hipStream_t)stream, h->err);
+    }
     return rc;
 }
 
 int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
+
+int soccdpt_profile_enable(void* handle, int on) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    h->prof.on = on != 0;
+    h->prof.recs.clear();
+    h->prof.used = 0;
+    return 0;
+}
+
+int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entries, int* n_entries) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !out || !n_entries) return 1;
+    int n = 0;
+    for (const ProfRec& r : h->prof.recs) {
+        if (hipEventSynchronize(r.e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: event sync failed");
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: elapsed failed");
+        int k = 0;
+        for (; k < n; ++k)
+            if (!std::strcmp(out[k].name, r.name)) break;
+        if (k == n) {
+            if (n == max_entries) continue;
+            std::memset(&out[n], 0, sizeof(out[n]));
+            std::strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
+            ++n;
+        }
+        out[k].launches += 1;
+        out[k].ms += ms;
+        out[k].flops += r.flops;
+        out[k].bytes += r.bytes;
+    }
+    *n_entries = n;
+    h->prof.recs.clear();
+    h->prof.used = 0;
+    return 0;
+}
 
 int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     if (!a) return fail(nullptr, "soccdpt_op_igemm: null args");

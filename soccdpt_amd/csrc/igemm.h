@@ -46,5 +46,7 @@ struct IgemmDesc {
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);
+const char* igemm_family(const IgemmDesc& d);  // name of the kernel configuration launch_igemm picks
+inline double igemm_flops(const IgemmDesc& d) { return 2.0 * d.M * d.N * (double)d.taps * d.Cin; }
 
 }  // namespace soccdpt

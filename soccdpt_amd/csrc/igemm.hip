@@ -249,6 +249,11 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) 
     return 0;
 }
 
+const char* igemm_family(const IgemmDesc& d) {
+    if (d.N <= 32) return "igemm_bf16_128x32x64";
+    return (d.Cin % 64 == 0) ? "igemm_bf16_128x128x64" : "igemm_bf16_128x128x32";
+}
+
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.M <= 0 || d.N <= 0 || d.Cin <= 0 || !d.X || !d.Wt) { err = "igemm: bad descriptor"; return 1; }
     if (d.N % 4 != 0) { err = "igemm: N must be a multiple of 4"; return 1; }

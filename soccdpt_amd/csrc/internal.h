@@ -39,6 +39,45 @@ struct WeightSlot {
 
 struct Prepared;  // model.cpp
 
+// hipEvent pairs around launches (soccdpt_profile_enable); aggregated per kernel family on collect.
+struct ProfRec {
+    const char* name;
+    double flops, bytes;
+    hipEvent_t e0, e1;
+};
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    hipEvent_t get() {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            (void)hipEventCreate(&e);
+            pool.push_back(e);
+        }
+        return pool[used++];
+    }
+    ~Profiler() {
+        for (auto e : pool) (void)hipEventDestroy(e);
+    }
+};
+struct ProfScope {
+    Profiler* p;
+    hipStream_t st;
+    hipEvent_t e1 = nullptr;
+    ProfScope(Profiler& prof, const char* name, double flops, double bytes, hipStream_t s) : p(prof.on ? &prof : nullptr), st(s) {
+        if (!p) return;
+        hipEvent_t e0 = p->get();
+        e1 = p->get();
+        (void)hipEventRecord(e0, st);
+        p->recs.push_back(ProfRec{name, flops, bytes, e0, e1});
+    }
+    ~ProfScope() {
+        if (p) (void)hipEventRecord(e1, st);
+    }
+};
+
 struct Handle {
     soccdpt_config cfg;
     int device = 0;
@@ -51,6 +90,7 @@ struct Handle {
     Prepared* prep = nullptr;
     bool is_prepared = false;
     int launches = 0;
+    Profiler prof;
     ~Handle();
 };
 

@@ -375,37 +375,45 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
     const int F = h.cfg.features;
     int launches = 0;
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
+#define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
+    auto gemm = [&](const IgemmDesc& d) { PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------
+    { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, W(ENC + "patch_embed.proj.weight"), W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
-                           W(ENC + "patch_embed.norm.bias"), w.xf, w.xb, B, a.img, a.embed, st, err));
+                           W(ENC + "patch_embed.norm.bias"), w.xf, w.xb, B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
             IgemmDesc d;
             d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_bf16 = w.qkv;
-            RUN(launch_igemm(d, st, err));
-            RUN(launch_window_attention(w.qkv, bw.bias_acc, bw.scale, w.attn, B, res, wsz, a.shift(s, j), H, st, err));
+            RUN(gemm(d));
+            { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
+              RUN(launch_window_attention(w.qkv, bw.bias_acc, bw.scale, w.attn, B, res, wsz, a.shift(s, j), H, st, err)); }
             d = IgemmDesc();
             d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b; d.out_f32 = w.y;
-            RUN(launch_igemm(d, st, err));
-            RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, w.xb, nullptr, M, C, 1, res, st, err));
+            RUN(gemm(d));
+            { PROF("ln_residual", 0.0, (double)M * C * 14.0);
+              RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, w.xb, nullptr, M, C, 1, res, st, err)); }
             d = IgemmDesc();
             d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_bf16 = w.hbuf;
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
             d = IgemmDesc();
             d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b; d.out_f32 = w.y;
-            RUN(launch_igemm(d, st, err));
-            RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, w.xb, j == a.hooks[s] ? w.feat[s] : nullptr, M, C, 1, res, st, err));
+            RUN(gemm(d));
+            { PROF("ln_residual", 0.0, (double)M * C * 14.0);
+              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, w.xb, j == a.hooks[s] ? w.feat[s] : nullptr, M, C, 1, res, st, err)); }
         }
         if (s < 3) {
-            RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, st, err));
+            { PROF("merge_gather", 0.0, (double)M * C * 4.0);
+              RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, st, err)); }
             IgemmDesc d;
             d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
-            RUN(launch_igemm(d, st, err));
-            RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, w.xb, nullptr, M / 4, 2 * C, 0, res / 2, st, err));
+            RUN(gemm(d));
+            { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
+              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, w.xb, nullptr, M / 4, 2 * C, 0, res / 2, st, err)); }
         }
     }
     // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------
@@ -419,7 +427,7 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
         {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd bf16 halo (RCU conv1 input)
             IgemmDesc d = conv(w.feat[l], a.dim(l), P.layer_rn[l], F, r);
             d.out_f32 = w.lrn_raw[l]; d.out_bf16 = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
         }
         const float* fused_raw = w.lrn_raw[l];
         const bf16_t* fused_relu = w.lrn_relu[l];
@@ -427,11 +435,11 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
             const RcuW& u1 = P.rcu[l][0];
             IgemmDesc d = conv(w.lrn_relu[l], F, u1.w1, F, r);
             d.bias = u1.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
             d = conv(w.t_relu[l], F, u1.w2, F, r);
             d.bias = u1.b2; d.res1 = w.lrn_raw[l]; d.res2 = w.path[l];
             d.out_f32 = w.out_raw[l]; d.out_bf16 = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
             fused_raw = w.out_raw[l];
             fused_relu = w.out_relu[l];
         }
@@ -439,36 +447,41 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
             const RcuW& u2 = P.rcu[l][1];
             IgemmDesc d = conv(fused_relu, F, u2.w1, F, r);
             d.bias = u2.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
             d = conv(w.t_relu[l], F, u2.w2, F, r);
             d.bias = u2.b2; d.res1 = fused_raw; d.out_bf16 = w.u[l];
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
         }
         {   // out_conv (1x1) BEFORE the bilinear resize: both are linear and the interpolation weights sum to 1
             IgemmDesc d;
             d.X = w.u[l]; d.Wt = P.oc_w[l]; d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = P.oc_b[l]; d.out_f32 = w.oc[l];
-            RUN(launch_igemm(d, st, err));
+            RUN(gemm(d));
         }
-        if (l > 0) RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err));
-        else RUN(launch_bilinear(w.oc[0], 0, nullptr, w.path1, 1, B, r, r, 2 * r, 2 * r, F, st, err));
+        if (l > 0) { PROF("bilinear_resize", 0.0, (double)M * F * 4.0 * 5.0);
+                     RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err)); }
+        else { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
+               RUN(launch_bilinear(w.oc[0], 0, nullptr, w.path1, 1, B, r, r, 2 * r, 2 * r, F, st, err)); }
     }
     // ---------------- heads ----------------
     const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
     {
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
         d.bias = P.d0_b; d.out_bf16 = w.d1;
-        RUN(launch_igemm(d, st, err));
-        RUN(launch_bilinear(w.d1, 1, nullptr, w.d1u, 1, B, r1, r1, r0, r0, F / 2, st, err));
+        RUN(gemm(d));
+        { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
+          RUN(launch_bilinear(w.d1, 1, nullptr, w.d1u, 1, B, r1, r1, r0, r0, F / 2, st, err)); }
         d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
         d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
-        RUN(launch_igemm(d, st, err));
+        RUN(gemm(d));
         d = conv(w.path1, F, P.s0_w, F, r1);
         d.bias = P.bn_shift; d.act = ACT_RELU; d.out_bf16 = w.s1;
-        RUN(launch_igemm(d, st, err));
-        RUN(launch_seg_tail(w.s1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err));
+        RUN(gemm(d));
+        { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
+          RUN(launch_seg_tail(w.s1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
         ++launches;
     }
 #undef RUN
+#undef PROF
     h.launches = launches;
     return 0;
 }

@@ -1,0 +1,70 @@
+"""Data-parallel sharding of the SOccDPT_V3 forward over the GPUs of one node.
+
+One process per GPU.  Frames are independent through encoder, decoder, heads and back-projection; the
+only cross-frame coupling of the reference is the occupancy grid, which is the UNION over the whole batch
+written to every batch row (/root/reference/SOccDPT/model/SOccDPT.py:449-455).  Each rank therefore ORs
+its own frames into a bit-packed grid (786,432 B for 256x256x32x3) and the ranks exchange only those
+packed grids: one RCCL all-gather (backend "nccl" is RCCL on ROCm) followed by a local OR-reduce kernel and
+the bits->f32 expansion.  The dense 25 MB f32 grids never cross xGMI.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous batch shard [lo, hi) of `rank`; the first (global_batch % world) ranks get one extra frame."""
+    base, rem = divmod(global_batch, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_occ_bits(bits: torch.Tensor, group=None) -> torch.Tensor:
+    """All-gather the packed local grids: [words] int32 -> [world, words] int32 (same device)."""
+    world = dist.get_world_size(group)
+    out = torch.empty((world, bits.numel()), dtype=bits.dtype, device=bits.device)
+    dist.all_gather_into_tensor(out, bits.contiguous(), group=group)
+    return out
+
+
+class OccExchange:
+    """Callable installed as `net.occ_exchange`: local packed grid -> union over all ranks."""
+
+    def __init__(self, group=None, or_reduce: Optional[Callable] = None):
+        self.group = group
+        self._or_reduce = or_reduce  # tests on CPU (gloo) inject a reducer; on GPU the HIP kernel is used
+
+    def __call__(self, eng, bits: torch.Tensor) -> torch.Tensor:
+        gathered = gather_occ_bits(bits, self.group)
+        if self._or_reduce is not None:
+            return self._or_reduce(gathered)
+        union = torch.zeros_like(bits)
+        eng.occ_or(union, gathered, gathered.shape[0])
+        return union
+
+
+def init_from_env(backend: str = "nccl"):
+    """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
+    import os
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world
+
+
+def attach(net, group=None):
+    """Make `net` (SOccDPT / SOccDPT_V3) produce the union-over-all-ranks occupancy grid."""
+    if dist.is_initialized() and dist.get_world_size(group) > 1:
+        net.occ_exchange = OccExchange(group)
+    return net

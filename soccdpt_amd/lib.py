@@ -41,6 +41,11 @@ class SoccdptConfig(ctypes.Structure):
     ]
 
 
+class KernelStat(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("launches", ctypes.c_int32), ("ms", ctypes.c_double),
+                ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
+
+
 class IgemmArgs(ctypes.Structure):
     _fields_ = [
         ("x", ctypes.c_void_p), ("wt", ctypes.c_void_p),
@@ -100,6 +105,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_words.restype = cs
     L.soccdpt_last_launch_count.argtypes = [vp]
     L.soccdpt_last_launch_count.restype = ci
+    L.soccdpt_profile_enable.argtypes = [vp, ci]
+    L.soccdpt_profile_enable.restype = ci
+    L.soccdpt_profile_collect.argtypes = [vp, ctypes.POINTER(KernelStat), ci, ctypes.POINTER(ci)]
+    L.soccdpt_profile_collect.restype = ci
     L.soccdpt_op_igemm.argtypes = [ctypes.POINTER(IgemmArgs), vp]
     L.soccdpt_op_igemm.restype = ci
     L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
@@ -265,6 +274,17 @@ class Engine:
             self._check(self.L.soccdpt_forward(self._h, _ptr(x), B, _ptr(inv_up), _ptr(seg_up), _ptr(points), _ptr(occ),
                                                _ptr(occ_bits), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
                         "soccdpt_forward")
+
+    def profile_enable(self, on: bool = True):
+        self._check(self.L.soccdpt_profile_enable(self._h, 1 if on else 0), "soccdpt_profile_enable")
+
+    def profile_collect(self):
+        """-> {family: dict(launches, ms, flops, bytes)} summed over everything recorded since enable/collect."""
+        buf = (KernelStat * 64)()
+        n = ctypes.c_int(0)
+        self._check(self.L.soccdpt_profile_collect(self._h, buf, 64, ctypes.byref(n)), "soccdpt_profile_collect")
+        return {buf[i].name.decode(): dict(launches=buf[i].launches, ms=buf[i].ms, flops=buf[i].flops, bytes=buf[i].bytes)
+                for i in range(n.value)}
 
     def launch_count(self) -> int:
         return int(self.L.soccdpt_last_launch_count(self._h))
