@@ -155,6 +155,7 @@ typedef struct soccdpt_igemm_args {
     const float* dot_w;
     float dot_b;
     float* out_dot;
+    int32_t tune; /* kernel configuration id, -1 = library heuristic (benchmarking) */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 

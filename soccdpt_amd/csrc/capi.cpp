@@ -189,7 +189,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.X = static_cast<const bf16_t*>(a->x); d.Wt = static_cast<const bf16_t*>(a->wt);
     d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
-    d.out_bf16 = static_cast<bf16_t*>(a->out_bf16); d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot;
+    d.out_bf16 = static_cast<bf16_t*>(a->out_bf16); d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;

@@ -43,6 +43,7 @@ struct IgemmDesc {
     const float* dot_w = nullptr;
     float dot_b = 0.f;
     float* out_dot = nullptr;
+    int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);

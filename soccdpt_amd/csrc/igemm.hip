@@ -25,9 +25,9 @@ namespace soccdpt {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-template <int BM_, int BN_, int BK_, int WM_, int WN_>
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NS_>
 struct Cfg {
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_;
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NS = NS_;  // NS: LDS stages (tiles in flight + 1)
     static constexpr int THREADS = WM * WN * 64;
     static constexpr int ROWB = BK * 2;    // bytes per LDS tile row
     static constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
@@ -37,7 +37,9 @@ struct Cfg {
     static constexpr int W_LOADS = W_BYTES / 16 / THREADS;
     static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 tiles per wave
     static constexpr int KS = BK / 32;
+    static constexpr int LOADS = X_LOADS + W_LOADS;  // LDS-DMA instructions per thread per k-tile
     static_assert(X_LOADS * THREADS * 16 == X_BYTES && W_LOADS * THREADS * 16 == W_BYTES, "tile/threads mismatch");
+    static_assert(NS >= 2 && (NS - 2) * LOADS <= 63, "vmcnt immediate is 6 bits");
 };
 
 template <int BK>
@@ -143,12 +145,19 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         wr_off[ks] = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB + q;
     }
 
-    stage(0, 0);
-    __syncthreads();  // glds in flight -> the compiler drains vmcnt(0) before the barrier
+    // ---- NS-stage LDS ring: up to NS-1 k-tiles of LDS-DMA in flight, ONE raw barrier per k-tile.
+    // Tile kt is waited for with a COUNTED vmcnt (the NS-2 younger tiles stay in flight), then the barrier
+    // both publishes it to the other waves and retires everybody's reads of ring slot (kt-1)%NS, which the
+    // next LDS-DMA group overwrites.  (__syncthreads() would drain vmcnt(0): cdna_hip_programming.md §5.)
+#pragma unroll
+    for (int s0 = 0; s0 < C::NS - 1; ++s0)
+        if (s0 < nk) stage(s0, s0);
     for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) stage(kt + 1, buf ^ 1);
-        const char* sb = smem + buf * C::STAGE;
+        if (kt + C::NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::NS - 2) * C::LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
+        const char* sb = smem + (kt % C::NS) * C::STAGE;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
             bf16x8 wf[C::TN], xf[C::TM];
@@ -162,7 +171,6 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 for (int j = 0; j < C::TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
         }
-        __syncthreads();
     }
 
     // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
@@ -236,7 +244,7 @@ template <class C>
 static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int nk = d.taps * d.Cin / C::BK, kpt = d.Cin / C::BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
-    const size_t lds = 2 * C::STAGE;
+    const size_t lds = (size_t)C::NS * C::STAGE;
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -249,10 +257,36 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) 
     return 0;
 }
 
-const char* igemm_family(const IgemmDesc& d) {
-    if (d.N <= 32) return "igemm_bf16_128x32x64";
-    return (d.Cin % 64 == 0) ? "igemm_bf16_128x128x64" : "igemm_bf16_128x128x32";
+// Kernel configurations.  id: name                 tile        ring
+//   0  igemm_bf16_128x128x64_s4   big N, K%64==0    4 stages (128 KB LDS, 1 block/CU)
+//   1  igemm_bf16_128x128x64_s2                     2 stages ( 64 KB LDS, 2 blocks/CU)
+//   2  igemm_bf16_64x64x64_s4     small M*N grids   4 stages ( 64 KB)
+//   3  igemm_bf16_128x128x32_s4   K%64!=0 (C=96)    4 stages ( 64 KB)
+//   4  igemm_bf16_64x64x32_s4
+//   5  igemm_bf16_128x32x64_s4    N<=32 (depth head tail)
+static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_128x128x64_s2", "igemm_bf16_64x64x64_s4",
+                                        "igemm_bf16_128x128x32_s4", "igemm_bf16_64x64x32_s4", "igemm_bf16_128x32x64_s4",
+                                        "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
+                                        "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2"};
+
+static int pick_cfg(const IgemmDesc& d) {
+    // Measured on MI355X (tools/igemm_bench.py, profiles/r01_igemm_configs.txt): the kernel is bound by the per-CU
+    // L2->LDS fill rate, so take the LARGEST tile (most FLOPs per staged byte) that still fills the 256 CUs.
+    if (d.tune >= 0) return d.tune;
+    const bool k64 = (d.Cin % 64 == 0);
+    if (d.N <= 32) return 5;
+    auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
+    if (!k64) return b128 < 384 ? 4 : 9;
+    if (d.N % 256 == 0) {
+        if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
+        if (cdiv(d.M, 128) * (d.N / 256) >= 224) return 10;  // 128(M)x256(N)
+    }
+    if (b128 >= 384) return 1;
+    return 2;  // 64x64: 4x the blocks of 128x128
 }
+
+const char* igemm_family(const IgemmDesc& d) { return kCfgNames[pick_cfg(d)]; }
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.M <= 0 || d.N <= 0 || d.Cin <= 0 || !d.X || !d.Wt) { err = "igemm: bad descriptor"; return 1; }
@@ -262,13 +296,25 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
     if (d.out_halo && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output needs H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if (d.N <= 32) {
-        if (!k64) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
-        return launch_cfg<Cfg<128, 32, 64, 4, 1>>(d, stream, err);
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || id == 10) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
+    switch (id) {
+        case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
+        case 1: return launch_cfg<Cfg<128, 128, 64, 2, 2, 2>>(d, stream, err);
+        case 2: return launch_cfg<Cfg<64, 64, 64, 2, 2, 4>>(d, stream, err);
+        case 3: return launch_cfg<Cfg<128, 128, 32, 2, 2, 4>>(d, stream, err);
+        case 4: return launch_cfg<Cfg<64, 64, 32, 2, 2, 4>>(d, stream, err);
+        case 5: return launch_cfg<Cfg<128, 32, 64, 4, 1, 4>>(d, stream, err);
+        case 6: return launch_cfg<Cfg<256, 128, 64, 4, 2, 2>>(d, stream, err);
+        case 7: return launch_cfg<Cfg<256, 128, 64, 4, 2, 3>>(d, stream, err);
+        case 8: return launch_cfg<Cfg<256, 256, 64, 2, 4, 2>>(d, stream, err);
+        case 9: return launch_cfg<Cfg<128, 128, 32, 2, 2, 3>>(d, stream, err);
+        case 10: return launch_cfg<Cfg<128, 256, 64, 2, 4, 2>>(d, stream, err);
     }
-    if (k64) return launch_cfg<Cfg<128, 128, 64, 2, 2>>(d, stream, err);
-    return launch_cfg<Cfg<128, 128, 32, 2, 2>>(d, stream, err);
+    err = "igemm: unknown configuration id";
+    return 1;
 }
 
 }  // namespace soccdpt

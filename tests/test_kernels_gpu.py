@@ -45,6 +45,12 @@ def test_igemm_linear(gpu_device, M, N, K):
     torch.cuda.synchronize()
     torch.testing.assert_close(outb.float(), F.gelu(ref), rtol=1e-2, atol=1e-2)
     torch.testing.assert_close(out2, ref + res, rtol=1e-4, atol=1e-4)
+    # every kernel configuration that accepts this K must agree
+    for tune in ((0, 1, 2, 3, 4) if K % 64 == 0 else (3, 4)):
+        o = torch.empty(M, N, device=gpu_device)
+        op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_f32=o, tune=tune)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(o, ref, rtol=1e-4, atol=1e-4, msg=f"tune={tune}")
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 256, 256), (3, 8, 96, 256), (1, 32, 192, 256), (2, 16, 256, 128), (1, 8, 768, 256)])
@@ -69,6 +75,11 @@ def test_igemm_conv3x3(gpu_device, B, H, Cin, Cout):
     torch.testing.assert_close(out, full, rtol=1e-4, atol=2e-4)                 # raw f32 (pre-activation)
     torch.testing.assert_close(outh[:, 1:-1, 1:-1].float(), F.relu(full), rtol=1e-2, atol=1e-2)
     assert float(outh[:, 0].abs().max()) == 0 and float(outh[:, :, 0].abs().max()) == 0  # halo untouched
+    for tune in ((0, 1, 2, 3, 4) if Cin % 64 == 0 else (3, 4)):
+        o = torch.empty(B, H, H, Cout, device=gpu_device)
+        op_igemm(xh, wt, M, Cout, Cin, taps=9, H=H, W=H, bias=bias, out_f32=o, tune=tune)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(o, ref, rtol=1e-4, atol=2e-4, msg=f"tune={tune}")
 
 
 def test_igemm_depth_tail(gpu_device):
