@@ -25,9 +25,9 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
 def gather_occ_bits(bits: torch.Tensor, group=None) -> torch.Tensor:
     """All-gather the packed local grids: [words] int32 -> [world, words] int32 (same device)."""
     world = dist.get_world_size(group)
-    out = torch.empty((world, bits.numel()), dtype=bits.dtype, device=bits.device)
-    dist.all_gather_into_tensor(out, bits.contiguous(), group=group)
-    return out
+    flat = torch.empty((world * bits.numel(),), dtype=bits.dtype, device=bits.device)
+    dist.all_gather_into_tensor(flat, bits.contiguous().reshape(-1), group=group)
+    return flat.reshape(world, bits.numel())
 
 
 class OccExchange:

@@ -12,9 +12,9 @@ def proj_inputs(seed: int = 1234, B: int = 2, S: int = 256):
     inv = inv + torch.randn((B, S, S), generator=g) * 0.002
     inv[:, 5, 7] = 0.0           # clamp path (-> 1e-8 -> depth 1e8)
     inv[:, 9, 11:14] = -0.5      # negative -> clamp
-    inv[0, 100, 50] = float("nan")
-    inv[B - 1, 33, 200] = float("inf")
-    inv[B - 1, 34, 200] = 1e-12
+    inv[0, min(100, S - 1), 50] = float("nan")
+    inv[B - 1, 33, min(200, S - 1)] = float("inf")
+    inv[B - 1, 34, min(200, S - 1)] = 1e-12
     logits = torch.randn((B, 3, S, S), generator=g) * 6.0
     seg = 0.5 * torch.tanh(logits) + 0.5   # ScaledTanh -> exact zeros for logits << 0
     return inv.contiguous(), seg.contiguous()
