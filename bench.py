@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     args = ap.parse_args()
@@ -56,7 +58,8 @@ def main():
     import contextlib
     import io
     with contextlib.redirect_stdout(io.StringIO()):
-        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True)
+        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
+                         graph=not args.no_graph)
     sd = synth_state_dict(alias_pretrained=True)
     net.load_state_dict(sd, strict=False)
     net = net.eval().to(dev)
@@ -122,13 +125,24 @@ def main():
             roofline = dict(bound="hbm", kernel=fam, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
                             frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
                             avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2))
+        # HBM traffic per launch of the dominant kernel: PMC counters cannot be read inside this process; they come from
+        # the committed rocprofv3 --pmc passes over this same command (profiles/, tools/pmc_summary.py)
+        try:
+            import glob
+            pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))[-1]
+            pmc = json.load(open(pmc_file))["kernels"].get(fam)
+            if pmc:
+                roofline["traffic"] = round(pmc["hbm_bytes_per_launch"])
+                roofline["traffic_source"] = os.path.basename(pmc_file)
+        except Exception:
+            pass
         result = {
             "metric": "frames/sec SOccDPT_V3 swin2_tiny_256 @256px (depth+seg+points+occupancy forward)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "SOccDPT_V3 dpt_swin2_tiny_256 full forward, compute_occ=True, camera 1920x1080",
-                       "batch_per_gpu": B, "global_batch": B * world, "image": 256,
+                       "batch_per_gpu": B, "global_batch": B * world, "image": 256, "streams_per_gpu": args.streams, "hip_graph": not args.no_graph,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
             "roofline": roofline,

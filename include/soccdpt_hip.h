@@ -94,6 +94,16 @@ int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, voi
 int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, float* dev_seg_up, float* dev_points,
                     float* dev_occ, uint32_t* dev_occ_bits, void* dev_workspace, size_t workspace_bytes, void* stream);
 
+/* Frames are independent through the network: the batch of a call is dealt to `n` sub-batches (1..8) that run
+ * concurrently on the caller's stream plus n-1 library-owned streams, forked from and joined into the caller's
+ * stream with events (no host synchronisation; results are stream-ordered on the caller's stream).  Changes the
+ * workspace size/layout: query soccdpt_workspace_bytes again and hand over a zero-filled workspace. */
+int soccdpt_set_streams(void* handle, int n);
+/* on != 0: soccdpt_network / soccdpt_forward capture their launch sequence into a hipGraph the second time they
+ * see the same (x, outputs, workspace, B) pointers and replay it afterwards (one host launch per forward).  Callers
+ * that pass fresh pointers every call simply keep running eagerly. */
+int soccdpt_set_graph(void* handle, int on);
+
 /* ---- stage-level entry points (parity tests, multi-GPU composition) ---- */
 
 /* Encoder + decoder + heads: DPTDepthModel.forward + seg_head (model/dpt.py:142-232,

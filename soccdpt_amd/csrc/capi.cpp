@@ -146,6 +146,26 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
 
 int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
 
+int soccdpt_set_streams(void* handle, int n) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    return model_set_streams(*h, n, h->err);
+}
+
+int soccdpt_set_graph(void* handle, int on) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (on && !h->graph_stream) {
+        if (hipStreamCreateWithFlags(&h->graph_stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&h->graph_in, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&h->graph_out, hipEventDisableTiming) != hipSuccess)
+            return fail(h, "soccdpt_set_graph: stream/event creation failed");
+    }
+    h->use_graph = on != 0;
+    if (!h->use_graph) model_drop_graph(*h);
+    return 0;
+}
+
 int soccdpt_profile_enable(void* handle, int on) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;

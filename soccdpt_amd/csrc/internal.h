@@ -91,6 +91,21 @@ struct Handle {
     bool is_prepared = false;
     int launches = 0;
     Profiler prof;
+    int n_streams = 1;                     // sub-batches run concurrently on n_streams streams (caller's + internal)
+    std::vector<hipStream_t> sub_streams;  // n_streams - 1 internal non-blocking streams
+    std::vector<hipEvent_t> join_events;   // [0] fork, [i] join of sub-stream i
+    // hipGraph replay of soccdpt_network (soccdpt_set_graph): captured once per argument tuple
+    bool use_graph = false;
+    struct GraphKey {
+        const void *x = nullptr, *inv = nullptr, *seg = nullptr, *ws = nullptr;
+        int B = 0, streams = 0;
+        bool operator==(const GraphKey& o) const { return x == o.x && inv == o.inv && seg == o.seg && ws == o.ws && B == o.B && streams == o.streams; }
+    } graph_key;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t graph_stream = nullptr;  // capture/replay stream (the caller's may be the legacy null stream, which cannot capture)
+    hipEvent_t graph_in = nullptr, graph_out = nullptr;
+    int eager_calls = 0;  // calls seen with the current key before capture (the first one warms up lazy state)
     ~Handle();
 };
 
@@ -102,6 +117,8 @@ int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t stream, s
 int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t stream,
                   std::string& err);
 
+int model_set_streams(Handle& h, int n, std::string& err);
+void model_drop_graph(Handle& h);
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C);
 
 // projection.hip

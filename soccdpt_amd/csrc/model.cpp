@@ -42,7 +42,15 @@ struct Prepared {
     const float *s4_w, *s4_b;
 };
 
-Handle::~Handle() { delete prep; }
+Handle::~Handle() {
+    model_drop_graph(*this);
+    if (graph_stream) (void)hipStreamDestroy(graph_stream);
+    if (graph_in) (void)hipEventDestroy(graph_in);
+    if (graph_out) (void)hipEventDestroy(graph_out);
+    delete prep;
+    for (auto s : sub_streams) (void)hipStreamDestroy(s);
+    for (auto e : join_events) (void)hipEventDestroy(e);
+}
 
 namespace {
 
@@ -179,9 +187,6 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const Arch& a = h.arch;
     const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
     const size_t M0 = (size_t)B * G * G;
-    // head: network outputs (inv [B,S,S], seg [B,C,S,S]) when called through soccdpt_forward.  Always reserved, so the
-    // zero-halo images occupy the same bytes whichever entry point runs (their borders must stay zero).
-    ar.take<float>((size_t)B * h.img * h.img * (1 + h.cfg.num_classes));
     w.xf = ar.take<float>(M0 * C0);
     w.y = ar.take<float>(M0 * C0);
     w.xb = ar.take<bf16_t>(M0 * C0);
@@ -214,6 +219,8 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
 }
 
 }  // namespace
+
+static void carve_all(const Handle& h, int B, Arena& ar, std::vector<Workspace>& ws);
 
 int model_init(Handle& h, std::string& err) {
     Arch a;
@@ -320,18 +327,14 @@ int model_bind(Handle& h, const char* key, const void* ptr, const int64_t* shape
     return 0;
 }
 
-size_t model_workspace_bytes(Handle& h, int B) {
-    Arena ar(nullptr, 0);
-    Workspace w;
-    carve(h, B, ar, w);
-    return ar.off + 256;
-}
 
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C) {
     char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);  // only offsets are used
     Arena ar(fake, ~size_t(0) >> 1);
-    Workspace w;
-    carve(h, B, ar, w);
+    std::vector<Workspace> wsp;
+    carve_all(h, B, ar, wsp);
+    if (wsp.size() != 1) return 2;  // taps are defined for the single-stream layout (set streams to 1 for diagnostics)
+    const Workspace& w = wsp[0];
     const Arch& a = h.arch;
     const std::string n(name);
     auto set = [&](const void* p, size_t e, int k, int hh, int ww, int cc) {
@@ -359,21 +362,16 @@ int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t st, std::
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { err = std::string("soccdpt_prepare: ") + hipGetErrorString(e); return 1; }
     h.is_prepared = true;
+    model_drop_graph(h);  // the captured kernel arguments point into the old prepared arena
     return 0;
 }
 
-int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t st,
-                  std::string& err) {
-    if (!h.is_prepared) { err = "soccdpt_network: call soccdpt_prepare after binding weights"; return 1; }
-    if (B <= 0 || !x || !inv256 || !seg256) { err = "soccdpt_network: bad argument"; return 1; }
+// The whole network for one contiguous sub-batch on one stream.
+static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float* inv256, float* seg256, hipStream_t st, int& launches,
+                     std::string& err) {
     const Arch& a = h.arch;
     const Prepared& P = *h.prep;
-    Arena ar(ws, ws_bytes);
-    Workspace w;
-    carve(h, B, ar, w);
-    if (ar.off > ws_bytes) { err = "soccdpt_network: workspace too small"; return 1; }
     const int F = h.cfg.features;
-    int launches = 0;
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](const IgemmDesc& d) { PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
@@ -482,7 +480,149 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
     }
 #undef RUN
 #undef PROF
+    return 0;
+}
+
+// Sub-batch split: frames [lo, hi) of chunk i when B frames are dealt to n chunks.
+static void chunk_range(int B, int n, int i, int& lo, int& hi) {
+    const int base = B / n, rem = B % n;
+    lo = i * base + (i < rem ? i : rem);
+    hi = lo + base + (i < rem ? 1 : 0);
+}
+
+static int n_chunks(const Handle& h, int B) {
+    int n = h.n_streams < 1 ? 1 : h.n_streams;
+    return n > B ? B : n;
+}
+
+static void carve_all(const Handle& h, int B, Arena& ar, std::vector<Workspace>& ws) {
+    // head: network outputs (inv [B,S,S], seg [B,C,S,S]) when called through soccdpt_forward.  Always reserved, so the
+    // zero-halo images occupy the same bytes whichever entry point runs (their borders must stay zero).
+    ar.take<float>((size_t)B * h.img * h.img * (1 + h.cfg.num_classes));
+    const int n = n_chunks(h, B);
+    ws.resize(n);
+    for (int i = 0; i < n; ++i) {
+        int lo, hi;
+        chunk_range(B, n, i, lo, hi);
+        carve(h, hi - lo, ar, ws[i]);
+    }
+}
+
+size_t model_workspace_bytes(Handle& h, int B) {
+    Arena ar(nullptr, 0);
+    std::vector<Workspace> ws;
+    carve_all(h, B, ar, ws);
+    return ar.off + 256;
+}
+
+int model_set_streams(Handle& h, int n, std::string& err) {
+    if (n < 1 || n > 8) { err = "soccdpt_set_streams: n must be in 1..8"; return 1; }
+    while ((int)h.sub_streams.size() < n - 1) {
+        hipStream_t s;
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) { err = "soccdpt_set_streams: stream creation failed"; return 1; }
+        h.sub_streams.push_back(s);
+    }
+    while ((int)h.join_events.size() < n) {
+        hipEvent_t e;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { err = "soccdpt_set_streams: event creation failed"; return 1; }
+        h.join_events.push_back(e);
+    }
+    h.n_streams = n;
+    model_drop_graph(h);
+    return 0;
+}
+
+// Frames are independent through the whole network, so the batch is dealt to n_streams sub-batches that run
+// CONCURRENTLY on internal streams (fork from / join into the caller's stream with events; no host sync).  The
+// encoder's and the coarse decoder levels' launches are latency-bound at small M, and co-scheduling independent
+// sub-batches fills the CUs they leave idle (measured: profiles/).
+static int network_eager(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t st,
+                         std::string& err) {
+    Arena ar(ws, ws_bytes);
+    std::vector<Workspace> wsp;
+    carve_all(h, B, ar, wsp);
+    if (ar.off > ws_bytes) { err = "soccdpt_network: workspace too small"; return 1; }
+    const int n = (int)wsp.size();
+    const size_t S2 = (size_t)h.img * h.img;
+    int launches = 0;
+    if (n == 1) {
+        if (run_chunk(h, wsp[0], x, B, inv256, seg256, st, launches, err)) return 1;
+        h.launches = launches;
+        return 0;
+    }
+    hipEvent_t fork = h.join_events[0];
+    if (hipEventRecord(fork, st) != hipSuccess) { err = "soccdpt_network: event record failed"; return 1; }
+    for (int i = 0; i < n; ++i) {
+        int lo, hi;
+        chunk_range(B, n, i, lo, hi);
+        hipStream_t cs = (i == 0) ? st : h.sub_streams[i - 1];
+        if (i > 0 && hipStreamWaitEvent(cs, fork, 0) != hipSuccess) { err = "soccdpt_network: stream wait failed"; return 1; }
+        if (run_chunk(h, wsp[i], x + (size_t)lo * 3 * S2, hi - lo, inv256 + (size_t)lo * S2, seg256 + (size_t)lo * h.cfg.num_classes * S2, cs,
+                      launches, err))
+            return 1;
+        if (i > 0) {
+            if (hipEventRecord(h.join_events[i], cs) != hipSuccess || hipStreamWaitEvent(st, h.join_events[i], 0) != hipSuccess) {
+                err = "soccdpt_network: join failed";
+                return 1;
+            }
+        }
+    }
     h.launches = launches;
+    return 0;
+}
+
+void model_drop_graph(Handle& h) {
+    if (h.graph_exec) (void)hipGraphExecDestroy(h.graph_exec);
+    if (h.graph) (void)hipGraphDestroy(h.graph);
+    h.graph_exec = nullptr;
+    h.graph = nullptr;
+    h.eager_calls = 0;
+}
+
+// With soccdpt_set_graph the launch sequence (all sub-batch streams, fork/join edges included) is captured into a
+// hipGraph the second time the same argument tuple is seen and replayed afterwards: ~130-1000 host launches per
+// forward become one graph launch, which is what lets the concurrent sub-batches actually overlap on the GPU
+// instead of being serialised by the host's launch rate.
+int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t st,
+                  std::string& err) {
+    if (!h.is_prepared) { err = "soccdpt_network: call soccdpt_prepare after binding weights"; return 1; }
+    if (B <= 0 || !x || !inv256 || !seg256) { err = "soccdpt_network: bad argument"; return 1; }
+    if (!h.use_graph || h.prof.on) return network_eager(h, x, B, inv256, seg256, ws, ws_bytes, st, err);
+    Handle::GraphKey key;
+    key.x = x; key.inv = inv256; key.seg = seg256; key.ws = ws; key.B = B; key.streams = h.n_streams;
+    if (!(key == h.graph_key)) {
+        model_drop_graph(h);
+        h.graph_key = key;
+    }
+    if (h.eager_calls++ == 0 && !h.graph_exec) return network_eager(h, x, B, inv256, seg256, ws, ws_bytes, st, err);  // warms lazy state
+    // run on the library's capture stream, ordered after / before the caller's stream by two events
+    hipStream_t cs = h.graph_stream;
+    if (hipEventRecord(h.graph_in, st) != hipSuccess || hipStreamWaitEvent(cs, h.graph_in, 0) != hipSuccess) {
+        err = "soccdpt_network: graph fork failed";
+        return 1;
+    }
+    if (!h.graph_exec) {
+        if (hipStreamBeginCapture(cs, hipStreamCaptureModeThreadLocal) != hipSuccess) { err = "soccdpt_network: begin capture failed"; return 1; }
+        const int rc = network_eager(h, x, B, inv256, seg256, ws, ws_bytes, cs, err);
+        hipGraph_t g = nullptr;
+        const hipError_t ec = hipStreamEndCapture(cs, &g);
+        if (rc || ec != hipSuccess || !g) {
+            if (g) (void)hipGraphDestroy(g);
+            if (!rc) err = std::string("soccdpt_network: end capture failed: ") + hipGetErrorString(ec);
+            return 1;
+        }
+        h.graph = g;
+        if (hipGraphInstantiate(&h.graph_exec, g, nullptr, nullptr, 0) != hipSuccess) {
+            model_drop_graph(h);
+            err = "soccdpt_network: graph instantiate failed";
+            return 1;
+        }
+    }
+    if (hipGraphLaunch(h.graph_exec, cs) != hipSuccess) { err = "soccdpt_network: hipGraphLaunch failed"; return 1; }
+    if (hipEventRecord(h.graph_out, cs) != hipSuccess || hipStreamWaitEvent(st, h.graph_out, 0) != hipSuccess) {
+        err = "soccdpt_network: graph join failed";
+        return 1;
+    }
     return 0;
 }
 

@@ -106,6 +106,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_words.restype = cs
     L.soccdpt_last_launch_count.argtypes = [vp]
     L.soccdpt_last_launch_count.restype = ci
+    L.soccdpt_set_streams.argtypes = [vp, ci]
+    L.soccdpt_set_streams.restype = ci
+    L.soccdpt_set_graph.argtypes = [vp, ci]
+    L.soccdpt_set_graph.restype = ci
     L.soccdpt_profile_enable.argtypes = [vp, ci]
     L.soccdpt_profile_enable.restype = ci
     L.soccdpt_profile_collect.argtypes = [vp, ctypes.POINTER(KernelStat), ci, ctypes.POINTER(ci)]
@@ -275,6 +279,15 @@ class Engine:
             self._check(self.L.soccdpt_forward(self._h, _ptr(x), B, _ptr(inv_up), _ptr(seg_up), _ptr(points), _ptr(occ),
                                                _ptr(occ_bits), ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
                         "soccdpt_forward")
+
+    def set_streams(self, n: int):
+        """Deal each batch to n concurrent sub-batches (see soccdpt_set_streams); invalidates the workspace."""
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_set_streams(self._h, int(n)), "soccdpt_set_streams")
+        self._workspace = None
+
+    def set_graph(self, on: bool = True):
+        self._check(self.L.soccdpt_set_graph(self._h, 1 if on else 0), "soccdpt_set_graph")
 
     def profile_enable(self, on: bool = True):
         self._check(self.L.soccdpt_profile_enable(self._h, 1 if on else 0), "soccdpt_profile_enable")

@@ -39,7 +39,7 @@ class SOccDPT(BaseModel):
                  camera_intrinsics_yaml=DEFAULT_CALIB, point_compute_method="torch",
                  grid_size=(256, 256, 32), scale=(2.0, 2.0, 0.666), shift=(0.0, 0.0, 0.0),
                  pc_scale=(10000.0, 50000.0, 800.0), pc_shift=(55.0, -20.0, 15.0), correction_angle=(7.0, 0, 0),
-                 compute_occ=False, precision: int = PREC_BF16, **kwargs):
+                 compute_occ=False, precision: int = PREC_BF16, streams: int = 1, graph: bool = False, **kwargs):
         super().__init__()
         self.compute_occ = compute_occ
         self.grid_size = grid_size
@@ -53,6 +53,8 @@ class SOccDPT(BaseModel):
         self.path = path
         self.num_classes = num_classes
         self.precision = precision
+        self.streams = int(streams)  # sub-batches of one forward run concurrently on this many HIP streams
+        self.graph = bool(graph)     # replay the network's launch sequence as a hipGraph when pointers repeat
         self.occupancy_shape = np.array([float(grid_size[i] / scale[i]) for i in range(len(grid_size))], dtype=np.float32)
         self.features = kwargs["features"] if "features" in kwargs else 256
         assert point_compute_method in ("torch", "numpy")
@@ -103,6 +105,10 @@ class SOccDPT(BaseModel):
                               self.grid_size, self.occupancy_shape, self.pc_scale, self.pc_shift, self.correction_angle,
                               precision=self.precision)
             eng = Engine(cfg, torch.device(key[0], key[1]))
+            if self.streams > 1:
+                eng.set_streams(self.streams)
+            if self.graph:
+                eng.set_graph(True)
             self._engines[key] = eng
         return eng
 
