@@ -26,6 +26,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_TFLOPS = 157.3     # f32-input MFMA (same table)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
 
 
@@ -35,8 +36,10 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
-    ap.add_argument("--streams", type=int, default=4, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
-    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a captured hipGraph")
+    ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
+    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
+                    help="bf16: bf16 MFMA operands (BASELINE config); f32: exact-f32 parity mode (1/16 MFMA rate)")
+    ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     args = ap.parse_args()
@@ -59,7 +62,7 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
-                         graph=not args.no_graph)
+                         graph=args.graph, precision=(1 if args.precision == "f32" else 0))
     sd = synth_state_dict(alias_pretrained=True)
     net.load_state_dict(sd, strict=False)
     net = net.eval().to(dev)
@@ -116,8 +119,9 @@ def main():
             kernels.append(k)
         if dom["flops"] > 0:
             ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                            frac=round(ach / PEAK_BF16_TFLOPS, 4), traffic=None,
+            peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_BF16_TFLOPS
+            roofline = dict(bound="mfma", kernel=fam, achieved=round(ach, 2), peak=peak, unit="TFLOP/s",
+                            frac=round(ach / peak, 4), traffic=None,
                             avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2),
                             flops_per_step=dom["flops"] / prof_steps, launches_per_step=dom["launches"] / prof_steps)
         else:
@@ -140,9 +144,9 @@ def main():
             "metric": "frames/sec SOccDPT_V3 swin2_tiny_256 @256px (depth+seg+points+occupancy forward)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": "SOccDPT_V3 dpt_swin2_tiny_256 full forward, compute_occ=True, camera 1920x1080",
-                       "batch_per_gpu": B, "global_batch": B * world, "image": 256, "streams_per_gpu": args.streams, "hip_graph": not args.no_graph,
+                       "batch_per_gpu": B, "global_batch": B * world, "image": 256, "streams_per_gpu": args.streams, "hip_graph": args.graph,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
             "roofline": roofline,

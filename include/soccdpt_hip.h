@@ -36,8 +36,9 @@ extern "C" {
 #define SOCCDPT_DTYPE_F32 0
 
 /* arithmetic of the encoder/decoder GEMMs and convolutions */
-#define SOCCDPT_PREC_BF16 0   /* bf16 MFMA operands, fp32 accumulate */
-#define SOCCDPT_PREC_BF16X3 1 /* split-bf16 (hi+lo) operands, 3 MFMAs per product: ~fp32 */
+#define SOCCDPT_PREC_BF16 0 /* bf16 MFMA operands, f32 accumulate (the benchmarked configuration) */
+#define SOCCDPT_PREC_F32 1  /* f32 operands, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32): the parity mode,
+                               1/16 of the bf16 MFMA rate */
 
 /* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
 typedef struct soccdpt_config {
@@ -166,6 +167,7 @@ typedef struct soccdpt_igemm_args {
     float dot_b;
     float* out_dot;
     int32_t tune; /* kernel configuration id, -1 = library heuristic (benchmarking) */
+    int32_t f32;  /* != 0: x, wt and out_bf16 hold f32 elements; exact-f32 MFMA (SOCCDPT_PREC_F32) */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 
@@ -177,7 +179,7 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
 
 /* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
  * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "xf" (final stage tokens f32).
- * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC.  Returns non-zero for unknown names. */
+ * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC.  Returns non-zero for unknown names. */
 int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind,
                              int* H, int* W, int* C);
 

@@ -197,6 +197,145 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact-f32 variant (SOCCDPT_PREC_F32, the parity mode): same decomposition with v_mfma_f32_32x32x2_f32.
+// q,k,v are f32 [M][3C]; Q-hat/K-hat rows are padded to 33 floats and V^T rows to N+1 floats (conflict-free
+// ds_read_b32); S^T accumulators feed O^T = V^T P^T directly: for accumulator register r the two lane halves
+// hold keys 32t + (r&3) + 8(r>>2) + 4h, which is exactly one K=2 MFMA step.
+// ---------------------------------------------------------------------------------------------
+template <int WS>
+struct AttnCfgF32 {
+    static constexpr int N = WS * WS;
+    static constexpr int WAVES = N / 64;
+    static constexpr int THREADS = WAVES * 64;
+    static constexpr int KT = N / 32, QB = N / 32;
+    static constexpr int QK_STRIDE = 33;     // floats
+    static constexpr int VT_STRIDE = N + 1;  // floats
+    static constexpr int LDS = (2 * N * QK_STRIDE + 32 * VT_STRIDE) * 4;
+};
+
+template <int WS>
+__global__ __launch_bounds__(AttnCfgF32<WS>::THREADS) void window_attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_acc,
+                                                                                       const float* __restrict__ scale, float* __restrict__ out,
+                                                                                       int res, int shift, int heads) {
+    using A = AttnCfgF32<WS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* Qs = reinterpret_cast<float*>(smem);
+    float* Ks = Qs + A::N * A::QK_STRIDE;
+    float* Vt = Ks + A::N * A::QK_STRIDE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * 32;
+    const int nw = res / WS;
+    int bid = blockIdx.x;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const float hscale = scale[head];
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / WS, c = p % WS;
+        int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+#pragma unroll
+    for (int it = 0; it < (A::N * 4) / A::THREADS; ++it) {
+        const int idx = it * A::THREADS + tid;
+        const int p = idx >> 2, c = idx & 3;
+        const float* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
+        float qf[8], kf[8], vf[8];
+        *reinterpret_cast<float4*>(qf) = *reinterpret_cast<const float4*>(src);
+        *reinterpret_cast<float4*>(qf + 4) = *reinterpret_cast<const float4*>(src + 4);
+        *reinterpret_cast<float4*>(kf) = *reinterpret_cast<const float4*>(src + C);
+        *reinterpret_cast<float4*>(kf + 4) = *reinterpret_cast<const float4*>(src + C + 4);
+        *reinterpret_cast<float4*>(vf) = *reinterpret_cast<const float4*>(src + 2 * C);
+        *reinterpret_cast<float4*>(vf + 4) = *reinterpret_cast<const float4*>(src + 2 * C + 4);
+        float qs = 0.f, ks = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            qs += qf[j] * qf[j];
+            ks += kf[j] * kf[j];
+        }
+        qs += __shfl_xor(qs, 1);
+        qs += __shfl_xor(qs, 2);
+        ks += __shfl_xor(ks, 1);
+        ks += __shfl_xor(ks, 2);
+        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
+        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            Qs[p * A::QK_STRIDE + c * 8 + j] = qf[j] * qi;
+            Ks[p * A::QK_STRIDE + c * 8 + j] = kf[j] * ki;
+            Vt[(c * 8 + j) * A::VT_STRIDE + p] = vf[j];
+        }
+    }
+    __syncthreads();
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+#pragma unroll 1
+    for (int qbi = 0; qbi < 2; ++qbi) {
+        const int qb = wave * 2 + qbi;
+        const int qrow = qb * 32 + r32;
+        float qfrag[16];
+#pragma unroll
+        for (int st = 0; st < 16; ++st) qfrag[st] = Qs[qrow * A::QK_STRIDE + 2 * st + h];
+        f32x16 s[A::KT];
+        const float* bp = bias_acc + ((size_t)(head * A::QB + qb) * A::KT) * 1024 + lane * 16;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t) {
+            const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)t * 1024);
+            const float4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+            f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+            if constexpr (WS == 16) {
+                if (lastrow || lastcol) {
+                    const bool rowdiff = lastrow && ((t >= 4) != (qb >= 4));
+                    const bool qc = (lane >> 3) & 1;
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const bool kc = (rg >> 2) & 1;
+                        if (rowdiff || (lastcol && (kc != qc))) acc[rg] += -100.0f;
+                    }
+                }
+            }
+            const float* krow = Ks + (t * 32 + r32) * A::QK_STRIDE + h;
+#pragma unroll
+            for (int st = 0; st < 16; ++st) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(krow[2 * st], qfrag[st], acc, 0, 0, 0);
+            s[t] = acc;
+        }
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) mx = fmaxf(mx, s[t][rg]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float sum = 0.f;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const float e = expf(s[t][rg] - mx);
+                s[t][rg] = e;
+                sum += e;
+            }
+        sum += __shfl_xor(sum, 32);
+        f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* vrow = Vt + r32 * A::VT_STRIDE + 4 * h;
+#pragma unroll
+        for (int t = 0; t < A::KT; ++t)
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg)
+                o = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32 + (rg & 3) + 8 * (rg >> 2)], s[t][rg], o, 0, 0, 0);
+        const float inv = 1.0f / sum;
+        float* orow = out + token_row(qrow) * (size_t)C + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+    }
+}
+
 // CPB bias in accumulator order: [head][qb][t][lane][16]; value for query 32qb+(lane&31),
 // key 32t + (reg&3) + 8(reg>>2) + 4(lane>>5)
 __global__ void attn_bias_kernel(const float* __restrict__ table, float* __restrict__ bias_acc, int ws, int heads) {
@@ -224,6 +363,29 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(attn_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, table, bias_acc, ws, heads);
     return check_launch("attn_bias", err);
+}
+
+int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* scale, float* out, int B, int res, int ws, int shift,
+                                int heads, hipStream_t st, std::string& err) {
+    if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
+    const int nw = res / ws;
+    const unsigned blocks = (unsigned)(B * nw * nw * heads);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_f32_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnCfgF32<16>::LDS);
+        attr_done = true;
+    }
+    if (ws == 16) {
+        using A = AttnCfgF32<16>;
+        hipLaunchKernelGGL((window_attention_f32_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+    } else if (ws == 8 && shift == 0) {
+        using A = AttnCfgF32<8>;
+        hipLaunchKernelGGL((window_attention_f32_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+    } else {
+        err = "window_attention_f32: window size not instantiated (16 and unshifted 8 are)";
+        return 1;
+    }
+    return check_launch("window_attention_f32", err);
 }
 
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,

@@ -33,6 +33,7 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
     if (cfg->num_classes != 3) return fail(nullptr, "soccdpt_create: num_classes must be 3 (model/SOccDPT.py:347-349)");
     if (cfg->features != 256) return fail(nullptr, "soccdpt_create: features must be 256");
     if (cfg->cam_width <= 0 || cfg->cam_height <= 0) return fail(nullptr, "soccdpt_create: bad camera size");
+    if (cfg->precision != SOCCDPT_PREC_BF16 && cfg->precision != SOCCDPT_PREC_F32) return fail(nullptr, "soccdpt_create: unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
@@ -206,10 +207,10 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
 int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     if (!a) return fail(nullptr, "soccdpt_op_igemm: null args");
     IgemmDesc d;
-    d.X = static_cast<const bf16_t*>(a->x); d.Wt = static_cast<const bf16_t*>(a->wt);
+    d.X = a->x; d.Wt = a->wt;
     d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
-    d.out_bf16 = static_cast<bf16_t*>(a->out_bf16); d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
+    d.out_op = a->out_bf16; d.f32 = a->f32; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;

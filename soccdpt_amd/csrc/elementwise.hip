@@ -59,12 +59,12 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
         if (lane < C0) {
             const float y = d0 * rstd * g[lane] + beta[lane];
             xf[(size_t)tok * C0 + lane] = y;
-            xb[(size_t)tok * C0 + lane] = f2bf(y);
+            if (xb) xb[(size_t)tok * C0 + lane] = f2bf(y);
         }
         if (lane + 64 < C0) {
             const float y = d1 * rstd * g[lane + 64] + beta[lane + 64];
             xf[(size_t)tok * C0 + lane + 64] = y;
-            xb[(size_t)tok * C0 + lane + 64] = f2bf(y);
+            if (xb) xb[(size_t)tok * C0 + lane + 64] = f2bf(y);
         }
     }
 }
@@ -89,8 +89,8 @@ int launch_patch_embed(const float* x, const float* w, const float* bias, const 
 template <int VPL>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
-                                                           bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, int M, int C, int residual,
-                                                           int res /*spatial size for halo*/) {
+                                                           bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
+                                                           int C, int residual, int res /*spatial size for halo*/) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
     size_t hoff = 0;
-    if (halo) {
+    if (halo || halo_f32) {
         const int hw = res * res, b = row / hw, r = row - b * hw, yy = r / res, xx = r - yy * res;
         hoff = ((size_t)(b * (res + 2) + yy + 1) * (res + 2) + xx + 1) * C;
     }
@@ -126,17 +126,18 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
             if (residual) o += xf[(size_t)row * C + c];
             xf[(size_t)row * C + c] = o;
             const bf16_t ob = f2bf(o);
-            xb[(size_t)row * C + c] = ob;
+            if (xb) xb[(size_t)row * C + c] = ob;
             if (halo) halo[hoff + c] = ob;
+            if (halo_f32) halo_f32[hoff + c] = o;
         }
     }
 }
 
-int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, int M, int C,
+int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int M, int C,
                        int residual, int res, hipStream_t st, std::string& err) {
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
-#define LN_CASE(V) hipLaunchKernelGGL((ln_residual_kernel<V>), grid, block, 0, st, y, g, beta, xf, xb, halo, M, C, residual, res)
+#define LN_CASE(V) hipLaunchKernelGGL((ln_residual_kernel<V>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);
     else if (vpl <= 8) LN_CASE(8);
@@ -151,8 +152,7 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
 // PatchMerging gather (timm PatchMerging; HF modeling_swinv2.py:333-352): [B,R,R,C] bf16 ->
 // [B,R/2,R/2,4C] with channel blocks (0,0),(1,0),(0,1),(1,1).  16-byte chunks.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void merge_gather_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out, int B, int R, int C) {
-    const int cpt = C / 8;  // 16-byte chunks per source token
+__global__ __launch_bounds__(256) void merge_gather_kernel(const uint4* __restrict__ in, uint4* __restrict__ out, int B, int R, int cpt /*16-byte chunks per token*/) {
     const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * cpt;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int ch = (int)(i % cpt);
@@ -165,16 +165,16 @@ __global__ __launch_bounds__(256) void merge_gather_kernel(const bf16_t* __restr
         const int oy = (int)(r % R2);
         const int b = (int)(r / R2);
         const int dy = blk & 1, dx = blk >> 1;  // block order: (0,0),(1,0),(0,1),(1,1) = (dy,dx)
-        const uint4 v = *reinterpret_cast<const uint4*>(in + ((size_t)(b * R + 2 * oy + dy) * R + 2 * ox + dx) * C + ch * 8);
-        *reinterpret_cast<uint4*>(out + i * 8) = v;
+        out[i] = in[((size_t)(b * R + 2 * oy + dy) * R + 2 * ox + dx) * cpt + ch];
     }
 }
 
-int launch_merge_gather(const bf16_t* in, bf16_t* out, int B, int R, int C, hipStream_t st, std::string& err) {
-    const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * (C / 8);
+int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err) {
+    const int cpt = C * elem_bytes / 16;
+    const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * cpt;
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, B, R, C);
+    hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(in), static_cast<uint4*>(out), B, R, cpt);
     return check_launch("merge_gather", err);
 }
 
@@ -197,7 +197,7 @@ __device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
 
 template <typename TIn>
 __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ in, float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16,
-                                                        int out_halo, int B, int h, int w, int H, int W, int C) {
+                                                        float* __restrict__ out_f32_halo, int out_halo, int B, int h, int w, int H, int W, int C) {
     const int c4 = C / 4;
     const size_t total = (size_t)B * H * W * c4;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ i
         o.w = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
         const size_t pix = ((size_t)b * H + oy) * W + ox;
         if (out_f32) *reinterpret_cast<float4*>(out_f32 + pix * C + cc) = o;
+        if (out_f32_halo) *reinterpret_cast<float4*>(out_f32_halo + ((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) = o;
         if (out_bf16) {
             const size_t off = out_halo ? (((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) : (pix * C + cc);
             uint2 p;
@@ -236,16 +237,16 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ i
     }
 }
 
-int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, int out_halo, int B, int h, int w, int H, int W,
-                    int C, hipStream_t st, std::string& err) {
+int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int B, int h, int w,
+                    int H, int W, int C, hipStream_t st, std::string& err) {
     if (C % 4) { err = "bilinear: C % 4 != 0"; return 1; }
     const size_t total = (size_t)B * H * W * (C / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (in_is_bf16)
-        hipLaunchKernelGGL((bilinear_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)in, out_f32, out_bf16, out_halo, B, h, w, H, W, C);
+        hipLaunchKernelGGL((bilinear_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C);
     else
-        hipLaunchKernelGGL((bilinear_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)in, out_f32, out_bf16, out_halo, B, h, w, H, W, C);
+        hipLaunchKernelGGL((bilinear_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C);
     return check_launch("bilinear", err);
 }
 
@@ -285,6 +286,34 @@ __global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restric
     }
 }
 
+__global__ __launch_bounds__(256) void conv1x1_c3_f32_kernel(const float* __restrict__ in, const float* __restrict__ w, const float* __restrict__ bias,
+                                                              float* __restrict__ out, int M) {
+    const int sub = threadIdx.x & 15;
+    const size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    if (pix >= (size_t)M) return;
+    const float* p = in + pix * 256 + sub * 16;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; k += 4) {
+        const float4 v = *reinterpret_cast<const float4*>(p + k);
+        const int c = sub * 16 + k;
+        s0 += v.x * w[c] + v.y * w[c + 1] + v.z * w[c + 2] + v.w * w[c + 3];
+        s1 += v.x * w[256 + c] + v.y * w[256 + c + 1] + v.z * w[256 + c + 2] + v.w * w[256 + c + 3];
+        s2 += v.x * w[512 + c] + v.y * w[512 + c + 1] + v.z * w[512 + c + 2] + v.w * w[512 + c + 3];
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        s0 += __shfl_xor(s0, o);
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (sub == 0) {
+        out[pix * 3 + 0] = s0 + bias[0];
+        out[pix * 3 + 1] = s1 + bias[1];
+        out[pix * 3 + 2] = s2 + bias[2];
+    }
+}
+
 __global__ __launch_bounds__(256) void seg_up_act_kernel(const float* __restrict__ in /*[B,h,w,3]*/, float* __restrict__ out /*[B,3,H,W]*/, int B,
                                                           int h, int w, int sigmoid) {
     const int H = 2 * h, W = 2 * w;
@@ -309,10 +338,12 @@ __global__ __launch_bounds__(256) void seg_up_act_kernel(const float* __restrict
     }
 }
 
-int launch_seg_tail(const bf16_t* feat, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd, int sigmoid,
-                    hipStream_t st, std::string& err) {
+int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
+                    int sigmoid, hipStream_t st, std::string& err) {
     const int M = B * h * wd;
-    hipLaunchKernelGGL(conv1x1_c3_kernel, dim3((unsigned)(((size_t)M * 16 + 255) / 256)), dim3(256), 0, st, feat, w, bias, tmp, M);
+    const dim3 grid((unsigned)(((size_t)M * 16 + 255) / 256));
+    if (feat_is_f32) hipLaunchKernelGGL(conv1x1_c3_f32_kernel, grid, dim3(256), 0, st, static_cast<const float*>(feat), w, bias, tmp, M);
+    else hipLaunchKernelGGL(conv1x1_c3_kernel, grid, dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
     if (check_launch("conv1x1_c3", err)) return 1;
     const size_t total = (size_t)B * 4 * h * wd;
     size_t blocks = (total + 255) / 256;
@@ -337,6 +368,17 @@ __global__ void conv_w_kernel(const float* __restrict__ in, const float* __restr
         float v = in[((size_t)co * Cin + ci) * 9 + tap];
         if (scale) v *= scale[co];
         out[i] = f2bf(v);
+    }
+}
+__global__ void conv_w_f32_kernel(const float* __restrict__ in, const float* __restrict__ scale, float* __restrict__ out, int Cout, int Cin) {
+    const size_t n = (size_t)Cout * Cin * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(i % Cin);
+        size_t r = i / Cin;
+        const int tap = (int)(r % 9), co = (int)(r / 9);
+        float v = in[((size_t)co * Cin + ci) * 9 + tap];
+        if (scale) v *= scale[co];
+        out[i] = v;
     }
 }
 // BatchNorm2d eval fold (model/SOccDPT.py:668): scale = g / sqrt(var + eps), shift = b - mean * scale
@@ -383,10 +425,11 @@ int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std:
     hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
     return check_launch("cvt_bf16", err);
 }
-int launch_conv_w(const float* in, const float* scale, bf16_t* out, int Cout, int Cin, hipStream_t st, std::string& err) {
+int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int Cout, int Cin, hipStream_t st, std::string& err) {
     size_t n = (size_t)Cout * Cin * 9, blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, out, Cout, Cin);
+    if (out_is_f32) hipLaunchKernelGGL(conv_w_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
+    else hipLaunchKernelGGL(conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<bf16_t*>(out), Cout, Cin);
     return check_launch("conv_w", err);
 }
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,

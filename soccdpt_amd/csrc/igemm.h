@@ -22,8 +22,9 @@ enum Act { ACT_NONE = 0, ACT_RELU = 1, ACT_GELU = 2 };
 
 struct IgemmDesc {
     // ---- operands ----
-    const bf16_t* X = nullptr;   // activations
-    const bf16_t* Wt = nullptr;  // weights [N][taps*Cin], K contiguous
+    const void* X = nullptr;   // activations, bf16 (or f32 when f32 != 0)
+    const void* Wt = nullptr;  // weights [N][taps*Cin], K contiguous, same element type
+    int f32 = 0;               // exact-f32 operands and f32 MFMA (SOCCDPT_PREC_F32)
     int M = 0, N = 0;
     int Cin = 0;      // channels per tap (K of a plain GEMM)
     int taps = 1;     // 1 (GEMM / 1x1) or 9 (3x3, pad 1)
@@ -37,7 +38,7 @@ struct IgemmDesc {
     int act = ACT_NONE;           // applied to every store except out_f32_raw
     float* out_f32 = nullptr;     // [M][N], value BEFORE `act` when act_on_f32 == 0
     int act_on_f32 = 0;
-    bf16_t* out_bf16 = nullptr;   // [M][N] plain (ld = N) or Halo image when out_halo != 0 (C = N)
+    void* out_op = nullptr;       // operand-typed copy (bf16 / f32): [M][N] plain (ld = N) or Halo image when out_halo != 0
     int out_halo = 0;
     // fused 1x1 tail of the depth head: out_dot[m] = relu(sum_n act(v)[n]*dot_w[n] + dot_b)   (N <= 32)
     const float* dot_w = nullptr;

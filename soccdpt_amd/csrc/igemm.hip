@@ -25,6 +25,8 @@ namespace soccdpt {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
+// BK_ is the k-tile depth in bf16 elements; a tile row is ROWB = 2*BK_ bytes (128 or 64).  With f32 operands
+// (SOCCDPT_PREC_F32) the same byte geometry holds BK_/2 elements per row.
 template <int BM_, int BN_, int BK_, int WM_, int WN_, int NS_>
 struct Cfg {
     static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NS = NS_;  // NS: LDS stages (tiles in flight + 1)
@@ -55,10 +57,15 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
     return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
 }
 
-template <class C>
+// T = bf16_t (v_mfma_f32_16x16x32_bf16) or float (v_mfma_f32_16x16x4_f32, exact f32: the parity mode).
+template <class C, typename T>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int BM = C::BM, BN = C::BN, BK = C::BK;
+    constexpr int BM = C::BM, BN = C::BN;
+    constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
+    constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
+    const T* const Xp = static_cast<const T*>(d.X);
+    const T* const Wtp = static_cast<const T*>(d.Wt);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         } else {
             base = (uint32_t)m * (uint32_t)d.ldx;
         }
-        x_off[i] = base + (uint32_t)((c ^ swz_of_row<BK>(row)) * 8);
+        x_off[i] = base + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
     }
 #pragma unroll
     for (int i = 0; i < C::W_LOADS; ++i) {
@@ -99,11 +106,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const int row = cid / C::CPR, c = cid % C::CPR;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
-        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<BK>(row)) * 8);
+        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
     }
 
     auto stage = [&](int kt, int buf) {
-        uint32_t xk, wk = (uint32_t)kt * BK;
+        uint32_t xk, wk = (uint32_t)kt * BK;  // elements of T
         if (d.taps == 9) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
             const int ky = tap / 3, kx = tap - ky * 3;
@@ -114,14 +121,14 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         char* sb = smem + buf * C::STAGE;
 #pragma unroll
         for (int i = 0; i < C::X_LOADS; ++i) {
-            const bf16_t* g = d.X + x_off[i] + xk;
+            const T* g = Xp + x_off[i] + xk;
             char* l = sb + (i * C::THREADS + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < C::W_LOADS; ++i) {
-            const bf16_t* g = d.Wt + w_off[i] + wk;
+            const T* g = Wtp + w_off[i] + wk;
             char* l = sb + C::X_BYTES + (i * C::THREADS + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -136,7 +143,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 
     // fragment read offsets (bytes within a stage), constant per lane
     const int frow = lane & 15, fq = lane >> 4;
-    const int fswz = swz_of_row<BK>(frow);
+    const int fswz = swz_of_row<C::BK>(frow);
     int xr_off[C::KS], wr_off[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
@@ -160,16 +167,33 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const char* sb = smem + (kt % C::NS) * C::STAGE;
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
-            bf16x8 wf[C::TN], xf[C::TM];
+            if constexpr (sizeof(T) == 2) {
+                bf16x8 wf[C::TN], xf[C::TM];
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i)
+                for (int i = 0; i < C::TN; ++i)
 #pragma unroll
-                for (int j = 0; j < C::TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < C::TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+            } else {
+                // f32: the lane's 16-byte chunk holds 4 consecutive k; element e of every lane forms MFMA k-step e
+                // (A and B use the same lane->k map, so any k permutation is a valid dot product order)
+                f32x4 wf[C::TN], xf[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const f32x4*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+            }
         }
     }
 
@@ -216,11 +240,15 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 const float* s = d.act_on_f32 ? a : v;
                 *reinterpret_cast<float4*>(d.out_f32 + orow + n) = make_float4(s[0], s[1], s[2], s[3]);
             }
-            if (d.out_bf16) {
-                uint2 p;
-                p.x = pack_bf16x2(a[0], a[1]);
-                p.y = pack_bf16x2(a[2], a[3]);
-                *reinterpret_cast<uint2*>(d.out_bf16 + (d.out_halo ? hrow : orow) + n) = p;
+            if (d.out_op) {
+                if constexpr (sizeof(T) == 2) {
+                    uint2 p;
+                    p.x = pack_bf16x2(a[0], a[1]);
+                    p.y = pack_bf16x2(a[2], a[3]);
+                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
+                }
             }
             if (d.out_dot) {
                 const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
@@ -240,21 +268,27 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }
 }
 
-template <class C>
-static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
-    const int nk = d.taps * d.Cin / C::BK, kpt = d.Cin / C::BK;
+template <class C, typename T>
+static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    constexpr int BK = C::ROWB / (int)sizeof(T);
+    const int nk = d.taps * d.Cin / BK, kpt = d.Cin / BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
     const size_t lds = (size_t)C::NS * C::STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<C>), dim3((unsigned)(mtiles * ntiles)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    hipLaunchKernelGGL((igemm_kernel<C, T>), dim3((unsigned)(mtiles * ntiles)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;
+}
+
+template <class C>
+static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    return launch_cfg_t<C, bf16_t>(d, stream, err);
 }
 
 // Kernel configurations.  id: name                 tile        ring
@@ -268,6 +302,13 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x32_s4", "igemm_bf16_64x64x32_s4", "igemm_bf16_128x32x64_s4",
                                         "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2"};
+
+static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
+static int pick_cfg_f32(const IgemmDesc& d) {
+    if (d.N <= 32) return 2;
+    const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    return b128 >= 384 ? 0 : 1;
+}
 
 static int pick_cfg(const IgemmDesc& d) {
     // Measured on MI355X (tools/igemm_bench.py, profiles/r01_igemm_configs.txt): the kernel is bound by the per-CU
@@ -286,7 +327,7 @@ static int pick_cfg(const IgemmDesc& d) {
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
-const char* igemm_family(const IgemmDesc& d) { return kCfgNames[pick_cfg(d)]; }
+const char* igemm_family(const IgemmDesc& d) { return d.f32 ? kCfgNamesF32[pick_cfg_f32(d)] : kCfgNames[pick_cfg(d)]; }
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.M <= 0 || d.N <= 0 || d.Cin <= 0 || !d.X || !d.Wt) { err = "igemm: bad descriptor"; return 1; }
@@ -296,6 +337,14 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
     if (d.out_halo && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output needs H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
+    if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
+        switch (pick_cfg_f32(d)) {
+            case 0: return launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float>(d, stream, err);
+            case 1: return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
+            default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, float>(d, stream, err);
+        }
+    }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || id == 10) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }

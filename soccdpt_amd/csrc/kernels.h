@@ -21,15 +21,15 @@ inline int check_launch(const char* what, std::string& err) {
 // elementwise.hip
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
                        int B, int S, int C0, hipStream_t st, std::string& err);
-int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, int M, int C,
+int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int M, int C,
                        int residual, int res, hipStream_t st, std::string& err);
-int launch_merge_gather(const bf16_t* in, bf16_t* out, int B, int R, int C, hipStream_t st, std::string& err);
-int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, int out_halo, int B, int h, int w, int H, int W,
-                    int C, hipStream_t st, std::string& err);
-int launch_seg_tail(const bf16_t* feat, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd, int sigmoid,
-                    hipStream_t st, std::string& err);
+int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err);
+int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int B, int h, int w,
+                    int H, int W, int C, hipStream_t st, std::string& err);
+int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
+                    int sigmoid, hipStream_t st, std::string& err);
 int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std::string& err);
-int launch_conv_w(const float* in, const float* scale, bf16_t* out, int Cout, int Cin, hipStream_t st, std::string& err);
+int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int Cout, int Cin, hipStream_t st, std::string& err);
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,
                    std::string& err);
 int launch_qkv_bias(const float* q, const float* v, float* out, int C, hipStream_t st, std::string& err);
@@ -43,5 +43,8 @@ size_t attn_bias_elems(int ws, int heads);
 int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hipStream_t st, std::string& err);
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,
                             int heads, hipStream_t st, std::string& err);
+
+int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* scale, float* out, int B, int res, int ws, int shift,
+                                int heads, hipStream_t st, std::string& err);
 
 }  // namespace soccdpt

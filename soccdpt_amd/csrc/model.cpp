@@ -15,29 +15,29 @@
 namespace soccdpt {
 
 struct BlockW {
-    const bf16_t *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;  // bf16 copies, or the bound f32 tensors in SOCCDPT_PREC_F32
     float *qkv_bias, *scale, *table, *bias_acc;
     const float *proj_b, *n1_g, *n1_b, *fc1_b, *fc2_b, *n2_g, *n2_b;
 };
 struct MergeW {
-    const bf16_t* red_w;
+    const void* red_w;
     const float *g, *b;
 };
 struct RcuW {
-    const bf16_t *w1, *w2;
+    const void *w1, *w2;
     const float *b1, *b2;
 };
 struct Prepared {
     std::vector<std::vector<BlockW>> blocks;  // [stage][block]
     MergeW merge[3];
-    const bf16_t* layer_rn[4];
+    const void* layer_rn[4];
     RcuW rcu[4][2];  // [refinenet-1][unit-1]
-    const bf16_t* oc_w[4];
+    const void* oc_w[4];
     const float* oc_b[4];
-    const bf16_t *d0_w, *d2_w;
+    const void *d0_w, *d2_w;
     const float *d0_b, *d2_b, *d4_w;
     float d4_b = 0.f;
-    const bf16_t* s0_w;
+    const void* s0_w;
     float *bn_scale, *bn_shift;
     const float *s4_w, *s4_b;
 };
@@ -83,15 +83,19 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     const Arch& a = h.arch;
     const bool run = ar.base != nullptr;
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
-    auto cvt = [&](const std::string& key, size_t n) -> const bf16_t* {
+    const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
+    static const char kNoCopy = 0;  // non-null placeholder while measuring
+    auto cvt = [&](const std::string& key, size_t n) -> const void* {
+        if (F32) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
         bf16_t* p = ar.take<bf16_t>(n);
         if (run && launch_cvt_bf16(W(key), p, n, st, err)) return nullptr;
-        return p;
+        return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const bf16_t* {
-        bf16_t* p = ar.take<bf16_t>((size_t)Cout * Cin * 9);
-        if (run && launch_conv_w(W(key), scale, p, Cout, Cin, st, err)) return nullptr;
-        return p;
+    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const void* {
+        const size_t n = (size_t)Cout * Cin * 9;
+        void* p = F32 ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, Cout, Cin, st, err)) return nullptr;
+        return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     if (run) P->blocks.assign(4, {});
     for (int s = 0; s < 4; ++s) {
@@ -124,7 +128,7 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
         if (s < 3) {
             const std::string d = ENC + "layers." + std::to_string(s) + ".downsample.";
-            const bf16_t* rw = cvt(d + "reduction.weight", (size_t)8 * C * C);
+            const void* rw = cvt(d + "reduction.weight", (size_t)8 * C * C);
             if (run) {
                 if (!rw) return 1;
                 P->merge[s] = MergeW{rw, W(d + "norm.weight"), W(d + "norm.bias")};
@@ -133,18 +137,18 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     }
     const int F = h.cfg.features;
     for (int i = 0; i < 4; ++i) {
-        const bf16_t* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.dim(i), nullptr);
+        const void* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.dim(i), nullptr);
         if (run) { if (!p) return 1; P->layer_rn[i] = p; }
     }
     for (int r = 1; r <= 4; ++r) {
         const std::string b = SCR + "refinenet" + std::to_string(r) + ".";
-        const bf16_t* ocw = cvt(b + "out_conv.weight", (size_t)F * F);
+        const void* ocw = cvt(b + "out_conv.weight", (size_t)F * F);
         if (run) { if (!ocw) return 1; P->oc_w[r - 1] = ocw; P->oc_b[r - 1] = W(b + "out_conv.bias"); }
         for (int u = 1; u <= 2; ++u) {
             if (r == 4 && u == 1) continue;
             const std::string ub = b + "resConfUnit" + std::to_string(u) + ".";
-            const bf16_t* w1 = convw(ub + "conv1.weight", F, F, nullptr);
-            const bf16_t* w2 = convw(ub + "conv2.weight", F, F, nullptr);
+            const void* w1 = convw(ub + "conv1.weight", F, F, nullptr);
+            const void* w2 = convw(ub + "conv2.weight", F, F, nullptr);
             if (run) {
                 if (!w1 || !w2) return 1;
                 P->rcu[r - 1][u - 1] = RcuW{w1, w2, W(ub + "conv1.bias"), W(ub + "conv2.bias")};
@@ -152,14 +156,14 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
     }
     {
-        const bf16_t* d0 = convw(SCR + "output_conv.0.weight", F / 2, F, nullptr);
-        const bf16_t* d2 = convw(SCR + "output_conv.2.weight", 32, F / 2, nullptr);
+        const void* d0 = convw(SCR + "output_conv.0.weight", F / 2, F, nullptr);
+        const void* d2 = convw(SCR + "output_conv.2.weight", 32, F / 2, nullptr);
         float* bscale = ar.take<float>(F);
         float* bshift = ar.take<float>(F);
         if (run && launch_bn_fold(W("seg_head.1.weight"), W("seg_head.1.bias"), W("seg_head.1.running_mean"), W("seg_head.1.running_var"),
                                   bscale, bshift, F, st, err))
             return 1;
-        const bf16_t* s0 = convw("seg_head.0.weight", F, F, bscale);
+        const void* s0 = convw("seg_head.0.weight", F, F, bscale);
         if (run) {
             if (!d0 || !d2 || !s0) return 1;
             P->d0_w = d0; P->d2_w = d2; P->s0_w = s0;
@@ -172,14 +176,15 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     return 0;
 }
 
+// "op" buffers hold GEMM/conv operands: bf16, or f32 in SOCCDPT_PREC_F32 (then xb aliases xf)
 struct Workspace {
     float *xf, *y;
-    bf16_t *xb, *qkv, *attn, *hbuf;
-    bf16_t* feat[4];  // halo
+    void *xb, *qkv, *attn, *hbuf;
+    void* feat[4];  // halo
     // decoder, index = level-1 (level 4 = coarsest)
     float *lrn_raw[4], *out_raw[4], *oc[4], *path[4];
-    bf16_t *lrn_relu[4], *t_relu[4], *out_relu[4], *u[4];
-    bf16_t *path1, *d1, *d1u, *s1;
+    void *lrn_relu[4], *t_relu[4], *out_relu[4], *u[4];
+    void *path1, *d1, *d1u, *s1;
     float* s2;
 };
 
@@ -187,15 +192,18 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const Arch& a = h.arch;
     const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
     const size_t M0 = (size_t)B * G * G;
+    const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
+    const size_t es = F32 ? 4 : 2;
+    auto op = [&](size_t elems) -> void* { return ar.take<char>(elems * es); };
     w.xf = ar.take<float>(M0 * C0);
     w.y = ar.take<float>(M0 * C0);
-    w.xb = ar.take<bf16_t>(M0 * C0);
-    w.qkv = ar.take<bf16_t>(M0 * 3 * C0);
-    w.attn = ar.take<bf16_t>(M0 * C0);
-    w.hbuf = ar.take<bf16_t>(M0 * 4 * C0);
+    w.xb = F32 ? static_cast<void*>(w.xf) : op(M0 * C0);
+    w.qkv = op(M0 * 3 * C0);
+    w.attn = op(M0 * C0);
+    w.hbuf = op(M0 * 4 * C0);
     for (int s = 0; s < 4; ++s) {
         Halo hl{a.res(s), a.res(s), a.dim(s)};
-        w.feat[s] = ar.take<bf16_t>(hl.elems(B));
+        w.feat[s] = op(hl.elems(B));
     }
     for (int l = 0; l < 4; ++l) {
         const int r = a.res(l);
@@ -205,16 +213,16 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
         w.out_raw[l] = ar.take<float>(M * F);
         w.oc[l] = ar.take<float>(M * F);
         w.path[l] = ar.take<float>(M * F);  // path arriving AT this level (from level l+1)
-        w.lrn_relu[l] = ar.take<bf16_t>(hl.elems(B));
-        w.t_relu[l] = ar.take<bf16_t>(hl.elems(B));
-        w.out_relu[l] = ar.take<bf16_t>(hl.elems(B));
-        w.u[l] = ar.take<bf16_t>(M * F);
+        w.lrn_relu[l] = op(hl.elems(B));
+        w.t_relu[l] = op(hl.elems(B));
+        w.out_relu[l] = op(hl.elems(B));
+        w.u[l] = op(M * F);
     }
     const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
-    w.path1 = ar.take<bf16_t>(Halo{r1, r1, F}.elems(B));
-    w.d1 = ar.take<bf16_t>((size_t)B * r1 * r1 * (F / 2));
-    w.d1u = ar.take<bf16_t>(Halo{r0, r0, F / 2}.elems(B));
-    w.s1 = ar.take<bf16_t>((size_t)B * r1 * r1 * F);
+    w.path1 = op(Halo{r1, r1, F}.elems(B));
+    w.d1 = op((size_t)B * r1 * r1 * (F / 2));
+    w.d1u = op(Halo{r0, r0, F / 2}.elems(B));
+    w.s1 = op((size_t)B * r1 * r1 * F);
     w.s2 = ar.take<float>((size_t)B * r1 * r1 * 4);
 }
 
@@ -341,10 +349,11 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
         return 0;
     };
+    const int hk = h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : 2;  // 3 = f32 zero-halo NHWC
     for (int s = 0; s < 4; ++s)
-        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), 2, a.res(s), a.res(s), a.dim(s));
+        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), hk, a.res(s), a.res(s), a.dim(s));
     const int r1 = 2 * a.res(0);
-    if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), 2, r1, r1, h.cfg.features);
+    if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
     if (n == "xf") return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     return 1;
 }
@@ -372,50 +381,59 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const Arch& a = h.arch;
     const Prepared& P = *h.prep;
     const int F = h.cfg.features;
+    const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
+    const int es = F32 ? 4 : 2;
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
-    auto gemm = [&](const IgemmDesc& d) { PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
+    auto gemm = [&](IgemmDesc d) { d.f32 = F32 ? 1 : 0; PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------
     { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, W(ENC + "patch_embed.proj.weight"), W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
-                           W(ENC + "patch_embed.norm.bias"), w.xf, w.xb, B, a.img, a.embed, st, err)); }
+                           W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
             IgemmDesc d;
-            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_bf16 = w.qkv;
+            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_op = w.qkv;
             RUN(gemm(d));
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
-              RUN(launch_window_attention(w.qkv, bw.bias_acc, bw.scale, w.attn, B, res, wsz, a.shift(s, j), H, st, err)); }
+              if (F32) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
+                                                       a.shift(s, j), H, st, err));
+              else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), B, res, wsz,
+                                               a.shift(s, j), H, st, err)); }
             d = IgemmDesc();
             d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b; d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-              RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, w.xb, nullptr, M, C, 1, res, st, err)); }
+              RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M, C, 1, res, st, err)); }
             d = IgemmDesc();
-            d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_bf16 = w.hbuf;
+            d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = w.hbuf;
             RUN(gemm(d));
             d = IgemmDesc();
             d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b; d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, w.xb, j == a.hooks[s] ? w.feat[s] : nullptr, M, C, 1, res, st, err)); }
+              const bool hook = (j == a.hooks[s]);
+              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb),
+                                     (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, M, C,
+                                     1, res, st, err)); }
         }
         if (s < 3) {
             { PROF("merge_gather", 0.0, (double)M * C * 4.0);
-              RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, st, err)); }
+              RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, es, st, err)); }
             IgemmDesc d;
             d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
-              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, w.xb, nullptr, M / 4, 2 * C, 0, res / 2, st, err)); }
+              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M / 4, 2 * C, 0,
+                                     res / 2, st, err)); }
         }
     }
     // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------
-    auto conv = [&](const bf16_t* X, int Cin, const bf16_t* Wt, int N, int r) {
+    auto conv = [&](const void* X, int Cin, const void* Wt, int N, int r) {
         IgemmDesc d;
         d.X = X; d.Wt = Wt; d.M = B * r * r; d.N = N; d.Cin = Cin; d.taps = 9; d.H = r; d.W = r;
         return d;
@@ -424,19 +442,19 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         const int r = a.res(l), M = B * r * r;
         {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd bf16 halo (RCU conv1 input)
             IgemmDesc d = conv(w.feat[l], a.dim(l), P.layer_rn[l], F, r);
-            d.out_f32 = w.lrn_raw[l]; d.out_bf16 = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            d.out_f32 = w.lrn_raw[l]; d.out_op = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
             RUN(gemm(d));
         }
         const float* fused_raw = w.lrn_raw[l];
-        const bf16_t* fused_relu = w.lrn_relu[l];
+        const void* fused_relu = w.lrn_relu[l];
         if (l < 3) {  // output = path + RCU1(layer_rn)
             const RcuW& u1 = P.rcu[l][0];
             IgemmDesc d = conv(w.lrn_relu[l], F, u1.w1, F, r);
-            d.bias = u1.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
+            d.bias = u1.b1; d.act = ACT_RELU; d.out_op = w.t_relu[l]; d.out_halo = 1;
             RUN(gemm(d));
             d = conv(w.t_relu[l], F, u1.w2, F, r);
             d.bias = u1.b2; d.res1 = w.lrn_raw[l]; d.res2 = w.path[l];
-            d.out_f32 = w.out_raw[l]; d.out_bf16 = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            d.out_f32 = w.out_raw[l]; d.out_op = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
             RUN(gemm(d));
             fused_raw = w.out_raw[l];
             fused_relu = w.out_relu[l];
@@ -444,10 +462,10 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         {   // RCU2
             const RcuW& u2 = P.rcu[l][1];
             IgemmDesc d = conv(fused_relu, F, u2.w1, F, r);
-            d.bias = u2.b1; d.act = ACT_RELU; d.out_bf16 = w.t_relu[l]; d.out_halo = 1;
+            d.bias = u2.b1; d.act = ACT_RELU; d.out_op = w.t_relu[l]; d.out_halo = 1;
             RUN(gemm(d));
             d = conv(w.t_relu[l], F, u2.w2, F, r);
-            d.bias = u2.b2; d.res1 = fused_raw; d.out_bf16 = w.u[l];
+            d.bias = u2.b2; d.res1 = fused_raw; d.out_op = w.u[l];
             RUN(gemm(d));
         }
         {   // out_conv (1x1) BEFORE the bilinear resize: both are linear and the interpolation weights sum to 1
@@ -456,26 +474,28 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             RUN(gemm(d));
         }
         if (l > 0) { PROF("bilinear_resize", 0.0, (double)M * F * 4.0 * 5.0);
-                     RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err)); }
+                     RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err)); }
         else { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
-               RUN(launch_bilinear(w.oc[0], 0, nullptr, w.path1, 1, B, r, r, 2 * r, 2 * r, F, st, err)); }
+               RUN(launch_bilinear(w.oc[0], 0, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.path1), F32 ? static_cast<float*>(w.path1) : nullptr, 1, B, r, r,
+                                   2 * r, 2 * r, F, st, err)); }
     }
     // ---------------- heads ----------------
     const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
     {
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
-        d.bias = P.d0_b; d.out_bf16 = w.d1;
+        d.bias = P.d0_b; d.out_op = w.d1;
         RUN(gemm(d));
         { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
-          RUN(launch_bilinear(w.d1, 1, nullptr, w.d1u, 1, B, r1, r1, r0, r0, F / 2, st, err)); }
+          RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, B, r1,
+                              r1, r0, r0, F / 2, st, err)); }
         d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
         d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
         RUN(gemm(d));
         d = conv(w.path1, F, P.s0_w, F, r1);
-        d.bias = P.bn_shift; d.act = ACT_RELU; d.out_bf16 = w.s1;
+        d.bias = P.bn_shift; d.act = ACT_RELU; d.out_op = w.s1;
         RUN(gemm(d));
         { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
-          RUN(launch_seg_tail(w.s1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
+          RUN(launch_seg_tail(w.s1, F32 ? 1 : 0, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
         ++launches;
     }
 #undef RUN

@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libsoccdpt_hip.so")
 ABI_VERSION = 1
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1}
 PREC_BF16 = 0
-PREC_BF16X3 = 1
+PREC_F32 = 1
 
 
 class SoccdptConfig(ctypes.Structure):
@@ -55,7 +55,7 @@ class IgemmArgs(ctypes.Structure):
         ("act", ctypes.c_int32), ("out_f32", ctypes.c_void_p), ("act_on_f32", ctypes.c_int32),
         ("out_bf16", ctypes.c_void_p), ("out_halo", ctypes.c_int32),
         ("dot_w", ctypes.c_void_p), ("dot_b", ctypes.c_float), ("out_dot", ctypes.c_void_p),
-        ("tune", ctypes.c_int32),
+        ("tune", ctypes.c_int32), ("f32", ctypes.c_int32),
     ]
 
 
@@ -316,6 +316,9 @@ class Engine:
         raw = self._workspace[off.value:]
         if kind.value == 0:
             return raw[: n.value * 4].view(torch.float32).reshape(B, H.value, W.value, C.value).clone()
+        if kind.value == 3:
+            t = raw[: n.value * 4].view(torch.float32).reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
+            return t.clone()
         t = raw[: n.value * 2].view(torch.bfloat16)
         if kind.value == 2:
             t = t.reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
@@ -325,11 +328,11 @@ class Engine:
 
 
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
-             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1):
+             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0):
     """Kernel-level entry (tests): one implicit-GEMM launch on the current stream."""
     L = load_library()
     a = IgemmArgs(_ptr(x), _ptr(wt), M, N, Cin, taps, ldx, H, W, _ptr(bias), _ptr(res1), _ptr(res2), act, _ptr(out_f32),
-                  act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune)
+                  act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune, f32)
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())

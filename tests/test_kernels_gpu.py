@@ -137,3 +137,38 @@ def test_window_attention(gpu_device, B, res, ws, shift, heads):
     ref = _attention_ref(qkv, table, scale, B, res, ws, shift, heads)
     err = (out.float() - ref).abs()
     assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
+
+
+# ---------------- exact-f32 parity mode (SOCCDPT_PREC_F32) ----------------
+@pytest.mark.parametrize("M,N,K", [(300, 288, 96), (2048, 384, 1536), (512, 2304, 768)])
+def test_igemm_linear_f32(gpu_device, M, N, K):
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(M + N + K)
+    x = torch.randn(M, K, generator=g).to(gpu_device)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    ref = (x.double() @ w.double().t() + bias.double()).float()
+    out = torch.empty(M, N, device=gpu_device)
+    outg = torch.empty(M, N, device=gpu_device)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_f32=out, act=2, out_bf16=outg, f32=1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(outg, F.gelu(ref), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout", [(2, 16, 256, 256), (3, 8, 96, 256), (1, 64, 128, 32)])
+def test_igemm_conv3x3_f32(gpu_device, B, H, Cin, Cout):
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(B * 1000 + H + Cin + Cout)
+    x = torch.randn(B, Cin, H, H, generator=g).to(gpu_device)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(gpu_device)
+    bias = torch.randn(Cout, generator=g).to(gpu_device)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1).permute(0, 2, 3, 1).float()
+    xh = _halo(x.permute(0, 2, 3, 1).contiguous())
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    out = torch.empty(B, H, H, Cout, device=gpu_device)
+    outh = torch.zeros(B, H + 2, H + 2, Cout, device=gpu_device)
+    op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, act=1, out_f32=out, out_bf16=outh, out_halo=1, f32=1)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
+    torch.testing.assert_close(outh[:, 1:-1, 1:-1], F.relu(ref), rtol=2e-5, atol=2e-5)

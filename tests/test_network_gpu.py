@@ -120,3 +120,55 @@ def test_multi_stream_sub_batches_match_single_stream(net, gpu_device):
     out4b = m4(x)
     torch.cuda.synchronize()
     assert torch.equal(out4b[0], out4[0]) and torch.equal(out4b[3], out4[3])
+
+
+# ---------------- exact-f32 parity mode: the north star's 1e-3 relative tolerance ----------------
+@pytest.fixture(scope="module")
+def net_f32(gpu_device):
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, precision=PREC_F32)
+    sd = synth_state_dict(alias_pretrained=True)
+    m.load_state_dict(sd, strict=False)
+    return m.eval().to(gpu_device), sd
+
+
+def test_f32_mode_meets_1e3_relative(net_f32, gpu_device):
+    """SOCCDPT_PREC_F32 (f32 operands, exact-f32 MFMA): depth maps, class probabilities and features within 1e-3
+    relative of the reference-equivalent CPU forward (tolerance stated by BASELINE.json's north star)."""
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = net_f32
+    x = synth_input(2, seed0=4)
+    inv, seg = m.network(x.to(gpu_device))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        layers = R.swin_encoder(sd, x, R.ARCHS["swin2t16_256"])
+        o_inv, o_p1 = R.dpt_decoder(sd, layers)
+        o_seg = R.seg_head(sd, o_p1, sigmoid=False)
+    eng = m._engine(gpu_device)
+    errs = {f"feat{s}": _rel_l2(eng.workspace_tensor(2, f"feat{s}").cpu().permute(0, 3, 1, 2), layers[s]) for s in range(4)}
+    errs["path1"] = _rel_l2(eng.workspace_tensor(2, "path1").cpu().permute(0, 3, 1, 2), o_p1)
+    errs["inv"] = _rel_l2(inv.cpu(), o_inv)
+    errs["seg"] = _rel_l2(seg.cpu(), o_seg)
+    maxrel_inv = float(((inv.cpu() - o_inv).abs() / o_inv.abs().clamp_min(1e-6)).max())
+    print("f32 mode, relative L2 vs fp32 CPU oracle:", {k: f"{v:.2e}" for k, v in errs.items()}, "max elementwise rel (inv):", f"{maxrel_inv:.2e}")
+    for k, v in errs.items():
+        assert v < 1e-3, (k, v)
+    assert maxrel_inv < 1e-3                       # every depth pixel within 1e-3 relative
+    assert float((seg.cpu() - o_seg).abs().max()) < 1e-3
+
+
+def test_f32_mode_full_forward_occupancy(net_f32, gpu_device):
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = net_f32
+    x = synth_input(2, seed0=10)
+    inv_up, seg_up, pts, occ = m(x.to(gpu_device))
+    torch.cuda.synchronize()
+    o_inv, o_seg, o_pts, o_occ = R.soccdpt_v3_forward(sd, x, sigmoid=False)
+    assert _rel_l2(inv_up.cpu(), o_inv) < 1e-3
+    a, b = occ[0].cpu() > 0, o_occ[0] > 0
+    iou = float((a & b).sum()) / max(float((a | b).sum()), 1.0)
+    print("f32 mode occupancy IoU vs oracle:", iou, int(a.sum()), int(b.sum()))
+    assert iou > 0.97
