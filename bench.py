@@ -72,8 +72,8 @@ def main():
     x = synth_input(B, seed0=rank * B).to(dev)   # different frames per rank
 
     def barrier():
-        if world > 1:
-            dist.barrier()
+        if dist.is_initialized():
+            dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
@@ -182,8 +182,8 @@ def main():
                                             f"(oracle/soccdpt_ref.py), {tcpu:.1f} s"}
     if rank == 0:
         print(json.dumps(result))
-    if world > 1:
-        dist.barrier()
+    if dist.is_initialized():
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
 
 

@@ -3,14 +3,24 @@
 // 3-channel tail of the seg head, and the one-time weight re-layout / CPB-table kernels.
 // Every kernel cites the reference computation it replaces; 64-lane waves, 16-byte accesses
 // where the layout allows, NHWC ("token-major") activations throughout.
+#include <type_traits>
+
 #include "kernels.h"
 
 namespace soccdpt {
 
+// 64-lane sum, result in every lane: 4 DPP steps inside each 16-lane row (VALU, no LDS traffic) + 4 v_readlane.
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, true));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    const int vi = __builtin_bit_cast(int, v);
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 0)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 16)) +
+           __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
 }
 
 __device__ __forceinline__ bf16_t f2bf(float f) {
@@ -28,41 +38,48 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
                                                            const float* __restrict__ bias, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, int B, int S, int C0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* wT = reinterpret_cast<float*>(smem);  // [48][C0]
-    for (int i = threadIdx.x; i < 48 * C0; i += blockDim.x) {
-        const int k = i / C0, n = i - k * C0;
-        wT[i] = w[n * 48 + k];
-    }
-    __syncthreads();
+    // lane owns output channels `lane` and `lane + 64`; their 2 x 48 weights live in registers for the whole kernel,
+    // the 48 patch values are broadcast lane -> SGPR with v_readlane (no LDS, no shuffles)
     const int G = S / 4, lane = threadIdx.x & 63;
+    const bool a0 = lane < C0, a1 = lane + 64 < C0;
+    float w0[48], w1[48];
+#pragma unroll
+    for (int k = 0; k < 48; ++k) {  // w is the prepared transpose [48][128] (zero-padded): coalesced
+        w0[k] = w[k * 128 + lane];
+        w1[k] = w[k * 128 + 64 + lane];
+    }
+    const float b0 = a0 ? bias[lane] : 0.f, b1 = a1 ? bias[lane + 64] : 0.f;
+    const float g0 = a0 ? g[lane] : 0.f, g1 = a1 ? g[lane + 64] : 0.f;
+    const float e0 = a0 ? beta[lane] : 0.f, e1 = a1 ? beta[lane + 64] : 0.f;
     const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
     const int M = B * G * G;
-    for (int tok = wave_global; tok < M; tok += nwaves) {
+    auto load_in = [&](int tok) -> float {
+        if (tok >= M || lane >= 48) return 0.f;
         const int b = tok / (G * G), r = tok - b * G * G, py = r / G, px = r - py * G;
-        float in = 0.f;
-        if (lane < 48) {
-            const int c = lane >> 4, ky = (lane >> 2) & 3, kx = lane & 3;
-            in = x[((size_t)(b * 3 + c) * S + py * 4 + ky) * S + px * 4 + kx];
-        }
-        float o0 = (lane < C0) ? bias[lane] : 0.f;
-        float o1 = (lane + 64 < C0) ? bias[lane + 64] : 0.f;
-#pragma unroll 8
+        const int c = lane >> 4, ky = (lane >> 2) & 3, kx = lane & 3;
+        return x[((size_t)(b * 3 + c) * S + py * 4 + ky) * S + px * 4 + kx];
+    };
+    float in_next = load_in(wave_global);
+    for (int tok = wave_global; tok < M; tok += nwaves) {
+        const float in = in_next;
+        in_next = load_in(tok + nwaves);  // prefetch the next token's patch under this token's FMAs
+        float o0 = b0, o1 = b1;
+#pragma unroll
         for (int k = 0; k < 48; ++k) {
-            const float v = __shfl(in, k);
-            if (lane < C0) o0 = fmaf(v, wT[k * C0 + lane], o0);
-            if (lane + 64 < C0) o1 = fmaf(v, wT[k * C0 + lane + 64], o1);
+            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in), k));
+            o0 = fmaf(v, w0[k], o0);
+            o1 = fmaf(v, w1[k], o1);
         }
-        const float mean = wave_sum(o0 + o1) / (float)C0;
-        const float d0 = (lane < C0) ? o0 - mean : 0.f, d1 = (lane + 64 < C0) ? o1 - mean : 0.f;
+        const float mean = wave_sum((a0 ? o0 : 0.f) + (a1 ? o1 : 0.f)) / (float)C0;
+        const float d0 = a0 ? o0 - mean : 0.f, d1 = a1 ? o1 - mean : 0.f;
         const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C0 + 1e-5f);
-        if (lane < C0) {
-            const float y = d0 * rstd * g[lane] + beta[lane];
+        if (a0) {
+            const float y = d0 * rstd * g0 + e0;
             xf[(size_t)tok * C0 + lane] = y;
             if (xb) xb[(size_t)tok * C0 + lane] = f2bf(y);
         }
-        if (lane + 64 < C0) {
-            const float y = d1 * rstd * g[lane + 64] + beta[lane + 64];
+        if (a1) {
+            const float y = d1 * rstd * g1 + e1;
             xf[(size_t)tok * C0 + lane + 64] = y;
             if (xb) xb[(size_t)tok * C0 + lane + 64] = f2bf(y);
         }
@@ -73,9 +90,10 @@ int launch_patch_embed(const float* x, const float* w, const float* bias, const 
                        int B, int S, int C0, hipStream_t st, std::string& err) {
     if (C0 > 128) { err = "patch_embed: C0 > 128"; return 1; }
     const int M = B * (S / 4) * (S / 4);
-    int blocks = (M + 3) / 4;
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(patch_embed_kernel, dim3(blocks), dim3(256), 48 * C0 * sizeof(float), st, x, w, bias, g, beta, xf, xb, B, S, C0);
+    int blocks = (M + 127) / 128;  // 32 tokens per wave amortise the weight registers
+    if (blocks > 512) blocks = 512;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0);
     return check_launch("patch_embed", err);
 }
 
@@ -380,6 +398,18 @@ __global__ void conv_w_f32_kernel(const float* __restrict__ in, const float* __r
         if (scale) v *= scale[co];
         out[i] = v;
     }
+}
+// patch-embed weight [C0][48] -> [48][128] zero-padded (coalesced per-lane loads in patch_embed_kernel)
+__global__ void patch_w_kernel(const float* __restrict__ w, float* __restrict__ out, int C0) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 48 * 128) {
+        const int k = i / 128, n = i % 128;
+        out[i] = n < C0 ? w[n * 48 + k] : 0.f;
+    }
+}
+int launch_patch_w(const float* w, float* out, int C0, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(patch_w_kernel, dim3(24), dim3(256), 0, st, w, out, C0);
+    return check_launch("patch_w", err);
 }
 // BatchNorm2d eval fold (model/SOccDPT.py:668): scale = g / sqrt(var + eps), shift = b - mean * scale
 __global__ void bn_fold_kernel(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C) {

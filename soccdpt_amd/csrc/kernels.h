@@ -28,6 +28,7 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
                     int H, int W, int C, hipStream_t st, std::string& err);
 int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
                     int sigmoid, hipStream_t st, std::string& err);
+int launch_patch_w(const float* w, float* out, int C0, hipStream_t st, std::string& err);
 int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std::string& err);
 int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int Cout, int Cin, hipStream_t st, std::string& err);
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,

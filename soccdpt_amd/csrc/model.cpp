@@ -40,6 +40,7 @@ struct Prepared {
     const void* s0_w;
     float *bn_scale, *bn_shift;
     const float *s4_w, *s4_b;
+    float* patch_wT = nullptr;  // [48][128]
 };
 
 Handle::~Handle() {
@@ -97,6 +98,13 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, Cout, Cin, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
+    {
+        float* pw = ar.take<float>(48 * 128);
+        if (run) {
+            if (launch_patch_w(W(ENC + "patch_embed.proj.weight"), pw, a.embed, st, err)) return 1;
+            P->patch_wT = pw;
+        }
+    }
     if (run) P->blocks.assign(4, {});
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), H = a.heads[s], ws = a.ws(s);
@@ -390,7 +398,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------
     { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
-    RUN(launch_patch_embed(x, W(ENC + "patch_embed.proj.weight"), W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
+    RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
                            W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];

@@ -207,6 +207,140 @@ __global__ __launch_bounds__(256) void project_kernel(ProjParams P) {
     }
 }
 
+// Row-segment variant (the one that runs for the camera sizes in use): one workgroup = one camera row x 1024
+// pixels.  The 4 bicubic source rows of inv and the nearest source row of each class are staged once in LDS
+// (7 x SW floats, coalesced), so the 16 bicubic taps per pixel are LDS reads instead of per-lane global gathers
+// (the gather form was bound by the texture-address path, not by HBM).  Arithmetic is identical to project_kernel.
+template <int C, int SW>
+__global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nseg) {
+    __shared__ float s_inv[4][SW];
+    __shared__ float s_seg[C][SW];
+    int bid = blockIdx.x;
+    const int seg = bid % nseg;
+    bid /= nseg;
+    const int u = bid % P.Hc;
+    const int b = bid / P.Hc;
+    const float sy = (float)P.h / (float)P.Hc;
+    const float sx = (float)P.w / (float)P.Wc;
+    const size_t npix = (size_t)P.Hc * P.Wc;
+    const int vlo = seg * 1024;
+    const int vhi = (vlo + 1024 < P.Wc) ? vlo + 1024 : P.Wc;
+    const Taps ty = cubic_taps(u, P.h, sy);
+    const int su = nearest_src(u, P.h, sy);
+    // source column window of this segment
+    int c_lo = (int)floorf(fmaf(sx, (float)vlo + 0.5f, -0.5f)) - 1;
+    c_lo = c_lo < 0 ? 0 : c_lo;
+    {
+        const float* src = P.inv + (size_t)b * P.h * P.w;
+        int col = c_lo + (int)threadIdx.x;
+        col = col > P.w - 1 ? P.w - 1 : col;
+        if (threadIdx.x < SW) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s_inv[i][threadIdx.x] = src[(size_t)ty.idx[i] * P.w + col];
+#pragma unroll
+            for (int c = 0; c < C; ++c) s_seg[c][threadIdx.x] = P.seg[(((size_t)b * C + c) * P.h + su) * P.w + col];
+        }
+    }
+    __syncthreads();
+    const int v0 = vlo + (int)threadIdx.x * 4;
+    if (v0 >= vhi) return;
+    const float yterm = (float)u - P.cy;
+    float iv[4], sem[C][4], pt[4][3];
+    int vkey[4];       // first cell index of the pixel's voxel (its C class bits are adjacent), -1 = not in the grid
+    uint32_t vcm[4];   // classes with non-zero probability
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int v = v0 + e;
+        const Taps tx = cubic_taps(v, P.w, sx);
+        const int i0 = tx.idx[0] - c_lo, i1 = tx.idx[1] - c_lo, i2 = tx.idx[2] - c_lo, i3 = tx.idx[3] - c_lo;
+        float t0 = dot4(s_inv[0][i0], s_inv[0][i1], s_inv[0][i2], s_inv[0][i3], tx.w);
+        float t1 = dot4(s_inv[1][i0], s_inv[1][i1], s_inv[1][i2], s_inv[1][i3], tx.w);
+        float t2 = dot4(s_inv[2][i0], s_inv[2][i1], s_inv[2][i2], s_inv[2][i3], tx.w);
+        float t3 = dot4(s_inv[3][i0], s_inv[3][i1], s_inv[3][i2], s_inv[3][i3], tx.w);
+        float val = dot4(t0, t1, t2, t3, ty.w);
+        if (val < 1e-8f) val = 1e-8f;  // NaN compares false and stays NaN
+        float d = 1.0f / val;
+        if (isinf(d) || isnan(d)) d = __builtin_inff();
+        iv[e] = val;
+        const int sv = nearest_src(v, P.w, sx) - c_lo;
+#pragma unroll
+        for (int c = 0; c < C; ++c) sem[c][e] = s_seg[c][sv];
+        float p[3];
+        p[0] = (((float)v - P.cx) * d) / P.fx;
+        p[1] = (yterm * d) / P.fy;
+        p[2] = d;
+        const size_t n = (size_t)u * P.Wc + v;
+        if (n < 3) {  // the reference scales/shifts flat pixels 0,1,2 of each image
+#pragma unroll
+            for (int k = 0; k < 3; ++k) p[k] = p[k] * P.pc_scale[n] + P.pc_shift[n];
+        }
+        pt[e][0] = p[0];
+        pt[e][1] = p[1];
+        pt[e][2] = p[2];
+        vkey[e] = -1;
+        vcm[e] = 0;
+        if (P.occ_bits) {
+            float a[3], bq[3], cq[3];
+            rot3(p, P.rot, a);
+            rot3(a, P.rot + 9, bq);
+            rot3(bq, P.rot + 18, cq);
+            const bool fin = isfinite(cq[0]) && isfinite(cq[1]) && isfinite(cq[2]);
+            const float fi = (cq[0] / P.occ_shape[0]) * (float)P.grid[0];
+            const float fj = (cq[1] / P.occ_shape[1]) * (float)P.grid[1];
+            const float fk = (cq[2] / P.occ_shape[2]) * (float)P.grid[2];
+            const bool inr = fin && fi > -1.0f && fi < 65536.0f && fj > -1.0f && fj < 65536.0f && fk > -1.0f && fk < 65536.0f;
+            if (inr) {
+                const int i = (int)fi, j = (int)fj, k = (int)fk;
+                if (0 < i && i < P.grid[0] && 0 < j && j < P.grid[1] && 0 < k && k < P.grid[2]) {
+                    uint32_t cm = 0;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) cm |= (sem[c][e] != 0.0f) ? (1u << c) : 0u;
+                    if (cm) {
+                        vkey[e] = ((i * P.grid[1] + j) * P.grid[2] + k) * C;
+                        vcm[e] = cm;
+                    }
+                }
+            }
+        }
+    }
+    // ---- voxel marking with run-length de-duplication along the camera row ----
+    // Neighbouring pixels mostly fall into the same voxel (a 0.5 m cell spans tens of pixels), so a pixel only touches
+    // the grid when its (voxel, class set) is not covered by its left neighbour's: by induction every pixel's bits are
+    // then set by the nearest acting pixel to its left.  The first pixel of each wave always acts.
+    if (P.occ_bits) {
+        int pk = __shfl_up(vkey[3], 1);
+        uint32_t pc = __shfl_up(vcm[3], 1);
+        if ((threadIdx.x & 63) == 0) { pk = -2; pc = 0; }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (vkey[e] >= 0 && (vkey[e] != pk || (vcm[e] & ~pc))) {
+                const uint32_t bit = (uint32_t)vkey[e];
+                const unsigned long long m = (unsigned long long)vcm[e] << (bit & 31);
+                const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+                uint32_t* wp = P.occ_bits + (bit >> 5);
+                // idempotent OR: a stale read only costs a redundant atomic
+                if ((__hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mlo) != mlo) atomicOr(wp, mlo);
+                if (mhi && (__hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & mhi) != mhi) atomicOr(wp + 1, mhi);
+            }
+            pk = vkey[e];
+            pc = vcm[e];
+        }
+    }
+    const size_t n0 = (size_t)u * P.Wc + v0;
+    if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
+    if (P.seg_up) {
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+            *reinterpret_cast<float4*>(P.seg_up + ((size_t)b * C + c) * npix + n0) = make_float4(sem[c][0], sem[c][1], sem[c][2], sem[c][3]);
+    }
+    if (P.points) {
+        float4* o = reinterpret_cast<float4*>(P.points + ((size_t)b * npix + n0) * 3);
+        o[0] = make_float4(pt[0][0], pt[0][1], pt[0][2], pt[1][0]);
+        o[1] = make_float4(pt[1][1], pt[1][2], pt[2][0], pt[2][1]);
+        o[2] = make_float4(pt[2][2], pt[3][0], pt[3][1], pt[3][2]);
+    }
+}
+
 // bits -> f32, every batch row gets the same union grid.  One thread = 4 consecutive cells.
 __global__ __launch_bounds__(256) void occ_expand_kernel(const uint32_t* __restrict__ bits, float* __restrict__ occ, size_t ncell, int B) {
     const size_t nq = ncell / 4;
@@ -257,6 +391,15 @@ int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg
         if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
     }
     const bool vec4 = (P.Wc % 4 == 0);
+    constexpr int SW = 256;
+    const float sx_h = (float)P.w / (float)P.Wc;
+    if (vec4 && (int)(1024.0f * sx_h) + 8 <= SW) {
+        const int nseg = (P.Wc + 1023) / 1024;
+        hipLaunchKernelGGL((project_rows_kernel<3, SW>), dim3((unsigned)(B * P.Hc * nseg)), dim3(256), 0, stream, P, nseg);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { err = hipGetErrorString(e2); return 1; }
+        return 0;
+    }
     const long long total = (long long)B * P.Hc * (vec4 ? P.Wc / 4 : P.Wc);
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU

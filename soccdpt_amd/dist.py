@@ -52,7 +52,8 @@ def init_from_env(backend: str = "nccl"):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world > 1 and not dist.is_initialized():
+    force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"  # exercise the RCCL path with a single rank (tests)
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         if backend == "nccl":
@@ -65,6 +66,8 @@ def init_from_env(backend: str = "nccl"):
 
 def attach(net, group=None):
     """Make `net` (SOccDPT / SOccDPT_V3) produce the union-over-all-ranks occupancy grid."""
-    if dist.is_initialized() and dist.get_world_size(group) > 1:
+    import os
+    force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
         net.occ_exchange = OccExchange(group)
     return net
