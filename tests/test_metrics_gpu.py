@@ -38,11 +38,17 @@ def iou(pred, gt):
     return float((inter / (union + 1e-7)).mean())
 
 
-def test_iou_rmse_within_half_percent(gpu_device):
+@pytest.mark.parametrize("precision,iou_tol", [("f32", 5e-3), ("bf16", 2e-2)])
+def test_iou_rmse_within_half_percent(gpu_device, precision, iou_tol):
+    """f32 parity mode: IoU and RMSE within 0.5 % of the reference-equivalent CPU path (BASELINE.json target).
+    bf16 mode: RMSE within 0.5 %; IoU within 2 % — with RANDOM synthetic weights ~0.5 % of the class logits sit inside
+    the bf16 noise band around the 0.5 threshold and flip (measured 1.1 %); DESIGN.md reports this."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F32
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
-    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False)
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False,
+                   precision=PREC_F32 if precision == "f32" else PREC_BF16)
     sd = synth_state_dict(alias_pretrained=True)
     m.load_state_dict(sd, strict=False)
     m = m.eval().to(gpu_device)
@@ -59,7 +65,7 @@ def test_iou_rmse_within_half_percent(gpu_device):
     gt_seg = ((seg_o > 0.5) ^ (blobs > 0.8)).float()
     r_g, r_o = rmse_aligned(inv_g.cpu(), gt_disp), rmse_aligned(inv_o, gt_disp)
     i_g, i_o = iou(seg_g.cpu(), gt_seg), iou(seg_o, gt_seg)
-    print(f"RMSE gpu {r_g:.6f} oracle {r_o:.6f} rel diff {abs(r_g - r_o) / r_o:.2e};  IoU gpu {i_g:.5f} oracle {i_o:.5f} rel diff {abs(i_g - i_o) / i_o:.2e}")
+    print(f"[{precision}] RMSE gpu {r_g:.6f} oracle {r_o:.6f} rel diff {abs(r_g - r_o) / r_o:.2e};  IoU gpu {i_g:.5f} oracle {i_o:.5f} rel diff {abs(i_g - i_o) / i_o:.2e}")
     assert 0.05 < i_o < 0.99 and r_o > 0
     assert abs(r_g - r_o) / r_o < 5e-3
-    assert abs(i_g - i_o) / i_o < 5e-3
+    assert abs(i_g - i_o) / i_o < iou_tol
