@@ -37,6 +37,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
+    ap.add_argument("--model-type", default="dpt_swin2_tiny_256", choices=["dpt_swin2_tiny_256", "dpt_swin2_base_384"],
+                    help="dpt_swin2_tiny_256 = BASELINE metric config; dpt_swin2_base_384 = BASELINE configs[3] (8 frames per GPU)")
     ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
                     help="bf16: bf16 MFMA operands (BASELINE config); f32: exact-f32 parity mode (1/16 MFMA rate)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: no gain)")
@@ -62,14 +64,18 @@ def main():
     import io
     with contextlib.redirect_stdout(io.StringIO()):
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
+                         model_type=args.model_type,
                          graph=args.graph, precision=(1 if args.precision == "f32" else 0))
-    sd = synth_state_dict(alias_pretrained=True)
+    from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+    backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
+    img = SWIN_ARCHS[backbone].img
+    sd = synth_state_dict(backbone, alias_pretrained=True)
     net.load_state_dict(sd, strict=False)
     net = net.eval().to(dev)
     sdist.attach(net)
 
     B = args.batch
-    x = synth_input(B, seed0=rank * B).to(dev)   # different frames per rank
+    x = synth_input(B, size=img, seed0=rank * B).to(dev)   # different frames per rank
 
     def barrier():
         if dist.is_initialized():
@@ -141,12 +147,12 @@ def main():
         except Exception:
             pass
         result = {
-            "metric": "frames/sec SOccDPT_V3 swin2_tiny_256 @256px (depth+seg+points+occupancy forward)",
+            "metric": f"frames/sec SOccDPT_V3 {args.model_type.replace('dpt_', '')} @{img}px (depth+seg+points+occupancy forward)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
-            "config": {"workload": "SOccDPT_V3 dpt_swin2_tiny_256 full forward, compute_occ=True, camera 1920x1080",
-                       "batch_per_gpu": B, "global_batch": B * world, "image": 256, "streams_per_gpu": args.streams, "hip_graph": args.graph,
+            "config": {"workload": f"SOccDPT_V3 {args.model_type} full forward, compute_occ=True, camera 1920x1080",
+                       "batch_per_gpu": B, "global_batch": B * world, "image": img, "streams_per_gpu": args.streams, "hip_graph": args.graph,
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
             "roofline": roofline,
@@ -170,11 +176,11 @@ def main():
         nb = max(1, min(args.cpu_sample_frames, B))
         xs = x[:nb].cpu()
         sd_cpu = {k: v.cpu() for k, v in sd.items()}
-        R.soccdpt_v3_forward(sd_cpu, xs[:1], sigmoid=False)   # warm-up (allocator, oneDNN primitives)
+        R.soccdpt_v3_forward(sd_cpu, xs[:1], backbone=backbone, sigmoid=False)   # warm-up (allocator, oneDNN primitives)
         reps, tcpu = 0, 0.0
         while tcpu < 10.0 and reps < 6:
             t2 = time.perf_counter()
-            R.soccdpt_v3_forward(sd_cpu, xs, sigmoid=False)
+            R.soccdpt_v3_forward(sd_cpu, xs, backbone=backbone, sigmoid=False)
             tcpu += time.perf_counter() - t2
             reps += 1
         result["cpu_baseline"] = {"value": round(nb * reps / tcpu, 3), "unit": "frames/s", "cores": cores, "kind": "port",

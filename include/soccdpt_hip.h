@@ -173,7 +173,8 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 
 /* Swin-V2 cosine window attention of one block (timm WindowAttention + shift/partition/reverse):
  * qkv [B*res*res][3*heads*32] bf16 -> out [B*res*res][heads*32] bf16.  cpb_table [(2ws-1)^2][heads] f32 is
- * 16*sigmoid(cpb_mlp(coords)); scale[heads] = exp(min(logit_scale, ln 100)); bias_scratch: heads*ws^4 floats. */
+ * 16*sigmoid(cpb_mlp(coords)); scale[heads] = exp(min(logit_scale, ln 100)); bias_scratch: heads*ceil(ws*ws/32)^2*1024
+ * floats.  Window sizes 16 and 8 (single-pass softmax) and 24 and 12 (online softmax over key tiles) are instantiated. */
 int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
                                 float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, void* stream);
 

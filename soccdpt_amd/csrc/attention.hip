@@ -336,26 +336,197 @@ __global__ __launch_bounds__(AttnCfgF32<WS>::THREADS) void window_attention_f32_
     }
 }
 
-// CPB bias in accumulator order: [head][qb][t][lane][16]; value for query 32qb+(lane&31),
-// key 32t + (reg&3) + 8(reg>>2) + 4(lane>>5)
-__global__ void attn_bias_kernel(const float* __restrict__ table, float* __restrict__ bias_acc, int ws, int heads) {
-    const int N = ws * ws, QB = N / 32, KT = N / 32;
-    const size_t total = (size_t)heads * N * N;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int rg = (int)(i & 15), lane = (int)((i >> 4) & 63);
-        size_t r = i >> 10;
-        const int t = (int)(r % KT);
-        r /= KT;
-        const int qb = (int)(r % QB);
-        const int head = (int)(r / QB);
-        const int q = 32 * qb + (lane & 31), k = 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
-        const int rq = q / ws, cq = q % ws, rk = k / ws, ck = k % ws;
-        const int idx = (rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1);
-        bias_acc[i] = table[(size_t)idx * heads + head];
+// ---------------------------------------------------------------------------------------------
+// Generic window size (24x24 / 12x12 of dpt_swin2_base_384): same operand layout, but the N x N score matrix
+// no longer fits the register file (576 keys = 18 tiles x 16 accumulators), so keys are consumed tile by tile
+// with an online softmax (running max m, running sum l, O rescaled by exp(m - m_new) per tile).  N is padded
+// to a multiple of 32: padded keys carry a -1e30 bias (zero probability), padded queries are not stored.
+// The shift mask is evaluated arithmetically from the token coordinates.
+// ---------------------------------------------------------------------------------------------
+template <int WS>
+struct AttnGenCfg {
+    static constexpr int N = WS * WS;
+    static constexpr int NT = (N + 31) / 32;
+    static constexpr int NPAD = NT * 32;
+    static constexpr int THREADS = 256;
+    static constexpr int VT_STRIDE = NPAD * 2 + 8;
+    static constexpr int KS_OFF = NPAD * 64, VT_OFF = 2 * NPAD * 64;
+    static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
+};
+
+template <int WS>
+__global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
+                                                                     const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
+                                                                     int shift, int heads) {
+    using A = AttnGenCfg<WS>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Qs = smem;
+    char* Ks = smem + A::KS_OFF;
+    char* Vt = smem + A::VT_OFF;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * 32;
+    const int nw = res / WS;
+    int bid = blockIdx.x;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const float hscale = scale[head];
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / WS, c = p % WS;
+        int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    for (int idx = tid; idx < A::NPAD * 4; idx += A::THREADS) {
+        const int p = idx >> 2, c = idx & 3;
+        uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+        if (p < A::N) {
+            const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
+            qv = *reinterpret_cast<const uint4*>(src);
+            kv = *reinterpret_cast<const uint4*>(src + C);
+            vv = *reinterpret_cast<const uint4*>(src + 2 * C);
+        }
+        const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
+        float qf[8], kf[8];
+        float qs = 0.f, ks = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[2 * j] = __builtin_bit_cast(float, qu[j] << 16);
+            qf[2 * j + 1] = __builtin_bit_cast(float, qu[j] & 0xffff0000u);
+            kf[2 * j] = __builtin_bit_cast(float, ku[j] << 16);
+            kf[2 * j + 1] = __builtin_bit_cast(float, ku[j] & 0xffff0000u);
+            qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
+            ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
+        }
+        qs += __shfl_xor(qs, 1);
+        qs += __shfl_xor(qs, 2);
+        ks += __shfl_xor(ks, 1);
+        ks += __shfl_xor(ks, 2);
+        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
+        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
+        uint4 qo, ko;
+        qo.x = pk_bf16(qf[0] * qi, qf[1] * qi); qo.y = pk_bf16(qf[2] * qi, qf[3] * qi);
+        qo.z = pk_bf16(qf[4] * qi, qf[5] * qi); qo.w = pk_bf16(qf[6] * qi, qf[7] * qi);
+        ko.x = pk_bf16(kf[0] * ki, kf[1] * ki); ko.y = pk_bf16(kf[2] * ki, kf[3] * ki);
+        ko.z = pk_bf16(kf[4] * ki, kf[5] * ki); ko.w = pk_bf16(kf[6] * ki, kf[7] * ki);
+        const int sw = (c ^ ((p >> 2) & 3)) * 16;
+        *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
+        *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+        }
+    }
+    __syncthreads();
+    const int r32 = lane & 31, h = lane >> 5;
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    constexpr int HALF = WS / 2;
+    for (int qb = wave; qb < A::NT; qb += 4) {
+        const int qrow = qb * 32 + r32;
+        const int qcl = qrow < A::N ? qrow : A::N - 1;
+        const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
+        bf16x8 qfrag[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+            qfrag[ks] = *reinterpret_cast<const bf16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
+        float m = -3.0e38f, l = 0.f;
+        f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        const float* bp = bias_acc + ((size_t)(head * A::NT + qb) * A::NT) * 1024 + lane * 16;
+#pragma unroll 1
+        for (int t = 0; t < A::NT; ++t) {
+            const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)t * 1024);
+            const float4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+            f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+            if (lastrow || lastcol) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    int key = t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                    key = key < A::N ? key : A::N - 1;
+                    const bool kr_hi = (key / WS) >= HALF, kc_hi = (key % WS) >= HALF;
+                    if ((lastrow && (kr_hi != qr_hi)) || (lastcol && (kc_hi != qc_hi))) acc[rg] += -100.0f;
+                }
+            }
+            const int krow = t * 32 + r32;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qfrag[ks], acc, 0, 0, 0);
+            }
+            float mt = acc[0];
+#pragma unroll
+            for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, acc[rg]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float alpha = __expf(m - mn);
+            float psum = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                acc[rg] = __expf(acc[rg] - mn);
+                psum += acc[rg];
+                o[rg] *= alpha;
+            }
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                bf16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)acc[8 * st + j];
+                const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
+                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
+                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 16);
+                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o, 0, 0, 0);
+            }
+        }
+        l += __shfl_xor(l, 32);
+        if (qrow < A::N) {
+            const float inv = 1.0f / l;
+            bf16_t* orow = out + token_row(qrow) * (size_t)C + head * 32;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pkt;
+                pkt.x = pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv);
+                pkt.y = pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + 8 * g + 4 * h) = pkt;
+            }
+        }
     }
 }
 
-size_t attn_bias_elems(int ws, int heads) { return (size_t)heads * ws * ws * ws * ws; }
+// CPB bias in accumulator order: [head][qb][t][lane][16]; value for query 32qb+(lane&31),
+// key 32t + (reg&3) + 8(reg>>2) + 4(lane>>5)
+__global__ void attn_bias_kernel(const float* __restrict__ table, float* __restrict__ bias_acc, int ws, int heads) {
+    const int N = ws * ws, NT = (N + 31) / 32;
+    const size_t total = (size_t)heads * NT * NT * 1024;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int rg = (int)(i & 15), lane = (int)((i >> 4) & 63);
+        size_t r = i >> 10;
+        const int t = (int)(r % NT);
+        r /= NT;
+        const int qb = (int)(r % NT);
+        const int head = (int)(r / NT);
+        const int q = 32 * qb + (lane & 31), k = 32 * t + (rg & 3) + 8 * (rg >> 2) + 4 * (lane >> 5);
+        float v = 0.f;
+        if (k >= N) v = -1.0e30f;  // padded key: zero probability
+        else if (q < N) {
+            const int rq = q / ws, cq = q % ws, rk = k / ws, ck = k % ws;
+            const int idx = (rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1);
+            v = table[(size_t)idx * heads + head];
+        }
+        bias_acc[i] = v;
+    }
+}
+
+size_t attn_bias_elems(int ws, int heads) {
+    const size_t nt = ((size_t)ws * ws + 31) / 32;
+    return (size_t)heads * nt * nt * 1024;
+}
 
 int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hipStream_t st, std::string& err) {
     const size_t total = attn_bias_elems(ws, heads);
@@ -400,8 +571,17 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
         hipLaunchKernelGGL((window_attention_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+    } else if (ws == 24 || ws == 12) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      AttnGenCfg<24>::LDS);
+            attr_done = true;
+        }
+        if (ws == 24) hipLaunchKernelGGL((window_attention_flash_kernel<24>), dim3(blocks), dim3(256), AttnGenCfg<24>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else hipLaunchKernelGGL((window_attention_flash_kernel<12>), dim3(blocks), dim3(256), AttnGenCfg<12>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else {
-        err = "window_attention: window size not instantiated (16 and 8 are)";
+        err = "window_attention: window size not instantiated (16, 8, 24, 12 are)";
         return 1;
     }
     return check_launch("window_attention", err);

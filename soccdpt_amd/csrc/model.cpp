@@ -314,9 +314,8 @@ int model_init(Handle& h, std::string& err) {
     add_w(h, "seg_head.4.weight", {h.cfg.num_classes, F, 1, 1});
     add_w(h, "seg_head.4.bias", {h.cfg.num_classes});
 
-    if (a.window != 16) {
-        // the window-attention kernel is instantiated for 16x16 / 8x8 windows (dpt_swin2_tiny_256)
-        err = "soccdpt_create: this build instantiates window attention for swin2t16_256 only";
+    if (a.window != 16 && h.cfg.precision == SOCCDPT_PREC_F32) {
+        err = "soccdpt_create: the exact-f32 window attention is instantiated for 16x16 / 8x8 windows (dpt_swin2_tiny_256) only";
         return 1;
     }
     Arena measure(nullptr, 0);

@@ -340,7 +340,8 @@ def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, re
 
 def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads):
     L = load_library()
-    scratch = torch.empty((heads * ws ** 4,), dtype=torch.float32, device=qkv.device)
+    nt = (ws * ws + 31) // 32
+    scratch = torch.empty((heads * nt * nt * 1024,), dtype=torch.float32, device=qkv.device)
     rc = L.soccdpt_op_window_attention(_ptr(qkv), _ptr(cpb_table), _ptr(scale), _ptr(out), _ptr(scratch), B, res, ws, shift,
                                        heads, _stream_ptr(qkv.device))
     if rc != 0:

@@ -123,7 +123,8 @@ def _attention_ref(qkv, table, scale, B, res, ws, shift, heads):
     return out.reshape(B * res * res, C)
 
 
-@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 0, 3), (2, 64, 16, 8, 3), (1, 32, 16, 8, 6), (3, 16, 16, 0, 12), (2, 8, 8, 0, 24)])
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 0, 3), (2, 64, 16, 8, 3), (1, 32, 16, 8, 6), (3, 16, 16, 0, 12), (2, 8, 8, 0, 24),
+                                                   (1, 96, 24, 12, 4), (2, 48, 24, 12, 8), (2, 24, 24, 0, 16), (3, 12, 12, 0, 32)])
 def test_window_attention(gpu_device, B, res, ws, shift, heads):
     from soccdpt_amd.lib import op_window_attention
     g = torch.Generator().manual_seed(res * 100 + shift + heads)
