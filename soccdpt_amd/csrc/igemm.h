@@ -35,6 +35,9 @@ struct IgemmDesc {
     const float* bias = nullptr;
     const float* res1 = nullptr;  // f32 [M][N]
     const float* res2 = nullptr;  // f32 [M][N]
+    // res2 sampled bilinearly (align_corners=True) from a LOW-RES f32 NHWC map [B][res2_h][res2_w][N] instead of read 1:1:
+    // fuses F.interpolate of the previous fusion block's output (model/blocks.py:488-493) into this epilogue
+    int res2_h = 0, res2_w = 0;
     int act = ACT_NONE;           // applied to every store except out_f32_raw
     float* out_f32 = nullptr;     // [M][N], value BEFORE `act` when act_on_f32 == 0
     int act_on_f32 = 0;

@@ -220,11 +220,28 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const bool mv = m < d.M;
         size_t orow = (size_t)m * N;
         size_t hrow = 0;
-        if (d.out_halo && mv) {
+        // bilinear source of res2 (4 low-res pixels + weights), computed once per pixel
+        size_t up00 = 0, up01 = 0, up10 = 0, up11 = 0;
+        float uly = 0.f, ulx = 0.f;
+        if ((d.out_halo || d.res2_h) && mv) {
             const int hw = d.H * d.W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / d.W, x = rem - y * d.W;
             hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+            if (d.res2_h) {
+                const float sy = d.H > 1 ? (float)(d.res2_h - 1) / (float)(d.H - 1) : 0.f;
+                const float sx = d.W > 1 ? (float)(d.res2_w - 1) / (float)(d.W - 1) : 0.f;
+                const float fy = sy * (float)y, fx = sx * (float)x;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < d.res2_h - 1), x1 = x0 + (x0 < d.res2_w - 1);
+                uly = fy - (float)y0;
+                ulx = fx - (float)x0;
+                const size_t pb = (size_t)b * d.res2_h * d.res2_w;
+                up00 = (pb + (size_t)y0 * d.res2_w + x0) * N;
+                up01 = (pb + (size_t)y0 * d.res2_w + x1) * N;
+                up10 = (pb + (size_t)y1 * d.res2_w + x0) * N;
+                up11 = (pb + (size_t)y1 * d.res2_w + x1) * N;
+            }
         }
 #pragma unroll
         for (int i = 0; i < C::TN; ++i) {
@@ -239,7 +256,15 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 const float4 r4 = *reinterpret_cast<const float4*>(d.res1 + orow + n);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
-            if (d.res2) {
+            if (d.res2 && d.res2_h) {
+                const float4 a00 = *reinterpret_cast<const float4*>(d.res2 + up00 + n), a01 = *reinterpret_cast<const float4*>(d.res2 + up01 + n);
+                const float4 a10 = *reinterpret_cast<const float4*>(d.res2 + up10 + n), a11 = *reinterpret_cast<const float4*>(d.res2 + up11 + n);
+                const float hy = 1.f - uly, hx = 1.f - ulx;
+                v[0] += hy * (hx * a00.x + ulx * a01.x) + uly * (hx * a10.x + ulx * a11.x);
+                v[1] += hy * (hx * a00.y + ulx * a01.y) + uly * (hx * a10.y + ulx * a11.y);
+                v[2] += hy * (hx * a00.z + ulx * a01.z) + uly * (hx * a10.z + ulx * a11.z);
+                v[3] += hy * (hx * a00.w + ulx * a01.w) + uly * (hx * a10.w + ulx * a11.w);
+            } else if (d.res2) {
                 const float4 r4 = *reinterpret_cast<const float4*>(d.res2 + orow + n);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
@@ -313,7 +338,9 @@ static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) 
 static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_128x128x64_s2", "igemm_bf16_64x64x64_s4",
                                         "igemm_bf16_128x128x32_s4", "igemm_bf16_64x64x32_s4", "igemm_bf16_128x32x64_s4",
                                         "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
-                                        "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2"};
+                                        "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
+                                        "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
+                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -347,7 +374,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.Cin % 32 != 0) { err = "igemm: Cin must be a multiple of 32"; return 1; }
     if (d.taps != 1 && d.taps != 9) { err = "igemm: taps must be 1 or 9"; return 1; }
     if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
-    if (d.out_halo && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output needs H, W"; return 1; }
+    if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
@@ -359,7 +386,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || id == 10) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -373,6 +400,14 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 8: return launch_cfg<Cfg<256, 256, 64, 2, 4, 2>>(d, stream, err);
         case 9: return launch_cfg<Cfg<128, 128, 32, 2, 2, 3>>(d, stream, err);
         case 10: return launch_cfg<Cfg<128, 256, 64, 2, 4, 2>>(d, stream, err);
+        case 11: return launch_cfg<Cfg<64, 64, 64, 2, 2, 6>>(d, stream, err);
+        case 12: return launch_cfg<Cfg<64, 64, 64, 2, 2, 8>>(d, stream, err);
+        case 13: return launch_cfg<Cfg<64, 128, 64, 2, 2, 4>>(d, stream, err);
+        case 14: return launch_cfg<Cfg<32, 64, 64, 2, 2, 6>>(d, stream, err);
+        case 15: return launch_cfg<Cfg<128, 256, 32, 2, 4, 3>>(d, stream, err);
+        case 16: return launch_cfg<Cfg<256, 128, 32, 4, 2, 3>>(d, stream, err);
+        case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
+        case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
     }
     err = "igemm: unknown configuration id";
     return 1;

@@ -460,7 +460,8 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.bias = u1.b1; d.act = ACT_RELU; d.out_op = w.t_relu[l]; d.out_halo = 1;
             RUN(gemm(d));
             d = conv(w.t_relu[l], F, u1.w2, F, r);
-            d.bias = u1.b2; d.res1 = w.lrn_raw[l]; d.res2 = w.path[l];
+            d.bias = u1.b2; d.res1 = w.lrn_raw[l];
+            d.res2 = w.oc[l + 1]; d.res2_h = a.res(l + 1); d.res2_w = a.res(l + 1);  // bilinear(out_conv output of the coarser level), on the fly
             d.out_f32 = w.out_raw[l]; d.out_op = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
             RUN(gemm(d));
             fused_raw = w.out_raw[l];
@@ -480,9 +481,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.X = w.u[l]; d.Wt = P.oc_w[l]; d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = P.oc_b[l]; d.out_f32 = w.oc[l];
             RUN(gemm(d));
         }
-        if (l > 0) { PROF("bilinear_resize", 0.0, (double)M * F * 4.0 * 5.0);
-                     RUN(launch_bilinear(w.oc[l], 0, w.path[l - 1], nullptr, nullptr, 0, B, r, r, 2 * r, 2 * r, F, st, err)); }
-        else { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
+        if (l == 0) { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
                RUN(launch_bilinear(w.oc[0], 0, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.path1), F32 ? static_cast<float*>(w.path1) : nullptr, 1, B, r, r,
                                    2 * r, 2 * r, F, st, err)); }
     }
