@@ -1,0 +1,180 @@
+// Fused tail of the depth head for gfx950 (bf16 mode):
+//   Interpolate(x2, bilinear, align_corners=True) -> Conv2d(128, 32, 3, pad 1) + bias -> ReLU -> Conv2d(32, 1, 1) + bias -> ReLU
+//   (/root/reference/SOccDPT/model/dpt.py:207-216), input d1 = output of Conv2d(256,128,3) at half resolution.
+// The unfused form writes and re-reads a 134 MB up-sampled bf16 image (B=8) and, as an implicit GEMM with N = 32,
+// stages every input pixel 9 times for only 32 output channels (25 FLOP per staged byte).  Here a persistent
+// workgroup keeps the whole 32 x 1152 weight matrix in LDS, builds the (8+2) x (16+2) up-sampled halo patch of
+// each 8 x 16 output tile directly from the low-resolution map (4 x 16-byte loads + lerp per 8 channels), and runs
+// the 9 taps x 4 k-steps of v_mfma_f32_16x16x32_bf16 out of LDS: no up-sampled image in HBM, ~12x fewer staged bytes.
+#include "kernels.h"
+
+namespace soccdpt {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+namespace {
+constexpr int CIN = 128, COUT = 32, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;
+constexpr int KTOT = 9 * CIN;                 // 1152
+constexpr int W_ROWB = KTOT * 2 + 16;         // 2320 B: row stride = 4 dwords mod 64 -> conflict-free ds_read_b128
+constexpr int P_ROWB = CIN * 2 + 16;          // 272 B per patch pixel, same trick
+constexpr int W_BYTES = COUT * W_ROWB;        // 74240
+constexpr int P_BYTES = PH * PW * P_ROWB;     // 48960
+constexpr int SRH = 8, SRW = 12;              // low-res source window of one patch: <= 7 x 11 pixels (+1 spare)
+constexpr int S_ROWB = CIN * 2;               // 256 B per source pixel
+constexpr int S_BYTES = SRH * SRW * S_ROWB;   // 24576
+constexpr int T_BYTES = 512;                   // per-tile row / column interpolation tables
+constexpr int LDS_BYTES = W_BYTES + P_BYTES + S_BYTES + T_BYTES;  // 148288
+constexpr int NTHR = 512;                      // 8 waves: one output row of the 8 x 16 tile each
+}  // namespace
+
+__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+__device__ __forceinline__ uint32_t pk2(float a, float b) {
+    __bf16 x = (__bf16)a, y = (__bf16)b;
+    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
+}
+
+// d1: bf16 [B][h][w][128] plain NHWC; wt: bf16 [32][9*128] tap-major; out: f32 [B][2h][2w]
+__global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restrict__ d1, const bf16_t* __restrict__ wt, const float* __restrict__ bias,
+                                                          const float* __restrict__ w4, float b4, float* __restrict__ out, int B, int h, int w) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* Ws = smem;
+    char* Ps = smem + W_BYTES;
+    char* Ss = smem + W_BYTES + P_BYTES;
+    int* Ti = reinterpret_cast<int*>(smem + W_BYTES + P_BYTES + S_BYTES);  // [0..9] row: src offset (bytes) of the upper row | valid<<30 ; [32..49] col
+    float* Tf = reinterpret_cast<float*>(Ti) + 64;                          // [0..9] ly ; [32..49] lx
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = 2 * h, W = 2 * w;
+    const int tiles_x = W / TW, tiles_y = H / TH;
+    const int ntiles = B * tiles_y * tiles_x;
+    // ---- weights -> LDS once per workgroup (16-byte chunks, padded rows) ----
+    for (int i = tid; i < COUT * (KTOT / 8); i += NTHR) {
+        const int n = i / (KTOT / 8), c = i % (KTOT / 8);
+        *reinterpret_cast<uint4*>(Ws + n * W_ROWB + c * 16) = *reinterpret_cast<const uint4*>(wt + (size_t)n * KTOT + c * 8);
+    }
+    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
+    const int frow = lane & 15, fq = lane >> 4;
+    float4 bia[2], w4v[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        bia[i] = *reinterpret_cast<const float4*>(bias + i * 16 + fq * 4);
+        w4v[i] = *reinterpret_cast<const float4*>(w4 + i * 16 + fq * 4);
+    }
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int tx = tile % tiles_x;
+        int r = tile / tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;  // up-sampled coordinates of the patch origin
+        __syncthreads();                               // previous tile's MFMAs are done with the patch (and the weights are in)
+        // ---- low-res source window -> LDS (each source pixel once, coalesced) + interpolation tables ----
+        const bf16_t* src = d1 + (size_t)b * h * w * CIN;
+        const int Yc0 = y0 < 0 ? 0 : y0, Xc0 = x0 < 0 ? 0 : x0;
+        const int sy0 = (int)(sy * (float)Yc0), sx0 = (int)(sx * (float)Xc0);  // first source row / column any patch pixel touches
+        for (int it = tid; it < SRH * SRW * (CIN / 8); it += NTHR) {
+            const int ch = it % (CIN / 8), p = it / (CIN / 8);
+            int yy = sy0 + p / SRW, xx = sx0 + p % SRW;
+            yy = yy > h - 1 ? h - 1 : yy;
+            xx = xx > w - 1 ? w - 1 : xx;
+            *reinterpret_cast<uint4*>(Ss + p * S_ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + ((size_t)yy * w + xx) * CIN + ch * 8);
+        }
+        if (tid < PH) {  // rows: byte offset of source row yy0 inside the window, step to yy1, weight
+            const int Y = y0 + tid;
+            const bool ok = Y >= 0 && Y < H;
+            const float fy = sy * (float)(ok ? Y : 0);
+            const int yy0 = (int)fy;
+            Ti[tid] = ((yy0 - sy0) * SRW * S_ROWB) | ((yy0 < h - 1) ? (1 << 28) : 0) | (ok ? (1 << 30) : 0);
+            Tf[tid] = fy - (float)yy0;
+        } else if (tid >= 32 && tid < 32 + PW) {
+            const int X = x0 + tid - 32;
+            const bool ok = X >= 0 && X < W;
+            const float fx = sx * (float)(ok ? X : 0);
+            const int xx0 = (int)fx;
+            Ti[tid] = ((xx0 - sx0) * S_ROWB) | ((xx0 < w - 1) ? (1 << 28) : 0) | (ok ? (1 << 30) : 0);
+            Tf[tid] = fx - (float)xx0;
+        }
+        __syncthreads();
+        // ---- build the up-sampled halo patch from the staged window: thread = fixed 8-channel chunk, strided pixels ----
+        {
+            const int ch = tid & 15;
+            const char* sb = Ss + ch * 16;
+            for (int p = tid >> 4; p < PH * PW; p += NTHR / 16) {
+                const int py = p / PW, px = p - py * PW;
+                const int ty_ = Ti[py], tx_ = Ti[32 + px];
+                uint4 o = make_uint4(0, 0, 0, 0);  // conv zero padding outside the image
+                if ((ty_ & tx_) >> 30) {
+                    const float ly = Tf[py], lx = Tf[32 + px], hy = 1.f - ly, hx = 1.f - lx;
+                    const int o00 = (ty_ & 0xfffffff) + (tx_ & 0xfffffff);
+                    const int dyo = ((ty_ >> 28) & 1) * SRW * S_ROWB, dxo = ((tx_ >> 28) & 1) * S_ROWB;
+                    const uint4 a00 = *reinterpret_cast<const uint4*>(sb + o00);
+                    const uint4 a01 = *reinterpret_cast<const uint4*>(sb + o00 + dxo);
+                    const uint4 a10 = *reinterpret_cast<const uint4*>(sb + o00 + dyo);
+                    const uint4 a11 = *reinterpret_cast<const uint4*>(sb + o00 + dyo + dxo);
+                    const uint32_t u00[4] = {a00.x, a00.y, a00.z, a00.w}, u01[4] = {a01.x, a01.y, a01.z, a01.w};
+                    const uint32_t u10[4] = {a10.x, a10.y, a10.z, a10.w}, u11[4] = {a11.x, a11.y, a11.z, a11.w};
+                    uint32_t ov[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float lo = hy * (hx * bf_lo(u00[j]) + lx * bf_lo(u01[j])) + ly * (hx * bf_lo(u10[j]) + lx * bf_lo(u11[j]));
+                        const float hi = hy * (hx * bf_hi(u00[j]) + lx * bf_hi(u01[j])) + ly * (hx * bf_hi(u10[j]) + lx * bf_hi(u11[j]));
+                        ov[j] = pk2(lo, hi);
+                    }
+                    o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
+                }
+                *reinterpret_cast<uint4*>(Ps + p * P_ROWB + ch * 16) = o;
+            }
+        }
+        __syncthreads();
+        // ---- 9 taps x 4 k-steps: wave = output row `wave` of the tile (16 px) x 32 channels ----
+        f32x4 acc[2];
+        acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
+        acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const int ky = tap / 3, kx = tap % 3;
+            const int prow = (wave + ky) * PW + frow + kx;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Ps + prow * P_ROWB + (ks * 32 + fq * 8) * 2);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (i * 16 + frow) * W_ROWB + (tap * CIN + ks * 32 + fq * 8) * 2);
+                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i], 0, 0, 0);
+                }
+            }
+        }
+        // ---- epilogue: + bias, ReLU, 1x1 (32 -> 1) + bias, ReLU ----
+        {
+            float s = 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                s += fmaxf(acc[i][0] + bia[i].x, 0.f) * w4v[i].x + fmaxf(acc[i][1] + bia[i].y, 0.f) * w4v[i].y +
+                     fmaxf(acc[i][2] + bia[i].z, 0.f) * w4v[i].z + fmaxf(acc[i][3] + bia[i].w, 0.f) * w4v[i].w;
+            }
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            if (fq == 0) {
+                const int Y = ty * TH + wave, X = tx * TW + frow;
+                out[((size_t)b * H + Y) * W + X] = fmaxf(s + b4, 0.f);
+            }
+        }
+    }
+}
+
+int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int B, int h, int w,
+                      hipStream_t st, std::string& err) {
+    if ((2 * h) % TH || (2 * w) % TW) { err = "depth_tail: output size must be a multiple of 8 x 16"; return 1; }
+    static bool attr_done = false;
+    if (!attr_done) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) { err = std::string("depth_tail: ") + hipGetErrorString(e); return 1; }
+        attr_done = true;
+    }
+    const int ntiles = B * (2 * h / TH) * (2 * w / TW);
+    const int blocks = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU keeps the weights resident
+    hipLaunchKernelGGL(depth_tail_kernel, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
+    return check_launch("depth_tail", err);
+}
+
+}  // namespace soccdpt

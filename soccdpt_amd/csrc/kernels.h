@@ -38,6 +38,10 @@ int launch_logit_scale(const float* ls, float* out, int H, hipStream_t st, std::
 int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* table, int ws, int pws, int H, hipStream_t st,
                      std::string& err);
 
+// depth_tail.hip: bilinear x2 + conv3x3(128->32) + ReLU + conv1x1(32->1) + ReLU fused (bf16 mode)
+int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int B, int h, int w,
+                      hipStream_t st, std::string& err);
+
 // attention.hip
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);

@@ -491,12 +491,18 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
         d.bias = P.d0_b; d.out_op = w.d1;
         RUN(gemm(d));
-        { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
-          RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, B, r1,
-                              r1, r0, r0, F / 2, st, err)); }
-        d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
-        d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
-        RUN(gemm(d));
+        if (!F32 && F == 256) {
+            // fused: up-sample + conv3x3(128->32) + ReLU + 1x1 + ReLU straight from the half-resolution map
+            PROF("depth_tail_fused", 2.0 * B * r0 * r0 * 32.0 * 9.0 * (F / 2), 0.0);
+            RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, B, r1, r1, st, err));
+        } else {
+            { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
+              RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, B, r1,
+                                  r1, r0, r0, F / 2, st, err)); }
+            d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
+            d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
+            RUN(gemm(d));
+        }
         d = conv(w.path1, F, P.s0_w, F, r1);
         d.bias = P.bn_shift; d.act = ACT_RELU; d.out_op = w.s1;
         RUN(gemm(d));
