@@ -128,6 +128,19 @@ size_t soccdpt_occ_words(void* handle);
 /* Number of kernel launches issued by the last soccdpt_network call (diagnostics). */
 int soccdpt_last_launch_count(void* handle);
 
+/* ---- evaluation metrics on the device (the step after the hot path; replaces the per-batch .cpu().numpy() round trip of
+ * utils/__init__.py:161-332).  No handle: stateless; `scratch` = soccdpt_metrics_scratch_bytes(B, C) bytes of device memory.
+ * soccdpt_metrics_depth: pred, gt [B][npix] f32, mask [B][npix] u8 -> out[0..6] = abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 over
+ *   all masked pixels of the batch after per-image least-squares scale/shift alignment (loss/ssi_loss.py:5-32,
+ *   utils/__init__.py:109-158,219-234); out[7+2b], out[8+2b] = scale, shift of image b.  out: 7 + 2B floats.
+ * soccdpt_metrics_iou: pred, gt [B][C][npix] f32 -> out[b] = mean_c |p>0.5 & g>0.5| / (|p>0.5 | g>0.5| + 1e-7)
+ *   (utils/__init__.py:314-330). */
+size_t soccdpt_metrics_scratch_bytes(int B, int C);
+int soccdpt_metrics_depth(const float* dev_pred, const float* dev_gt, const uint8_t* dev_mask, int B, size_t npix, float* dev_out,
+                          void* dev_scratch, void* stream);
+int soccdpt_metrics_iou(const float* dev_pred, const float* dev_gt, int B, int C, size_t npix, float* dev_out, void* dev_scratch,
+                        void* stream);
+
 /* ---- per-kernel timing with HIP events on the caller's stream (bench.py roofline) ----
  * While enabled, every kernel launch of soccdpt_network / soccdpt_project / soccdpt_occ_expand /
  * soccdpt_forward is bracketed by a hipEvent pair on `stream`.  soccdpt_profile_collect synchronises the

@@ -147,6 +147,24 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
 
 int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
 
+size_t soccdpt_metrics_scratch_bytes(int B, int C) { return metrics_scratch_bytes(B, C); }
+
+int soccdpt_metrics_depth(const float* dev_pred, const float* dev_gt, const uint8_t* dev_mask, int B, size_t npix, float* dev_out,
+                          void* dev_scratch, void* stream) {
+    std::string err;
+    if (!dev_pred || !dev_gt || !dev_mask || !dev_out || !dev_scratch) return fail(nullptr, "soccdpt_metrics_depth: null argument");
+    if (launch_depth_metrics(dev_pred, dev_gt, dev_mask, B, npix, dev_out, dev_scratch, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_metrics_iou(const float* dev_pred, const float* dev_gt, int B, int C, size_t npix, float* dev_out, void* dev_scratch,
+                        void* stream) {
+    std::string err;
+    if (!dev_pred || !dev_gt || !dev_out || !dev_scratch) return fail(nullptr, "soccdpt_metrics_iou: null argument");
+    if (launch_iou_metrics(dev_pred, dev_gt, B, C, npix, dev_out, dev_scratch, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_set_streams(void* handle, int n) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;

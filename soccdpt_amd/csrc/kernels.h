@@ -42,6 +42,12 @@ int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* t
 int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int B, int h, int w,
                       hipStream_t st, std::string& err);
 
+// metrics.hip
+size_t metrics_scratch_bytes(int B, int C);
+int launch_depth_metrics(const float* pred, const float* gt, const uint8_t* mask, int B, size_t npix, float* out, void* scratch, hipStream_t st,
+                         std::string& err);
+int launch_iou_metrics(const float* pred, const float* gt, int B, int C, size_t npix, float* out, void* scratch, hipStream_t st, std::string& err);
+
 // attention.hip
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);

@@ -106,6 +106,12 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_words.restype = cs
     L.soccdpt_last_launch_count.argtypes = [vp]
     L.soccdpt_last_launch_count.restype = ci
+    L.soccdpt_metrics_scratch_bytes.argtypes = [ci, ci]
+    L.soccdpt_metrics_scratch_bytes.restype = cs
+    L.soccdpt_metrics_depth.argtypes = [vp, vp, vp, ci, cs, vp, vp, vp]
+    L.soccdpt_metrics_depth.restype = ci
+    L.soccdpt_metrics_iou.argtypes = [vp, vp, ci, ci, cs, vp, vp, vp]
+    L.soccdpt_metrics_iou.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]
     L.soccdpt_set_streams.restype = ci
     L.soccdpt_set_graph.argtypes = [vp, ci]

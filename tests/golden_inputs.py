@@ -23,3 +23,15 @@ def proj_inputs(seed: int = 1234, B: int = 2, S: int = 256):
 def decoder_features(seed: int = 77, B: int = 1, dims=(96, 192, 384, 768), res=(64, 32, 16, 8)):
     g = torch.Generator().manual_seed(seed)
     return [torch.randn((B, c, r, r), generator=g) for c, r in zip(dims, res)]
+
+
+def metrics_inputs(seed: int = 321, B: int = 3, H: int = 135, W: int = 240):
+    """Synthetic (prediction, ground truth, mask) triples for the evaluation metrics (SURVEY.md §8f #2)."""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand((B, 1, 9, 16), generator=g) * 0.2 + 0.02
+    gt = torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)[:, 0]
+    pred = 0.7 * gt + 0.013 + 0.004 * torch.randn((B, H, W), generator=g)
+    mask = torch.rand((B, H, W), generator=g) > 0.2
+    seg_gt = (torch.rand((B, 3, H, W), generator=g) > 0.6).float()
+    seg_pred = (0.45 * seg_gt + 0.6 * torch.rand((B, 3, H, W), generator=g)).contiguous()
+    return pred.contiguous(), gt.contiguous(), mask.contiguous(), seg_pred, seg_gt
