@@ -363,6 +363,10 @@ static int pick_cfg(const IgemmDesc& d) {
         if (cdiv(d.M, 128) * (d.N / 256) >= 224) return 10;  // 128(M)x256(N)
     }
     if (b128 >= 384) return 1;
+    // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring); measured with
+    // rocprofv3 device durations (tools/igemm_trace.py): 14.8 -> 9.6 us at M=2048,N=384,K=1536; 15.6 -> 13.4 at M=512,N=768,K=3072
+    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
+    if (b64 < 256 && (long)d.taps * d.Cin >= 1536) return 14;
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
