@@ -3,7 +3,7 @@
 //   (/root/reference/SOccDPT/model/dpt.py:207-216), input d1 = output of Conv2d(256,128,3) at half resolution.
 // The unfused form writes and re-reads a 134 MB up-sampled bf16 image (B=8) and, as an implicit GEMM with N = 32,
 // stages every input pixel 9 times for only 32 output channels (25 FLOP per staged byte).  Here a persistent
-// workgroup keeps the whole 32 x 1152 weight matrix in LDS, builds the (8+2) x (16+2) up-sampled halo patch of
+// workgroup keeps the 32 x 1152 weight matrix in REGISTERS (each wave its 16 channels as 36 MFMA fragments), builds the (8+2) x (16+2) up-sampled halo patch of
 // each 8 x 16 output tile directly from the low-resolution map (4 x 16-byte loads + lerp per 8 channels), and runs
 // the 9 taps x 4 k-steps of v_mfma_f32_16x16x32_bf16 out of LDS: no up-sampled image in HBM, ~12x fewer staged bytes.
 #include "kernels.h"
@@ -24,7 +24,8 @@ constexpr int SRH = 8, SRW = 12;              // low-res source window of one pa
 constexpr int S_ROWB = CIN * 2;               // 256 B per source pixel
 constexpr int S_BYTES = SRH * SRW * S_ROWB;   // 24576
 constexpr int T_BYTES = 512;                   // per-tile row / column interpolation tables
-constexpr int LDS_BYTES = W_BYTES + P_BYTES + S_BYTES + T_BYTES;  // 148288
+constexpr int R_BYTES = TH * TW * 4;            // cross-wave reduction of the two channel tiles
+constexpr int LDS_BYTES = P_BYTES + S_BYTES + T_BYTES + R_BYTES;  // 74560
 constexpr int NTHR = 512;                      // 8 waves: one output row of the 8 x 16 tile each
 }  // namespace
 
@@ -39,28 +40,25 @@ __device__ __forceinline__ uint32_t pk2(float a, float b) {
 __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restrict__ d1, const bf16_t* __restrict__ wt, const float* __restrict__ bias,
                                                           const float* __restrict__ w4, float b4, float* __restrict__ out, int B, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* Ws = smem;
-    char* Ps = smem + W_BYTES;
-    char* Ss = smem + W_BYTES + P_BYTES;
-    int* Ti = reinterpret_cast<int*>(smem + W_BYTES + P_BYTES + S_BYTES);  // [0..9] row: src offset (bytes) of the upper row | valid<<30 ; [32..49] col
+    char* Ps = smem;
+    char* Ss = smem + P_BYTES;
+    int* Ti = reinterpret_cast<int*>(smem + P_BYTES + S_BYTES);  // [0..9] row: src offset (bytes) of the upper row | valid<<30 ; [32..49] col
     float* Tf = reinterpret_cast<float*>(Ti) + 64;                          // [0..9] ly ; [32..49] lx
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = 2 * h, W = 2 * w;
     const int tiles_x = W / TW, tiles_y = H / TH;
     const int ntiles = B * tiles_y * tiles_x;
-    // ---- weights -> LDS once per workgroup (16-byte chunks, padded rows) ----
-    for (int i = tid; i < COUT * (KTOT / 8); i += NTHR) {
-        const int n = i / (KTOT / 8), c = i % (KTOT / 8);
-        *reinterpret_cast<uint4*>(Ws + n * W_ROWB + c * 16) = *reinterpret_cast<const uint4*>(wt + (size_t)n * KTOT + c * 8);
-    }
-    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
+    // ---- weights: this wave's 16 output channels x 1152 k as 36 MFMA A-fragments, resident in registers for the whole
+    // persistent loop (144 VGPRs; an LDS-resident copy made every wave re-read 74 KB per tile and the kernel LDS-read-bound)
     const int frow = lane & 15, fq = lane >> 4;
-    float4 bia[2], w4v[2];
+    const int ntile = wave & 1, rowpair = wave >> 1;  // 8 waves = 2 channel tiles x 4 row pairs of the 8 x 16 output tile
+    bf16x8 wf[36];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        bia[i] = *reinterpret_cast<const float4*>(bias + i * 16 + fq * 4);
-        w4v[i] = *reinterpret_cast<const float4*>(w4 + i * 16 + fq * 4);
-    }
+    for (int k = 0; k < 36; ++k) wf[k] = *reinterpret_cast<const bf16x8*>(wt + (size_t)(ntile * 16 + frow) * KTOT + k * 32 + fq * 8);
+    const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
+    const float4 bia = *reinterpret_cast<const float4*>(bias + ntile * 16 + fq * 4);
+    const float4 w4v = *reinterpret_cast<const float4*>(w4 + ntile * 16 + fq * 4);
+    float* red = reinterpret_cast<float*>(smem + P_BYTES + S_BYTES + T_BYTES);  // [8 rows][16 px] partial dots of channel tile 1
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int tx = tile % tiles_x;
         int r = tile / tiles_x;
@@ -126,37 +124,43 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
             }
         }
         __syncthreads();
-        // ---- 9 taps x 4 k-steps: wave = output row `wave` of the tile (16 px) x 32 channels ----
+        // ---- 9 taps x 4 k-steps: wave = 2 output rows x 16 channels, weights from registers, patch rows from LDS ----
         f32x4 acc[2];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
         acc[1] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
             const int ky = tap / 3, kx = tap % 3;
-            const int prow = (wave + ky) * PW + frow + kx;
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Ps + prow * P_ROWB + (ks * 32 + fq * 8) * 2);
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const bf16x8 wf = *reinterpret_cast<const bf16x8*>(Ws + (i * 16 + frow) * W_ROWB + (tap * CIN + ks * 32 + fq * 8) * 2);
-                    acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, xf, acc[i], 0, 0, 0);
+                for (int j = 0; j < 2; ++j) {
+                    const int prow = (2 * rowpair + j + ky) * PW + frow + kx;
+                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Ps + prow * P_ROWB + (ks * 32 + fq * 8) * 2);
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap * 4 + ks], xf, acc[j], 0, 0, 0);
                 }
             }
         }
-        // ---- epilogue: + bias, ReLU, 1x1 (32 -> 1) + bias, ReLU ----
-        {
-            float s = 0.f;
+        // ---- epilogue: + bias, ReLU, 1x1 (32 -> 1) + bias, ReLU; the two channel tiles meet through LDS ----
+        float part[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                s += fmaxf(acc[i][0] + bia[i].x, 0.f) * w4v[i].x + fmaxf(acc[i][1] + bia[i].y, 0.f) * w4v[i].y +
-                     fmaxf(acc[i][2] + bia[i].z, 0.f) * w4v[i].z + fmaxf(acc[i][3] + bia[i].w, 0.f) * w4v[i].w;
-            }
-            s += __shfl_xor(s, 16);
-            s += __shfl_xor(s, 32);
-            if (fq == 0) {
-                const int Y = ty * TH + wave, X = tx * TW + frow;
-                out[((size_t)b * H + Y) * W + X] = fmaxf(s + b4, 0.f);
+        for (int j = 0; j < 2; ++j) {
+            float sdot = fmaxf(acc[j][0] + bia.x, 0.f) * w4v.x + fmaxf(acc[j][1] + bia.y, 0.f) * w4v.y + fmaxf(acc[j][2] + bia.z, 0.f) * w4v.z +
+                         fmaxf(acc[j][3] + bia.w, 0.f) * w4v.w;
+            sdot += __shfl_xor(sdot, 16);
+            sdot += __shfl_xor(sdot, 32);
+            part[j] = sdot;
+        }
+        if (ntile == 1 && fq == 0) {
+            red[(2 * rowpair + 0) * TW + frow] = part[0];
+            red[(2 * rowpair + 1) * TW + frow] = part[1];
+        }
+        __syncthreads();
+        if (ntile == 0 && fq == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int Y = ty * TH + 2 * rowpair + j, X = tx * TW + frow;
+                out[((size_t)b * H + Y) * W + X] = fmaxf(part[j] + red[(2 * rowpair + j) * TW + frow] + b4, 0.f);
             }
         }
     }
