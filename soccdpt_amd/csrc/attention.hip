@@ -499,6 +499,94 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Exact-f32 attention for ANY window size (parity mode of dpt_swin2_base_384: 24x24 / 12x12 windows).
+// Not a throughput kernel: one thread owns one query (q-hat and the output row in registers), keys are staged
+// 64 at a time in LDS (normalised K and V rows, read by broadcast), online softmax in f32, CPB bias read from the
+// (2ws-1)^2 x heads table by relative position, shift mask from the token coordinates.  One workgroup = 64 queries
+// of one (batch, window, head).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void window_attention_f32_any_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
+                                                                      const float* __restrict__ scale, float* __restrict__ out, int res, int ws,
+                                                                      int shift, int heads) {
+    __shared__ float Ks[64][33];
+    __shared__ float Vs[64][33];
+    const int N = ws * ws, nqb = (N + 63) / 64;
+    const int C = heads * 32, nw = res / ws;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb;
+    bid /= nqb;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const int tid = threadIdx.x;
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / ws, c = p % ws;
+        int sy = wy * ws + r + shift, sx = wx * ws + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    const int q = qb * 64 + tid;
+    const bool qv = q < N;
+    const int qc = qv ? q : N - 1;
+    const int rq = qc / ws, cq = qc % ws;
+    float qh[32], o[32];
+    {
+        const float* src = qkv + token_row(qc) * (size_t)(3 * C) + head * 32;
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qh[d] = src[d]; ss += qh[d] * qh[d]; o[d] = 0.f; }
+        const float qi = scale[head] / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) qh[d] *= qi;
+    }
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    const int half = ws / 2;
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        __syncthreads();
+        {   // stage 64 keys: thread = key
+            const int k = k0 + tid;
+            const int kc = k < N ? k : N - 1;
+            const float* src = qkv + token_row(kc) * (size_t)(3 * C) + head * 32;
+            float ss = 0.f;
+            float kr[32];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { kr[d] = src[C + d]; ss += kr[d] * kr[d]; }
+            const float ki = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { Ks[tid][d] = kr[d] * ki; Vs[tid][d] = src[2 * C + d]; }
+        }
+        __syncthreads();
+        const int kn = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < kn; ++kk) {
+            const int k = k0 + kk;
+            const int rk = k / ws, ck = k % ws;
+            float sdot = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) sdot = fmaf(qh[d], Ks[kk][d], sdot);
+            sdot += table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
+            if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) sdot += -100.0f;
+            const float mn = fmaxf(m, sdot);
+            const float alpha = expf(m - mn), p = expf(sdot - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) o[d] = fmaf(p, Vs[kk][d], o[d] * alpha);
+            m = mn;
+        }
+    }
+    if (qv) {
+        const float inv = 1.0f / l;
+        float* orow = out + token_row(q) * (size_t)C + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+}
+
 // CPB bias in accumulator order: [head][qb][t][lane][16]; value for query 32qb+(lane&31),
 // key 32t + (reg&3) + 8(reg>>2) + 4(lane>>5)
 __global__ void attn_bias_kernel(const float* __restrict__ table, float* __restrict__ bias_acc, int ws, int heads) {
@@ -536,10 +624,16 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
     return check_launch("attn_bias", err);
 }
 
-int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* scale, float* out, int B, int res, int ws, int shift,
-                                int heads, hipStream_t st, std::string& err) {
+int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
+                                int ws, int shift, int heads, hipStream_t st, std::string& err) {
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
     const int nw = res / ws;
+    if (ws != 16 && !(ws == 8 && shift == 0)) {  // any other window size: the generic exact kernel (parity mode of base_384)
+        const int nqb = (ws * ws + 63) / 64;
+        hipLaunchKernelGGL(window_attention_f32_any_kernel, dim3((unsigned)(B * nw * nw * heads * nqb)), dim3(64), 0, st, qkv, table, scale, out, res, ws,
+                           shift, heads);
+        return check_launch("window_attention_f32_any", err);
+    }
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
     static bool attr_done = false;
     if (!attr_done) {

@@ -55,7 +55,7 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,
                             int heads, hipStream_t st, std::string& err);
 
-int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* scale, float* out, int B, int res, int ws, int shift,
-                                int heads, hipStream_t st, std::string& err);
+int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
+                                int ws, int shift, int heads, hipStream_t st, std::string& err);
 
 }  // namespace soccdpt

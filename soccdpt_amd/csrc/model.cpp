@@ -314,10 +314,6 @@ int model_init(Handle& h, std::string& err) {
     add_w(h, "seg_head.4.weight", {h.cfg.num_classes, F, 1, 1});
     add_w(h, "seg_head.4.bias", {h.cfg.num_classes});
 
-    if (a.window != 16 && h.cfg.precision == SOCCDPT_PREC_F32) {
-        err = "soccdpt_create: the exact-f32 window attention is instantiated for 16x16 / 8x8 windows (dpt_swin2_tiny_256) only";
-        return 1;
-    }
     Arena measure(nullptr, 0);
     if (lay_out(h, measure, nullptr, nullptr, err)) return 1;
     h.prepared_bytes = measure.off + 256;
@@ -407,7 +403,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_op = w.qkv;
             RUN(gemm(d));
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
-              if (F32) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
+              if (F32) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
                                                        a.shift(s, j), H, st, err));
               else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), B, res, wsz,
                                                a.shift(s, j), H, st, err)); }
