@@ -202,3 +202,34 @@ def test_swin2_base_384_network_vs_oracle(gpu_device, precision):
         assert e_inv < 1e-3 and e_seg < 1e-3
     else:
         assert e_inv < 3e-2 and e_seg < 5e-2
+
+
+def test_full_batch_8_sigmoid_and_plugin_pattern(gpu_device):
+    """BASELINE configs[1] size (B=8), sigmoid head; plus the reference's subclass-plugin pattern
+    (scripts/eval_others.py:54-247): a SOccDPT subclass feeds its own (inv_depth, segmentation) to get_semantic_occupancy."""
+    from soccdpt_amd.model.SOccDPT import SOccDPT, SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True)
+    sd = synth_state_dict(alias_pretrained=True)
+    m.load_state_dict(sd, strict=False)
+    m = m.eval().to(gpu_device)
+    x = synth_input(8, seed0=100)
+    inv, seg = m.network(x.to(gpu_device))
+    out = m(x.to(gpu_device))
+    torch.cuda.synchronize()
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        o_inv, o_seg, _ = R.soccdpt_v3_network(sd, x, sigmoid=True)
+    assert _rel_l2(inv.cpu(), o_inv) < 2e-2 and _rel_l2(seg.cpu(), o_seg) < 5e-2   # seg: x12 synthetic logit gain
+    assert tuple(out[3].shape) == (8, 256, 256, 32, 3)
+    for b in range(1, 8):
+        assert torch.equal(out[3][0], out[3][b])          # the union grid in every batch row
+
+    class Plugin(SOccDPT):
+        def forward(self, x):
+            return self.get_semantic_occupancy(inv, seg)
+    p = Plugin(camera_intrinsics_yaml=calib, compute_occ=True)
+    o2 = p(x.to(gpu_device))
+    torch.cuda.synchronize()
+    assert torch.equal(o2[3], out[3]) and torch.equal(torch.nan_to_num(o2[2]), torch.nan_to_num(out[2]))
