@@ -47,6 +47,13 @@ struct IgemmDesc {
     const float* dot_w = nullptr;
     float dot_b = 0.f;
     float* out_dot = nullptr;
+    // fused Swin-V2 residual post-norm (N <= tile width, one n-tile): xf[m][:] = (residual ? xf[m][:] : 0) + LN(v[m][:]) * g + b;
+    // also writes the operand-typed copy to out_op (plain) and, when ln_halo != nullptr, to a zero-halo image (hooked stage)
+    const float* ln_g = nullptr;
+    const float* ln_b = nullptr;
+    float* ln_xf = nullptr;
+    void* ln_halo = nullptr;
+    int ln_residual = 1;
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
 };
 

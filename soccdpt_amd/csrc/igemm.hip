@@ -209,8 +209,96 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         }
     }
 
-    // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
     const int N = d.N;
+    if (d.ln_g) {
+        // ---- fused post-norm epilogue: out = (x +) LayerNorm(acc + bias) over the N (<= BN) channels of each row.
+        // A row's channels are spread over the TN tiles x 4 lane groups of a wave and over the WN waves: two-pass mean /
+        // variance with an in-wave shuffle reduction and a cross-wave exchange through LDS (the staging ring is free now).
+        float* red = reinterpret_cast<float*>(smem);  // [BM][WN]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i) {
+            const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) {
+                acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
+            }
+        }
+        float mean[C::TM], rstd[C::TM];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) {
+                    const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                    if (n < N) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = pass == 0 ? acc[i][j][r] : (acc[i][j][r] - mean[j]) * (acc[i][j][r] - mean[j]);
+                            sum += t;
+                        }
+                    }
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                if ((lane >> 4) == 0) red[(wm * C::TM * 16 + j * 16 + (lane & 15)) * C::WN + wn] = sum;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) {
+                float tot = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < C::WN; ++wv) tot += red[(wm * C::TM * 16 + j * 16 + (lane & 15)) * C::WN + wv];
+                if (pass == 0) mean[j] = tot / (float)N;
+                else rstd[j] = rsqrtf(tot / (float)N + 1e-5f);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < C::TM; ++j) {
+            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+            if (m >= d.M) continue;
+            const size_t orow = (size_t)m * N;
+            size_t hrow = 0;
+            if (d.ln_halo) {
+                const int hw = d.H * d.W;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / d.W, x = rem - y * d.W;
+                hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+            }
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) {
+                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                if (n >= N) continue;
+                const float4 g4 = *reinterpret_cast<const float4*>(d.ln_g + n), e4 = *reinterpret_cast<const float4*>(d.ln_b + n);
+                float o[4];
+                o[0] = (acc[i][j][0] - mean[j]) * rstd[j] * g4.x + e4.x;
+                o[1] = (acc[i][j][1] - mean[j]) * rstd[j] * g4.y + e4.y;
+                o[2] = (acc[i][j][2] - mean[j]) * rstd[j] * g4.z + e4.z;
+                o[3] = (acc[i][j][3] - mean[j]) * rstd[j] * g4.w + e4.w;
+                if (d.ln_residual) {
+                    const float4 x4 = *reinterpret_cast<const float4*>(d.ln_xf + orow + n);
+                    o[0] += x4.x; o[1] += x4.y; o[2] += x4.z; o[3] += x4.w;
+                }
+                *reinterpret_cast<float4*>(d.ln_xf + orow + n) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (sizeof(T) == 2) {
+                    uint2 p;
+                    p.x = pack_bf16x2(o[0], o[1]);
+                    p.y = pack_bf16x2(o[2], o[3]);
+                    if (d.out_op) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.out_op) + orow + n) = p;
+                    if (d.ln_halo) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.ln_halo) + hrow + n) = p;
+                } else {
+                    if (d.ln_halo) *reinterpret_cast<float4*>(static_cast<float*>(d.ln_halo) + hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
     float dot_part[C::TM];
 #pragma unroll
     for (int j = 0; j < C::TM; ++j) dot_part[j] = 0.f;
@@ -340,16 +428,23 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
-                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3"};
+                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
+                                        "igemm_bf16_32x256x64_s3", "igemm_bf16_64x256x64_s2"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
+    if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
     if (d.N <= 32) return 2;
     const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
     return b128 >= 384 ? 0 : 1;
 }
 
 static int pick_cfg(const IgemmDesc& d) {
+    if (d.tune < 0 && d.ln_g) {  // fused LayerNorm needs the whole row in one workgroup: one n-tile
+        const bool k64ln = (d.Cin % 64 == 0);
+        if (d.N <= 128) return k64ln ? 13 : 19;  // 64(M) x 128(N)
+        return d.M >= 16384 ? 21 : 20;           // 64 / 32 (M) x 256(N), needs Cin % 64 == 0
+    }
     // Measured on MI355X (tools/igemm_bench.py, profiles/r01_igemm_configs.txt): the kernel is bound by the per-CU
     // L2->LDS fill rate, so take the LARGEST tile (most FLOPs per staged byte) that still fills the 256 CUs.
     if (d.tune >= 0) return d.tune;
@@ -380,6 +475,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 256 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         switch (pick_cfg_f32(d)) {
@@ -390,7 +486,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || id == 20 || id == 21) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -412,6 +508,9 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 16: return launch_cfg<Cfg<256, 128, 32, 4, 2, 3>>(d, stream, err);
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
+        case 19: return launch_cfg<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
+        case 20: return launch_cfg<Cfg<32, 256, 64, 1, 4, 3>>(d, stream, err);
+        case 21: return launch_cfg<Cfg<64, 256, 64, 1, 4, 2>>(d, stream, err);
     }
     err = "igemm: unknown configuration id";
     return 1;

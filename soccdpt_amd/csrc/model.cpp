@@ -407,22 +407,37 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                                                        a.shift(s, j), H, st, err));
               else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), B, res, wsz,
                                                a.shift(s, j), H, st, err)); }
+            const bool fuse_ln = F32 ? (C <= 128) : (C <= 256 && (C <= 128 || C % 64 == 0));  // whole rows fit one igemm tile
             d = IgemmDesc();
-            d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b; d.out_f32 = w.y;
-            RUN(gemm(d));
-            { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-              RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M, C, 1, res, st, err)); }
+            d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b;
+            if (fuse_ln) {
+                d.ln_g = bw.n1_g; d.ln_b = bw.n1_b; d.ln_xf = w.xf; d.out_op = F32 ? nullptr : w.xb;
+                RUN(gemm(d));
+            } else {
+                d.out_f32 = w.y;
+                RUN(gemm(d));
+                { PROF("ln_residual", 0.0, (double)M * C * 14.0);
+                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M, C, 1, res, st, err)); }
+            }
             d = IgemmDesc();
             d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = w.hbuf;
             RUN(gemm(d));
             d = IgemmDesc();
-            d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b; d.out_f32 = w.y;
+            d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b;
+            if (fuse_ln) {
+                const bool hook = (j == a.hooks[s]);
+                d.ln_g = bw.n2_g; d.ln_b = bw.n2_b; d.ln_xf = w.xf; d.out_op = F32 ? nullptr : w.xb;
+                if (hook) { d.ln_halo = w.feat[s]; d.H = res; d.W = res; }
+                RUN(gemm(d));
+            } else {
+            d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
               const bool hook = (j == a.hooks[s]);
               RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb),
                                      (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, M, C,
                                      1, res, st, err)); }
+            }
         }
         if (s < 3) {
             { PROF("merge_gather", 0.0, (double)M * C * 4.0);
