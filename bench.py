@@ -39,8 +39,9 @@ def main():
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
     ap.add_argument("--model-type", default="dpt_swin2_tiny_256", choices=["dpt_swin2_tiny_256", "dpt_swin2_base_384"],
                     help="dpt_swin2_tiny_256 = BASELINE metric config; dpt_swin2_base_384 = BASELINE configs[3] (8 frames per GPU)")
-    ap.add_argument("--precision", choices=["bf16", "f32"], default="bf16",
-                    help="bf16: bf16 MFMA operands (BASELINE config); f32: exact-f32 parity mode (1/16 MFMA rate)")
+    ap.add_argument("--precision", choices=["bf16", "f16", "f32"], default="bf16",
+                    help="bf16: bf16 MFMA operands (BASELINE config); f16: IEEE fp16 operands, same kernels and MFMA rate, "
+                         "meets the 1e-3 tolerance; f32: exact-f32 parity mode (1/16 MFMA rate)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: no gain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
@@ -65,7 +66,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
                          model_type=args.model_type,
-                         graph=args.graph, precision=(1 if args.precision == "f32" else 0))
+                         graph=args.graph, precision={"bf16": 0, "f32": 1, "f16": 2}[args.precision])
     from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
     backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
     img = SWIN_ARCHS[backbone].img
@@ -162,6 +163,27 @@ def main():
             "launches_per_step": eng.launch_count() + 2,
             "paper_hz": 47.0, "x_paper_hz": round(fps / 47.0, 2),
         }
+
+    # ---- the same workload with IEEE fp16 MFMA operands (SOCCDPT_PREC_F16): same kernels and MFMA rate; this is the mode that
+    # meets the north star's 1e-3 tolerance (tests/test_network_gpu.py::test_f16_mode_meets_1e3_relative).  N = 1 only.
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net16 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
+                               model_type=args.model_type, precision=2)
+        net16.load_state_dict(sd, strict=False)
+        net16 = net16.eval().to(dev)
+        for _ in range(args.warmup):
+            out = net16(x)
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net16(x)
+        torch.cuda.synchronize()
+        e16 = time.perf_counter() - t3
+        result["f16_operands"] = {"value": round(B * args.steps / e16, 2), "unit": "frames/s", "ms_per_step": round(e16 / args.steps * 1e3, 3),
+                                  "note": "same forward with fp16 instead of bf16 MFMA operands (f32 accumulate); depth / logits / features "
+                                          "within 1e-3 rel-L2 of the fp32 CPU oracle, bf16 is at 3e-3"}
+        del net16
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, rank 0 at N = 1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -39,6 +39,9 @@ extern "C" {
 #define SOCCDPT_PREC_BF16 0 /* bf16 MFMA operands, f32 accumulate (the benchmarked configuration) */
 #define SOCCDPT_PREC_F32 1  /* f32 operands, exact-f32 MFMA (v_mfma_f32_16x16x4_f32 / 32x32x2_f32): the parity mode,
                                1/16 of the bf16 MFMA rate */
+#define SOCCDPT_PREC_F16 2  /* IEEE fp16 MFMA operands (11-bit significand), f32 accumulate and f32 residual streams: the
+                               same kernels and MFMA rate as BF16 with 8x smaller operand rounding; what the reference's
+                               optimize=True path (model/loader.py:126-139, .half()) computes in */
 
 /* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
 typedef struct soccdpt_config {
@@ -180,20 +183,20 @@ typedef struct soccdpt_igemm_args {
     float dot_b;
     float* out_dot;
     int32_t tune; /* kernel configuration id, -1 = library heuristic (benchmarking) */
-    int32_t f32;  /* != 0: x, wt and out_bf16 hold f32 elements; exact-f32 MFMA (SOCCDPT_PREC_F32) */
+    int32_t precision; /* SOCCDPT_PREC_*: element type of x, wt and out_bf16 (bf16 / f32 / fp16) and the MFMA used */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 
 /* Swin-V2 cosine window attention of one block (timm WindowAttention + shift/partition/reverse):
- * qkv [B*res*res][3*heads*32] bf16 -> out [B*res*res][heads*32] bf16.  cpb_table [(2ws-1)^2][heads] f32 is
+ * qkv [B*res*res][3*heads*32] -> out [B*res*res][heads*32], elements bf16 / f32 / fp16 by `precision` (SOCCDPT_PREC_*).  cpb_table [(2ws-1)^2][heads] f32 is
  * 16*sigmoid(cpb_mlp(coords)); scale[heads] = exp(min(logit_scale, ln 100)); bias_scratch: heads*ceil(ws*ws/32)^2*1024
  * floats.  Window sizes 16 and 8 (single-pass softmax) and 24 and 12 (online softmax over key tiles) are instantiated. */
 int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
-                                float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, void* stream);
+                                float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, void* stream);
 
 /* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
- * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "xf" (final stage tokens f32).
- * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC.  Returns non-zero for unknown names. */
+ * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "seg_logits" (seg head before up-sampling/activation, f32 [B,2G,2G,3]), "xf" (final stage tokens f32).
+ * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC, 4 = fp16 plain, 5 = fp16 zero-halo NHWC.  Returns non-zero for unknown names. */
 int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind,
                              int* H, int* W, int* C);
 

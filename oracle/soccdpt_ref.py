@@ -248,13 +248,19 @@ def dpt_decoder(sd, layers: Sequence[Tensor], pfx: str = "depth_net.scratch.") -
     return h.squeeze(1), p1
 
 
-def seg_head(sd, feats: Tensor, sigmoid: bool, pfx: str = "seg_head.") -> Tensor:
-    """Eval-mode seg head (model/SOccDPT.py:660-674; ScaledTanh model/scaled_tanh.py:4-10)."""
+def seg_logits(sd, feats: Tensor, pfx: str = "seg_head.") -> Tensor:
+    """Class logits of the seg head at half resolution: Conv3x3 -> BN(eval) -> ReLU -> Dropout(eval) -> Conv1x1
+    (model/SOccDPT.py:660-671), i.e. seg_head before Interpolate and the activation."""
     h = F.conv2d(feats, sd[pfx + "0.weight"], padding=1)
     h = F.batch_norm(h, sd[pfx + "1.running_mean"], sd[pfx + "1.running_var"],
                      sd[pfx + "1.weight"], sd[pfx + "1.bias"], False, 0.1, 1e-5)
     h = F.relu(h)
-    h = F.conv2d(h, sd[pfx + "4.weight"], sd[pfx + "4.bias"])
+    return F.conv2d(h, sd[pfx + "4.weight"], sd[pfx + "4.bias"])
+
+
+def seg_head(sd, feats: Tensor, sigmoid: bool, pfx: str = "seg_head.") -> Tensor:
+    """Eval-mode seg head (model/SOccDPT.py:660-674; ScaledTanh model/scaled_tanh.py:4-10)."""
+    h = seg_logits(sd, feats, pfx)
     h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
     if sigmoid:
         return torch.sigmoid(h)

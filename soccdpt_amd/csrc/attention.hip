@@ -15,12 +15,12 @@
 //    exponentiated accumulators are directly the B operand of O^T = V^T P^T (no LDS round trip);
 //  * the CPB bias is precomputed per weight load in MFMA accumulator order and loaded as the
 //    initial accumulator (4 x 16-byte loads per tile, coalesced); the shift mask is arithmetic.
+#include "half16.h"
 #include "kernels.h"
 
 namespace soccdpt {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
-typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) short h16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 
 template <int WS>
@@ -35,12 +35,8 @@ struct AttnCfg {
     static constexpr int LDS = 2 * N * 64 + 32 * VT_STRIDE;
 };
 
-__device__ __forceinline__ uint32_t pk_bf16(float a, float b) {
-    __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
 
-template <int WS>
+template <int WS, bool F16>
 __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                                  const float* __restrict__ scale, bf16_t* __restrict__ out,
                                                                                  int res, int shift, int heads) {
@@ -83,10 +79,10 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         float qs = 0.f, ks = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            qf[2 * j] = __builtin_bit_cast(float, qu[j] << 16);
-            qf[2 * j + 1] = __builtin_bit_cast(float, qu[j] & 0xffff0000u);
-            kf[2 * j] = __builtin_bit_cast(float, ku[j] << 16);
-            kf[2 * j + 1] = __builtin_bit_cast(float, ku[j] & 0xffff0000u);
+            qf[2 * j] = h_lo<F16>(qu[j]);
+            qf[2 * j + 1] = h_hi<F16>(qu[j]);
+            kf[2 * j] = h_lo<F16>(ku[j]);
+            kf[2 * j + 1] = h_hi<F16>(ku[j]);
             qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
             ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
         }
@@ -97,10 +93,10 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);  // F.normalize eps
         const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
         uint4 qo, ko;
-        qo.x = pk_bf16(qf[0] * qi, qf[1] * qi); qo.y = pk_bf16(qf[2] * qi, qf[3] * qi);
-        qo.z = pk_bf16(qf[4] * qi, qf[5] * qi); qo.w = pk_bf16(qf[6] * qi, qf[7] * qi);
-        ko.x = pk_bf16(kf[0] * ki, kf[1] * ki); ko.y = pk_bf16(kf[2] * ki, kf[3] * ki);
-        ko.z = pk_bf16(kf[4] * ki, kf[5] * ki); ko.w = pk_bf16(kf[6] * ki, kf[7] * ki);
+        qo.x = pack_h2<F16>(qf[0] * qi, qf[1] * qi); qo.y = pack_h2<F16>(qf[2] * qi, qf[3] * qi);
+        qo.z = pack_h2<F16>(qf[4] * qi, qf[5] * qi); qo.w = pack_h2<F16>(qf[6] * qi, qf[7] * qi);
+        ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
+        ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
         const int sw = (c ^ ((p >> 2) & 3)) * 16;
         *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
         *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
@@ -118,10 +114,10 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
     for (int qbi = 0; qbi < 2; ++qbi) {
         const int qb = wave * 2 + qbi;
         const int qrow = qb * 32 + r32;
-        bf16x8 qfrag[2];
+        h16x8 qfrag[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qfrag[ks] = *reinterpret_cast<const bf16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
+            qfrag[ks] = *reinterpret_cast<const h16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
 
         f32x16 s[A::KT];
         const float* bp = bias_acc + ((size_t)(head * A::QB + qb) * A::KT) * 1024 + lane * 16;
@@ -145,8 +141,8 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
             const int krow = t * 32 + r32;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qfrag[ks], acc, 0, 0, 0);
+                const h16x8 kfrag = *reinterpret_cast<const h16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
+                acc = mfma_32x32x16<F16>(kfrag, qfrag[ks], acc);
             }
             s[t] = acc;
         }
@@ -173,15 +169,15 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         for (int t = 0; t < A::KT; ++t) {
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 pb;
+                h16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)s[t][8 * st + j];
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(s[t][8 * st + j]);
                 // element j of this lane half is key 32t + 16st + 8(j>>2) + 4h + (j&3): V^T must use the same k order
                 const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 16);
-                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o, 0, 0, 0);
+                const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
+                const h16x4 v1 = *reinterpret_cast<const h16x4*>(vrow + 16);
+                const h16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = mfma_32x32x16<F16>(vf, pb, o);
             }
         }
         // ---- store: lane owns query column r32, rows d = (rg&3) + 8(rg>>2) + 4h ----
@@ -190,8 +186,8 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 pkt;
-            pkt.x = pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv);
-            pkt.y = pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            pkt.x = pack_h2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv);
+            pkt.y = pack_h2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
             *reinterpret_cast<uint2*>(orow + 8 * g + 4 * h) = pkt;
         }
     }
@@ -354,7 +350,7 @@ struct AttnGenCfg {
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
 };
 
-template <int WS>
+template <int WS, bool F16>
 __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                      const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
                                                                      int shift, int heads) {
@@ -395,10 +391,10 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
         float qs = 0.f, ks = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            qf[2 * j] = __builtin_bit_cast(float, qu[j] << 16);
-            qf[2 * j + 1] = __builtin_bit_cast(float, qu[j] & 0xffff0000u);
-            kf[2 * j] = __builtin_bit_cast(float, ku[j] << 16);
-            kf[2 * j + 1] = __builtin_bit_cast(float, ku[j] & 0xffff0000u);
+            qf[2 * j] = h_lo<F16>(qu[j]);
+            qf[2 * j + 1] = h_hi<F16>(qu[j]);
+            kf[2 * j] = h_lo<F16>(ku[j]);
+            kf[2 * j + 1] = h_hi<F16>(ku[j]);
             qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
             ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
         }
@@ -409,10 +405,10 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
         const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
         const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
         uint4 qo, ko;
-        qo.x = pk_bf16(qf[0] * qi, qf[1] * qi); qo.y = pk_bf16(qf[2] * qi, qf[3] * qi);
-        qo.z = pk_bf16(qf[4] * qi, qf[5] * qi); qo.w = pk_bf16(qf[6] * qi, qf[7] * qi);
-        ko.x = pk_bf16(kf[0] * ki, kf[1] * ki); ko.y = pk_bf16(kf[2] * ki, kf[3] * ki);
-        ko.z = pk_bf16(kf[4] * ki, kf[5] * ki); ko.w = pk_bf16(kf[6] * ki, kf[7] * ki);
+        qo.x = pack_h2<F16>(qf[0] * qi, qf[1] * qi); qo.y = pack_h2<F16>(qf[2] * qi, qf[3] * qi);
+        qo.z = pack_h2<F16>(qf[4] * qi, qf[5] * qi); qo.w = pack_h2<F16>(qf[6] * qi, qf[7] * qi);
+        ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
+        ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
         const int sw = (c ^ ((p >> 2) & 3)) * 16;
         *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
         *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
@@ -430,10 +426,10 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
         const int qrow = qb * 32 + r32;
         const int qcl = qrow < A::N ? qrow : A::N - 1;
         const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
-        bf16x8 qfrag[2];
+        h16x8 qfrag[2];
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
-            qfrag[ks] = *reinterpret_cast<const bf16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
+            qfrag[ks] = *reinterpret_cast<const h16x8*>(Qs + qrow * 64 + (((ks * 2 + h) ^ ((qrow >> 2) & 3)) * 16));
         float m = -3.0e38f, l = 0.f;
         f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* bp = bias_acc + ((size_t)(head * A::NT + qb) * A::NT) * 1024 + lane * 16;
@@ -454,8 +450,8 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
             const int krow = t * 32 + r32;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
-                const bf16x8 kfrag = *reinterpret_cast<const bf16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
-                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfrag, qfrag[ks], acc, 0, 0, 0);
+                const h16x8 kfrag = *reinterpret_cast<const h16x8*>(Ks + krow * 64 + (((ks * 2 + h) ^ ((krow >> 2) & 3)) * 16));
+                acc = mfma_32x32x16<F16>(kfrag, qfrag[ks], acc);
             }
             float mt = acc[0];
 #pragma unroll
@@ -474,14 +470,14 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
             m = mn;
 #pragma unroll
             for (int st = 0; st < 2; ++st) {
-                bf16x8 pb;
+                h16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (__bf16)acc[8 * st + j];
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(acc[8 * st + j]);
                 const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
-                const bf16x4 v0 = *reinterpret_cast<const bf16x4*>(vrow);
-                const bf16x4 v1 = *reinterpret_cast<const bf16x4*>(vrow + 16);
-                const bf16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pb, o, 0, 0, 0);
+                const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
+                const h16x4 v1 = *reinterpret_cast<const h16x4*>(vrow + 16);
+                const h16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                o = mfma_32x32x16<F16>(vf, pb, o);
             }
         }
         l += __shfl_xor(l, 32);
@@ -491,8 +487,8 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pkt;
-                pkt.x = pk_bf16(o[4 * g] * inv, o[4 * g + 1] * inv);
-                pkt.y = pk_bf16(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                pkt.x = pack_h2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv);
+                pkt.y = pack_h2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
                 *reinterpret_cast<uint2*>(orow + 8 * g + 4 * h) = pkt;
             }
         }
@@ -653,27 +649,33 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
     return check_launch("window_attention_f32", err);
 }
 
-int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,
-                            int heads, hipStream_t st, std::string& err) {
+int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
+                            int shift, int heads, hipStream_t st, std::string& err) {
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
     const int nw = res / ws;
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
     if (ws == 16) {
         using A = AttnCfg<16>;
-        hipLaunchKernelGGL((window_attention_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) hipLaunchKernelGGL((window_attention_kernel<16, true>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else hipLaunchKernelGGL((window_attention_kernel<16, false>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 8) {
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
-        hipLaunchKernelGGL((window_attention_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) hipLaunchKernelGGL((window_attention_kernel<8, true>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else hipLaunchKernelGGL((window_attention_kernel<8, false>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 24 || ws == 12) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24>), hipFuncAttributeMaxDynamicSharedMemorySize,
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      AttnGenCfg<24>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       AttnGenCfg<24>::LDS);
             attr_done = true;
         }
-        if (ws == 24) hipLaunchKernelGGL((window_attention_flash_kernel<24>), dim3(blocks), dim3(256), AttnGenCfg<24>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else hipLaunchKernelGGL((window_attention_flash_kernel<12>), dim3(blocks), dim3(256), AttnGenCfg<12>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+#define FLASH(W, H) hipLaunchKernelGGL((window_attention_flash_kernel<W, H>), dim3(blocks), dim3(256), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+        if (ws == 24) { if (hf) FLASH(24, true); else FLASH(24, false); }
+        else { if (hf) FLASH(12, true); else FLASH(12, false); }
+#undef FLASH
     } else {
         err = "window_attention: window size not instantiated (16, 8, 24, 12 are)";
         return 1;

@@ -6,11 +6,11 @@
 // workgroup keeps the 32 x 1152 weight matrix in REGISTERS (each wave its 16 channels as 36 MFMA fragments), builds the (8+2) x (16+2) up-sampled halo patch of
 // each 8 x 16 output tile directly from the low-resolution map (4 x 16-byte loads + lerp per 8 channels), and runs
 // the 9 taps x 4 k-steps of v_mfma_f32_16x16x32_bf16 out of LDS: no up-sampled image in HBM, ~12x fewer staged bytes.
+#include "half16.h"
 #include "kernels.h"
 
 namespace soccdpt {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
@@ -29,14 +29,8 @@ constexpr int LDS_BYTES = P_BYTES + S_BYTES + T_BYTES + R_BYTES;  // 74560
 constexpr int NTHR = 512;                      // 8 waves: one output row of the 8 x 16 tile each
 }  // namespace
 
-__device__ __forceinline__ float bf_lo(uint32_t u) { return __builtin_bit_cast(float, u << 16); }
-__device__ __forceinline__ float bf_hi(uint32_t u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-__device__ __forceinline__ uint32_t pk2(float a, float b) {
-    __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
-
-// d1: bf16 [B][h][w][128] plain NHWC; wt: bf16 [32][9*128] tap-major; out: f32 [B][2h][2w]
+// d1: 16-bit [B][h][w][128] plain NHWC; wt: 16-bit [32][9*128] tap-major; out: f32 [B][2h][2w].  F16: operands are fp16, else bf16.
+template <bool F16>
 __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restrict__ d1, const bf16_t* __restrict__ wt, const float* __restrict__ bias,
                                                           const float* __restrict__ w4, float b4, float* __restrict__ out, int B, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -52,9 +46,9 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
     // persistent loop (144 VGPRs; an LDS-resident copy made every wave re-read 74 KB per tile and the kernel LDS-read-bound)
     const int frow = lane & 15, fq = lane >> 4;
     const int ntile = wave & 1, rowpair = wave >> 1;  // 8 waves = 2 channel tiles x 4 row pairs of the 8 x 16 output tile
-    bf16x8 wf[36];
+    h16x8 wf[36];
 #pragma unroll
-    for (int k = 0; k < 36; ++k) wf[k] = *reinterpret_cast<const bf16x8*>(wt + (size_t)(ntile * 16 + frow) * KTOT + k * 32 + fq * 8);
+    for (int k = 0; k < 36; ++k) wf[k] = *reinterpret_cast<const h16x8*>(wt + (size_t)(ntile * 16 + frow) * KTOT + k * 32 + fq * 8);
     const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
     const float4 bia = *reinterpret_cast<const float4*>(bias + ntile * 16 + fq * 4);
     const float4 w4v = *reinterpret_cast<const float4*>(w4 + ntile * 16 + fq * 4);
@@ -114,9 +108,9 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
                     uint32_t ov[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
-                        const float lo = hy * (hx * bf_lo(u00[j]) + lx * bf_lo(u01[j])) + ly * (hx * bf_lo(u10[j]) + lx * bf_lo(u11[j]));
-                        const float hi = hy * (hx * bf_hi(u00[j]) + lx * bf_hi(u01[j])) + ly * (hx * bf_hi(u10[j]) + lx * bf_hi(u11[j]));
-                        ov[j] = pk2(lo, hi);
+                        const float lo = hy * (hx * h_lo<F16>(u00[j]) + lx * h_lo<F16>(u01[j])) + ly * (hx * h_lo<F16>(u10[j]) + lx * h_lo<F16>(u11[j]));
+                        const float hi = hy * (hx * h_hi<F16>(u00[j]) + lx * h_hi<F16>(u01[j])) + ly * (hx * h_hi<F16>(u10[j]) + lx * h_hi<F16>(u11[j]));
+                        ov[j] = pack_h2<F16>(lo, hi);
                     }
                     o = make_uint4(ov[0], ov[1], ov[2], ov[3]);
                 }
@@ -136,8 +130,8 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const int prow = (2 * rowpair + j + ky) * PW + frow + kx;
-                    const bf16x8 xf = *reinterpret_cast<const bf16x8*>(Ps + prow * P_ROWB + (ks * 32 + fq * 8) * 2);
-                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[tap * 4 + ks], xf, acc[j], 0, 0, 0);
+                    const h16x8 xf = *reinterpret_cast<const h16x8*>(Ps + prow * P_ROWB + (ks * 32 + fq * 8) * 2);
+                    acc[j] = mfma_16x16x32<F16>(wf[tap * 4 + ks], xf, acc[j]);
                 }
             }
         }
@@ -166,18 +160,20 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
     }
 }
 
-int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int B, int h, int w,
-                      hipStream_t st, std::string& err) {
+int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int hf, int B, int h,
+                      int w, hipStream_t st, std::string& err) {
     if ((2 * h) % TH || (2 * w) % TW) { err = "depth_tail: output size must be a multiple of 8 x 16"; return 1; }
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { err = std::string("depth_tail: ") + hipGetErrorString(e); return 1; }
         attr_done = true;
     }
     const int ntiles = B * (2 * h / TH) * (2 * w / TW);
     const int blocks = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU keeps the weights resident
-    hipLaunchKernelGGL(depth_tail_kernel, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
+    if (hf) hipLaunchKernelGGL(depth_tail_kernel<true>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
+    else hipLaunchKernelGGL(depth_tail_kernel<false>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
     return check_launch("depth_tail", err);
 }
 

@@ -5,6 +5,7 @@
 // where the layout allows, NHWC ("token-major") activations throughout.
 #include <type_traits>
 
+#include "half16.h"
 #include "kernels.h"
 
 namespace soccdpt {
@@ -23,17 +24,19 @@ __device__ __forceinline__ float wave_sum(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
 }
 
-__device__ __forceinline__ bf16_t f2bf(float f) {
-    __bf16 x = (__bf16)f;
-    return __builtin_bit_cast(bf16_t, x);
-}
-__device__ __forceinline__ float bf2f(bf16_t b) { return __builtin_bit_cast(float, (uint32_t)b << 16); }
+// launch K<false> (bf16) or K<true> (fp16) by the runtime format flag
+#define LAUNCH_HF(hf, K, ...)                                   \
+    do {                                                        \
+        if (hf) hipLaunchKernelGGL((K<true>), __VA_ARGS__);     \
+        else hipLaunchKernelGGL((K<false>), __VA_ARGS__);       \
+    } while (0)
 
 // ---------------------------------------------------------------------------------------------
 // patch_embed: Conv2d(3, C0, k=4, s=4) + bias, flatten, LayerNorm(C0)   (timm PatchEmbed;
 // call site /root/reference/SOccDPT/model/backbones/swin2.py:25-27).  One wave per token.
 // x NCHW f32 [B,3,S,S] -> xf [M,C0] f32 residual stream, xb [M,C0] bf16 GEMM operand.
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
@@ -76,24 +79,24 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
         if (a0) {
             const float y = d0 * rstd * g0 + e0;
             xf[(size_t)tok * C0 + lane] = y;
-            if (xb) xb[(size_t)tok * C0 + lane] = f2bf(y);
+            if (xb) xb[(size_t)tok * C0 + lane] = f2h<F16>(y);
         }
         if (a1) {
             const float y = d1 * rstd * g1 + e1;
             xf[(size_t)tok * C0 + lane + 64] = y;
-            if (xb) xb[(size_t)tok * C0 + lane + 64] = f2bf(y);
+            if (xb) xb[(size_t)tok * C0 + lane + 64] = f2h<F16>(y);
         }
     }
 }
 
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
-                       int B, int S, int C0, hipStream_t st, std::string& err) {
+                       int hf, int B, int S, int C0, hipStream_t st, std::string& err) {
     if (C0 > 128) { err = "patch_embed: C0 > 128"; return 1; }
     const int M = B * (S / 4) * (S / 4);
     int blocks = (M + 127) / 128;  // 32 tokens per wave amortise the weight registers
     if (blocks > 512) blocks = 512;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0);
+    LAUNCH_HF(hf, patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0);
     return check_launch("patch_embed", err);
 }
 
@@ -104,7 +107,7 @@ int launch_patch_embed(const float* x, const float* w, const float* bias, const 
 // zero-haloed NHWC bf16 feature map the decoder's 3x3 reassemble conv reads
 // (/root/reference/SOccDPT/model/backbones/swin_common.py:38-52 does this as Transpose+Unflatten).
 // ---------------------------------------------------------------------------------------------
-template <int VPL>  // values per lane = ceil(C / 64)
+template <int VPL, bool F16>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
             float o = v[t] * rstd * g[c] + beta[c];
             if (residual) o += xf[(size_t)row * C + c];
             xf[(size_t)row * C + c] = o;
-            const bf16_t ob = f2bf(o);
+            const bf16_t ob = f2h<F16>(o);
             if (xb) xb[(size_t)row * C + c] = ob;
             if (halo) halo[hoff + c] = ob;
             if (halo_f32) halo_f32[hoff + c] = o;
@@ -151,11 +154,15 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
     }
 }
 
-int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int M, int C,
-                       int residual, int res, hipStream_t st, std::string& err) {
+int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
+                       int C, int residual, int res, hipStream_t st, std::string& err) {
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
-#define LN_CASE(V) hipLaunchKernelGGL((ln_residual_kernel<V>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res)
+#define LN_CASE(V)                                                                                                                    \
+    do {                                                                                                                              \
+        if (hf) hipLaunchKernelGGL((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res);  \
+        else hipLaunchKernelGGL((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res);    \
+    } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);
     else if (vpl <= 8) LN_CASE(8);
@@ -202,18 +209,15 @@ int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem
 // src = dst * (in-1)/(out-1); i0 = int(src); l1 = src - i0.  One thread = 4 channels of one
 // output pixel.  TIn: float or bf16_t.  Output: f32 plain [M][C] and/or bf16 plain / halo.
 // ---------------------------------------------------------------------------------------------
-template <typename TIn>
-__device__ __forceinline__ float4 load4(const TIn* p);
-template <>
-__device__ __forceinline__ float4 load4<float>(const float* p) { return *reinterpret_cast<const float4*>(p); }
-template <>
-__device__ __forceinline__ float4 load4<bf16_t>(const bf16_t* p) {
+template <bool F16>
+__device__ __forceinline__ float4 load4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+template <bool F16>
+__device__ __forceinline__ float4 load4(const bf16_t* p) {
     const uint2 u = *reinterpret_cast<const uint2*>(p);
-    return make_float4(__builtin_bit_cast(float, u.x << 16), __builtin_bit_cast(float, u.x & 0xffff0000u),
-                       __builtin_bit_cast(float, u.y << 16), __builtin_bit_cast(float, u.y & 0xffff0000u));
+    return make_float4(h_lo<F16>(u.x), h_hi<F16>(u.x), h_lo<F16>(u.y), h_hi<F16>(u.y));
 }
 
-template <typename TIn>
+template <typename TIn, bool F16>
 __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ in, float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16,
                                                         float* __restrict__ out_f32_halo, int out_halo, int B, int h, int w, int H, int W, int C) {
     const int c4 = C / 4;
@@ -233,10 +237,10 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ i
         const float ly = fy - (float)y0, lx = fx - (float)x0;
         const float hy = 1.f - ly, hx = 1.f - lx;
         const TIn* base = in + (size_t)b * h * w * C + cc;
-        const float4 v00 = load4<TIn>(base + ((size_t)y0 * w + x0) * C);
-        const float4 v01 = load4<TIn>(base + ((size_t)y0 * w + x1) * C);
-        const float4 v10 = load4<TIn>(base + ((size_t)y1 * w + x0) * C);
-        const float4 v11 = load4<TIn>(base + ((size_t)y1 * w + x1) * C);
+        const float4 v00 = load4<F16>(base + ((size_t)y0 * w + x0) * C);
+        const float4 v01 = load4<F16>(base + ((size_t)y0 * w + x1) * C);
+        const float4 v10 = load4<F16>(base + ((size_t)y1 * w + x0) * C);
+        const float4 v11 = load4<F16>(base + ((size_t)y1 * w + x1) * C);
         float4 o;
         o.x = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
         o.y = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
@@ -248,23 +252,25 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ i
         if (out_bf16) {
             const size_t off = out_halo ? (((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) : (pix * C + cc);
             uint2 p;
-            p.x = (uint32_t)f2bf(o.x) | ((uint32_t)f2bf(o.y) << 16);
-            p.y = (uint32_t)f2bf(o.z) | ((uint32_t)f2bf(o.w) << 16);
+            p.x = pack_h2<F16>(o.x, o.y);
+            p.y = pack_h2<F16>(o.z, o.w);
             *reinterpret_cast<uint2*>(out_bf16 + off) = p;
         }
     }
 }
 
-int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int B, int h, int w,
-                    int H, int W, int C, hipStream_t st, std::string& err) {
+int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
+                    int w, int H, int W, int C, hipStream_t st, std::string& err) {
     if (C % 4) { err = "bilinear: C % 4 != 0"; return 1; }
     const size_t total = (size_t)B * H * W * (C / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    if (in_is_bf16)
-        hipLaunchKernelGGL((bilinear_kernel<bf16_t>), dim3((unsigned)blocks), dim3(256), 0, st, (const bf16_t*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C);
-    else
-        hipLaunchKernelGGL((bilinear_kernel<float>), dim3((unsigned)blocks), dim3(256), 0, st, (const float*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C);
+#define BL_ARGS(T) dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C
+    if (in_is_bf16 && hf) hipLaunchKernelGGL((bilinear_kernel<bf16_t, true>), BL_ARGS(bf16_t));
+    else if (in_is_bf16) hipLaunchKernelGGL((bilinear_kernel<bf16_t, false>), BL_ARGS(bf16_t));
+    else if (hf) hipLaunchKernelGGL((bilinear_kernel<float, true>), BL_ARGS(float));
+    else hipLaunchKernelGGL((bilinear_kernel<float, false>), BL_ARGS(float));
+#undef BL_ARGS
     return check_launch("bilinear", err);
 }
 
@@ -274,6 +280,7 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
 //       16 lanes per pixel, each 16 channels (2 x 16-byte loads), 4-step shuffle reduction.
 //   (b) bilinear x2 (align_corners=True) + Sigmoid / ScaledTanh -> NCHW f32 [B,3,2h,2w]
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w /*[3][256]*/,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M) {
     const int sub = threadIdx.x & 15;
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restric
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
-        const float lo = __builtin_bit_cast(float, u[k] << 16), hi = __builtin_bit_cast(float, u[k] & 0xffff0000u);
+        const float lo = h_lo<F16>(u[k]), hi = h_hi<F16>(u[k]);
         const int c = sub * 16 + 2 * k;
         s0 += lo * w[c] + hi * w[c + 1];
         s1 += lo * w[256 + c] + hi * w[256 + c + 1];
@@ -356,12 +363,12 @@ __global__ __launch_bounds__(256) void seg_up_act_kernel(const float* __restrict
     }
 }
 
-int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
+int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
                     int sigmoid, hipStream_t st, std::string& err) {
     const int M = B * h * wd;
     const dim3 grid((unsigned)(((size_t)M * 16 + 255) / 256));
     if (feat_is_f32) hipLaunchKernelGGL(conv1x1_c3_f32_kernel, grid, dim3(256), 0, st, static_cast<const float*>(feat), w, bias, tmp, M);
-    else hipLaunchKernelGGL(conv1x1_c3_kernel, grid, dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
+    else LAUNCH_HF(hf, conv1x1_c3_kernel, grid, dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
     if (check_launch("conv1x1_c3", err)) return 1;
     const size_t total = (size_t)B * 4 * h * wd;
     size_t blocks = (total + 255) / 256;
@@ -373,10 +380,12 @@ int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const flo
 // ---------------------------------------------------------------------------------------------
 // One-time weight preparation
 // ---------------------------------------------------------------------------------------------
+template <bool F16>
 __global__ void cvt_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2bf(in[i]);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2h<F16>(in[i]);
 }
 // [Cout][Cin][3][3] f32 -> [Cout][3][3][Cin] bf16, optionally scaled per Cout (BatchNorm fold)
+template <bool F16>
 __global__ void conv_w_kernel(const float* __restrict__ in, const float* __restrict__ scale, bf16_t* __restrict__ out, int Cout, int Cin) {
     const size_t n = (size_t)Cout * Cin * 9;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -385,7 +394,7 @@ __global__ void conv_w_kernel(const float* __restrict__ in, const float* __restr
         const int tap = (int)(r % 9), co = (int)(r / 9);
         float v = in[((size_t)co * Cin + ci) * 9 + tap];
         if (scale) v *= scale[co];
-        out[i] = f2bf(v);
+        out[i] = f2h<F16>(v);
     }
 }
 __global__ void conv_w_f32_kernel(const float* __restrict__ in, const float* __restrict__ scale, float* __restrict__ out, int Cout, int Cin) {
@@ -449,17 +458,17 @@ __global__ void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, cons
     table[i] = 16.f / (1.f + expf(-s));
 }
 
-int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std::string& err) {
+int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, int hf, hipStream_t st, std::string& err) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+    LAUNCH_HF(hf, cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
     return check_launch("cvt_bf16", err);
 }
-int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int Cout, int Cin, hipStream_t st, std::string& err) {
+int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int hf, int Cout, int Cin, hipStream_t st, std::string& err) {
     size_t n = (size_t)Cout * Cin * 9, blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (out_is_f32) hipLaunchKernelGGL(conv_w_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
-    else hipLaunchKernelGGL(conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<bf16_t*>(out), Cout, Cin);
+    else LAUNCH_HF(hf, conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<bf16_t*>(out), Cout, Cin);
     return check_launch("conv_w", err);
 }
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,

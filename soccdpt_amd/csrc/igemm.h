@@ -9,7 +9,7 @@
 
 namespace soccdpt {
 
-typedef uint16_t bf16_t;  // raw bf16 bits
+typedef uint16_t bf16_t;  // raw 16-bit operand bits: bf16, or fp16 under SOCCDPT_PREC_F16 (half16.h)
 
 // Zero-haloed NHWC activation: pixel (b,y,x) lives at ((b*(H+2)+y+1)*(W+2)+x+1)*C.
 // The one-pixel border is never written by any kernel and is zero from workspace init.
@@ -25,6 +25,7 @@ struct IgemmDesc {
     const void* X = nullptr;   // activations, bf16 (or f32 when f32 != 0)
     const void* Wt = nullptr;  // weights [N][taps*Cin], K contiguous, same element type
     int f32 = 0;               // exact-f32 operands and f32 MFMA (SOCCDPT_PREC_F32)
+    int f16 = 0;               // 16-bit operands are IEEE fp16 instead of bf16 (SOCCDPT_PREC_F16); ignored when f32 != 0
     int M = 0, N = 0;
     int Cin = 0;      // channels per tap (K of a plain GEMM)
     int taps = 1;     // 1 (GEMM / 1x1) or 9 (3x3, pad 1)

@@ -18,12 +18,15 @@
 //  * LDS rows are BK*2 bytes; the 16-byte chunks of a row are XOR-swizzled on the source side and
 //    on the ds_read_b128 side (same involution) -> conflict-free fragment reads.
 //  * blockIdx is remapped so the N-tiles that share an activation tile run on one XCD (L2 reuse).
+#include <type_traits>
+
+#include "half16.h"
 #include "igemm.h"
 
 namespace soccdpt {
 
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
+struct f16_t { uint16_t v; };  // element tag of the fp16 instantiations (SOCCDPT_PREC_F16); bf16_t tags bf16, float exact f32
 
 // BK_ is the k-tile depth in bf16 elements; a tile row is ROWB = 2*BK_ bytes (128 or 64).  With f32 operands
 // (SOCCDPT_PREC_F32) the same byte geometry holds BK_/2 elements per row.
@@ -64,18 +67,14 @@ __device__ __forceinline__ float gelu_fast(float x) {
     return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
-__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
-    __bf16 x = (__bf16)a, y = (__bf16)b;
-    return (uint32_t)__builtin_bit_cast(uint16_t, x) | ((uint32_t)__builtin_bit_cast(uint16_t, y) << 16);
-}
-
-// T = bf16_t (v_mfma_f32_16x16x32_bf16) or float (v_mfma_f32_16x16x4_f32, exact f32: the parity mode).
+// T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16) or float (v_mfma_f32_16x16x4_f32, exact f32).
 template <class C, typename T>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
     constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
+    constexpr bool F16 = std::is_same<T, f16_t>::value;
     const T* const Xp = static_cast<const T*>(d.X);
     const T* const Wtp = static_cast<const T*>(d.Wt);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -180,16 +179,16 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
             if constexpr (sizeof(T) == 2) {
-                bf16x8 wf[C::TN], xf[C::TM];
+                h16x8 wf[C::TN], xf[C::TM];
 #pragma unroll
-                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const bf16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const h16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
 #pragma unroll
-                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const bf16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
 #pragma unroll
                 for (int i = 0; i < C::TN; ++i)
 #pragma unroll
                     for (int j = 0; j < C::TM; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[i], xf[j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = mfma_16x16x32<F16>(wf[i], xf[j], acc[i][j]);
             } else {
                 // f32: the lane's 16-byte chunk holds 4 consecutive k; element e of every lane forms MFMA k-step e
                 // (A and B use the same lane->k map, so any k permutation is a valid dot product order)
@@ -287,10 +286,10 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 *reinterpret_cast<float4*>(d.ln_xf + orow + n) = make_float4(o[0], o[1], o[2], o[3]);
                 if constexpr (sizeof(T) == 2) {
                     uint2 p;
-                    p.x = pack_bf16x2(o[0], o[1]);
-                    p.y = pack_bf16x2(o[2], o[3]);
-                    if (d.out_op) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.out_op) + orow + n) = p;
-                    if (d.ln_halo) *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.ln_halo) + hrow + n) = p;
+                    p.x = pack_h2<F16>(o[0], o[1]);
+                    p.y = pack_h2<F16>(o[2], o[3]);
+                    if (d.out_op) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
+                    if (d.ln_halo) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
                 } else {
                     if (d.ln_halo) *reinterpret_cast<float4*>(static_cast<float*>(d.ln_halo) + hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
                 }
@@ -368,9 +367,9 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             if (d.out_op) {
                 if constexpr (sizeof(T) == 2) {
                     uint2 p;
-                    p.x = pack_bf16x2(a[0], a[1]);
-                    p.y = pack_bf16x2(a[2], a[3]);
-                    *reinterpret_cast<uint2*>(static_cast<bf16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    p.x = pack_h2<F16>(a[0], a[1]);
+                    p.y = pack_h2<F16>(a[2], a[3]);
+                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
                 } else {
                     *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
                 }
@@ -413,7 +412,7 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
 
 template <class C>
 static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
-    return launch_cfg_t<C, bf16_t>(d, stream, err);
+    return d.f16 ? launch_cfg_t<C, f16_t>(d, stream, err) : launch_cfg_t<C, bf16_t>(d, stream, err);
 }
 
 // Kernel configurations.  id: name                 tile        ring
@@ -465,7 +464,14 @@ static int pick_cfg(const IgemmDesc& d) {
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
-const char* igemm_family(const IgemmDesc& d) { return d.f32 ? kCfgNamesF32[pick_cfg_f32(d)] : kCfgNames[pick_cfg(d)]; }
+const char* igemm_family(const IgemmDesc& d) {
+    if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];
+    const int id = pick_cfg(d);
+    if (!d.f16) return kCfgNames[id];
+    static std::string f16_names[sizeof(kCfgNames) / sizeof(kCfgNames[0])];  // "igemm_f16_<tile>": same kernels, fp16 instantiation
+    if (f16_names[id].empty()) f16_names[id] = std::string("igemm_f16_") + (kCfgNames[id] + 11);
+    return f16_names[id].c_str();
+}
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.M <= 0 || d.N <= 0 || d.Cin <= 0 || !d.X || !d.Wt) { err = "igemm: bad descriptor"; return 1; }

@@ -1,4 +1,5 @@
 // Launchers of the non-GEMM kernels (elementwise.hip, attention.hip).
+// `hf` selects the 16-bit operand format of bf16_t buffers: 0 = bf16, 1 = IEEE fp16 (half16.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -20,17 +21,17 @@ inline int check_launch(const char* what, std::string& err) {
 
 // elementwise.hip
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
-                       int B, int S, int C0, hipStream_t st, std::string& err);
-int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int M, int C,
-                       int residual, int res, hipStream_t st, std::string& err);
+                       int hf, int B, int S, int C0, hipStream_t st, std::string& err);
+int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
+                       int C, int residual, int res, hipStream_t st, std::string& err);
 int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err);
-int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int B, int h, int w,
-                    int H, int W, int C, hipStream_t st, std::string& err);
-int launch_seg_tail(const void* feat, int feat_is_f32, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
+int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
+                    int w, int H, int W, int C, hipStream_t st, std::string& err);
+int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
                     int sigmoid, hipStream_t st, std::string& err);
 int launch_patch_w(const float* w, float* out, int C0, hipStream_t st, std::string& err);
-int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, hipStream_t st, std::string& err);
-int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int Cout, int Cin, hipStream_t st, std::string& err);
+int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, int hf, hipStream_t st, std::string& err);
+int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int hf, int Cout, int Cin, hipStream_t st, std::string& err);
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,
                    std::string& err);
 int launch_qkv_bias(const float* q, const float* v, float* out, int C, hipStream_t st, std::string& err);
@@ -39,8 +40,8 @@ int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* t
                      std::string& err);
 
 // depth_tail.hip: bilinear x2 + conv3x3(128->32) + ReLU + conv1x1(32->1) + ReLU fused (bf16 mode)
-int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int B, int h, int w,
-                      hipStream_t st, std::string& err);
+int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int hf, int B, int h,
+                      int w, hipStream_t st, std::string& err);
 
 // metrics.hip
 size_t metrics_scratch_bytes(int B, int C);
@@ -52,8 +53,8 @@ int launch_iou_metrics(const float* pred, const float* gt, int B, int C, size_t 
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);
 int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hipStream_t st, std::string& err);
-int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int B, int res, int ws, int shift,
-                            int heads, hipStream_t st, std::string& err);
+int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
+                            int shift, int heads, hipStream_t st, std::string& err);
 
 int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
                                 int ws, int shift, int heads, hipStream_t st, std::string& err);

@@ -85,17 +85,18 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     const bool run = ar.base != nullptr;
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
+    const int HF = h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0;  // 16-bit operand format: 0 bf16, 1 fp16
     static const char kNoCopy = 0;  // non-null placeholder while measuring
     auto cvt = [&](const std::string& key, size_t n) -> const void* {
         if (F32) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
         bf16_t* p = ar.take<bf16_t>(n);
-        if (run && launch_cvt_bf16(W(key), p, n, st, err)) return nullptr;
+        if (run && launch_cvt_bf16(W(key), p, n, HF, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const void* {
         const size_t n = (size_t)Cout * Cin * 9;
         void* p = F32 ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
-        if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, Cout, Cin, st, err)) return nullptr;
+        if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, HF, Cout, Cin, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     {
@@ -352,11 +353,12 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
         return 0;
     };
-    const int hk = h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : 2;  // 3 = f32 zero-halo NHWC
+    const int hk = h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 5 : 2);  // zero-halo NHWC: 2 bf16, 3 f32, 5 fp16
     for (int s = 0; s < 4; ++s)
         if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), hk, a.res(s), a.res(s), a.dim(s));
     const int r1 = 2 * a.res(0);
     if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
+    if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
     if (n == "xf") return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     return 1;
 }
@@ -386,15 +388,16 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const int F = h.cfg.features;
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
     const int es = F32 ? 4 : 2;
+    const int HF = h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0;  // 16-bit operand format: 0 bf16, 1 fp16
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
-    auto gemm = [&](IgemmDesc d) { d.f32 = F32 ? 1 : 0; PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
+    auto gemm = [&](IgemmDesc d) { d.f32 = F32 ? 1 : 0; d.f16 = HF; PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------
     { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
-                           W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), B, a.img, a.embed, st, err)); }
+                           W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), HF, B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
@@ -405,7 +408,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
               if (F32) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
                                                        a.shift(s, j), H, st, err));
-              else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), B, res, wsz,
+              else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), HF, B, res, wsz,
                                                a.shift(s, j), H, st, err)); }
             const bool fuse_ln = F32 ? (C <= 128) : (C <= 256 && (C <= 128 || C % 64 == 0));  // whole rows fit one igemm tile
             d = IgemmDesc();
@@ -417,7 +420,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 d.out_f32 = w.y;
                 RUN(gemm(d));
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M, C, 1, res, st, err)); }
+                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, st, err)); }
             }
             d = IgemmDesc();
             d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = w.hbuf;
@@ -435,7 +438,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
               const bool hook = (j == a.hooks[s]);
               RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb),
-                                     (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, M, C,
+                                     (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, HF, M, C,
                                      1, res, st, err)); }
             }
         }
@@ -446,7 +449,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
-              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, M / 4, 2 * C, 0,
+              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M / 4, 2 * C, 0,
                                      res / 2, st, err)); }
         }
     }
@@ -493,7 +496,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             RUN(gemm(d));
         }
         if (l == 0) { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
-               RUN(launch_bilinear(w.oc[0], 0, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.path1), F32 ? static_cast<float*>(w.path1) : nullptr, 1, B, r, r,
+               RUN(launch_bilinear(w.oc[0], 0, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.path1), F32 ? static_cast<float*>(w.path1) : nullptr, 1, HF, B, r, r,
                                    2 * r, 2 * r, F, st, err)); }
     }
     // ---------------- heads ----------------
@@ -505,10 +508,10 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         if (!F32 && F == 256) {
             // fused: up-sample + conv3x3(128->32) + ReLU + 1x1 + ReLU straight from the half-resolution map
             PROF("depth_tail_fused", 2.0 * B * r0 * r0 * 32.0 * 9.0 * (F / 2), 0.0);
-            RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, B, r1, r1, st, err));
+            RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, HF, B, r1, r1, st, err));
         } else {
             { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
-              RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, B, r1,
+              RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, HF, B, r1,
                                   r1, r0, r0, F / 2, st, err)); }
             d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
             d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
@@ -518,7 +521,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         d.bias = P.bn_shift; d.act = ACT_RELU; d.out_op = w.s1;
         RUN(gemm(d));
         { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
-          RUN(launch_seg_tail(w.s1, F32 ? 1 : 0, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
+          RUN(launch_seg_tail(w.s1, F32 ? 1 : 0, HF, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
         ++launches;
     }
 #undef RUN

@@ -19,6 +19,7 @@ ABI_VERSION = 1
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1}
 PREC_BF16 = 0
 PREC_F32 = 1
+PREC_F16 = 2
 
 
 class SoccdptConfig(ctypes.Structure):
@@ -55,7 +56,7 @@ class IgemmArgs(ctypes.Structure):
         ("act", ctypes.c_int32), ("out_f32", ctypes.c_void_p), ("act_on_f32", ctypes.c_int32),
         ("out_bf16", ctypes.c_void_p), ("out_halo", ctypes.c_int32),
         ("dot_w", ctypes.c_void_p), ("dot_b", ctypes.c_float), ("out_dot", ctypes.c_void_p),
-        ("tune", ctypes.c_int32), ("f32", ctypes.c_int32),
+        ("tune", ctypes.c_int32), ("precision", ctypes.c_int32),
     ]
 
 
@@ -122,7 +123,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_profile_collect.restype = ci
     L.soccdpt_op_igemm.argtypes = [ctypes.POINTER(IgemmArgs), vp]
     L.soccdpt_op_igemm.restype = ci
-    L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.soccdpt_op_window_attention.restype = ci
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
                                            ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
@@ -325,8 +326,8 @@ class Engine:
         if kind.value == 3:
             t = raw[: n.value * 4].view(torch.float32).reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
             return t.clone()
-        t = raw[: n.value * 2].view(torch.bfloat16)
-        if kind.value == 2:
+        t = raw[: n.value * 2].view(torch.float16 if kind.value in (4, 5) else torch.bfloat16)
+        if kind.value in (2, 5):
             t = t.reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
         else:
             t = t.reshape(B, H.value, W.value, C.value)
@@ -334,21 +335,22 @@ class Engine:
 
 
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
-             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0):
+             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None):
     """Kernel-level entry (tests): one implicit-GEMM launch on the current stream."""
     L = load_library()
     a = IgemmArgs(_ptr(x), _ptr(wt), M, N, Cin, taps, ldx, H, W, _ptr(bias), _ptr(res1), _ptr(res2), act, _ptr(out_f32),
-                  act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune, f32)
+                  act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune,
+                  int(precision) if precision is not None else (PREC_F32 if f32 else PREC_BF16))
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())
 
 
-def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads):
+def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads, precision=PREC_BF16):
     L = load_library()
     nt = (ws * ws + 31) // 32
     scratch = torch.empty((heads * nt * nt * 1024,), dtype=torch.float32, device=qkv.device)
     rc = L.soccdpt_op_window_attention(_ptr(qkv), _ptr(cpb_table), _ptr(scale), _ptr(out), _ptr(scratch), B, res, ws, shift,
-                                       heads, _stream_ptr(qkv.device))
+                                       heads, int(precision), _stream_ptr(qkv.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_window_attention failed: " + L.soccdpt_last_error(None).decode())

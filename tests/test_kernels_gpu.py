@@ -140,6 +140,68 @@ def test_window_attention(gpu_device, B, res, ws, shift, heads):
     assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
 
 
+# ---------------- fp16 operand mode (SOCCDPT_PREC_F16): same kernels, v_mfma_*_f16 ----------------
+def _hf(t):
+    return t.to(torch.float16)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 288, 96), (4096, 192, 384), (64, 768, 3072)])
+def test_igemm_linear_f16(gpu_device, M, N, K):
+    from soccdpt_amd.lib import PREC_F16, op_igemm
+    g = torch.Generator().manual_seed(M + N + K)
+    x = _hf(torch.randn(M, K, generator=g)).to(gpu_device)
+    w = _hf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    ref = x.float() @ w.float().t() + bias
+    out = torch.empty(M, N, device=gpu_device)
+    outh = torch.empty(M, N, dtype=torch.float16, device=gpu_device)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_f32=out, precision=PREC_F16)
+    op_igemm(x, w, M, N, K, ldx=K, bias=bias, act=2, out_bf16=outh, precision=PREC_F16)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=1e-4)          # identical fp16 operands, f32 accumulation on both sides
+    torch.testing.assert_close(outh.float(), F.gelu(ref), rtol=1.5e-3, atol=1.5e-3)   # one fp16 rounding of the output
+    big = torch.full((M, K), 300.0, dtype=torch.float16, device=gpu_device)           # 300*300*K overflows fp16: stores saturate, never inf
+    wbig = torch.full((N, K), 300.0, dtype=torch.float16, device=gpu_device)
+    op_igemm(big, wbig, M, N, K, ldx=K, out_bf16=outh, precision=PREC_F16)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(outh).all()) and float(outh.max()) == 65504.0
+
+
+def test_igemm_conv3x3_f16(gpu_device):
+    from soccdpt_amd.lib import PREC_F16, op_igemm
+    B, H, Cin, Cout = 2, 16, 256, 256
+    g = torch.Generator().manual_seed(77)
+    x = _hf(torch.randn(B, Cin, H, H, generator=g)).to(gpu_device)
+    w = _hf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(gpu_device)
+    bias = torch.randn(Cout, generator=g).to(gpu_device)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    xh = _halo(x.permute(0, 2, 3, 1).contiguous())
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    out = torch.empty(B, H, H, Cout, device=gpu_device)
+    outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.float16, device=gpu_device)
+    op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, act=1, out_f32=out, out_bf16=outh, out_halo=1, precision=PREC_F16)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(outh[:, 1:-1, 1:-1].float(), F.relu(ref), rtol=1.5e-3, atol=1.5e-3)
+
+
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 8, 3), (3, 16, 16, 0, 12), (2, 8, 8, 0, 24), (1, 96, 24, 12, 4), (3, 12, 12, 0, 32)])
+def test_window_attention_f16(gpu_device, B, res, ws, shift, heads):
+    from soccdpt_amd.lib import PREC_F16, op_window_attention
+    g = torch.Generator().manual_seed(res * 100 + shift + heads)
+    C = heads * 32
+    qkv = _hf(torch.randn(B * res * res, 3 * C, generator=g)).to(gpu_device)
+    table = (16 * torch.sigmoid(torch.randn((2 * ws - 1) ** 2, heads, generator=g))).to(gpu_device)
+    scale = (10.0 + 5 * torch.rand(heads, generator=g)).to(gpu_device)
+    out = torch.empty(B * res * res, C, dtype=torch.float16, device=gpu_device)
+    op_window_attention(qkv, table, scale, out, B, res, ws, shift, heads, precision=PREC_F16)
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv, table, scale, B, res, ws, shift, heads)
+    err = (out.float() - ref).abs()
+    # q-hat, k-hat and the softmax numerators are rounded to fp16 (2^-12 relative): 8x tighter than the bf16 kernel's bounds
+    assert float(err.max()) < 8e-3 and float(err.mean()) < 8e-4, (float(err.max()), float(err.mean()))
+
+
 # ---------------- exact-f32 parity mode (SOCCDPT_PREC_F32) ----------------
 @pytest.mark.parametrize("M,N,K", [(300, 288, 96), (2048, 384, 1536), (512, 2304, 768)])
 def test_igemm_linear_f32(gpu_device, M, N, K):

@@ -174,16 +174,16 @@ def test_f32_mode_full_forward_occupancy(net_f32, gpu_device):
     assert iou > 0.97
 
 
-@pytest.mark.parametrize("precision", ["bf16", "f32"])
+@pytest.mark.parametrize("precision", ["bf16", "f16", "f32"])
 def test_swin2_base_384_network_vs_oracle(gpu_device, precision):
     """BASELINE config 4 model (dpt_swin2_base_384: 24x24 / 12x12 windows, 384x384 input), B=1; bf16 mode within the
     bf16 tolerance, exact-f32 mode within the north star's 1e-3."""
-    from soccdpt_amd.lib import PREC_BF16, PREC_F32
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, PREC_F32
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     m = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type="dpt_swin2_base_384",
-                   precision=PREC_F32 if precision == "f32" else PREC_BF16)
+                   precision={"f32": PREC_F32, "f16": PREC_F16, "bf16": PREC_BF16}[precision])
     sd = synth_state_dict("swin2b24_384", alias_pretrained=True)
     r = m.load_state_dict(sd, strict=False)
     assert not r.unexpected_keys
@@ -198,7 +198,7 @@ def test_swin2_base_384_network_vs_oracle(gpu_device, precision):
     e_inv, e_seg = _rel_l2(inv.cpu(), o_inv), _rel_l2(seg.cpu(), o_seg)
     print(f"swin2_base_384 {precision}: rel L2 inv", f"{e_inv:.2e}", "seg", f"{e_seg:.2e}")
     assert tuple(inv.shape) == (1, 384, 384) and tuple(out[3].shape) == (1, 256, 256, 32, 3)
-    if precision == "f32":
+    if precision in ("f32", "f16"):
         assert e_inv < 1e-3 and e_seg < 1e-3
     else:
         assert e_inv < 3e-2 and e_seg < 5e-2
@@ -233,3 +233,58 @@ def test_full_batch_8_sigmoid_and_plugin_pattern(gpu_device):
     o2 = p(x.to(gpu_device))
     torch.cuda.synchronize()
     assert torch.equal(o2[3], out[3]) and torch.equal(torch.nan_to_num(o2[2]), torch.nan_to_num(out[2]))
+
+
+# ---------------- fp16 operand mode: the 1e-3 tolerance at the full MFMA rate ----------------
+@pytest.fixture(scope="module")
+def net_f16(gpu_device):
+    from soccdpt_amd.lib import PREC_F16
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, precision=PREC_F16)
+    sd = synth_state_dict(alias_pretrained=True)
+    m.load_state_dict(sd, strict=False)
+    return m.eval().to(gpu_device), sd
+
+
+def test_f16_mode_meets_1e3_relative(net_f16, gpu_device):
+    """SOCCDPT_PREC_F16 (fp16 MFMA operands, f32 accumulate / residual streams): the network OUTPUTS the north star names
+    (depth maps, class logits) and every hooked feature map within 1e-3 relative L2 of the reference-equivalent fp32 CPU
+    forward (measured 4.3e-4 / 7.4e-4 / 4.4e-4..9.8e-4; bf16 operands give 3.3e-3 / - / 3.6e-3..8.1e-3)."""
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = net_f16
+    x = synth_input(2, seed0=4)
+    inv, seg = m.network(x.to(gpu_device))
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        layers = R.swin_encoder(sd, x, R.ARCHS["swin2t16_256"])
+        o_inv, o_p1 = R.dpt_decoder(sd, layers)
+        o_seg = R.seg_head(sd, o_p1, sigmoid=False)
+    eng = m._engine(gpu_device)
+    errs = {f"feat{s}": _rel_l2(eng.workspace_tensor(2, f"feat{s}").cpu().permute(0, 3, 1, 2), layers[s]) for s in range(4)}
+    errs["path1"] = _rel_l2(eng.workspace_tensor(2, "path1").cpu().permute(0, 3, 1, 2), o_p1)
+    errs["inv"] = _rel_l2(inv.cpu(), o_inv)
+    errs["seg"] = _rel_l2(seg.cpu(), o_seg)
+    errs["seg_logits"] = _rel_l2(eng.workspace_tensor(2, "seg_logits").cpu().permute(0, 3, 1, 2), R.seg_logits(sd, o_p1))
+    print("f16 mode, relative L2 vs fp32 CPU oracle:", {k: f"{v:.2e}" for k, v in errs.items()},
+          "max |seg diff|:", f"{float((seg.cpu() - o_seg).abs().max()):.2e}")
+    assert errs["inv"] < 1e-3 and errs["seg_logits"] < 1e-3
+    for k in ("feat0", "feat1", "feat2", "feat3", "path1"):
+        assert errs[k] < 1.2e-3, (k, errs[k])   # feat3 measured 9.8e-4: the deepest stage carries 12 blocks of roundings
+    # the ScaledTanh probabilities amplify the logit error by the synthetic logit scale (|logit| ~ 6, SURVEY.md 8d weights)
+    assert errs["seg"] < 1e-2
+
+
+def test_f16_mode_full_forward_occupancy(net_f16, gpu_device):
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = net_f16
+    x = synth_input(2, seed0=10)
+    inv_up, seg_up, pts, occ = m(x.to(gpu_device))
+    torch.cuda.synchronize()
+    o_inv, o_seg, o_pts, o_occ = R.soccdpt_v3_forward(sd, x, sigmoid=False)
+    assert _rel_l2(inv_up.cpu(), o_inv) < 1e-3
+    a, b = occ[0].cpu() > 0, o_occ[0] > 0
+    iou = float((a & b).sum()) / max(float((a | b).sum()), 1.0)
+    print("f16 mode occupancy IoU vs oracle:", iou, int(a.sum()), int(b.sum()))
+    assert iou > 0.97
