@@ -45,46 +45,63 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
     // the 48 patch values are broadcast lane -> SGPR with v_readlane (no LDS, no shuffles)
     const int G = S / 4, lane = threadIdx.x & 63;
     const bool a0 = lane < C0, a1 = lane + 64 < C0;
-    float w0[48], w1[48];
+    typedef __attribute__((ext_vector_type(2))) float f32x2;
+    f32x2 wv[48];  // (channel lane, channel lane + 64) pairs: one v_pk_fma_f32 per patch value
 #pragma unroll
     for (int k = 0; k < 48; ++k) {  // w is the prepared transpose [48][128] (zero-padded): coalesced
-        w0[k] = w[k * 128 + lane];
-        w1[k] = w[k * 128 + 64 + lane];
+        wv[k] = f32x2{w[k * 128 + lane], w[k * 128 + 64 + lane]};
     }
     const float b0 = a0 ? bias[lane] : 0.f, b1 = a1 ? bias[lane + 64] : 0.f;
     const float g0 = a0 ? g[lane] : 0.f, g1 = a1 ? g[lane + 64] : 0.f;
     const float e0 = a0 ? beta[lane] : 0.f, e1 = a1 ? beta[lane + 64] : 0.f;
     const int wave_global = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), nwaves = gridDim.x * (blockDim.x >> 6);
-    const int M = B * G * G;
-    auto load_in = [&](int tok) -> float {
-        if (tok >= M || lane >= 48) return 0.f;
-        const int b = tok / (G * G), r = tok - b * G * G, py = r / G, px = r - py * G;
-        const int c = lane >> 4, ky = (lane >> 2) & 3, kx = lane & 3;
-        return x[((size_t)(b * 3 + c) * S + py * 4 + ky) * S + px * 4 + kx];
-    };
-    float in_next = load_in(wave_global);
-    for (int tok = wave_global; tok < M; tok += nwaves) {
-        const float in = in_next;
-        in_next = load_in(tok + nwaves);  // prefetch the next token's patch under this token's FMAs
-        float o0 = b0, o1 = b1;
+    // A wave walks STRIPS of 8 horizontally adjacent tokens: the strip's 12 (channel, ky) rows are 12 x 128 contiguous bytes of x,
+    // fetched with 6 fully coalesced loads (one token at a time touched 12 lines for 16 bytes each, and the 8 tokens sharing a line
+    // sat in 8 different waves).  Element (row, col) of the strip sits in register (row*32+col)/64 of lane (row*32+col)%64.
+    const int strips_per_row = G / 8, nstrips = B * G * strips_per_row;
+    auto load_strip = [&](int sidx, float (&r)[6]) {
+        if (sidx >= nstrips) return;
+        const int b = sidx / (G * strips_per_row), rem = sidx - b * G * strips_per_row, py = rem / strips_per_row, px0 = (rem - py * strips_per_row) * 8;
 #pragma unroll
-        for (int k = 0; k < 48; ++k) {
-            const float v = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, in), k));
-            o0 = fmaf(v, w0[k], o0);
-            o1 = fmaf(v, w1[k], o1);
+        for (int i = 0; i < 6; ++i) {
+            const int idx = i * 64 + lane, row = idx >> 5, col = idx & 31;  // row = c*4 + ky
+            r[i] = x[((size_t)(b * 3 + (row >> 2)) * S + py * 4 + (row & 3)) * S + px0 * 4 + col];
         }
-        const float mean = wave_sum((a0 ? o0 : 0.f) + (a1 ? o1 : 0.f)) / (float)C0;
-        const float d0 = a0 ? o0 - mean : 0.f, d1 = a1 ? o1 - mean : 0.f;
-        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C0 + 1e-5f);
-        if (a0) {
-            const float y = d0 * rstd * g0 + e0;
-            xf[(size_t)tok * C0 + lane] = y;
-            if (xb) xb[(size_t)tok * C0 + lane] = f2h<F16>(y);
-        }
-        if (a1) {
-            const float y = d1 * rstd * g1 + e1;
-            xf[(size_t)tok * C0 + lane + 64] = y;
-            if (xb) xb[(size_t)tok * C0 + lane + 64] = f2h<F16>(y);
+    };
+    float cur[6], nxt[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    load_strip(wave_global, nxt);
+    for (int sidx = wave_global; sidx < nstrips; sidx += nwaves) {
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cur[i] = nxt[i];
+        load_strip(sidx + nwaves, nxt);  // prefetch the next strip under this strip's FMAs
+        const int b = sidx / (G * strips_per_row), rem = sidx - b * G * strips_per_row, py = rem / strips_per_row, px0 = (rem - py * strips_per_row) * 8;
+        const int tok0 = (b * G + py) * G + px0;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            f32x2 oa = f32x2{b0, b1}, ob = f32x2{0.f, 0.f};  // two accumulator chains halve the dependent-FMA latency
+#pragma unroll
+            for (int k = 0; k < 48; k += 2) {
+                const int ia = (k >> 2) * 32 + t * 4 + (k & 3), ib = ia + 1;  // k = (c*4 + ky)*4 + kx; kx and kx+1 share the row
+                const float va = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[ia >> 6]), ia & 63));
+                const float vb = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, cur[ib >> 6]), ib & 63));
+                oa = __builtin_elementwise_fma(f32x2{va, va}, wv[k], oa);
+                ob = __builtin_elementwise_fma(f32x2{vb, vb}, wv[k + 1], ob);
+            }
+            const float o0 = oa[0] + ob[0], o1 = oa[1] + ob[1];
+            const int tok = tok0 + t;
+            const float mean = wave_sum((a0 ? o0 : 0.f) + (a1 ? o1 : 0.f)) / (float)C0;
+            const float d0 = a0 ? o0 - mean : 0.f, d1 = a1 ? o1 - mean : 0.f;
+            const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1) / (float)C0 + 1e-5f);
+            if (a0) {
+                const float y = d0 * rstd * g0 + e0;
+                xf[(size_t)tok * C0 + lane] = y;
+                if (xb) xb[(size_t)tok * C0 + lane] = f2h<F16>(y);
+            }
+            if (a1) {
+                const float y = d1 * rstd * g1 + e1;
+                xf[(size_t)tok * C0 + lane + 64] = y;
+                if (xb) xb[(size_t)tok * C0 + lane + 64] = f2h<F16>(y);
+            }
         }
     }
 }
@@ -92,9 +109,10 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
                        int hf, int B, int S, int C0, hipStream_t st, std::string& err) {
     if (C0 > 128) { err = "patch_embed: C0 > 128"; return 1; }
-    const int M = B * (S / 4) * (S / 4);
-    int blocks = (M + 127) / 128;  // 32 tokens per wave amortise the weight registers
-    if (blocks > 512) blocks = 512;
+    if (S % 32) { err = "patch_embed: image size must be a multiple of 32 (strips of 8 patches)"; return 1; }
+    const int nstrips = B * (S / 4) * (S / 32);
+    int blocks = (nstrips + 3) / 4;  // one 8-token strip per wave and pass; the FMA chain is latency-bound, so favour waves per SIMD
+    if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
     LAUNCH_HF(hf, patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0);
     return check_launch("patch_embed", err);
@@ -198,7 +216,7 @@ int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem
     const int cpt = C * elem_bytes / 16;
     const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * cpt;
     size_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(in), static_cast<uint4*>(out), B, R, cpt);
     return check_launch("merge_gather", err);
 }
@@ -372,7 +390,7 @@ int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, c
     if (check_launch("conv1x1_c3", err)) return 1;
     const size_t total = (size_t)B * 4 * h * wd;
     size_t blocks = (total + 255) / 256;
-    if (blocks > 4096) blocks = 4096;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(seg_up_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tmp, seg, B, h, wd, sigmoid);
     return check_launch("seg_up_act", err);
 }
