@@ -437,8 +437,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
-                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
-                                        "igemm_bf16_32x256x64_s3", "igemm_bf16_64x256x64_s2"};
+                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -449,28 +448,27 @@ static int pick_cfg_f32(const IgemmDesc& d) {
 }
 
 static int pick_cfg(const IgemmDesc& d) {
-    if (d.tune < 0 && d.ln_g) {  // fused LayerNorm needs the whole row in one workgroup: one n-tile
-        const bool k64ln = (d.Cin % 64 == 0);
-        if (d.N <= 128) return k64ln ? 13 : 19;  // 64(M) x 128(N)
-        return d.M >= 16384 ? 21 : 20;           // 64 / 32 (M) x 256(N), needs Cin % 64 == 0
-    }
-    // Measured on MI355X (tools/igemm_bench.py, profiles/r01_igemm_configs.txt): the kernel is bound by the per-CU
-    // L2->LDS fill rate, so take the LARGEST tile (most FLOPs per staged byte) that still fills the 256 CUs.
-    if (d.tune >= 0) return d.tune;
     const bool k64 = (d.Cin % 64 == 0);
+    if (d.tune < 0 && d.ln_g) return k64 ? 13 : 19;  // fused LayerNorm: the whole row (N <= 128) in one 64(M) x 128(N) tile
+    // Ranked by rocprofv3 DEVICE durations of every shape x configuration (tools/igemm_tune.py,
+    // profiles/r01d_igemm_device_durations.txt; event timing from Python is host-bound below ~10 us and cannot rank these).
+    // Big problems are bound by the per-CU L2->LDS fill rate: take the LARGEST tile (most FLOPs per staged byte) that still
+    // fills the 256 CUs.  Small ones are latency-bound: take small tiles / short k-tiles so that many blocks are resident.
+    if (d.tune >= 0) return d.tune;
     if (d.N <= 32) return 5;
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
-    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
-    if (!k64) return b128 < 384 ? 4 : 9;
+    const long K = (long)d.taps * d.Cin;
+    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128), b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
+    if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 15 : 4;  // C = 96: layer1_rn (128x256x32) / stage-0 Linear layers (64x64x32)
     if (d.N % 256 == 0) {
         if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
         if (cdiv(d.M, 128) * (d.N / 256) >= 224) return 10;  // 128(M)x256(N)
     }
+    // short K, many output tiles (qkv / fc1 of stages 1-2): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
+    if (K <= 384 && b64 >= 512) return 4;
     if (b128 >= 384) return 1;
-    // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring); measured with
-    // rocprofv3 device durations (tools/igemm_trace.py): 14.8 -> 9.6 us at M=2048,N=384,K=1536; 15.6 -> 13.4 at M=512,N=768,K=3072
-    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
-    if (b64 < 256 && (long)d.taps * d.Cin >= 1536) return 14;
+    // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring)
+    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return 14;
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
@@ -491,7 +489,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
-    if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 256 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
+    if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         switch (pick_cfg_f32(d)) {
@@ -503,7 +501,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || id == 20 || id == 21) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -526,8 +524,6 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
-        case 20: return launch_cfg_ln<Cfg<32, 256, 64, 1, 4, 3>>(d, stream, err);
-        case 21: return launch_cfg_ln<Cfg<64, 256, 64, 1, 4, 2>>(d, stream, err);
     }
     err = "igemm: unknown configuration id";
     return 1;

@@ -1,0 +1,50 @@
+"""Every GEMM / conv shape of the B=8 dpt_swin2_tiny_256 forward x every viable kernel configuration, a few launches each.
+Run under `rocprofv3 --kernel-trace --output-format csv`; tools/igemm_tune_parse.py turns the trace into a table of DEVICE
+durations (event timing from Python is host-bound below ~10 us per launch and cannot rank these kernels)."""
+import sys, os, math, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from soccdpt_amd.lib import op_igemm
+dev = torch.device("cuda:0")
+g = torch.Generator().manual_seed(0)
+B = 8
+lin = [("s0_qkv", 32768, 288, 96), ("s0_fc1", 32768, 384, 96), ("s0_proj", 32768, 96, 96), ("s0_fc2", 32768, 96, 384),
+       ("s1_merge", 8192, 192, 384), ("s1_qkv", 8192, 576, 192), ("s1_proj", 8192, 192, 192), ("s1_fc1", 8192, 768, 192), ("s1_fc2", 8192, 192, 768),
+       ("s2_merge", 2048, 384, 768), ("s2_qkv", 2048, 1152, 384), ("s2_proj", 2048, 384, 384), ("s2_fc1", 2048, 1536, 384), ("s2_fc2", 2048, 384, 1536),
+       ("s3_merge", 512, 768, 1536), ("s3_qkv", 512, 2304, 768), ("s3_proj", 512, 768, 768), ("s3_fc1", 512, 3072, 768), ("s3_fc2", 512, 768, 3072),
+       ("oc8", 512, 256, 256), ("oc16", 2048, 256, 256), ("oc32", 8192, 256, 256), ("oc64", 32768, 256, 256)]
+conv = [("rn4", 8, 768, 256), ("rn3", 16, 384, 256), ("rn2", 32, 192, 256), ("rn1", 64, 96, 256),
+        ("rcu8", 8, 256, 256), ("rcu16", 16, 256, 256), ("rcu32", 32, 256, 256), ("rcu64", 64, 256, 256),
+        ("head_d", 128, 256, 128), ("head_s", 128, 256, 256)]
+K64 = [2, 1, 13, 10, 14, 11, 8, 6]
+K32 = [4, 9, 3, 19, 15, 16]
+order = []
+def run_all(name, M, N, Cin, call):
+    cfgs = [-1] + (K64 + K32 if Cin % 64 == 0 else K32)
+    for t in cfgs:
+        ok = True
+        for _ in range(4):
+            try:
+                call(t)
+            except RuntimeError:
+                ok = False
+                break
+        torch.cuda.synchronize()
+        if ok:
+            order.extend([[name, t, M, N, Cin]] * 4)
+for name, M, N, K in lin:
+    x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(N, generator=g).to(dev)
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
+    run_all(name, M, N, K, lambda t: op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_bf16=out, tune=t))
+for name, H, Cin, Cout in conv:
+    M = B * H * H
+    x = torch.zeros(B, H + 2, H + 2, Cin, dtype=torch.bfloat16, device=dev)
+    x[:, 1:-1, 1:-1] = torch.randn(B, H, H, Cin, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(Cout, 9 * Cin, generator=g) / math.sqrt(9 * Cin)).to(torch.bfloat16).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=dev)
+    outf = torch.empty(M, Cout, device=dev)
+    run_all(name, M, Cout, Cin * 9, lambda t: op_igemm(x, w, M, Cout, Cin, taps=9, H=H, W=H, bias=bias, act=1, out_f32=outf, out_bf16=outh, out_halo=1, tune=t))
+json.dump(order, open("gpurun_out/tune_order.json", "w"))
