@@ -36,7 +36,10 @@ struct AttnCfg {
 };
 
 
-template <int WS, bool F16>
+// QS: query split.  QS == 2 gives each (batch, window, head) to two workgroups that stage all of K-hat / V^T but own half of the
+// query blocks: stages 1-2 of the B = 8 forward have only 192 / 96 (window, head) pairs for 256 CUs (0.258 -> 0.216 ms per
+// forward; a 4-way split with two staging-only waves measured slower again).
+template <int WS, bool F16, int QS>
 __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                                  const float* __restrict__ scale, bf16_t* __restrict__ out,
                                                                                  int res, int shift, int heads) {
@@ -49,6 +52,8 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
     const int C = heads * 32;
     const int nw = res / WS;
     int bid = blockIdx.x;
+    const int qh = QS > 1 ? bid % QS : 0;  // which part of the query blocks this workgroup owns
+    bid /= QS;
     const int head = bid % heads;
     bid /= heads;
     const int wx = bid % nw;
@@ -65,13 +70,14 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         return (size_t)(b * res + sy) * res + sx;
     };
 
-    // ---- stage Q-hat, K-hat, V^T ----
+    // ---- stage Q-hat (own query rows only), K-hat, V^T ----
 #pragma unroll
     for (int it = 0; it < (A::N * 4) / A::THREADS; ++it) {
         const int idx = it * A::THREADS + tid;
         const int p = idx >> 2, c = idx & 3;
         const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
-        const uint4 qv = *reinterpret_cast<const uint4*>(src);
+        const bool own_q = QS == 1 || (p / (A::N / QS)) == qh;  // uniform over the 4 lanes of a token
+        const uint4 qv = own_q ? *reinterpret_cast<const uint4*>(src) : make_uint4(0u, 0u, 0u, 0u);
         const uint4 kv = *reinterpret_cast<const uint4*>(src + C);
         const uint4 vv = *reinterpret_cast<const uint4*>(src + 2 * C);
         const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -98,7 +104,7 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
         ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
         const int sw = (c ^ ((p >> 2) & 3)) * 16;
-        *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
+        if (own_q) *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
         *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -110,9 +116,10 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
 
     const int r32 = lane & 31, h = lane >> 5;
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    static_assert(QS == 1 || QS == 2, "query split");
 #pragma unroll 1
-    for (int qbi = 0; qbi < 2; ++qbi) {
-        const int qb = wave * 2 + qbi;
+    for (int qbi = 0; qbi < 2 / QS; ++qbi) {
+        const int qb = qh * (A::QB / QS) + wave * (2 / QS) + qbi;
         const int qrow = qb * 32 + r32;
         h16x8 qfrag[2];
 #pragma unroll
@@ -656,13 +663,15 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
     if (ws == 16) {
         using A = AttnCfg<16>;
-        if (hf) hipLaunchKernelGGL((window_attention_kernel<16, true>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else hipLaunchKernelGGL((window_attention_kernel<16, false>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+#define ATT16(H, Q) hipLaunchKernelGGL((window_attention_kernel<16, H, Q>), dim3(blocks * Q), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+        if (blocks < 512) { if (hf) ATT16(true, 2); else ATT16(false, 2); }   // too few (window, head) pairs to fill 256 CUs evenly: split the queries
+        else { if (hf) ATT16(true, 1); else ATT16(false, 1); }
+#undef ATT16
     } else if (ws == 8) {
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
-        if (hf) hipLaunchKernelGGL((window_attention_kernel<8, true>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else hipLaunchKernelGGL((window_attention_kernel<8, false>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) hipLaunchKernelGGL((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else hipLaunchKernelGGL((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 24 || ws == 12) {
         static bool attr_done = false;
         if (!attr_done) {
