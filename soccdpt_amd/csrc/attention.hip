@@ -161,11 +161,12 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
             for (int rg = 0; rg < 16; ++rg) mx = fmaxf(mx, s[t][rg]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         float sum = 0.f;
+        const float mxl = mx * 1.4426950408889634f;  // exp(s - mx) = 2^(s*log2e - mx*log2e): one v_fma + one v_exp per logit
 #pragma unroll
         for (int t = 0; t < A::KT; ++t)
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
-                const float e = __expf(s[t][rg] - mx);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[t][rg], 1.4426950408889634f, -mxl));
                 s[t][rg] = e;
                 sum += e;
             }
