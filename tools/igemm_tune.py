@@ -17,6 +17,7 @@ conv = [("rn4", 8, 768, 256), ("rn3", 16, 384, 256), ("rn2", 32, 192, 256), ("rn
         ("rcu8", 8, 256, 256), ("rcu16", 16, 256, 256), ("rcu32", 32, 256, 256), ("rcu64", 64, 256, 256),
         ("head_d", 128, 256, 128), ("head_s", 128, 256, 256)]
 K64 = [2, 1, 13, 10, 14, 11, 8, 6]
+ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None   # optional: comma-separated shape names
 K32 = [4, 9, 3, 19, 15, 16]
 order = []
 def run_all(name, M, N, Cin, call):
@@ -33,12 +34,16 @@ def run_all(name, M, N, Cin, call):
         if ok:
             order.extend([[name, t, M, N, Cin]] * 4)
 for name, M, N, K in lin:
+    if ONLY and name not in ONLY:
+        continue
     x = torch.randn(M, K, generator=g).to(torch.bfloat16).to(dev)
     w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16).to(dev)
     bias = torch.randn(N, generator=g).to(dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     run_all(name, M, N, K, lambda t: op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_bf16=out, tune=t))
 for name, H, Cin, Cout in conv:
+    if ONLY and name not in ONLY:
+        continue
     M = B * H * H
     x = torch.zeros(B, H + 2, H + 2, Cin, dtype=torch.bfloat16, device=dev)
     x[:, 1:-1, 1:-1] = torch.randn(B, H, H, Cin, generator=g).to(torch.bfloat16).to(dev)
