@@ -1,16 +1,24 @@
 """Summarise two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md §HBM
 prescribes) into per-kernel HBM bytes per launch.  Units: the counters are in KiB; on gfx950 FETCH_SIZE reports
 half of the bytes of wide coalesced reads, so the read side is doubled (upper bound for other access shapes).
-usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json>"""
+usage: python tools/pmc_summary.py <fetch_counter_collection.csv> <write_counter_collection.csv> <out.json> [<mfma_counter_collection.csv>]"""
 import collections, csv, json, re, sys
 
 def family(kernel_name: str) -> str:
+    """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
     n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
-    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), \d+, \d+, (\d+)> >", n)
+    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), \d+, \d+, (\d+)>, ([\w ]+), (true|false)>", n)
     if m:
-        return f"igemm_bf16_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(4)}"
-    return {"project_kernel<3, 4>": "project_voxelise", "occ_expand_kernel": "occ_expand",
-            "window_attention_kernel<16>": "window_attention", "window_attention_kernel<8>": "window_attention_8"}.get(n, n)
+        t = m.group(5)
+        if t == "float":
+            return f"igemm_f32_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(4)}"
+        return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(4)}"
+    for prefix, fam in (("window_attention", "window_attention"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
+                        ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
+                        ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail")):
+        if n.startswith(prefix):
+            return fam
+    return n
 
 def load(path, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
@@ -28,7 +36,16 @@ for k in f:
     out[k] = dict(launches=fl[0], fetch_bytes_per_launch_raw=fl[1] / fl[0] * 1024, fetch_bytes_per_launch=2 * fl[1] / fl[0] * 1024,
                   write_bytes_per_launch=wl[1] / max(wl[0], 1) * 1024)
     out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 3 --warmup 1`; KiB->bytes; "
+if len(sys.argv) > 4:  # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -> MFMA pipe utilisation per kernel family
+    mf, ga = load(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), load(sys.argv[4], "GRBM_GUI_ACTIVE")
+    for k in out:
+        if k in mf and k in ga and ga[k][1] > 0:
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 256 CUs x 4 SIMDs (16 cycles per v_mfma_f32_16x16x32: checked against the
+            # analytic MFMA count of the 256x256 conv, 9,437,184 x 16 = 150,994,944); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+            out[k]["mfma_busy_cycles_per_launch"] = mf[k][1] / mf[k][0]
+            out[k]["gpu_active_cycles_per_launch_sum_of_8_xcds"] = ga[k][1] / ga[k][0]
+            out[k]["mfma_util"] = mf[k][1] / (ga[k][1] / 8.0 * 256 * 4)
+json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 3 --warmup 1 --no-cpu-baseline`; KiB->bytes; "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads)", kernels=out),
           open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out), "kernels")
