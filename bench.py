@@ -83,6 +83,12 @@ def main():
             dist.barrier(device_ids=[local])
         torch.cuda.synchronize()
 
+    # clock / allocator pre-warm (untimed, in addition to the W warm-up steps): a GPU that has just been handed over from another
+    # process can sit in a low power state for the first ~100 ms (observed once: 4.4 instead of 2.2 ms per step)
+    tw = time.perf_counter()
+    while time.perf_counter() - tw < 0.3:
+        out = net(x)
+        torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = net(x)
     barrier()

@@ -184,6 +184,12 @@ typedef struct soccdpt_igemm_args {
     float* out_dot;
     int32_t tune; /* kernel configuration id, -1 = library heuristic (benchmarking) */
     int32_t precision; /* SOCCDPT_PREC_*: element type of x, wt and out_bf16 (bf16 / f32 / fp16) and the MFMA used */
+    int32_t splitk;    /* > 1: slice K over this many workgroups per output tile (deterministic partial-tile exchange);
+                          needs sk_part (splitk*M*N floats) and sk_count (ceil(M/32)*ceil(N/64) zero words, left zero) */
+    float* sk_part;
+    uint32_t* sk_count;
+    size_t sk_part_floats; /* capacity of sk_part in floats  */
+    size_t sk_count_words; /* capacity of sk_count in words */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 

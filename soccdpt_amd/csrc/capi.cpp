@@ -229,6 +229,8 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
     d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
+    d.splitk = a->splitk > 1 ? a->splitk : 1; d.sk_part = a->sk_part; d.sk_count = a->sk_count;
+    d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words;
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;

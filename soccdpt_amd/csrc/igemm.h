@@ -55,10 +55,20 @@ struct IgemmDesc {
     float* ln_xf = nullptr;
     void* ln_halo = nullptr;
     int ln_residual = 1;
+    // split-K (igemm.hip, SK): splitk > 1 slices the k-tiles over splitk workgroups per output tile; sk_part holds splitk x M x N
+    // floats (any contents), sk_count one zero-initialised word per 32 x 64 output tile (left zero again by the kernel)
+    int splitk = 1;
+    float* sk_part = nullptr;
+    unsigned* sk_count = nullptr;
+    size_t sk_part_floats = 0, sk_count_words = 0;  // capacities, validated by launch_igemm
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);
+// Split factor the heuristic would use for this problem (1 = none) given scratch for `part_floats` floats / `count_words` tiles.
+int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words);
+constexpr size_t kSplitKPartFloats = 2u << 20;  // 8 MB of f32 partials per workspace: splitk * M * N <= this
+constexpr size_t kSplitKCountWords = 4096;
 const char* igemm_family(const IgemmDesc& d);  // name of the kernel configuration launch_igemm picks
 inline double igemm_flops(const IgemmDesc& d) { return 2.0 * d.M * d.N * (double)d.taps * d.Cin; }
 

@@ -70,7 +70,11 @@ __device__ __forceinline__ float gelu_fast(float x) {
 // T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16) or float (v_mfma_f32_16x16x4_f32, exact f32).
 // LN: the fused post-norm LayerNorm + residual epilogue (d.ln_g) instead of the generic one; a separate instantiation so that
 // its registers (row statistics) do not inflate the generic kernels (measured: 110 -> 158 VGPRs, one block per CU less).
-template <class C, typename T, bool LN>
+// SK: split-K.  gridDim.x = tiles x d.splitk; every workgroup accumulates its slice of the k-tiles, stores the f32 partial
+// tile to d.sk_part[split][M][N], and the LAST workgroup to arrive at the tile (a counter in d.sk_count, left at 0 again) sums
+// the splitk partials in split order -- deterministic, no float atomics -- and runs the epilogue.  No workgroup ever waits
+// for another one.  For long-K problems whose output grid cannot fill the 256 CUs (coarse decoder levels, stage-3 fc2).
+template <class C, typename T, bool LN, bool SK = false>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = C::BM, BN = C::BN;
@@ -89,6 +93,14 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
+    int split = 0, kbase = 0;
+    if constexpr (SK) {  // splits of one tile are consecutive logical ids: same XCD, their partials meet in one L2
+        split = bid % d.splitk;
+        bid /= d.splitk;
+        kbase = (int)((long)split * nk / d.splitk);
+        nk = (int)((long)(split + 1) * nk / d.splitk) - kbase;
+    }
+    const int tile_id = bid;
     const int nt = bid % ntiles, mt = bid / ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int Ktot = d.taps * d.Cin;
@@ -123,6 +135,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }
 
     auto stage = [&](int kt, int buf) {
+        kt += kbase;
         uint32_t xk, wk = (uint32_t)kt * BK;  // elements of T
         if (d.taps == 9) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
@@ -211,6 +224,50 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }
 
     const int N = d.N;
+    if constexpr (SK) {
+        // Cross-workgroup exchange WITHOUT fences: a release/acquire fence at agent scope writes back / invalidates the whole
+        // per-XCD L2 on gfx950 (measured: ~30 us per split).  Instead every partial is stored and loaded with agent-scope
+        // (sc1, L2-bypassing) relaxed atomics, and "stored before counted" is enforced by s_waitcnt vmcnt(0) + the barrier.
+        const size_t MN = (size_t)d.M * N;
+        float* mine = d.sk_part + (size_t)split * MN;
+#pragma unroll
+        for (int j = 0; j < C::TM; ++j) {
+            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) {
+                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                if (m < d.M && n < N) {
+                    float* q = mine + (size_t)m * N + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) __hip_atomic_store(q + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's partial stores are acknowledged at device scope
+        __syncthreads();                                   // ... and so are everybody else's in this workgroup
+        unsigned* arrival = reinterpret_cast<unsigned*>(smem);  // the staging ring is free after the barrier above
+        if (tid == 0) *arrival = __hip_atomic_fetch_add(d.sk_count + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*arrival != (unsigned)d.splitk - 1) return;   // not the last split of this tile: done (nobody waits)
+        if (tid == 0) __hip_atomic_store(d.sk_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+#pragma unroll
+        for (int j = 0; j < C::TM; ++j) {
+            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i) {
+                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                if (m < d.M && n < N) {
+                    for (int sp = 0; sp < d.splitk; ++sp) {   // fixed order: bitwise reproducible
+                        const float* q = d.sk_part + (size_t)sp * MN + (size_t)m * N + n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] += __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                acc[i][j] = sum;
+            }
+        }
+    }
     if constexpr (LN) {
         // ---- fused post-norm epilogue: out = (x +) LayerNorm(acc + bias) over the N (<= BN) channels of each row.
         // A row's channels are spread over the TN tiles x 4 lane groups of a wave and over the WN waves: two-pass mean /
@@ -395,20 +452,24 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }  // generic epilogue
 }
 
-template <class C, typename T, bool LN = false>
+template <class C, typename T, bool LN = false, bool SK = false>
 static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (LN != (d.ln_g != nullptr)) { err = "igemm: this configuration has no fused-LayerNorm instantiation"; return 1; }
+    if (SK != (d.splitk > 1)) { err = "igemm: this configuration has no split-K instantiation"; return 1; }
     constexpr int BK = C::ROWB / (int)sizeof(T);
     const int nk = d.taps * d.Cin / BK, kpt = d.Cin / BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
     const size_t lds = (size_t)C::NS * C::STAGE;
     static bool attr_done = false;
     if (!attr_done) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done = true;
     }
-    hipLaunchKernelGGL((igemm_kernel<C, T, LN>), dim3((unsigned)(mtiles * ntiles)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    const int splits = SK ? d.splitk : 1;
+    if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
+               (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
+    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;
@@ -417,6 +478,12 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
 template <class C>
 static int launch_cfg(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     return d.f16 ? launch_cfg_t<C, f16_t>(d, stream, err) : launch_cfg_t<C, bf16_t>(d, stream, err);
+}
+// configurations that also carry the split-K instantiation
+template <class C>
+static int launch_cfg_sk(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (d.splitk <= 1) return launch_cfg<C>(d, stream, err);
+    return d.f16 ? launch_cfg_t<C, f16_t, false, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, true>(d, stream, err);
 }
 // configurations that also carry the fused-LayerNorm epilogue (one n-tile covers the row)
 template <class C>
@@ -455,6 +522,7 @@ static int pick_cfg(const IgemmDesc& d) {
     // Big problems are bound by the per-CU L2->LDS fill rate: take the LARGEST tile (most FLOPs per staged byte) that still
     // fills the 256 CUs.  Small ones are latency-bound: take small tiles / short k-tiles so that many blocks are resident.
     if (d.tune >= 0) return d.tune;
+    if (d.splitk > 1) return 14;  // the split-K instantiation: 32(M) x 64(N) tiles, 6-stage ring
     if (d.N <= 32) return 5;
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long K = (long)d.taps * d.Cin;
@@ -472,9 +540,24 @@ static int pick_cfg(const IgemmDesc& d) {
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
+int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words) {
+    // Measured (tools/igemm_tune.py, rocprofv3 durations): the partial-tile exchange costs ~5 us per split (L2-bypassing stores
+    // and loads: the 8 XCD L2s are not coherent with each other inside a kernel), about one kernel floor.  It only pays for the
+    // longest K on the smallest grid: layer4_rn (M=512, N=256, K=6912) 30.9 -> 18.3 us at 4 splits; K=2304..3456 on 64..256
+    // tiles and the stage-3 Linear layers (K <= 3072) are break-even or slower and stay unsplit.
+    if (d.f32 || d.ln_g || d.out_dot || d.N <= 32 || d.Cin % 64 != 0 || d.tune >= 0) return 1;
+    auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+    const long nk = (long)d.taps * d.Cin / 64, blocks = cdiv(d.M, 32) * cdiv(d.N, 64);
+    if (blocks > 128 || nk < 96 || (size_t)blocks > count_words) return 1;
+    long S = 4;
+    while (S > 1 && (size_t)S * d.M * d.N > part_floats) --S;
+    return (int)S;
+}
+
 const char* igemm_family(const IgemmDesc& d) {
     if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
+    if (d.splitk > 1) return d.f16 ? "igemm_f16_32x64x64_s6_splitk" : "igemm_bf16_32x64x64_s6_splitk";
     if (!d.f16) return kCfgNames[id];
     static std::string f16_names[sizeof(kCfgNames) / sizeof(kCfgNames[0])];  // "igemm_f16_<tile>": same kernels, fp16 instantiation
     if (f16_names[id].empty()) f16_names[id] = std::string("igemm_f16_") + (kCfgNames[id] + 11);
@@ -518,7 +601,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 11: return launch_cfg<Cfg<64, 64, 64, 2, 2, 6>>(d, stream, err);
         case 12: return launch_cfg<Cfg<64, 64, 64, 2, 2, 8>>(d, stream, err);
         case 13: return launch_cfg_ln<Cfg<64, 128, 64, 2, 2, 4>>(d, stream, err);
-        case 14: return launch_cfg<Cfg<32, 64, 64, 2, 2, 6>>(d, stream, err);
+        case 14: return launch_cfg_sk<Cfg<32, 64, 64, 2, 2, 6>>(d, stream, err);
         case 15: return launch_cfg<Cfg<128, 256, 32, 2, 4, 3>>(d, stream, err);
         case 16: return launch_cfg<Cfg<256, 128, 32, 4, 2, 3>>(d, stream, err);
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);

@@ -195,6 +195,8 @@ struct Workspace {
     void *lrn_relu[4], *t_relu[4], *out_relu[4], *u[4];
     void *path1, *d1, *d1u, *s1;
     float* s2;
+    float* sk_part;      // split-K partial tiles (igemm.h): kSplitKPartFloats floats
+    unsigned* sk_count;  // split-K arrival counters: zero from workspace init, left zero by every launch
 };
 
 void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
@@ -233,6 +235,8 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     w.d1u = op(Halo{r0, r0, F / 2}.elems(B));
     w.s1 = op((size_t)B * r1 * r1 * F);
     w.s2 = ar.take<float>((size_t)B * r1 * r1 * 4);
+    w.sk_part = ar.take<float>(kSplitKPartFloats);
+    w.sk_count = ar.take<unsigned>(kSplitKCountWords);
 }
 
 }  // namespace
@@ -391,7 +395,11 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const int HF = h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0;  // 16-bit operand format: 0 bf16, 1 fp16
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
-    auto gemm = [&](IgemmDesc d) { d.f32 = F32 ? 1 : 0; d.f16 = HF; PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
+    auto gemm = [&](IgemmDesc d) {
+        d.f32 = F32 ? 1 : 0; d.f16 = HF;
+        d.splitk = igemm_pick_splitk(d, kSplitKPartFloats, kSplitKCountWords);
+        if (d.splitk > 1) { d.sk_part = w.sk_part; d.sk_count = w.sk_count; d.sk_part_floats = kSplitKPartFloats; d.sk_count_words = kSplitKCountWords; }
+        PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------

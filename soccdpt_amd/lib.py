@@ -57,6 +57,8 @@ class IgemmArgs(ctypes.Structure):
         ("out_bf16", ctypes.c_void_p), ("out_halo", ctypes.c_int32),
         ("dot_w", ctypes.c_void_p), ("dot_b", ctypes.c_float), ("out_dot", ctypes.c_void_p),
         ("tune", ctypes.c_int32), ("precision", ctypes.c_int32),
+        ("splitk", ctypes.c_int32), ("sk_part", ctypes.c_void_p), ("sk_count", ctypes.c_void_p),
+        ("sk_part_floats", ctypes.c_size_t), ("sk_count_words", ctypes.c_size_t),
     ]
 
 
@@ -335,12 +337,13 @@ class Engine:
 
 
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
-             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None):
+             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None, splitk=1, sk_part=None, sk_count=None):
     """Kernel-level entry (tests): one implicit-GEMM launch on the current stream."""
     L = load_library()
     a = IgemmArgs(_ptr(x), _ptr(wt), M, N, Cin, taps, ldx, H, W, _ptr(bias), _ptr(res1), _ptr(res2), act, _ptr(out_f32),
                   act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune,
-                  int(precision) if precision is not None else (PREC_F32 if f32 else PREC_BF16))
+                  int(precision) if precision is not None else (PREC_F32 if f32 else PREC_BF16), int(splitk), _ptr(sk_part), _ptr(sk_count),
+                  0 if sk_part is None else sk_part.numel(), 0 if sk_count is None else sk_count.numel())
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())

@@ -140,6 +140,50 @@ def test_window_attention(gpu_device, B, res, ws, shift, heads):
     assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
 
 
+# ---------------- split-K (deterministic partial-tile exchange, last arriver runs the epilogue) ----------------
+@pytest.mark.parametrize("splitk", [2, 3, 8])
+def test_igemm_splitk(gpu_device, splitk):
+    from soccdpt_amd.lib import op_igemm
+    g = torch.Generator().manual_seed(splitk)
+    part = torch.full((2 << 20,), float("nan"), device=gpu_device)       # stale contents must not matter
+    count = torch.zeros(4096, dtype=torch.int32, device=gpu_device)
+    # Linear: M not a multiple of the 32-row tile, N not a multiple of 64
+    M, N, K = 300, 736, 3072
+    x = _bf(torch.randn(M, K, generator=g)).to(gpu_device)
+    w = _bf(torch.randn(N, K, generator=g) / math.sqrt(K)).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    res = torch.randn(M, N, generator=g).to(gpu_device)
+    ref = x.float() @ w.float().t() + bias + res
+    outs = []
+    for _ in range(3):
+        o = torch.empty(M, N, device=gpu_device)
+        op_igemm(x, w, M, N, K, ldx=K, bias=bias, res1=res, out_f32=o, splitk=splitk, sk_part=part, sk_count=count)
+        outs.append(o)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(outs[0], ref, rtol=1e-4, atol=1e-4)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])   # fixed summation order: bitwise reproducible
+    assert int(count.abs().sum()) == 0                                       # counters are left at zero
+    with pytest.raises(RuntimeError):                                        # scratch too small is refused, not overrun
+        op_igemm(x, w, M, N, K, ldx=K, out_f32=outs[0], splitk=splitk, sk_part=part[: M * N], sk_count=count)
+    # 3x3 convolution with the full decoder epilogue
+    B, H, Cin, Cout = 2, 8, 256, 256
+    xc = _bf(torch.randn(B, Cin, H, H, generator=g)).to(gpu_device)
+    wc = _bf(torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(gpu_device)
+    bc = torch.randn(Cout, generator=g).to(gpu_device)
+    r1 = torch.randn(B, H, H, Cout, generator=g).to(gpu_device)
+    refc = F.conv2d(xc.float(), wc.float(), bc, padding=1).permute(0, 2, 3, 1) + r1
+    xh = _halo(xc.permute(0, 2, 3, 1).contiguous())
+    wt = wc.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    oc = torch.empty(B, H, H, Cout, device=gpu_device)
+    oh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=gpu_device)
+    op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bc, res1=r1, act=1, out_f32=oc, out_bf16=oh, out_halo=1,
+             splitk=splitk, sk_part=part, sk_count=count)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(oc, refc, rtol=1e-4, atol=2e-4)
+    torch.testing.assert_close(oh[:, 1:-1, 1:-1].float(), F.relu(refc), rtol=1e-2, atol=1e-2)
+    assert int(count.abs().sum()) == 0
+
+
 # ---------------- fp16 operand mode (SOCCDPT_PREC_F16): same kernels, v_mfma_*_f16 ----------------
 def _hf(t):
     return t.to(torch.float16)

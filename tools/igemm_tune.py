@@ -20,6 +20,18 @@ K64 = [2, 1, 13, 10, 14, 11, 8, 6]
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None   # optional: comma-separated shape names
 K32 = [4, 9, 3, 19, 15, 16]
 order = []
+sk_part = torch.empty(2 << 20, dtype=torch.float32, device=dev)
+sk_count = torch.zeros(4096, dtype=torch.int32, device=dev)
+def run_splitk(name, M, N, Cin, call_sk):   # label 100 + S in the table
+    if Cin % 64 or (M + 31) // 32 * ((N + 63) // 64) >= 512:
+        return
+    for S in (2, 3, 4, 6, 8):
+        if S * M * N > sk_part.numel() or S > Cin // 64 * (1 if name.startswith(("s", "oc")) else 9):
+            continue
+        for _ in range(4):
+            call_sk(S)
+        torch.cuda.synchronize()
+        order.extend([[name, 100 + S, M, N, Cin]] * 4)
 def run_all(name, M, N, Cin, call):
     cfgs = [-1] + (K64 + K32 if Cin % 64 == 0 else K32)
     for t in cfgs:
@@ -41,6 +53,7 @@ for name, M, N, K in lin:
     bias = torch.randn(N, generator=g).to(dev)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
     run_all(name, M, N, K, lambda t: op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_bf16=out, tune=t))
+    run_splitk(name, M, N, K, lambda S: op_igemm(x, w, M, N, K, ldx=K, bias=bias, out_bf16=out, splitk=S, sk_part=sk_part, sk_count=sk_count))
 for name, H, Cin, Cout in conv:
     if ONLY and name not in ONLY:
         continue
@@ -52,4 +65,6 @@ for name, H, Cin, Cout in conv:
     outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=dev)
     outf = torch.empty(M, Cout, device=dev)
     run_all(name, M, Cout, Cin * 9, lambda t: op_igemm(x, w, M, Cout, Cin, taps=9, H=H, W=H, bias=bias, act=1, out_f32=outf, out_bf16=outh, out_halo=1, tune=t))
+    run_splitk(name, M, Cout, Cin, lambda S: op_igemm(x, w, M, Cout, Cin, taps=9, H=H, W=H, bias=bias, act=1, out_f32=outf, out_bf16=outh, out_halo=1,
+                                                     splitk=S, sk_part=sk_part, sk_count=sk_count))
 json.dump(order, open("gpurun_out/tune_order.json", "w"))
