@@ -85,10 +85,9 @@ def main():
 
     # clock / allocator pre-warm (untimed, in addition to the W warm-up steps): a GPU that has just been handed over from another
     # process can sit in a low power state for the first ~100 ms (observed once: 4.4 instead of 2.2 ms per step)
-    tw = time.perf_counter()
-    while time.perf_counter() - tw < 0.3:
+    for _ in range(100):   # a FIXED count: with N > 1 every forward holds a collective, so all ranks must run the same number
         out = net(x)
-        torch.cuda.synchronize()
+    torch.cuda.synchronize()
     for _ in range(args.warmup):
         out = net(x)
     barrier()
