@@ -43,6 +43,7 @@ def main():
                     help="bf16: bf16 MFMA operands (BASELINE config); f16: IEEE fp16 operands, same kernels and MFMA rate, "
                          "meets the 1e-3 tolerance; f32: exact-f32 parity mode (1/16 MFMA rate)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: no gain)")
+    ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     args = ap.parse_args()
@@ -85,7 +86,7 @@ def main():
 
     # clock / allocator pre-warm (untimed, in addition to the W warm-up steps): a GPU that has just been handed over from another
     # process can sit in a low power state for the first ~100 ms (observed once: 4.4 instead of 2.2 ms per step)
-    for _ in range(100):   # a FIXED count: with N > 1 every forward holds a collective, so all ranks must run the same number
+    for _ in range(args.prewarm):   # a FIXED count: with N > 1 every forward holds a collective, so all ranks must run the same number
         out = net(x)
     torch.cuda.synchronize()
     for _ in range(args.warmup):

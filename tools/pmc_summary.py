@@ -7,12 +7,12 @@ import collections, csv, json, re, sys
 def family(kernel_name: str) -> str:
     """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
     n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
-    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), \d+, \d+, (\d+)>, ([\w ]+), (true|false)>", n)
+    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), \d+, \d+, (\d+)>, ([\w ]+), (true|false), (true|false)>", n)
     if m:
         t = m.group(5)
         if t == "float":
             return f"igemm_f32_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(4)}"
-        return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(4)}"
+        return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(4)}" + ("_splitk" if m.group(7) == "true" else "")
     for prefix, fam in (("window_attention", "window_attention"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
                         ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
                         ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail")):
@@ -22,11 +22,11 @@ def family(kernel_name: str) -> str:
 
 def load(path, counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    for r in csv.DictReader(open(path)):
+    for r in csv.DictReader(open(path)):   # per-dispatch rocprofv3 rows, or the per-kernel aggregate tools/install_profiles.py writes
         if r["Counter_Name"] == counter:
             a = agg[family(r["Kernel_Name"])]
-            a[0] += 1
-            a[1] += float(r["Counter_Value"])
+            a[0] += int(r["Dispatches"]) if "Dispatches" in r else 1
+            a[1] += float(r["Counter_Value_Sum"]) if "Counter_Value_Sum" in r else float(r["Counter_Value"])
     return agg
 
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
