@@ -24,10 +24,11 @@ def load_model(arch, model_kwargs: dict, device: torch.device, model_path: str, 
         kwargs.update(head_features_1=64, head_features_2=8)
     model = arch(path=model_path, backbone=MODEL_TYPE_TO_BACKBONE[model_type], **kwargs)
     print("Model loaded, number of parameters = {:.0f}M".format(sum(p.numel() for p in model.parameters()) / 1e6))
-    if optimize and (device == torch.device("cuda")):
-        # the reference switches to channels_last + fp16 here (loader.py:132-134); the MI355X path is
-        # already NHWC with bf16 MFMA operands, so there is nothing to switch
-        pass
+    if optimize and torch.device(device).type == "cuda" and hasattr(model, "precision"):
+        # the reference switches to channels_last + fp16 here (loader.py:132-134, model.half()); the MI355X path is already
+        # NHWC, so "optimize" selects the fp16 operand mode of the same kernels (SOCCDPT_PREC_F16)
+        from ..lib import PREC_F16
+        model.precision = PREC_F16
     model.to(device)
     return model
 

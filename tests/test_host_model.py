@@ -130,3 +130,19 @@ def test_checkpoint_roundtrip_and_depth_only_checkpoint(tmp_path):
     # a missing default checkpoint raises like the reference (load_depth=None -> weights/dpt_swin2_tiny_256.pt)
     with pytest.raises(FileNotFoundError):
         SOccDPT_V3(load_depth=None, camera_intrinsics_yaml=calib)
+
+
+def test_eval_script_flags_match_reference():
+    """scripts/eval_SOccDPT.py:289-363: -v -dt -t -d -l -cm -o -b -ld -ls, same choices and defaults."""
+    from soccdpt_amd.scripts.eval_SOccDPT import build_parser
+    from soccdpt_amd.model.SOccDPT import model_types
+    p = build_parser()
+    a = p.parse_args(["-v", "3", "-dt", "bdd", "-t", "dpt_swin2_tiny_256"])
+    assert a.version == 3 and a.dataset == "bdd" and a.device == "cpu" and a.compile is False and a.optimize is False
+    assert a.load_depth is None and a.load_seg is None and a.base_path.endswith("Depth_Dataset_Bengaluru")
+    a = p.parse_args(["--version", "1", "--dataset", "idd", "--model_type", "dpt_swin2_base_384", "--device", "cuda:0", "--load", "x.pth",
+                      "--compile", "--optimize", "--base_path", "/d", "--load_depth", "d.pt", "--load_seg", "s.pt"])
+    assert (a.version, a.dataset, a.load, a.compile, a.optimize, a.load_depth, a.load_seg) == (1, "idd", "x.pth", True, True, "d.pt", "s.pt")
+    with pytest.raises(SystemExit):
+        p.parse_args(["-v", "4", "-dt", "bdd", "-t", "dpt_swin2_tiny_256"])
+    assert "dpt_swin2_tiny_256" in model_types
