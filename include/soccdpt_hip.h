@@ -159,6 +159,20 @@ typedef struct soccdpt_kernel_stat {
 int soccdpt_profile_enable(void* handle, int on);
 int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entries, int* n_entries);
 
+/* ---- training criterion (first component of the patch-wise training step) ----
+ * loss = loss_depth_w * ScaleAndShiftInvariantLoss(clamp(bicubic(inv)), y_disp, mask_disp)      (loss/ssi_loss.py:5-158)
+ *      + loss_seg_w * BCELoss(mean)(nearest(seg)[mask_seg], y_seg[mask_seg])                    (scripts/train_SOccDPT.py:323-338,380-386)
+ * with the prediction side of model/SOccDPT.py:264-290, and its gradient w.r.t. the network outputs.
+ * inv [B,h,w] f32, seg [B,C,h,w] f32 in (0,1): the network outputs (soccdpt_network's inv256 / seg256);
+ * y_disp [B,H,W] f32, mask_disp [B,H,W] u8, y_seg [B,C,H,W] f32, mask_seg [B,C,H,W] u8: targets at camera resolution.
+ * out[0..2] = loss, loss_disp, loss_seg; out[3+2b], out[4+2b] = per-image scale, shift.  d_inv [B,h,w], d_seg [B,C,h,w].
+ * scratch: soccdpt_loss_scratch_bytes(B,H,W,h,w) bytes, any contents. */
+size_t soccdpt_loss_scratch_bytes(int B, int H, int W, int h, int w);
+int soccdpt_training_loss(int B, int H, int W, int h, int w, int C, int compute_scale_and_shift, float alpha, float loss_depth_w,
+                          float loss_seg_w, const float* inv, const float* seg, const float* y_disp, const uint8_t* mask_disp,
+                          const float* y_seg, const uint8_t* mask_seg, float* out, float* d_inv, float* d_seg, void* scratch,
+                          void* stream);
+
 /* ---- kernel-level entry points (parity tests of the individual HIP kernels) ---- */
 
 /* One implicit-GEMM launch: out[m][n] = epilogue(sum_k X[m][k] * Wt[n][k]) with bf16 operands and f32

@@ -222,6 +222,19 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
     return 0;
 }
 
+size_t soccdpt_loss_scratch_bytes(int B, int H, int W, int h, int w) { return loss_scratch_bytes(B, H, W, h, w); }
+
+int soccdpt_training_loss(int B, int H, int W, int h, int w, int C, int compute_scale_and_shift, float alpha, float loss_depth_w,
+                          float loss_seg_w, const float* inv, const float* seg, const float* y_disp, const uint8_t* mask_disp,
+                          const float* y_seg, const uint8_t* mask_seg, float* out, float* d_inv, float* d_seg, void* scratch,
+                          void* stream) {
+    std::string err;
+    if (launch_training_loss(B, H, W, h, w, C, compute_scale_and_shift, alpha, loss_depth_w, loss_seg_w, inv, seg, y_disp, mask_disp, y_seg,
+                             mask_seg, out, d_inv, d_seg, scratch, (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     if (!a) return fail(nullptr, "soccdpt_op_igemm: null args");
     IgemmDesc d;

@@ -14,11 +14,10 @@ namespace soccdpt {
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 namespace {
-constexpr int CIN = 128, COUT = 32, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;
+constexpr int CIN = 128, TH = 8, TW = 16, PH = TH + 2, PW = TW + 2;
 constexpr int KTOT = 9 * CIN;                 // 1152
-constexpr int W_ROWB = KTOT * 2 + 16;         // 2320 B: row stride = 4 dwords mod 64 -> conflict-free ds_read_b128
 constexpr int P_ROWB = CIN * 2 + 16;          // 272 B per patch pixel, same trick
-constexpr int W_BYTES = COUT * W_ROWB;        // 74240
+
 constexpr int P_BYTES = PH * PW * P_ROWB;     // 48960
 constexpr int SRH = 8, SRW = 12;              // low-res source window of one patch: <= 7 x 11 pixels (+1 spare)
 constexpr int S_ROWB = CIN * 2;               // 256 B per source pixel

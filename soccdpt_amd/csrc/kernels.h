@@ -49,6 +49,12 @@ int launch_depth_metrics(const float* pred, const float* gt, const uint8_t* mask
                          std::string& err);
 int launch_iou_metrics(const float* pred, const float* gt, int B, int C, size_t npix, float* out, void* scratch, hipStream_t st, std::string& err);
 
+// loss.hip: SSI + BCE training criterion at camera resolution, value and gradient w.r.t. the network outputs
+size_t loss_scratch_bytes(int B, int H, int W, int h, int w);
+int launch_training_loss(int B, int H, int W, int h, int w, int C, int compute_ss, float alpha, float w_d, float w_s, const float* inv,
+                         const float* seg, const float* y_disp, const uint8_t* mask_disp, const float* y_seg, const uint8_t* mask_seg,
+                         float* out, float* d_inv, float* d_seg, void* scratch, hipStream_t st, std::string& err);
+
 // attention.hip
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);

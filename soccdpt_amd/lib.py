@@ -115,6 +115,11 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_metrics_depth.restype = ci
     L.soccdpt_metrics_iou.argtypes = [vp, vp, ci, ci, cs, vp, vp, vp]
     L.soccdpt_metrics_iou.restype = ci
+    cf = ctypes.c_float
+    L.soccdpt_loss_scratch_bytes.argtypes = [ci, ci, ci, ci, ci]
+    L.soccdpt_loss_scratch_bytes.restype = cs
+    L.soccdpt_training_loss.argtypes = [ci, ci, ci, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.soccdpt_training_loss.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]
     L.soccdpt_set_streams.restype = ci
     L.soccdpt_set_graph.argtypes = [vp, ci]

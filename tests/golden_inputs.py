@@ -35,3 +35,19 @@ def metrics_inputs(seed: int = 321, B: int = 3, H: int = 135, W: int = 240):
     seg_gt = (torch.rand((B, 3, H, W), generator=g) > 0.6).float()
     seg_pred = (0.45 * seg_gt + 0.6 * torch.rand((B, 3, H, W), generator=g)).contiguous()
     return pred.contiguous(), gt.contiguous(), mask.contiguous(), seg_pred, seg_gt
+
+
+def loss_inputs(B=2, h=64, w=64, H=135, W=240, C=3, seed=7):
+    """Seeded inputs of the training criterion (oracle/loss_ref.py): network-resolution predictions (a few non-positive inverse
+    depths so the 1e-8 clamp is hit), camera-resolution targets, ~90 % true masks with one fully masked-out row block."""
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand((B, 1, 6, 8), generator=g)
+    inv = torch.nn.functional.interpolate(lo, size=(h, w), mode="bilinear", align_corners=False)[:, 0] * 0.3 - 0.02
+    inv = inv + 0.01 * torch.randn((B, h, w), generator=g)
+    seg = torch.sigmoid(2.5 * torch.randn((B, C, h, w), generator=g))
+    y_disp = torch.nn.functional.interpolate(torch.rand((B, 1, 9, 16), generator=g), size=(H, W), mode="bilinear", align_corners=False)[:, 0] * 0.4 + 0.01
+    y_seg = (torch.nn.functional.interpolate(torch.rand((B, C, 7, 11), generator=g), size=(H, W), mode="bilinear", align_corners=False) > 0.55).float()
+    mask_disp = torch.rand((B, H, W), generator=g) > 0.1
+    mask_disp[:, : H // 8] = False
+    mask_seg = torch.rand((B, C, H, W), generator=g) > 0.1
+    return inv.float().contiguous(), seg.float().contiguous(), y_disp.contiguous(), mask_disp, y_seg.contiguous(), mask_seg
