@@ -206,21 +206,33 @@ __global__ __launch_bounds__(256) void loss_terms_kernel(LossParams P, const flo
     if (threadIdx.x == 0) atomicAdd(&img[IMG_GT], s);
 }
 
-// dL/dp at one camera pixel: through ssi = s p + t directly, and through s(p), t(p) of the masked least-squares solve
-__device__ __forceinline__ float dldp_at(const LossParams& P, const Solve& q, float Gs, float Gt, float raw, float yv, bool m, float g) {
-    if (raw < 1e-8f) return 0.f;  // clamped in place: no gradient (model/SOccDPT.py:284-285)
-    float v = q.s * g;
-    if (q.ok && m) {
-        const double p = raw, yd = yv;
+// dL/dp at one camera pixel: through ssi = s p + t directly, and through s(p), t(p) of the masked least-squares solve.
+// d s / d p_i and d t / d p_i are m_i times affine functions of (p_i, y_i) with per-image coefficients, so
+//   dL/dp_i = [raw_i >= 1e-8] * w_d * ( s g_i + m_i (c0 + c1 p_i + c2 y_i) ),   c = Gs * coef(ds) + Gt * coef(dt)
+// The coefficients subtract sums of ~1e6 terms of similar size and are formed in f64 once per image.
+struct Chain {
+    float s, c0, c1, c2;
+};
+__device__ __forceinline__ Chain chain_image(const LossParams& P, const double* img) {
+    const Solve q = solve_image(P, img);
+    Chain ch{q.s, 0.f, 0.f, 0.f};
+    if (q.ok) {
+        const double Gs = img[IMG_GS], Gt = img[IMG_GT], inv_det = 1.0 / q.det;
         const double num_s = q.a11 * q.b0 - q.a01 * q.b1, num_t = -q.a01 * q.b0 + q.a00 * q.b1;
-        const double ddet = 2.0 * (q.a11 * p - q.a01);             // d a00 = 2 p, d a01 = 1, d b0 = y
-        const double dnum_s = q.a11 * yd - q.b1;
-        const double dnum_t = -q.b0 - q.a01 * yd + 2.0 * p * q.b1;
-        const double inv_det = 1.0 / q.det;
-        const double ds = (dnum_s - num_s * inv_det * ddet) * inv_det;
-        const double dt = (dnum_t - num_t * inv_det * ddet) * inv_det;
-        v += (float)((double)Gs * ds + (double)Gt * dt);
+        // d det = 2 (a11 p - a01);  d num_s = a11 y - b1;  d num_t = -b0 - a01 y + 2 b1 p     (d a00 = 2p, d a01 = 1, d b0 = y)
+        const double ks = num_s * inv_det, kt = num_t * inv_det;
+        const double ds0 = (-q.b1 + 2.0 * ks * q.a01) * inv_det, ds1 = (-2.0 * ks * q.a11) * inv_det, ds2 = q.a11 * inv_det;
+        const double dt0 = (-q.b0 + 2.0 * kt * q.a01) * inv_det, dt1 = (2.0 * q.b1 - 2.0 * kt * q.a11) * inv_det, dt2 = -q.a01 * inv_det;
+        ch.c0 = (float)(Gs * ds0 + Gt * dt0);
+        ch.c1 = (float)(Gs * ds1 + Gt * dt1);
+        ch.c2 = (float)(Gs * ds2 + Gt * dt2);
     }
+    return ch;
+}
+__device__ __forceinline__ float dldp_at(const LossParams& P, const Chain& ch, float raw, float yv, bool m, float g) {
+    if (raw < 1e-8f) return 0.f;  // clamped in place: no gradient (model/SOccDPT.py:284-285)
+    float v = ch.s * g;
+    if (m) v += ch.c0 + ch.c1 * raw + ch.c2 * yv;
     return P.w_d * v;
 }
 
@@ -231,9 +243,7 @@ __global__ __launch_bounds__(256) void loss_bwd_vert_kernel(LossParams P, const 
     const int b = blockIdx.z, ys = blockIdx.y;
     const int X = blockIdx.x * blockDim.x + threadIdx.x;
     if (X >= P.W) return;
-    const double* img = sc + (size_t)b * IMG_N;
-    const Solve q = solve_image(P, img);
-    const float Gs = (float)img[IMG_GS], Gt = (float)img[IMG_GT];
+    const Chain ch = chain_image(P, sc + (size_t)b * IMG_N);
     const float sy = (float)P.h / (float)P.H;
     const size_t npix = (size_t)P.H * P.W;
     // camera rows that can touch source row ys: floor(real) in [ys-2, ys+1] (+ border clamping: scan a safe superset)
@@ -252,7 +262,7 @@ __global__ __launch_bounds__(256) void loss_bwd_vert_kernel(LossParams P, const 
             if (ty.idx[k] == ys) wsum += ty.w[k];
         if (wsum == 0.f) continue;
         const size_t o = (size_t)b * npix + (size_t)Y * P.W + X;
-        acc += wsum * dldp_at(P, q, Gs, Gt, raw_up[o], y[o], mask[o] != 0, g[o]);
+        acc += wsum * dldp_at(P, ch, raw_up[o], y[o], mask[o] != 0, g[o]);
     }
     T[((size_t)b * P.h + ys) * P.W + X] = acc;
 }
@@ -377,15 +387,17 @@ int launch_training_loss(int B, int H, int W, int h, int w, int C, int compute_s
     float* T = g + (size_t)B * npix;
     hipError_t e = hipMemsetAsync(sc, 0, nsc * sizeof(double), st);
     if (e != hipSuccess) { err = std::string("training_loss: ") + hipGetErrorString(e); return 1; }
+    // few, fat workgroups: every workgroup ends with ~8 f64 atomics on the same handful of addresses, and those serialise
+    // (2048 x B workgroups: 590 us; 256 x B: see tools/loss_bench.py)
     unsigned gx = (unsigned)((npix + 255) / 256);
-    if (gx > 2048) gx = 2048;
+    if (gx > 256) gx = 256;
     hipLaunchKernelGGL(loss_up_stats_kernel, dim3(gx, B), dim3(256), 0, st, P, inv, y_disp, mask_disp, raw_up, sc);
     hipLaunchKernelGGL(loss_terms_kernel, dim3(gx, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc);
     hipLaunchKernelGGL(loss_bwd_vert_kernel, dim3((W + 255) / 256, h, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc, T);
     hipLaunchKernelGGL(loss_bwd_horz_kernel, dim3((unsigned)(((size_t)B * h * w + 255) / 256)), dim3(256), 0, st, P, T, d_inv);
     const size_t nseg = (size_t)B * C * h * w;
     unsigned gs = (unsigned)((nseg + 255) / 256);
-    if (gs > 4096) gs = 4096;
+    if (gs > 1024) gs = 1024;
     hipLaunchKernelGGL(loss_bce_kernel, dim3(gs), dim3(256), 0, st, P, seg, y_seg, mask_seg, d_seg, sc);
     hipLaunchKernelGGL(loss_scale_dseg_kernel, dim3(gs), dim3(256), 0, st, P, sc, d_seg);
     hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, P, sc, out);
