@@ -173,6 +173,13 @@ int soccdpt_training_loss(int B, int H, int W, int h, int w, int C, int compute_
                           const float* y_seg, const uint8_t* mask_seg, float* out, float* d_inv, float* d_seg, void* scratch,
                           void* stream);
 
+/* Fused multi-tensor Adam step, in place (torch.optim.Adam of scripts/train_SOccDPT.py:311-318; amsgrad=False):
+ * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors DEVICE pointers (f32), sizes[i] elements each; step >= 1 is
+ * the step count AFTER this update (bias corrections 1 - beta^step). */
+int soccdpt_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const size_t* sizes, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int step, void* stream);
+
 /* ---- kernel-level entry points (parity tests of the individual HIP kernels) ---- */
 
 /* One implicit-GEMM launch: out[m][n] = epilogue(sum_k X[m][k] * Wt[n][k]) with bf16 operands and f32

@@ -44,7 +44,31 @@ def reference_step(inv, seg, y_disp, mask_disp, y_seg, mask_seg, compute_ss, w_d
     return loss.detach(), loss_disp.detach(), loss_seg.detach(), inv.grad, seg.grad
 
 
+def patchwise_schedule():
+    """requires_grad patterns produced by THE REFERENCE'S PatchWiseInplace (patchwise_training/__init__.py:148-252) on a small
+    module with some frozen parameters -> tests/golden/patchwise.json."""
+    import json
+    spec2 = importlib.util.spec_from_file_location("ref_patchwise", "/root/reference/SOccDPT/patchwise_training/__init__.py")
+    pw = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(pw)
+    out = {}
+    for pct in (1.0, 0.5, 0.3, 0.1, 0.01):
+        net = torch.nn.Sequential(*[torch.nn.Linear(3, 3) for _ in range(7)])      # 14 parameters
+        frozen = (0, 5, 6)
+        for i, p in enumerate(net.parameters()):
+            p.requires_grad = i not in frozen
+        it = pw.PatchWiseInplace(net, pct)
+        pats = []
+        for net_patch in it:
+            pats.append([int(p.requires_grad) for p in net_patch.parameters()])
+        out[str(pct)] = dict(len=len(it), patterns=pats, after=[int(p.requires_grad) for p in net.parameters()])
+    path = os.path.join(REPO, "tests", "golden", "patchwise.json")
+    json.dump(dict(n_params=14, frozen=[0, 5, 6], schedules=out), open(path, "w"), indent=1)
+    print("wrote", path)
+
+
 def main():
+    patchwise_schedule()
     torch.manual_seed(0)
     torch.set_num_threads(1)
     out = {}

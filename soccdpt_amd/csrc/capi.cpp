@@ -222,6 +222,15 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
     return 0;
 }
 
+int soccdpt_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
+                      float* const* exp_avg_sq, const size_t* sizes, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, int step, void* stream) {
+    std::string err;
+    if (launch_adam(n_tensors, params, grads, exp_avg, exp_avg_sq, sizes, lr, beta1, beta2, eps, weight_decay, step, (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
 size_t soccdpt_loss_scratch_bytes(int B, int H, int W, int h, int w) { return loss_scratch_bytes(B, H, W, h, w); }
 
 int soccdpt_training_loss(int B, int H, int W, int h, int w, int C, int compute_scale_and_shift, float alpha, float loss_depth_w,

@@ -120,6 +120,9 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_loss_scratch_bytes.restype = cs
     L.soccdpt_training_loss.argtypes = [ci, ci, ci, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.soccdpt_training_loss.restype = ci
+    cd = ctypes.c_double
+    L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
+    L.soccdpt_adam_step.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]
     L.soccdpt_set_streams.restype = ci
     L.soccdpt_set_graph.argtypes = [vp, ci]

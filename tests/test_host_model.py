@@ -146,3 +146,21 @@ def test_eval_script_flags_match_reference():
     with pytest.raises(SystemExit):
         p.parse_args(["-v", "4", "-dt", "bdd", "-t", "dpt_swin2_tiny_256"])
     assert "dpt_swin2_tiny_256" in model_types
+
+
+def test_patchwise_schedule_matches_reference():
+    """PatchWiseInplace (patchwise_training/__init__.py:148-252): same number of patches, same requires_grad pattern per patch,
+    flags restored afterwards — against patterns recorded from the reference's class (oracle/make_golden_loss.py)."""
+    from soccdpt_amd.utils.optim import PatchWiseInplace
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "patchwise.json")))
+    for pct, ref in g["schedules"].items():
+        net = torch.nn.Sequential(*[torch.nn.Linear(3, 3) for _ in range(7)])
+        for i, p in enumerate(net.parameters()):
+            p.requires_grad = i not in g["frozen"]
+        it = PatchWiseInplace(net, float(pct))
+        assert len(it) == ref["len"]
+        pats = [[int(p.requires_grad) for p in net_patch.parameters()] for net_patch in it]
+        assert pats == ref["patterns"], pct
+        assert [int(p.requires_grad) for p in net.parameters()] == ref["after"]
+    with pytest.raises(AssertionError):
+        PatchWiseInplace(torch.nn.Linear(2, 2).requires_grad_(False), 0.5)     # nothing trainable
