@@ -18,11 +18,14 @@ conv = [("rn4", 8, 768, 256), ("rn3", 16, 384, 256), ("rn2", 32, 192, 256), ("rn
         ("head_d", 128, 256, 128), ("head_s", 128, 256, 256)]
 K64 = [2, 1, 13, 10, 14, 11, 8, 6]
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None   # optional: comma-separated shape names
+ONLY_CFG = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # optional: comma-separated configuration ids
 K32 = [4, 9, 3, 19, 15, 16]
 order = []
 sk_part = torch.empty(2 << 20, dtype=torch.float32, device=dev)
 sk_count = torch.zeros(4096, dtype=torch.int32, device=dev)
 def run_splitk(name, M, N, Cin, call_sk):   # label 100 + S in the table
+    if ONLY_CFG:
+        return
     if Cin % 64 or (M + 31) // 32 * ((N + 63) // 64) >= 512:
         return
     for S in (2, 3, 4, 6, 8):
@@ -33,7 +36,7 @@ def run_splitk(name, M, N, Cin, call_sk):   # label 100 + S in the table
         torch.cuda.synchronize()
         order.extend([[name, 100 + S, M, N, Cin]] * 4)
 def run_all(name, M, N, Cin, call):
-    cfgs = [-1] + (K64 + K32 if Cin % 64 == 0 else K32)
+    cfgs = ONLY_CFG if ONLY_CFG else [-1] + (K64 + K32 if Cin % 64 == 0 else K32)
     for t in cfgs:
         ok = True
         for _ in range(4):
