@@ -580,6 +580,7 @@ static int pick_cfg(const IgemmDesc& d) {
     const long K = (long)d.taps * d.Cin;
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128), b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
     if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 15 : 4;  // C = 96: layer1_rn (128x256x32) / stage-0 Linear layers (64x64x32)
+    if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output): 2 blocks per CU overlap it with the other block's main loop
     if (d.N % 256 == 0) {
         if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
         if (cdiv(d.M, 128) * (d.N / 256) >= 224) return 10;  // 128(M)x256(N)

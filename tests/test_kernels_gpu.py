@@ -82,6 +82,30 @@ def test_igemm_conv3x3(gpu_device, B, H, Cin, Cout):
         torch.testing.assert_close(o, ref, rtol=1e-4, atol=2e-4, msg=f"tune={tune}")
 
 
+@pytest.mark.parametrize("tune", [6, 7, 8, 10, 13, 14, 15, 16, 17, 18])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_igemm_big_tiles_ragged(gpu_device, tune, prec):
+    """The 8-wave tiles (incl. the skewed wave-row schedule of the 2 x 4 layouts) and the other heuristic-only configurations on a
+    problem whose M is not a multiple of any tile (1600 rows) and whose K is odd in k-tiles (9 x 128 / 64 = 18, 9 x 96 / 32 = 27)."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, op_igemm
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    B, H, Cout = 1, 40, 256
+    Cin = 128 if tune in (6, 7, 8, 10, 13, 14) else 96      # the x32 configurations also take Cin % 64 != 0
+    g = torch.Generator().manual_seed(tune)
+    x = torch.randn(B, Cin, H, H, generator=g).to(dt).to(gpu_device)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dt).to(gpu_device)
+    bias = torch.randn(Cout, generator=g).to(gpu_device)
+    ref = F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+    xh = _halo(x.permute(0, 2, 3, 1).contiguous())
+    wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    out = torch.empty(B, H, H, Cout, device=gpu_device)
+    for _ in range(3):   # repeated launches: a schedule race would show as a sporadic wrong tile
+        op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, out_f32=out, tune=tune,
+                 precision=PREC_BF16 if prec == "bf16" else PREC_F16)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(out, ref, rtol=1e-4, atol=2e-4, msg=f"tune={tune}")
+
+
 def test_igemm_depth_tail(gpu_device):
     """conv3x3 128->32 + bias, ReLU, 1x1 32->1 + bias, ReLU fused (model/dpt.py:209-216)."""
     from soccdpt_amd.lib import op_igemm
