@@ -358,7 +358,8 @@ struct AttnGenCfg {
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
 };
 
-template <int WS, bool F16>
+// QS: query split as in window_attention_kernel (each workgroup stages all keys / values, owns 1/QS of the 32-query blocks).
+template <int WS, bool F16, int QS>
 __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                      const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
                                                                      int shift, int heads) {
@@ -371,6 +372,10 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
     const int C = heads * 32;
     const int nw = res / WS;
     int bid = blockIdx.x;
+    const int qh = QS > 1 ? bid % QS : 0;
+    bid /= QS;
+    constexpr int QB0 = (AttnGenCfg<WS>::NT + QS - 1) / QS;   // query blocks per workgroup
+    const int qb_lo = qh * QB0, qb_hi = (qb_lo + QB0) < AttnGenCfg<WS>::NT ? (qb_lo + QB0) : AttnGenCfg<WS>::NT;
     const int head = bid % heads;
     bid /= heads;
     const int wx = bid % nw;
@@ -388,9 +393,10 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
     for (int idx = tid; idx < A::NPAD * 4; idx += A::THREADS) {
         const int p = idx >> 2, c = idx & 3;
         uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+        const bool own_q = QS == 1 || ((p >> 5) >= qb_lo && (p >> 5) < qb_hi);
         if (p < A::N) {
             const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
-            qv = *reinterpret_cast<const uint4*>(src);
+            if (own_q) qv = *reinterpret_cast<const uint4*>(src);
             kv = *reinterpret_cast<const uint4*>(src + C);
             vv = *reinterpret_cast<const uint4*>(src + 2 * C);
         }
@@ -418,7 +424,7 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
         ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
         ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
         const int sw = (c ^ ((p >> 2) & 3)) * 16;
-        *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
+        if (own_q) *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
         *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -430,7 +436,7 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
     const int r32 = lane & 31, h = lane >> 5;
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     constexpr int HALF = WS / 2;
-    for (int qb = wave; qb < A::NT; qb += 4) {
+    for (int qb = qb_lo + wave; qb < qb_hi; qb += 4) {
         const int qrow = qb * 32 + r32;
         const int qcl = qrow < A::N ? qrow : A::N - 1;
         const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
@@ -441,10 +447,20 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
         float m = -3.0e38f, l = 0.f;
         f32x16 o = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
         const float* bp = bias_acc + ((size_t)(head * A::NT + qb) * A::NT) * 1024 + lane * 16;
+        // the bias tile is the initial accumulator: fetch tile t+1 under tile t's MFMAs / softmax (the loop is not unrolled, and an
+        // un-prefetched L2 read per key tile was the critical path of this kernel)
+        float4 nb0, nb1, nb2, nb3;
+        {
+            const float4* b4 = reinterpret_cast<const float4*>(bp);
+            nb0 = b4[0]; nb1 = b4[1]; nb2 = b4[2]; nb3 = b4[3];
+        }
 #pragma unroll 1
         for (int t = 0; t < A::NT; ++t) {
-            const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)t * 1024);
-            const float4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+            const float4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
+            if (t + 1 < A::NT) {
+                const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)(t + 1) * 1024);
+                nb0 = b4[0]; nb1 = b4[1]; nb2 = b4[2]; nb3 = b4[3];
+            }
             f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
             if (lastrow || lastcol) {
 #pragma unroll
@@ -676,15 +692,15 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
     } else if (ws == 24 || ws == 12) {
         static bool attr_done = false;
         if (!attr_done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, false>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      AttnGenCfg<24>::LDS);
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, true>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      AttnGenCfg<24>::LDS);
+#define FLASH_ATTR(H, Q) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, H, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<24>::LDS)
+            FLASH_ATTR(false, 1); FLASH_ATTR(true, 1); FLASH_ATTR(false, 2); FLASH_ATTR(true, 2);
+#undef FLASH_ATTR
             attr_done = true;
         }
-#define FLASH(W, H) hipLaunchKernelGGL((window_attention_flash_kernel<W, H>), dim3(blocks), dim3(256), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
-        if (ws == 24) { if (hf) FLASH(24, true); else FLASH(24, false); }
-        else { if (hf) FLASH(12, true); else FLASH(12, false); }
+#define FLASH(W, H, Q) hipLaunchKernelGGL((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(256), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+        if (ws == 24 && blocks < 256) { if (hf) FLASH(24, true, 2); else FLASH(24, false, 2); }   // too few (window, head) pairs: split the queries
+        else if (ws == 24) { if (hf) FLASH(24, true, 1); else FLASH(24, false, 1); }
+        else { if (hf) FLASH(12, true, 1); else FLASH(12, false, 1); }
 #undef FLASH
     } else {
         err = "window_attention: window size not instantiated (16, 8, 24, 12 are)";
