@@ -581,12 +581,16 @@ static int pick_cfg(const IgemmDesc& d) {
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128), b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
     if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 15 : 4;  // C = 96: layer1_rn (128x256x32) / stage-0 Linear layers (64x64x32)
     if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output): 2 blocks per CU overlap it with the other block's main loop
+    // short K on a big problem (dpt_swin2_base_384 stages 0-2: K = 128..512, profiles/r01g_igemm_device_durations_base384.txt):
+    // the k-loop is a few tiles long, so prologue / epilogue dominate: 256x128 tiles with 32-deep k-tiles (3-stage ring)
+    if (K <= 512 && b128 >= 512) return 16;
     if (d.N % 256 == 0) {
         if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
-        if (cdiv(d.M, 128) * (d.N / 256) >= 224) return 10;  // 128(M)x256(N)
+        if (cdiv(d.M, 128) * (d.N / 256) >= 128) return 10;  // 128(M)x256(N)
     }
-    // short K, many output tiles (qkv / fc1 of stages 1-2): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
-    if (K <= 384 && b64 >= 512) return 4;
+    // short K, many output tiles (qkv / fc1 / proj / merge of the mid stages): write-heavy; 32-deep k-tiles halve the LDS
+    // footprint -> 5 blocks per CU
+    if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 384) return 1;
     // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring)
     if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return 14;
