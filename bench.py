@@ -48,6 +48,12 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     args = ap.parse_args()
 
+    # stdout must carry exactly ONE JSON line: RCCL prints a version banner to stdout when a communicator is created, and
+    # libraries may print too.  Keep the real stdout aside and point fd 1 at stderr for everything else.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     from soccdpt_amd import dist as sdist
@@ -237,7 +243,8 @@ def main():
                                   "sample": f"{reps} x batch {nb} of the same synthetic workload, fp32 PyTorch-CPU oracle "
                                             f"(oracle/soccdpt_ref.py), {tcpu:.1f} s"}
     if rank == 0:
-        print(json.dumps(result))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist.is_initialized():
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
