@@ -22,10 +22,12 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def gather_occ_bits(bits: torch.Tensor, group=None) -> torch.Tensor:
-    """All-gather the packed local grids: [words] int32 -> [world, words] int32 (same device)."""
+def gather_occ_bits(bits: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """All-gather the packed local grids: [words] int32 -> [world, words] int32 (same device).  `out`: reusable flat buffer."""
     world = dist.get_world_size(group)
-    flat = torch.empty((world * bits.numel(),), dtype=bits.dtype, device=bits.device)
+    n = world * bits.numel()
+    flat = out if (out is not None and out.numel() == n and out.device == bits.device and out.dtype == bits.dtype) else \
+        torch.empty((n,), dtype=bits.dtype, device=bits.device)
     dist.all_gather_into_tensor(flat, bits.contiguous().reshape(-1), group=group)
     return flat.reshape(world, bits.numel())
 
@@ -36,14 +38,15 @@ class OccExchange:
     def __init__(self, group=None, or_reduce: Optional[Callable] = None):
         self.group = group
         self._or_reduce = or_reduce  # tests on CPU (gloo) inject a reducer; on GPU the HIP kernel is used
+        self._flat: Optional[torch.Tensor] = None   # reused receive buffer (world x 786,432 B)
 
     def __call__(self, eng, bits: torch.Tensor) -> torch.Tensor:
-        gathered = gather_occ_bits(bits, self.group)
+        gathered = gather_occ_bits(bits, self.group, out=self._flat)
+        self._flat = gathered.reshape(-1)
         if self._or_reduce is not None:
             return self._or_reduce(gathered)
-        union = torch.zeros_like(bits)
-        eng.occ_or(union, gathered, gathered.shape[0])
-        return union
+        eng.occ_or(bits, gathered, gathered.shape[0])   # in place: bits |= every rank's grid (its own is among them)
+        return bits
 
 
 def init_from_env(backend: str = "nccl"):
