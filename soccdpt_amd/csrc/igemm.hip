@@ -189,54 +189,14 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 #pragma unroll
     for (int s0 = 0; s0 < C::NS - 1; ++s0)
         if (s0 < nk) stage(s0, s0);
-    // SKEW (8-wave tiles, 2 x 4 waves, two k-steps per k-tile): waves (0, wn) and (1, wn) share SIMD wn and would otherwise
-    // run in lock step -- both issuing LDS-DMA / ds_reads, then both queueing MFMAs.  The wm == 1 row runs its schedule half
-    // a k-step out of phase:   wm == 0:  | R0 M0 R1 M1 |        wm == 1:  | M1' R0 M0 R1 |     (per k-tile, M1' = previous tile)
-    // so one wave of every SIMD is in its load half while the other feeds the matrix pipe.  Same barriers, same LDS
-    // lifetimes (every read of tile kt is issued and completed inside period kt), no extra registers.
-    constexpr bool SKEW = (sizeof(T) == 2) && C::WM == 2 && C::THREADS == 512 && C::KS == 2;
-    if constexpr (SKEW) {
-        h16x8 wf[C::TN], xf[C::TM];
-        auto read_frags = [&](const char* sb, int ks) {
-#pragma unroll
-            for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const h16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
-#pragma unroll
-            for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
-        };
-        auto mma = [&]() {
-#pragma unroll
-            for (int i = 0; i < C::TN; ++i)
-#pragma unroll
-                for (int j = 0; j < C::TM; ++j) acc[i][j] = mfma_16x16x32<F16>(wf[i], xf[j], acc[i][j]);
-        };
-        if (wm == 0) {
-            for (int kt = 0; kt < nk; ++kt) {
-                wait_tile(kt);
-                __builtin_amdgcn_s_barrier();
-                if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
-                const char* sb = smem + (kt % C::NS) * C::STAGE;
-                read_frags(sb, 0);
-                mma();
-                read_frags(sb, 1);
-                mma();
-            }
-        } else {
-            for (int kt = 0; kt < nk; ++kt) {
-                wait_tile(kt);
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the k-step-1 fragments read at the end of the last period
-                __builtin_amdgcn_s_barrier();
-                if (kt > 0) mma();                                  // M1 of tile kt-1
-                __builtin_amdgcn_sched_barrier(0);                  // keep the load half behind the MFMA half
-                if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
-                const char* sb = smem + (kt % C::NS) * C::STAGE;
-                read_frags(sb, 0);
-                mma();
-                read_frags(sb, 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            mma();  // M1 of the last tile
-        }
-    } else {
+    // (Tried and REMOVED: running the wm == 1 wave row of the 8-wave tiles half a k-step out of phase, | M1' R0 M0 R1 | against
+    //  | R0 M0 R1 M1 |, so that the two waves of a SIMD alternate load and MFMA halves.  It was worth 5-8 % on the 256x256 and
+    //  128x256 convs only when the lagging row also issued its LDS-DMA late, and exactly that variant produced rare wrong
+    //  tiles once another kernel's waves were co-resident -- tools/skew_race_probe.py, found by the hipGraph replay test --
+    //  although every read followed its covering vmcnt + barrier.  With the DMA issue moved back to the barrier it was clean
+    //  and no faster.  cdna_hip_programming.md warns that staggered wave groups need one more barrier per phase; that is
+    //  the 8-phase template's job, not a patch on this loop.)
+    {
     for (int kt = 0; kt < nk; ++kt) {
         wait_tile(kt);
         __builtin_amdgcn_s_barrier();
