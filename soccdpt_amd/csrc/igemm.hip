@@ -543,7 +543,7 @@ static int pick_cfg(const IgemmDesc& d) {
     if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output): 2 blocks per CU overlap it with the other block's main loop
     // short K on a big problem (dpt_swin2_base_384 stages 0-2: K = 128..512, profiles/r01g_igemm_device_durations_base384.txt):
     // the k-loop is a few tiles long, so prologue / epilogue dominate: 256x128 tiles with 32-deep k-tiles (3-stage ring)
-    if (K <= 512 && b128 >= 512) return 16;
+    if (K <= 512 && b128 >= 512 && d.N > 256) return 16;   // (N <= 256: the out_conv shapes with their f32 stores measured slower in the network)
     if (d.N % 256 == 0) {
         if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
         if (cdiv(d.M, 128) * (d.N / 256) >= 128) return 10;  // 128(M)x256(N)
