@@ -1,4 +1,5 @@
-"""Reproducer of a timing-dependent mismatch seen with the skewed igemm schedule: graph(2 streams) -> eager(2 streams) ->
+"""Reproducer of the timing-dependent mismatch that the (removed) skewed igemm schedule produced -- kept as a stress probe for
+any future schedule change of igemm_kernel: graph(2 streams) -> eager(2 streams) ->
 eager(1 stream) launched back to back without host synchronisation; counts seg elements of the eager 2-stream result that differ
 from the single-stream one."""
 import os, sys, tempfile
