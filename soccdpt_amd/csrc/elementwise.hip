@@ -349,31 +349,43 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
 template <bool F16>
 __global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restrict__ in, const float* __restrict__ w /*[3][256]*/,
                                                           const float* __restrict__ bias, float* __restrict__ out, int M) {
+    // 16 lanes per pixel, 16 channels per lane; a lane's 3 x 16 weights stay in registers over a grid-stride loop of pixels
     const int sub = threadIdx.x & 15;
-    const size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
-    if (pix >= (size_t)M) return;  // M % 16 == 0 rows per block keeps shuffles within full groups
-    const bf16_t* p = in + pix * 256 + sub * 16;
-    const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
-    const uint32_t u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+    float w0[16], w1[16], w2[16];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const float lo = h_lo<F16>(u[k]), hi = h_hi<F16>(u[k]);
-        const int c = sub * 16 + 2 * k;
-        s0 += lo * w[c] + hi * w[c + 1];
-        s1 += lo * w[256 + c] + hi * w[256 + c + 1];
-        s2 += lo * w[512 + c] + hi * w[512 + c + 1];
+    for (int k = 0; k < 16; k += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(w + sub * 16 + k), b = *reinterpret_cast<const float4*>(w + 256 + sub * 16 + k),
+                     c = *reinterpret_cast<const float4*>(w + 512 + sub * 16 + k);
+        w0[k] = a.x; w0[k + 1] = a.y; w0[k + 2] = a.z; w0[k + 3] = a.w;
+        w1[k] = b.x; w1[k + 1] = b.y; w1[k + 2] = b.z; w1[k + 3] = b.w;
+        w2[k] = c.x; w2[k + 1] = c.y; w2[k + 2] = c.z; w2[k + 3] = c.w;
     }
+    const float b0 = bias[0], b1 = bias[1], b2 = bias[2];
+    const size_t stride = ((size_t)gridDim.x * blockDim.x) >> 4;
+    // M % 16 == 0 pixels per 256-thread pass keeps every 16-lane group entirely inside or outside the loop
+    for (size_t pix = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4; pix < (size_t)M; pix += stride) {
+        const bf16_t* p = in + pix * 256 + sub * 16;
+        const uint4 a = *reinterpret_cast<const uint4*>(p), b = *reinterpret_cast<const uint4*>(p + 8);
+        const uint32_t u[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) {
-        s0 += __shfl_xor(s0, o);
-        s1 += __shfl_xor(s1, o);
-        s2 += __shfl_xor(s2, o);
-    }
-    if (sub == 0) {
-        out[pix * 3 + 0] = s0 + bias[0];
-        out[pix * 3 + 1] = s1 + bias[1];
-        out[pix * 3 + 2] = s2 + bias[2];
+        for (int k = 0; k < 8; ++k) {
+            const float lo = h_lo<F16>(u[k]), hi = h_hi<F16>(u[k]);
+            s0 += lo * w0[2 * k] + hi * w0[2 * k + 1];
+            s1 += lo * w1[2 * k] + hi * w1[2 * k + 1];
+            s2 += lo * w2[2 * k] + hi * w2[2 * k + 1];
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o);
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+        }
+        if (sub == 0) {
+            out[pix * 3 + 0] = s0 + b0;
+            out[pix * 3 + 1] = s1 + b1;
+            out[pix * 3 + 2] = s2 + b2;
+        }
     }
 }
 
@@ -433,8 +445,9 @@ int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, c
                     int sigmoid, hipStream_t st, std::string& err) {
     const int M = B * h * wd;
     const dim3 grid((unsigned)(((size_t)M * 16 + 255) / 256));
+    unsigned gl = grid.x > 2048 ? 2048 : grid.x;   // grid-stride (16-bit path): weights are loaded once per thread
     if (feat_is_f32) hipLaunchKernelGGL(conv1x1_c3_f32_kernel, grid, dim3(256), 0, st, static_cast<const float*>(feat), w, bias, tmp, M);
-    else LAUNCH_HF(hf, conv1x1_c3_kernel, grid, dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
+    else LAUNCH_HF(hf, conv1x1_c3_kernel, dim3(gl), dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
     if (check_launch("conv1x1_c3", err)) return 1;
     const size_t total = (size_t)B * 4 * h * wd;
     size_t blocks = (total + 255) / 256;
