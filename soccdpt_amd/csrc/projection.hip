@@ -199,11 +199,17 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
     }
     __syncthreads();
     const int v0 = vlo + (int)threadIdx.x * 4;
-    if (v0 >= vhi) return;
+    const bool valid = v0 < vhi;   // (no early return: every thread reaches the barrier of the voxel de-duplication below)
     const float yterm = (float)u - P.cy;
     float iv[4], sem[C][4], pt[4][3];
     int vkey[4];       // first cell index of the pixel's voxel (its C class bits are adjacent), -1 = not in the grid
     uint32_t vcm[4];   // classes with non-zero probability
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        vkey[e] = -1;
+        vcm[e] = 0;
+    }
+    if (valid) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
         const int v = v0 + e;
@@ -233,8 +239,6 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
         pt[e][0] = p[0];
         pt[e][1] = p[1];
         pt[e][2] = p[2];
-        vkey[e] = -1;
-        vcm[e] = 0;
         if (P.occ_bits) {
             float a[3], bq[3], cq[3];
             rot3(p, P.rot, a);
@@ -259,14 +263,24 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
             }
         }
     }
+    }  // valid
     // ---- voxel marking with run-length de-duplication along the camera row ----
     // Neighbouring pixels mostly fall into the same voxel (a 0.5 m cell spans tens of pixels), so a pixel only touches
     // the grid when its (voxel, class set) is not covered by its left neighbour's: by induction every pixel's bits are
-    // then set by the nearest acting pixel to its left.  The first pixel of each wave always acts.
+    // then set by the nearest acting pixel to its left.  The first pixel of each WORKGROUP always acts; the first lane of the
+    // other waves takes its left neighbour from the previous wave through LDS (a forced action per wave is a dependent
+    // load -> atomic chain that keeps the wave alive for a memory round trip).
     if (P.occ_bits) {
+        __shared__ int s_lk[4];
+        __shared__ uint32_t s_lc[4];
+        if ((threadIdx.x & 63) == 63) { s_lk[threadIdx.x >> 6] = vkey[3]; s_lc[threadIdx.x >> 6] = vcm[3]; }
+        __syncthreads();
         int pk = __shfl_up(vkey[3], 1);
         uint32_t pc = __shfl_up(vcm[3], 1);
-        if ((threadIdx.x & 63) == 0) { pk = -2; pc = 0; }
+        if ((threadIdx.x & 63) == 0) {
+            if (threadIdx.x == 0) { pk = -2; pc = 0; }
+            else { pk = s_lk[(threadIdx.x >> 6) - 1]; pc = s_lc[(threadIdx.x >> 6) - 1]; }
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (vkey[e] >= 0 && (vkey[e] != pk || (vcm[e] & ~pc))) {
@@ -283,6 +297,7 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
             pc = vcm[e];
         }
     }
+    if (!valid) return;
     const size_t n0 = (size_t)u * P.Wc + v0;
     if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
     if (P.seg_up) {
