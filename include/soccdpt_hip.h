@@ -173,6 +173,18 @@ int soccdpt_training_loss(int B, int H, int W, int h, int w, int C, int compute_
                           const float* y_seg, const uint8_t* mask_seg, float* out, float* d_inv, float* d_seg, void* scratch,
                           void* stream);
 
+/* ---- ground-truth occupancy generator (datasets/bdd_helper.py:238-530 OccupancyProcessor) ----
+ * disparity [B,H,W] f32, seg_class [B,H,W] i32 (class ids after rgb_seg_to_class) ->
+ *   depth  [B,H,W] f32 or NULL        baseline*focal/disparity, upper half hidden, inf/nan -> 0          (:446-455)
+ *   points [B,H*W,3] f64 or NULL      scaled, shifted, rotated camera points (what frame["points"] holds)  (:457-489)
+ *   occ    [B,g0,g1,g2,C] u8          counts > point_count_threshold                                       (:288-347)
+ * counts [B,g0,g1,g2,C] u32 is scratch (zeroed by the call, holds the per-voxel point counts afterwards).
+ * intr = {fx, fy, cx, cy, baseline} (float64); rot27 = Ra^T, Rb^T, Rc^T row-major float64 as rotate_points builds them (:604-652);
+ * occ_shape = float32(grid_size / scale) (:264-270).  Arithmetic follows numpy 2.x promotion (oracle/gt_occ_ref.c). */
+int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const double* pc_scale, const double* pc_shift,
+                         const double* rot27, const float* occ_shape, const int* grid, float threshold, const float* disparity,
+                         const int32_t* seg_class, float* depth, double* points, uint32_t* counts, uint8_t* occ, void* stream);
+
 /* Fused multi-tensor Adam step, in place (torch.optim.Adam of scripts/train_SOccDPT.py:311-318; amsgrad=False):
  * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors DEVICE pointers (f32), sizes[i] elements each; step >= 1 is
  * the step count AFTER this update (bias corrections 1 - beta^step). */

@@ -16,8 +16,8 @@ _lib = None
 
 
 def build(force: bool = False) -> str:
-    src = os.path.join(_HERE, "projection_ref.c")
-    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+    srcs = [os.path.join(_HERE, f) for f in ("projection_ref.c", "gt_occ_ref.c")]
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < max(os.path.getmtime(f) for f in srcs):
         subprocess.check_call(["make", "-s", "-C", _HERE])
     return _SO
 
@@ -74,3 +74,53 @@ def pack_occ(occ_row: torch.Tensor) -> np.ndarray:
     if pad:
         flat = np.concatenate([flat, np.zeros(pad, bool)])
     return np.packbits(flat, bitorder="little").view(np.uint32)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Ground-truth occupancy generator (oracle/gt_occ_ref.c; datasets/bdd_helper.py:238-530)
+# ---------------------------------------------------------------------------------------------------------------------
+class GtOccParams(ctypes.Structure):
+    _fields_ = [("H", ctypes.c_int), ("W", ctypes.c_int), ("C", ctypes.c_int),
+                ("fx", ctypes.c_double), ("fy", ctypes.c_double), ("cx", ctypes.c_double), ("cy", ctypes.c_double), ("base_focal", ctypes.c_double),
+                ("pc_scale", ctypes.c_double * 3), ("pc_shift", ctypes.c_double * 3), ("rot", ctypes.c_double * 27),
+                ("occ_shape", ctypes.c_float * 3), ("grid", ctypes.c_int * 3), ("threshold", ctypes.c_float)]
+
+
+def gt_rot_matrices(angles=(7.0, 0.0, 0.0)) -> np.ndarray:
+    """Ra^T, Rb^T, Rc^T (27 float64) built like rotate_points (datasets/bdd_helper.py:604-652): math.cos / math.sin of radians."""
+    import math
+    a, b, c = [math.radians(v) for v in angles]
+    Ra = np.array([[1, 0, 0], [0, math.cos(a), -math.sin(a)], [0, math.sin(a), math.cos(a)]])
+    Rb = np.array([[math.cos(b), 0, math.sin(b)], [0, 1, 0], [-math.sin(b), 0, math.cos(b)]])
+    Rc = np.array([[math.cos(c), -math.sin(c), 0], [math.sin(c), math.cos(c), 0], [0, 0, 1]])
+    return np.concatenate([Ra.T.reshape(-1), Rb.T.reshape(-1), Rc.T.reshape(-1)]).astype(np.float64)
+
+
+def gt_params(H, W, C, fx, fy, cx, cy, grid_size=(256, 256, 32), scale=(2.0, 2.0, 0.666), pc_scale=(500.0, 2500.0, 200.0),
+              pc_shift=(100.0, 40.0, 0.0), threshold=10, angles=(7.0, 0.0, 0.0), baseline=1.0 * 10**-2) -> GtOccParams:
+    P = GtOccParams()
+    P.H, P.W, P.C = H, W, C
+    P.fx, P.fy, P.cx, P.cy = fx, fy, cx, cy
+    P.base_focal = baseline * ((fx + fy) / 2.0)
+    for k in range(3):
+        P.pc_scale[k], P.pc_shift[k] = pc_scale[k], pc_shift[k]
+        P.grid[k] = grid_size[k]
+        P.occ_shape[k] = np.float32(float(grid_size[k] / scale[k]))
+    for i, v in enumerate(gt_rot_matrices(angles)):
+        P.rot[i] = v
+    P.threshold = threshold
+    return P
+
+
+def gt_occupancy(disparity: np.ndarray, seg_class: np.ndarray, P: GtOccParams, want_points: bool = True):
+    """disparity [H,W] f32, seg_class [H,W] i32 -> dict(depth f32 [H,W], points f64 [H*W,3], counts u32, grid bool [g0,g1,g2,C])."""
+    L = lib()
+    d = np.ascontiguousarray(disparity, dtype=np.float32)
+    sc = np.ascontiguousarray(seg_class, dtype=np.int32)
+    g = (P.grid[0], P.grid[1], P.grid[2], P.C)
+    depth = np.empty((P.H, P.W), dtype=np.float32)
+    pts = np.empty((P.H * P.W, 3), dtype=np.float64) if want_points else None
+    counts = np.empty(g, dtype=np.uint32)
+    grid = np.empty(g, dtype=np.uint8)
+    L.gt_occupancy_ref(ctypes.byref(P), _p(d), _p(sc), _p(depth), _p(pts), _p(counts), _p(grid))
+    return dict(depth=depth, points=pts, counts=counts, grid=grid.astype(bool))

@@ -222,6 +222,16 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
     return 0;
 }
 
+int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const double* pc_scale, const double* pc_shift,
+                         const double* rot27, const float* occ_shape, const int* grid, float threshold, const float* disparity,
+                         const int32_t* seg_class, float* depth, double* points, uint32_t* counts, uint8_t* occ, void* stream) {
+    std::string err;
+    if (launch_gt_occupancy(B, H, W, C, intr, pc_scale, pc_shift, rot27, occ_shape, grid, threshold, disparity, seg_class, depth, points, counts, occ,
+                            (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const size_t* sizes, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, void* stream) {

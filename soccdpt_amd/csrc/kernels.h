@@ -55,6 +55,11 @@ int launch_training_loss(int B, int H, int W, int h, int w, int C, int compute_s
                          const float* seg, const float* y_disp, const uint8_t* mask_disp, const float* y_seg, const uint8_t* mask_seg,
                          float* out, float* d_inv, float* d_seg, void* scratch, hipStream_t st, std::string& err);
 
+// gt_occ.hip: ground-truth occupancy generator (counting voxelisation of a disparity frame + class map, float64 like numpy)
+int launch_gt_occupancy(int B, int H, int W, int C, const double* intr, const double* pc_scale, const double* pc_shift, const double* rot27,
+                        const float* occ_shape, const int* grid, float threshold, const float* disparity, const int32_t* seg_class, float* depth,
+                        double* points, uint32_t* counts, uint8_t* occ, hipStream_t st, std::string& err);
+
 // adam.hip: fused multi-tensor Adam (host arrays of device pointers)
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                 const size_t* sizes, double lr, double beta1, double beta2, double eps, double weight_decay, int step, hipStream_t st,

@@ -121,6 +121,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_training_loss.argtypes = [ci, ci, ci, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.soccdpt_training_loss.restype = ci
     cd = ctypes.c_double
+    L.soccdpt_gt_occupancy.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp]
+    L.soccdpt_gt_occupancy.restype = ci
     L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
     L.soccdpt_adam_step.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]

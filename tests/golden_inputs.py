@@ -51,3 +51,19 @@ def loss_inputs(B=2, h=64, w=64, H=135, W=240, C=3, seed=7):
     mask_disp[:, : H // 8] = False
     mask_seg = torch.rand((B, C, H, W), generator=g) > 0.1
     return inv.float().contiguous(), seg.float().contiguous(), y_disp.contiguous(), mask_disp, y_seg.contiguous(), mask_seg
+
+
+def gt_occ_inputs(H=270, W=480, C=3, seed=11):
+    """Seeded frame for the ground-truth occupancy generator (datasets/bdd_helper.py:433-530): a smooth positive disparity with a
+    few zeros / NaN / negatives (-> inf / nan / negative depth), a blocky class map, intrinsics scaled to the frame."""
+    import numpy as np
+    g = torch.Generator().manual_seed(seed)
+    lo = torch.rand((1, 1, 9, 16), generator=g)
+    # depth = 0.01 * focal / disparity must land in the grid after pc_scale = (500, 2500, 200): depth ~ 0.02 .. 0.1 -> disparity 30 .. 180
+    disp = (torch.nn.functional.interpolate(lo, size=(H, W), mode="bilinear", align_corners=False)[0, 0] * 150.0 + 30.0).numpy().astype(np.float32)
+    disp[H // 2 + 5, 10:20] = 0.0
+    disp[H // 2 + 9, 30:35] = np.nan
+    disp[H // 2 + 12, 50:60] = -0.3
+    seg = (torch.nn.functional.interpolate(torch.rand((1, 1, 6, 10), generator=g), size=(H, W), mode="nearest")[0, 0] * C).long().clamp(0, C - 1).numpy().astype(np.int64)
+    K = np.array([[1250.6 * W / 1920.0, 0.0, 978.4 * W / 1920.0], [0.0, 1254.8 * H / 1080.0, 562.1 * H / 1080.0], [0.0, 0.0, 1.0]])
+    return disp, seg, K, H, W, C
