@@ -49,7 +49,8 @@ struct Cfg {
 
 template <int BK>
 __device__ __forceinline__ int swz_of_row(int row) {
-    if constexpr (BK == 64) return row & 7;          // 128-byte rows: 8 chunks
+    if constexpr (BK == 128) return row & 15;        // 256-byte rows (one full bank sweep each): 16 chunks
+    else if constexpr (BK == 64) return row & 7;     // 128-byte rows: 8 chunks
     else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
 }
 
@@ -516,7 +517,8 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_256x128x64_s2", "igemm_bf16_256x128x64_s3", "igemm_bf16_256x256x64_s2",
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
-                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4"};
+                                        "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
+                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_64x64x128_s3"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -534,7 +536,7 @@ static int pick_cfg(const IgemmDesc& d) {
     // Big problems are bound by the per-CU L2->LDS fill rate: take the LARGEST tile (most FLOPs per staged byte) that still
     // fills the 256 CUs.  Small ones are latency-bound: take small tiles / short k-tiles so that many blocks are resident.
     if (d.tune >= 0) return d.tune;
-    if (d.splitk > 1) return 14;  // the split-K instantiation: 32(M) x 64(N) tiles, 6-stage ring
+    if (d.splitk > 1) return d.Cin % 128 == 0 ? 20 : 14;  // the split-K instantiations: 32(M) x 64(N) tiles
     if (d.N <= 32) return 5;
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long K = (long)d.taps * d.Cin;
@@ -553,7 +555,8 @@ static int pick_cfg(const IgemmDesc& d) {
     if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 384) return 1;
     // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring)
-    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return 14;
+    // (128-deep k-tiles halve the barriers of these latency-bound loops: 8-15 % over the 64-deep 6-stage ring)
+    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return d.Cin % 128 == 0 ? 20 : 14;
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
@@ -574,7 +577,10 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
 const char* igemm_family(const IgemmDesc& d) {
     if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
-    if (d.splitk > 1) return d.f16 ? "igemm_f16_32x64x64_s6_splitk" : "igemm_bf16_32x64x64_s6_splitk";
+    if (d.splitk > 1) {
+        if (id == 20) return d.f16 ? "igemm_f16_32x64x128_s3_splitk" : "igemm_bf16_32x64x128_s3_splitk";
+        return d.f16 ? "igemm_f16_32x64x64_s6_splitk" : "igemm_bf16_32x64x64_s6_splitk";
+    }
     if (!d.f16) return kCfgNames[id];
     static std::string f16_names[sizeof(kCfgNames) / sizeof(kCfgNames[0])];  // "igemm_f16_<tile>": same kernels, fp16 instantiation
     if (f16_names[id].empty()) f16_names[id] = std::string("igemm_f16_") + (kCfgNames[id] + 11);
@@ -602,6 +608,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 20 || id == 21) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -624,6 +631,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
+        case 20: return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
+        case 21: return launch_cfg<Cfg<64, 64, 128, 2, 2, 3>>(d, stream, err);
     }
     err = "igemm: unknown configuration id";
     return 1;

@@ -25,7 +25,7 @@ if os.environ.get("TUNE_SET") == "base384":   # dpt_swin2_base_384, B = 8 (BASEL
     conv = [("brn4", 12, 1024, 256), ("brn3", 24, 512, 256), ("brn2", 48, 256, 256), ("brn1", 96, 128, 256),
             ("brcu12", 12, 256, 256), ("brcu24", 24, 256, 256), ("brcu48", 48, 256, 256), ("brcu96", 96, 256, 256),
             ("bhead_d", 192, 256, 128), ("bhead_s", 192, 256, 256)]
-K64 = [2, 1, 13, 10, 14, 11, 8, 6]
+K64 = [2, 1, 13, 10, 14, 11, 8, 6, 20, 21]
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None   # optional: comma-separated shape names
 ONLY_CFG = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # optional: comma-separated configuration ids
 K32 = [4, 9, 3, 19, 15, 16]
