@@ -518,7 +518,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
                                         "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
-                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_64x64x128_s3"};
+                                        "igemm_bf16_32x64x128_s3"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -548,15 +548,19 @@ static int pick_cfg(const IgemmDesc& d) {
     if (K <= 512 && b128 >= 512 && d.N > 256) return 16;   // (N <= 256: the out_conv shapes with their f32 stores measured slower in the network)
     if (d.N % 256 == 0) {
         if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
-        if (cdiv(d.M, 128) * (d.N / 256) >= 128) return 10;  // 128(M)x256(N)
+        const long t10 = cdiv(d.M, 128) * (d.N / 256);
+        if (t10 >= 224 || (t10 >= 128 && K >= 512)) return 10;  // 128(M)x256(N); on a half-filled chip only with enough K per tile
     }
     // short K, many output tiles (qkv / fc1 / proj / merge of the mid stages): write-heavy; 32-deep k-tiles halve the LDS
     // footprint -> 5 blocks per CU
     if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 384) return 1;
     // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring)
-    // (128-deep k-tiles halve the barriers of these latency-bound loops: 8-15 % over the 64-deep 6-stage ring)
-    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return d.Cin % 128 == 0 ? 20 : 14;
+    // (128-deep k-tiles halve the barriers of these latency-bound loops: 8-15 % over the 64-deep 6-stage ring.  A two-stage
+    //  variant (48 KB, 3 workgroups per CU) and the extension of 32x64x128 tiles to the shapes that run on 64x64 tiles both win
+    //  in warm micro-benchmarks (profiles/r01j_igemm_device_durations_k128.txt) and LOSE in the network, where weights and
+    //  activations arrive cold: 3712 -> 3580 frames/s.  Tune against the network, not only against a repeated launch.)
+    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return d.Cin % 128 != 0 ? 14 : 20;
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
@@ -608,7 +612,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
-    if ((id == 20 || id == 21) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
+    if (id == 20 && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -632,7 +636,6 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
         case 20: return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
-        case 21: return launch_cfg<Cfg<64, 64, 128, 2, 2, 3>>(d, stream, err);
     }
     err = "igemm: unknown configuration id";
     return 1;

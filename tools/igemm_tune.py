@@ -1,4 +1,6 @@
-"""Every GEMM / conv shape of the B=8 dpt_swin2_tiny_256 forward x every viable kernel configuration, a few launches each.
+"""Every GEMM / conv shape of the B=8 dpt_swin2_tiny_256 forward x every viable kernel configuration, a few launches each
+(WARM caches: a configuration that wins here by re-reading weights more often can lose in the network, where they arrive cold --
+confirm a heuristic change with bench.py before keeping it).
 Run under `rocprofv3 --kernel-trace --output-format csv`; tools/igemm_tune_parse.py turns the trace into a table of DEVICE
 durations (event timing from Python is host-bound below ~10 us per launch and cannot rank these kernels)."""
 import sys, os, math, json
@@ -25,7 +27,7 @@ if os.environ.get("TUNE_SET") == "base384":   # dpt_swin2_base_384, B = 8 (BASEL
     conv = [("brn4", 12, 1024, 256), ("brn3", 24, 512, 256), ("brn2", 48, 256, 256), ("brn1", 96, 128, 256),
             ("brcu12", 12, 256, 256), ("brcu24", 24, 256, 256), ("brcu48", 48, 256, 256), ("brcu96", 96, 256, 256),
             ("bhead_d", 192, 256, 128), ("bhead_s", 192, 256, 256)]
-K64 = [2, 1, 13, 10, 14, 11, 8, 6, 20, 21]
+K64 = [2, 1, 13, 10, 14, 11, 8, 6, 20]
 ONLY = set(sys.argv[1].split(",")) if len(sys.argv) > 1 else None   # optional: comma-separated shape names
 ONLY_CFG = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else None   # optional: comma-separated configuration ids
 K32 = [4, 9, 3, 19, 15, 16]
