@@ -192,6 +192,17 @@ int soccdpt_adam_step(int n_tensors, float* const* params, const float* const* g
                       float* const* exp_avg_sq, const size_t* sizes, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, void* stream);
 
+/* ---- in-network tile tuning (tools/autotune_network.py): a warm micro-benchmark mis-ranks tile configurations whose weights and
+ * activations arrive cold in the real launch sequence, so candidates are timed inside the forward.
+ * soccdpt_profile_sites(h, 1): soccdpt_profile_collect then reports every distinct igemm shape as "site<i>" instead of per tile
+ * family; soccdpt_site_count / soccdpt_site_get list those shapes (K = taps * Cin) with the configuration the heuristic picked.
+ * soccdpt_tune_set forces configuration `cfg` for one shape (cfg < 0 removes the override); soccdpt_tune_clear removes all. */
+int soccdpt_profile_sites(void* handle, int on);
+int soccdpt_site_count(void* handle);
+int soccdpt_site_get(void* handle, int i, int* M, int* N, int* K, int* taps, int* cfg, int* launches);
+int soccdpt_tune_set(void* handle, int M, int N, int K, int taps, int cfg);
+int soccdpt_tune_clear(void* handle);
+
 /* ---- kernel-level entry points (parity tests of the individual HIP kernels) ---- */
 
 /* One implicit-GEMM launch: out[m][n] = epilogue(sum_k X[m][k] * Wt[n][k]) with bf16 operands and f32

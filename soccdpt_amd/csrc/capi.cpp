@@ -222,6 +222,42 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
     return 0;
 }
 
+int soccdpt_profile_sites(void* handle, int on) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    h->prof_sites = on != 0;
+    h->sites.clear();
+    h->sites.reserve(1024);   // the profiler records keep pointers to SiteRec::name: no reallocation while profiling
+    return 0;
+}
+int soccdpt_site_count(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    return h ? (int)h->sites.size() : 0;
+}
+int soccdpt_site_get(void* handle, int i, int* M, int* N, int* K, int* taps, int* cfg, int* launches) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || i < 0 || i >= (int)h->sites.size()) return 1;
+    const SiteRec& r = h->sites[i];
+    *M = r.M; *N = r.N; *K = r.K; *taps = r.taps; *cfg = r.cfg; *launches = r.count;
+    return 0;
+}
+int soccdpt_tune_set(void* handle, int M, int N, int K, int taps, int cfg) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    const long long key = (((long long)M * 8192 + N) * 65536 + K) * 16 + taps;
+    if (cfg < 0) h->tune_by_shape.erase(key);
+    else h->tune_by_shape[key] = cfg;
+    model_drop_graph(*h);
+    return 0;
+}
+int soccdpt_tune_clear(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    h->tune_by_shape.clear();
+    model_drop_graph(*h);
+    return 0;
+}
+
 int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const double* pc_scale, const double* pc_shift,
                          const double* rot27, const float* occ_shape, const int* grid, float threshold, const float* disparity,
                          const int32_t* seg_class, float* depth, double* points, uint32_t* counts, uint8_t* occ, void* stream) {

@@ -24,6 +24,18 @@ __device__ __forceinline__ float wave_sum(float v) {
            __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 32)) + __builtin_bit_cast(float, __builtin_amdgcn_readlane(vi, 48));
 }
 
+// Sum over each 16-lane row, result in every lane of the row: 4 DPP rotations (VALU only).
+__device__ __forceinline__ float row_sum(float v) {
+    auto ror = [](float x, auto n) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x120 + decltype(n)::value, 0xf, 0xf, true));
+    };
+    v += ror(v, std::integral_constant<int, 8>{});
+    v += ror(v, std::integral_constant<int, 4>{});
+    v += ror(v, std::integral_constant<int, 2>{});
+    v += ror(v, std::integral_constant<int, 1>{});
+    return v;
+}
+
 // launch K<false> (bf16) or K<true> (fp16) by the runtime format flag
 #define LAUNCH_HF(hf, K, ...)                                   \
     do {                                                        \
@@ -375,12 +387,7 @@ __global__ __launch_bounds__(256) void conv1x1_c3_kernel(const bf16_t* __restric
             s1 += lo * w1[2 * k] + hi * w1[2 * k + 1];
             s2 += lo * w2[2 * k] + hi * w2[2 * k + 1];
         }
-#pragma unroll
-        for (int o = 8; o > 0; o >>= 1) {
-            s0 += __shfl_xor(s0, o);
-            s1 += __shfl_xor(s1, o);
-            s2 += __shfl_xor(s2, o);
-        }
+        s0 = row_sum(s0); s1 = row_sum(s1); s2 = row_sum(s2);
         if (sub == 0) {
             out[pix * 3 + 0] = s0 + b0;
             out[pix * 3 + 1] = s1 + b1;

@@ -531,10 +531,9 @@ static int pick_cfg_f32(const IgemmDesc& d) {
 static int pick_cfg(const IgemmDesc& d) {
     const bool k64 = (d.Cin % 64 == 0);
     if (d.tune < 0 && d.ln_g) return k64 ? 13 : 19;  // fused LayerNorm: the whole row (N <= 128) in one 64(M) x 128(N) tile
-    // Ranked by rocprofv3 DEVICE durations of every shape x configuration (tools/igemm_tune.py,
-    // profiles/r01d_igemm_device_durations.txt; event timing from Python is host-bound below ~10 us and cannot rank these).
-    // Big problems are bound by the per-CU L2->LDS fill rate: take the LARGEST tile (most FLOPs per staged byte) that still
-    // fills the 256 CUs.  Small ones are latency-bound: take small tiles / short k-tiles so that many blocks are resident.
+    // History of this heuristic: first ranked by event timing from Python (host-bound below ~10 us: useless for the small
+    // launches), then by rocprofv3 device durations of repeated launches (tools/igemm_tune.py; warm caches flatter big
+    // one-workgroup-per-CU tiles and tiles that re-read weights), finally by timing every candidate inside the forward.
     if (d.tune >= 0) return d.tune;
     if (d.splitk > 1) return d.Cin % 128 == 0 ? 20 : 14;  // the split-K instantiations: 32(M) x 64(N) tiles
     if (d.N <= 32) return 5;
@@ -542,25 +541,20 @@ static int pick_cfg(const IgemmDesc& d) {
     const long K = (long)d.taps * d.Cin;
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128), b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
     if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 15 : 4;  // C = 96: layer1_rn (128x256x32) / stage-0 Linear layers (64x64x32)
-    if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output): 2 blocks per CU overlap it with the other block's main loop
-    // short K on a big problem (dpt_swin2_base_384 stages 0-2: K = 128..512, profiles/r01g_igemm_device_durations_base384.txt):
-    // the k-loop is a few tiles long, so prologue / epilogue dominate: 256x128 tiles with 32-deep k-tiles (3-stage ring)
-    if (K <= 512 && b128 >= 512 && d.N > 256) return 16;   // (N <= 256: the out_conv shapes with their f32 stores measured slower in the network)
-    if (d.N % 256 == 0) {
-        if (cdiv(d.M, 256) * (d.N / 256) >= 448) return 8;   // 256x256
-        const long t10 = cdiv(d.M, 128) * (d.N / 256);
-        if (t10 >= 224 || (t10 >= 128 && K >= 512)) return 10;  // 128(M)x256(N); on a half-filled chip only with enough K per tile
-    }
-    // short K, many output tiles (qkv / fc1 / proj / merge of the mid stages): write-heavy; 32-deep k-tiles halve the LDS
-    // footprint -> 5 blocks per CU
+    // The rules below were re-derived from IN-NETWORK timings of every candidate at every launch site of both models
+    // (tools/autotune_network.py, profiles/r01j_autotune_in_network_*.txt).  In the real launch sequence weights and activations
+    // arrive cold, and tiles that keep TWO workgroups per CU (128x128x64 s2, 256x128x32 s3, 64x64) beat the one-workgroup-per-CU
+    // tiles (128x256x64, 256x256x64) that win a warm repeated-launch benchmark: the second workgroup hides the cold misses.
+    if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output)
+    if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return 16;   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
+    // short K, many output tiles (qkv / fc1 / proj / merge): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
     if (K <= 1024 && b64 >= 512) return 4;
-    if (b128 >= 384) return 1;
-    // long-K problems whose 64x64 grid cannot fill the chip: halve the M tile (2x the blocks, 6-stage ring)
-    // (128-deep k-tiles halve the barriers of these latency-bound loops: 8-15 % over the 64-deep 6-stage ring.  A two-stage
-    //  variant (48 KB, 3 workgroups per CU) and the extension of 32x64x128 tiles to the shapes that run on 64x64 tiles both win
-    //  in warm micro-benchmarks (profiles/r01j_igemm_device_durations_k128.txt) and LOSE in the network, where weights and
-    //  activations arrive cold: 3712 -> 3580 frames/s.  Tune against the network, not only against a repeated launch.)
-    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return d.Cin % 128 != 0 ? 14 : 20;
+    if (b128 >= 256) return 1;
+    // small grids: halve the M tile (2x the workgroups) and use 128-deep k-tiles (half the barriers: 8-15 % over a 64-deep
+    // 6-stage ring).  A two-stage variant and a wider use of 32-row tiles both win warm and lose in the network (doubled weight
+    // re-reads): 3712 -> 3580 frames/s, reverted.
+    if (d.Cin % 128 == 0 && ((b64 < 256 && K >= 384) || (b64 <= 128 && K >= 256))) return 20;
+    if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return 14;
     return 2;  // 64x64: 4x the blocks of 128x128
 }
 
@@ -577,6 +571,8 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     while (S > 1 && (size_t)S * d.M * d.N > part_floats) --S;
     return (int)S;
 }
+
+int igemm_config_id(const IgemmDesc& d) { return d.f32 ? -1 : pick_cfg(d); }
 
 const char* igemm_family(const IgemmDesc& d) {
     if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];

@@ -78,12 +78,21 @@ struct ProfScope {
     }
 };
 
+// One distinct GEMM / conv shape of the launch sequence (in-network tuning: soccdpt_profile_sites, tools/autotune_network.py)
+struct SiteRec {
+    int M, N, K, taps, cfg, count;
+    char name[16];
+};
+
 struct Handle {
     soccdpt_config cfg;
     int device = 0;
     int img = 256;
     Arch arch;
     std::string err;
+    bool prof_sites = false;                              // profile igemm launches per shape ("site000", ...) instead of per tile family
+    std::vector<SiteRec> sites;                           // shapes seen while prof_sites was on, in first-launch order
+    std::unordered_map<long long, int> tune_by_shape;     // shape key -> forced tile configuration (in-network tuning)
     std::vector<WeightSlot> weights;
     std::unordered_map<std::string, int> index;
     size_t prepared_bytes = 0;

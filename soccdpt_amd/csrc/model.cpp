@@ -54,6 +54,8 @@ Handle::~Handle() {
 }
 
 namespace {
+inline long long shape_key(int M, int N, int K, int taps) { return (((long long)M * 8192 + N) * 65536 + K) * 16 + taps; }
+
 
 struct Arena {
     char* base;
@@ -242,6 +244,7 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
 }  // namespace
 
 static void carve_all(const Handle& h, int B, Arena& ar, std::vector<Workspace>& ws);
+static void chunk_range(int B, int n, int i, int& lo, int& hi);
 
 int model_init(Handle& h, std::string& err) {
     Arch a;
@@ -349,10 +352,16 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
     Arena ar(fake, ~size_t(0) >> 1);
     std::vector<Workspace> wsp;
     carve_all(h, B, ar, wsp);
-    if (wsp.size() != 1) return 2;  // taps are defined for the single-stream layout (set streams to 1 for diagnostics)
-    const Workspace& w = wsp[0];
+    // "name" addresses the single-stream layout; "name@i" the i-th concurrent sub-batch of a multi-stream layout (diagnostics)
+    std::string n(name);
+    size_t chunk = 0;
+    const size_t at = n.find('@');
+    if (at != std::string::npos) { chunk = (size_t)atoi(n.c_str() + at + 1); n.resize(at); }
+    else if (wsp.size() != 1) return 2;
+    if (chunk >= wsp.size()) return 2;
+    const Workspace& w = wsp[chunk];
     const Arch& a = h.arch;
-    const std::string n(name);
+    { int lo, hi; chunk_range(B, (int)wsp.size(), (int)chunk, lo, hi); B = hi - lo; }
     auto set = [&](const void* p, size_t e, int k, int hh, int ww, int cc) {
         *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
         return 0;
@@ -362,6 +371,7 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), hk, a.res(s), a.res(s), a.dim(s));
     const int r1 = 2 * a.res(0);
     if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
+    if (n == "seg_feat") return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, hk == 3 ? 0 : hk - 1, r1, r1, h.cfg.features);  // seg head conv3x3 + BN + ReLU output
     if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
     if (n == "xf") return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     return 1;
@@ -397,9 +407,28 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d) {
         d.f32 = F32 ? 1 : 0; d.f16 = HF;
+        const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps);
+        if (!h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py)
+            auto it = h.tune_by_shape.find(key);
+            if (it != h.tune_by_shape.end()) d.tune = it->second;
+        }
         d.splitk = igemm_pick_splitk(d, kSplitKPartFloats, kSplitKCountWords);
         if (d.splitk > 1) { d.sk_part = w.sk_part; d.sk_count = w.sk_count; d.sk_part_floats = kSplitKPartFloats; d.sk_count_words = kSplitKCountWords; }
-        PROF(igemm_family(d), igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
+        const char* pname = igemm_family(d);
+        if (h.prof_sites && h.prof.on) {
+            size_t i = 0;
+            for (; i < h.sites.size(); ++i)
+                if (shape_key(h.sites[i].M, h.sites[i].N, h.sites[i].K, h.sites[i].taps) == key) break;
+            if (i == h.sites.size() && h.sites.size() >= 1024) { err = "soccdpt: too many distinct igemm shapes for site profiling"; return 1; }
+            if (i == h.sites.size()) {
+                SiteRec r{d.M, d.N, d.taps * d.Cin, d.taps, igemm_config_id(d), 0, {0}};
+                snprintf(r.name, sizeof(r.name), "site%03zu", i);
+                h.sites.push_back(r);
+            }
+            h.sites[i].count++;
+            pname = h.sites[i].name;
+        }
+        PROF(pname, igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     // ---------------- encoder ----------------

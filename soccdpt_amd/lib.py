@@ -121,6 +121,12 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_training_loss.argtypes = [ci, ci, ci, ci, ci, ci, ci, cf, cf, cf, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     L.soccdpt_training_loss.restype = ci
     cd = ctypes.c_double
+    L.soccdpt_profile_sites.argtypes = [vp, ci]
+    L.soccdpt_site_count.argtypes = [vp]
+    ip = ctypes.POINTER(ctypes.c_int)
+    L.soccdpt_site_get.argtypes = [vp, ci, ip, ip, ip, ip, ip, ip]
+    L.soccdpt_tune_set.argtypes = [vp, ci, ci, ci, ci, ci]
+    L.soccdpt_tune_clear.argtypes = [vp]
     L.soccdpt_gt_occupancy.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp]
     L.soccdpt_gt_occupancy.restype = ci
     L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
@@ -274,6 +280,24 @@ class Engine:
                                                _ptr(points), _ptr(occ_bits), 1 if clear_bits else 0,
                                                _stream_ptr(self.device)), "soccdpt_project")
 
+    # ---- in-network tile tuning (tools/autotune_network.py) ----
+    def profile_sites(self, on: bool):
+        self._check(self.L.soccdpt_profile_sites(self._h, int(bool(on))), "soccdpt_profile_sites")
+
+    def sites(self):
+        out = []
+        for i in range(self.L.soccdpt_site_count(self._h)):
+            v = [ctypes.c_int() for _ in range(6)]
+            self._check(self.L.soccdpt_site_get(self._h, i, *[ctypes.byref(x) for x in v]), "soccdpt_site_get")
+            out.append(dict(site=f"site{i:03d}", M=v[0].value, N=v[1].value, K=v[2].value, taps=v[3].value, cfg=v[4].value, launches=v[5].value))
+        return out
+
+    def tune_set(self, M: int, N: int, K: int, taps: int, cfg: int):
+        self._check(self.L.soccdpt_tune_set(self._h, M, N, K, taps, cfg), "soccdpt_tune_set")
+
+    def tune_clear(self):
+        self._check(self.L.soccdpt_tune_clear(self._h), "soccdpt_tune_clear")
+
     def occ_or(self, dst_bits: torch.Tensor, src_bits: torch.Tensor, n_sets: int):
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_occ_or(self._h, _ptr(dst_bits), _ptr(src_bits), n_sets, _stream_ptr(self.device)),
@@ -333,6 +357,9 @@ class Engine:
         if rc != 0:
             raise KeyError(name)
         raw = self._workspace[off.value:]
+        if "@" in name:  # one concurrent sub-batch of a multi-stream layout: its frame count follows from the element count
+            halo = kind.value in (2, 3, 5)
+            B = n.value // ((H.value + 2 * halo) * (W.value + 2 * halo) * C.value)
         if kind.value == 0:
             return raw[: n.value * 4].view(torch.float32).reshape(B, H.value, W.value, C.value).clone()
         if kind.value == 3:

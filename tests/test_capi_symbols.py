@@ -47,3 +47,24 @@ def test_no_cpu_fallback():
                     cfg.grid_size, cfg.occupancy_shape(), cfg.pc_scale, cfg.pc_shift, cfg.correction_angle)
     with pytest.raises(RuntimeError):
         Engine(c, torch.device("cuda:0"))
+
+
+def test_device_code_has_no_packed_f32_ops(tmp_path):
+    """The shipped gfx950 code objects carry no v_pk_*_f32 instructions (soccdpt_amd/csrc/Makefile NOPK; DESIGN.md section 6:
+    a kernel dense in packed-f32 math returned wrong sums when it shared CUs with another stream's MFMA kernel)."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    so = os.path.join(REPO, "soccdpt_amd", "libsoccdpt_hip.so")
+    if not os.path.exists(objdump) or not os.path.exists(so):
+        pytest.skip("llvm-objdump or the built library is not present")
+    local = str(tmp_path / "lib.so")
+    shutil.copy(so, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=str(tmp_path))
+    bundles = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
+    assert bundles, "no gfx950 code object found in libsoccdpt_hip.so"
+    packed = 0
+    for b in bundles:
+        asm = subprocess.run([objdump, "-d", str(tmp_path / b)], check=True, capture_output=True, text=True).stdout
+        packed += len(re.findall(r"\bv_pk_(?:mul|add|fma)_f32\b", asm))
+    assert packed == 0, f"{packed} packed-f32 instructions in the device code"
