@@ -50,7 +50,7 @@ def test_no_cpu_fallback():
 
 
 def test_device_code_has_no_packed_f32_ops(tmp_path):
-    """The shipped gfx950 code objects carry no v_pk_*_f32 instructions (soccdpt_amd/csrc/Makefile NOPK; DESIGN.md section 6:
+    """The shipped gfx950 code objects carry no v_pk_*_f32 instructions (soccdpt_amd/csrc/Makefile NOPK; DESIGN.md section 4:
     a kernel dense in packed-f32 math returned wrong sums when it shared CUs with another stream's MFMA kernel)."""
     import shutil
     import subprocess
