@@ -185,6 +185,15 @@ int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const d
                          const double* rot27, const float* occ_shape, const int* grid, float threshold, const float* disparity,
                          const int32_t* seg_class, float* depth, double* points, uint32_t* counts, uint8_t* occ, void* stream);
 
+/* ---- input transform (model/loader.py:256-270 Compose([Resize, NormalizeImage, PrepareForNet])) ----
+ * img [B,Hs,Ws,3] u8 (RGB frames as the datasets hand them over, datasets/bengaluru_driving_dataset.py:118-130) ->
+ * out [B,3,Hd,Wd] f32 = (cv2.resize(img, (Wd,Hd), INTER_CUBIC) - mean) / std, channels first (model/transforms.py:178-251).
+ * The resampling is OpenCV's 8-bit bicubic fixed-point path (oracle/input_transform_ref.py states it; cv2 itself is not in the
+ * image, so this entry point is parity-unpinned).  Hd, Wd come from Resize.get_size (host side: soccdpt_amd/model/transforms.py).
+ * mean, std: 3 host doubles each (numpy evaluates the normalisation in float64). */
+int soccdpt_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd, int Wd, const double* mean, const double* stdv, float* out,
+                               void* stream);
+
 /* Fused multi-tensor Adam step, in place (torch.optim.Adam of scripts/train_SOccDPT.py:311-318; amsgrad=False):
  * params / grads / exp_avg / exp_avg_sq: HOST arrays of n_tensors DEVICE pointers (f32), sizes[i] elements each; step >= 1 is
  * the step count AFTER this update (bias corrections 1 - beta^step). */

@@ -268,6 +268,13 @@ int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const d
     return 0;
 }
 
+int soccdpt_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd, int Wd, const double* mean, const double* stdv, float* out,
+                               void* stream) {
+    std::string err;
+    if (launch_input_transform_u8(img, B, Hs, Ws, Hd, Wd, mean, stdv, out, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_adam_step(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg,
                       float* const* exp_avg_sq, const size_t* sizes, double lr, double beta1, double beta2, double eps,
                       double weight_decay, int step, void* stream) {

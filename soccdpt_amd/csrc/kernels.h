@@ -60,6 +60,10 @@ int launch_gt_occupancy(int B, int H, int W, int C, const double* intr, const do
                         const float* occ_shape, const int* grid, float threshold, const float* disparity, const int32_t* seg_class, float* depth,
                         double* points, uint32_t* counts, uint8_t* occ, hipStream_t st, std::string& err);
 
+// input_transform.hip: uint8 HWC frame -> bicubic (OpenCV 8-bit fixed point) resize -> (x - mean) / std -> float32 CHW
+int launch_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd, int Wd, const double* mean, const double* stdv, float* out,
+                              hipStream_t st, std::string& err);
+
 // adam.hip: fused multi-tensor Adam (host arrays of device pointers)
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                 const size_t* sizes, double lr, double beta1, double beta2, double eps, double weight_decay, int step, hipStream_t st,

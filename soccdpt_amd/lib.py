@@ -129,6 +129,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_tune_clear.argtypes = [vp]
     L.soccdpt_gt_occupancy.argtypes = [ci, ci, ci, ci, vp, vp, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, vp, vp]
     L.soccdpt_gt_occupancy.restype = ci
+    L.soccdpt_input_transform_u8.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(cd), ctypes.POINTER(cd), vp, vp]
+    L.soccdpt_input_transform_u8.restype = ci
     L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
     L.soccdpt_adam_step.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]
@@ -384,6 +386,20 @@ def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, re
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_input_transform_u8(frames: torch.Tensor, Hd: int, Wd: int, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)) -> torch.Tensor:
+    """uint8 [B,Hs,Ws,3] device frames -> float32 [B,3,Hd,Wd] network input (soccdpt_input_transform_u8) on the current stream."""
+    L = load_library()
+    assert frames.dtype == torch.uint8 and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_cuda
+    B, Hs, Ws, _ = frames.shape
+    out = torch.empty((B, 3, Hd, Wd), dtype=torch.float32, device=frames.device)
+    m, s = (ctypes.c_double * 3)(*mean), (ctypes.c_double * 3)(*std)
+    with torch.cuda.device(frames.device):
+        rc = L.soccdpt_input_transform_u8(_ptr(frames), B, Hs, Ws, Hd, Wd, m, s, _ptr(out), _stream_ptr(frames.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_input_transform_u8 failed: " + L.soccdpt_last_error(None).decode())
+    return out
 
 
 def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads, precision=PREC_BF16):

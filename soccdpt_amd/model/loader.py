@@ -7,6 +7,7 @@ import torch
 
 from .base_model import BaseModel
 from .spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+from .transforms import InputTransform
 
 
 def load_model(arch, model_kwargs: dict, device: torch.device, model_path: str, model_type: str = "dpt_large_384",
@@ -33,29 +34,18 @@ def load_model(arch, model_kwargs: dict, device: torch.device, model_path: str, 
     return model
 
 
-class _NormalizePrepare:
-    """NormalizeImage(mean=0.5,std=0.5) + PrepareForNet (model/transforms.py:206-251) for images that are
-    already at network resolution; the cv2 Resize step of the reference is host-side preprocessing outside
-    the hot path (SURVEY.md §8f #3)."""
-
-    def __init__(self, net_w, net_h):
-        self.net_w, self.net_h = net_w, net_h
-
-    def __call__(self, sample):
-        img = np.asarray(sample["image"], dtype=np.float32)
-        assert img.shape[0] == self.net_h and img.shape[1] == self.net_w, "resize to network resolution first"
-        img = (img - 0.5) / 0.5
-        sample["image"] = np.ascontiguousarray(np.transpose(img, (2, 0, 1))).astype(np.float32)
-        return sample
-
-
 def load_transforms(model_type: str = "dpt_large_384", height: int = 0, square: bool = False):
-    """Returns (transform, net_w, net_h) (loader.py:141-272).  Sizes follow the model (the reference
-    returns 256 for dpt_swin2_base_384, an inconsistency noted in SURVEY.md §3.4)."""
+    """Returns (transform, net_w, net_h) (loader.py:141-272): Resize(cubic, ensure_multiple_of=32, "minimal") + NormalizeImage(0.5, 0.5)
+    + PrepareForNet as one GPU transform (model/transforms.py here).  Sizes follow the model (the reference returns 256 for
+    dpt_swin2_base_384, an inconsistency noted in SURVEY.md section 3.4); the Swin-V2 types do not keep the aspect ratio
+    (loader.py:183-204), the others do unless `square`."""
     if model_type not in MODEL_TYPE_TO_BACKBONE:
         print(f"model_type '{model_type}' not implemented")
         assert False, f"model_type '{model_type}' not implemented"
     backbone = MODEL_TYPE_TO_BACKBONE[model_type]
     size = SWIN_ARCHS[backbone].img if backbone in SWIN_ARCHS else 384
     net_w = net_h = size
-    return _NormalizePrepare(net_w, net_h), net_w, net_h
+    keep_aspect_ratio = False if backbone in SWIN_ARCHS else (not square)
+    if height != 0:
+        net_w = net_h = height
+    return InputTransform(net_w, net_h, keep_aspect_ratio=keep_aspect_ratio, ensure_multiple_of=32, resize_method="minimal"), net_w, net_h
