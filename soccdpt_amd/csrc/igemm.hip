@@ -190,13 +190,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 #pragma unroll
     for (int s0 = 0; s0 < C::NS - 1; ++s0)
         if (s0 < nk) stage(s0, s0);
-    // (Tried and REMOVED: running the wm == 1 wave row of the 8-wave tiles half a k-step out of phase, | M1' R0 M0 R1 | against
-    //  | R0 M0 R1 M1 |, so that the two waves of a SIMD alternate load and MFMA halves.  It was worth 5-8 % on the 256x256 and
-    //  128x256 convs only when the lagging row also issued its LDS-DMA late, and exactly that variant produced rare wrong
-    //  tiles once another kernel's waves were co-resident -- tools/skew_race_probe.py, found by the hipGraph replay test --
-    //  although every read followed its covering vmcnt + barrier.  With the DMA issue moved back to the barrier it was clean
-    //  and no faster.  cdna_hip_programming.md warns that staggered wave groups need one more barrier per phase; that is
-    //  the 8-phase template's job, not a patch on this loop.)
+    // (Tried and removed: running the wm == 1 wave row of the 8-wave tiles half a k-step out of phase, | M1' R0 M0 R1 | against
+    //  | R0 M0 R1 M1 |, so that the two waves of a SIMD alternate load and MFMA halves: 5-8 % on the 256x256 / 128x256 convs.
+    //  It was dropped when wrong seg pixels showed up in the eager two-stream mode; the same signature was later traced to
+    //  packed-f32 math in the seg head's 1x1 kernel under co-residency, so the schedule was probably
+    //  innocent -- but the retuned heuristics no longer pick the tiles it applied to.)
     {
     for (int kt = 0; kt < nk; ++kt) {
         wait_tile(kt);

@@ -318,7 +318,7 @@ def test_hip_graph_replay_matches_eager(net, gpu_device, streams):
 
 
 def test_back_to_back_modes_without_host_sync(net, gpu_device):
-    """Regression test for a timing-dependent schedule race (tools/skew_race_probe.py): graph(2 streams) -> eager(2 streams) ->
+    """Regression test for a timing-dependent schedule race (tools/multistream_probe.py): graph(2 streams) -> eager(2 streams) ->
     eager(1 stream) enqueued back to back, no host synchronisation in between, so that the sub-batch streams really overlap and
     kernels of different launches are co-resident.  Every mode must give the single-stream result."""
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
