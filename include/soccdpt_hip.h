@@ -185,6 +185,14 @@ int soccdpt_gt_occupancy(int B, int H, int W, int C, const double* intr, const d
                          const double* rot27, const float* occ_shape, const int* grid, float threshold, const float* disparity,
                          const int32_t* seg_class, float* depth, double* points, uint32_t* counts, uint8_t* occ, void* stream);
 
+/* Fused MLP half-block of a Swin-V2 block (kernel-level entry for parity tests; the network uses it for the narrow stages):
+ *   x_f32[m][:] += LayerNorm(fc2(GELU(fc1(x_op[m][:]))))      fc1: w1 [4C][C] + b1, fc2: w2 [C][4C] + b2, LayerNorm eps 1e-5
+ * (timm Mlp + res-post-norm).  x_op [M][C] 16-bit operand copy of x (bf16 / fp16 by precision), w1 / w2 in the
+ * same format; x_op_out (may alias x_op) receives the operand copy of the new x, halo (nullable) a zero-halo NHWC image of it
+ * ([B][H+2][W+2][C], M = B*H*W).  C in {96, 128, 192, 256}. */
+int soccdpt_op_mlp_ln(const void* x_op, float* x_f32, const void* w1, const float* b1, const void* w2, const float* b2, const float* ln_g,
+                      const float* ln_b, void* x_op_out, void* halo, int precision, int M, int C, int H, int W, void* stream);
+
 /* ---- input transform (model/loader.py:256-270 Compose([Resize, NormalizeImage, PrepareForNet])) ----
  * img [B,Hs,Ws,3] u8 (RGB frames as the datasets hand them over, datasets/bengaluru_driving_dataset.py:118-130) ->
  * out [B,3,Hd,Wd] f32 = (cv2.resize(img, (Wd,Hd), INTER_CUBIC) - mean) / std, channels first (model/transforms.py:178-251).

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstring>
+#include <cstdlib>
 #include <string>
 
 #include "internal.h"
@@ -38,6 +39,7 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
     Handle* h = new Handle();
+    if (const char* e = getenv("SOCCDPT_MLP_FUSE_MAX")) h->mlp_fuse_max = atoi(e);   // measurement switch (0 = unfused everywhere)
     h->cfg = *cfg;
     (void)hipGetDevice(&h->device);
     std::string err;
@@ -272,6 +274,16 @@ int soccdpt_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd
                                void* stream) {
     std::string err;
     if (launch_input_transform_u8(img, B, Hs, Ws, Hd, Wd, mean, stdv, out, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_op_mlp_ln(const void* x_op, float* x_f32, const void* w1, const float* b1, const void* w2, const float* b2, const float* ln_g,
+                      const float* ln_b, void* x_op_out, void* halo, int precision, int M, int C, int H, int W, void* stream) {
+    std::string err;
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16) return fail(nullptr, "soccdpt_op_mlp_ln: 16-bit operand modes only");
+    if (launch_mlp_ln(static_cast<const bf16_t*>(x_op), x_f32, static_cast<const bf16_t*>(w1), b1, static_cast<const bf16_t*>(w2), b2, ln_g, ln_b,
+                      static_cast<bf16_t*>(x_op_out), static_cast<bf16_t*>(halo), precision == SOCCDPT_PREC_F16, M, C, H, W, (hipStream_t)stream, err))
+        return fail(nullptr, err);
     return 0;
 }
 

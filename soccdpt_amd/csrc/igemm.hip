@@ -20,6 +20,7 @@
 //  * blockIdx is remapped so the N-tiles that share an activation tile run on one XCD (L2 reuse).
 #include <type_traits>
 
+#include "gelu.h"
 #include "half16.h"
 #include "igemm.h"
 
@@ -52,20 +53,6 @@ __device__ __forceinline__ int swz_of_row(int row) {
     if constexpr (BK == 128) return row & 15;        // 256-byte rows (one full bank sweep each): 16 chunks
     else if constexpr (BK == 64) return row & 7;     // 128-byte rows: 8 chunks
     else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
-}
-
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-// erf by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute): 1 rcp + 1 exp + 7 fma.  Used on the bf16 path,
-// whose outputs are rounded to 8 mantissa bits anyway; the exact-f32 path keeps erff.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __frcp_rn(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = 1.0f - p * t * __expf(-z * z);  // erf(|x|/sqrt2)
-    return 0.5f * x * (1.0f + copysignf(e, x));
 }
 
 // T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16) or float (v_mfma_f32_16x16x4_f32, exact f32).

@@ -93,6 +93,7 @@ struct Handle {
     bool prof_sites = false;                              // profile igemm launches per shape ("site000", ...) instead of per tile family
     std::vector<SiteRec> sites;                           // shapes seen while prof_sites was on, in first-launch order
     std::unordered_map<long long, int> tune_by_shape;     // shape key -> forced tile configuration (in-network tuning)
+    int mlp_fuse_max = 128;                               // widest stage whose MLP half-block runs as one fused launch (mlp_fused.hip; wider ones lose)
     std::vector<WeightSlot> weights;
     std::unordered_map<std::string, int> index;
     size_t prepared_bytes = 0;

@@ -64,6 +64,11 @@ int launch_gt_occupancy(int B, int H, int W, int C, const double* intr, const do
 int launch_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd, int Wd, const double* mean, const double* stdv, float* out,
                               hipStream_t st, std::string& err);
 
+// mlp_fused.hip: x <- x + LN(fc2(GELU(fc1(x_op)))) in one launch for the narrow stages (C = 96 / 128 / 192 / 256), 16-bit operands
+bool mlp_ln_supported(int C);
+int launch_mlp_ln(const bf16_t* xop, float* xf, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, const float* g, const float* be,
+                  bf16_t* xop_out, bf16_t* halo, int hf, int M, int C, int H, int W, hipStream_t st, std::string& err);
+
 // adam.hip: fused multi-tensor Adam (host arrays of device pointers)
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                 const size_t* sizes, double lr, double beta1, double beta2, double eps, double weight_decay, int step, hipStream_t st,

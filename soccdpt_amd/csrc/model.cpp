@@ -459,6 +459,14 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
                   RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, st, err)); }
             }
+            if (!F32 && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
+                const bool hook = (j == a.hooks[s]);
+                PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
+                RUN(launch_mlp_ln(static_cast<const bf16_t*>(w.xb), w.xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
+                                  bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(w.xb), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, HF, M, C, res, res,
+                                  st, err));
+                continue;
+            }
             d = IgemmDesc();
             d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = w.hbuf;
             RUN(gemm(d));

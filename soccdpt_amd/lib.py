@@ -131,6 +131,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_gt_occupancy.restype = ci
     L.soccdpt_input_transform_u8.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(cd), ctypes.POINTER(cd), vp, vp]
     L.soccdpt_input_transform_u8.restype = ci
+    L.soccdpt_op_mlp_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
+    L.soccdpt_op_mlp_ln.restype = ci
     L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
     L.soccdpt_adam_step.restype = ci
     L.soccdpt_set_streams.argtypes = [vp, ci]
@@ -400,6 +402,16 @@ def op_input_transform_u8(frames: torch.Tensor, Hd: int, Wd: int, mean=(0.5, 0.5
     if rc != 0:
         raise RuntimeError("soccdpt_input_transform_u8 failed: " + L.soccdpt_last_error(None).decode())
     return out
+
+
+def op_mlp_ln(x_op, x_f32, w1, b1, w2, b2, ln_g, ln_b, x_op_out=None, halo=None, precision=PREC_BF16, H=0, W=0):
+    """Kernel-level entry (tests): x_f32 += LN(fc2(GELU(fc1(x_op)))) in one launch (soccdpt_op_mlp_ln) on the current stream."""
+    L = load_library()
+    M, C = x_op.shape
+    rc = L.soccdpt_op_mlp_ln(_ptr(x_op), _ptr(x_f32), _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2), _ptr(ln_g), _ptr(ln_b), _ptr(x_op_out), _ptr(halo),
+                             int(precision), M, C, H, W, _stream_ptr(x_op.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_mlp_ln failed: " + L.soccdpt_last_error(None).decode())
 
 
 def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads, precision=PREC_BF16):

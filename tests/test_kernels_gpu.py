@@ -303,3 +303,45 @@ def test_igemm_conv3x3_f32(gpu_device, B, H, Cin, Cout):
     torch.cuda.synchronize()
     torch.testing.assert_close(out, ref, rtol=2e-5, atol=2e-5)
     torch.testing.assert_close(outh[:, 1:-1, 1:-1], F.relu(ref), rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("M,C,prec,hook", [(640, 96, "bf16", False), (2 * 16 * 16, 96, "bf16", True), (300, 128, "f16", False), (1000, 192, "bf16", False),
+                                           (2 * 8 * 8, 256, "f16", True), (64, 128, "bf16", False)])
+def test_mlp_ln_fused(gpu_device, M, C, prec, hook):
+    """soccdpt_op_mlp_ln: x += LayerNorm(fc2(GELU(fc1(x_op)))) in one launch against the same chain in torch fp32 on the rounded
+    operands (hidden activation rounded to the operand format, as the unfused path stores it); ragged M, both formats, halo copy."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, op_mlp_ln
+    dt, pr = (torch.bfloat16, PREC_BF16) if prec == "bf16" else (torch.float16, PREC_F16)
+    g = torch.Generator().manual_seed(M + C)
+    x = torch.randn(M, C, generator=g)
+    xop = x.to(dt).to(gpu_device)
+    xf = x.clone().to(gpu_device)
+    w1 = (torch.randn(4 * C, C, generator=g) / math.sqrt(C)).to(dt).to(gpu_device)
+    b1 = (0.2 * torch.randn(4 * C, generator=g)).to(gpu_device)
+    w2 = (torch.randn(C, 4 * C, generator=g) / math.sqrt(4 * C)).to(dt).to(gpu_device)
+    b2 = (0.2 * torch.randn(C, generator=g)).to(gpu_device)
+    lg = (1 + 0.3 * torch.randn(C, generator=g)).to(gpu_device)
+    lb = (0.3 * torch.randn(C, generator=g)).to(gpu_device)
+    hid = F.gelu(xop.float() @ w1.float().t() + b1).to(dt).float()
+    ref = xf + F.layer_norm(hid @ w2.float().t() + b2, (C,), lg, lb, eps=1e-5)
+    out_op = torch.zeros(M, C, dtype=dt, device=gpu_device)
+    halo = None
+    Hh = 0
+    if hook:
+        Hh = int(round(math.sqrt(M / 2)))
+        halo = torch.zeros(2, Hh + 2, Hh + 2, C, dtype=dt, device=gpu_device)
+    got = xf.clone()
+    op_mlp_ln(xop, got, w1, b1, w2, b2, lg, lb, x_op_out=out_op, halo=halo, precision=pr, H=Hh, W=Hh)
+    torch.cuda.synchronize()
+    tol = 2e-2 if prec == "bf16" else 3e-3     # LayerNorm output is O(1); the hidden tile is rounded to 8 / 11 significand bits
+    torch.testing.assert_close(got, ref, rtol=tol, atol=tol)
+    assert float((got - ref).pow(2).sum().sqrt() / ref.pow(2).sum().sqrt()) < (4e-3 if prec == "bf16" else 5e-4)
+    torch.testing.assert_close(out_op.float(), got.to(dt).float(), rtol=0, atol=0)
+    if hook:
+        torch.testing.assert_close(halo[:, 1:-1, 1:-1].reshape(M, C).float(), got.to(dt).float(), rtol=0, atol=0)
+        assert float(halo[:, 0].abs().max()) == 0 and float(halo[:, :, -1].abs().max()) == 0
+    # in place on the operand copy (how the network calls it)
+    xop2, got2 = xop.clone(), xf.clone()
+    op_mlp_ln(xop2, got2, w1, b1, w2, b2, lg, lb, x_op_out=xop2, precision=pr)
+    torch.cuda.synchronize()
+    assert torch.equal(got2, got) and torch.equal(xop2, out_op)
