@@ -128,10 +128,16 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
 
         f32x16 s[A::KT];
         const float* bp = bias_acc + ((size_t)(head * A::QB + qb) * A::KT) * 1024 + lane * 16;
+        // the bias tile of key tile t + 1 is requested before the MFMAs of tile t (the accumulator cannot start without it)
+        float4 n0, n1, n2, n3;
+        { const float4* b4 = reinterpret_cast<const float4*>(bp); n0 = b4[0]; n1 = b4[1]; n2 = b4[2]; n3 = b4[3]; }
 #pragma unroll
         for (int t = 0; t < A::KT; ++t) {
-            const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)t * 1024);
-            const float4 b0 = b4[0], b1 = b4[1], b2 = b4[2], b3 = b4[3];
+            const float4 b0 = n0, b1 = n1, b2 = n2, b3 = n3;
+            if (t + 1 < A::KT) {
+                const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)(t + 1) * 1024);
+                n0 = b4[0]; n1 = b4[1]; n2 = b4[2]; n3 = b4[3];
+            }
             f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
             if constexpr (WS == 16) {
                 // shift mask (0 / -100): region differs in the last window row (token rows >= 8) or column (cols >= 8)
