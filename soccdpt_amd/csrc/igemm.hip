@@ -282,6 +282,21 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
             }
         }
+        // the residual rows are requested before the two reduction passes (their latency hides behind the barriers)
+        float4 xres[C::TN][C::TM];
+        if (d.ln_residual) {
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) {
+                int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+                m = m < d.M ? m : d.M - 1;
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) {
+                    int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                    n = n < N ? n : 0;
+                    xres[i][j] = *reinterpret_cast<const float4*>(d.ln_xf + (size_t)m * N + n);
+                }
+            }
+        }
         float mean[C::TM], rstd[C::TM];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 o[2] = (acc[i][j][2] - mean[j]) * rstd[j] * g4.z + e4.z;
                 o[3] = (acc[i][j][3] - mean[j]) * rstd[j] * g4.w + e4.w;
                 if (d.ln_residual) {
-                    const float4 x4 = *reinterpret_cast<const float4*>(d.ln_xf + orow + n);
+                    const float4 x4 = xres[i][j];
                     o[0] += x4.x; o[1] += x4.y; o[2] += x4.z; o[3] += x4.w;
                 }
                 *reinterpret_cast<float4*>(d.ln_xf + orow + n) = make_float4(o[0], o[1], o[2], o[3]);

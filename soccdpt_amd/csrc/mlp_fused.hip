@@ -170,6 +170,10 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
 #pragma unroll
     for (int t = 0; t < K::TM2; ++t) {
         const int m = m0 + (wave * K::TM2 + t) * 16 + frow;
+        const int mc = m < M ? m : M - 1;
+        float4 xres[K::TN2];   // the residual row is requested before the LayerNorm reductions, not after them
+#pragma unroll
+        for (int i = 0; i < K::TN2; ++i) xres[i] = *reinterpret_cast<const float4*>(xf + (size_t)mc * C + i * 16 + fq * 4);
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < K::TN2; ++i) {
@@ -201,7 +205,7 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
         for (int i = 0; i < K::TN2; ++i) {
             const int n = i * 16 + fq * 4;
             const float4 g4 = *reinterpret_cast<const float4*>(g + n), e4 = *reinterpret_cast<const float4*>(be + n);
-            const float4 x4 = *reinterpret_cast<const float4*>(xf + orow + n);
+            const float4 x4 = xres[i];
             float o[4];
             o[0] = x4.x + ((acc2[t][i][0] - mean) * rstd * g4.x + e4.x);
             o[1] = x4.y + ((acc2[t][i][1] - mean) * rstd * g4.y + e4.y);
