@@ -155,6 +155,28 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 #pragma unroll
         for (int j = 0; j < C::TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
+    // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
+    // its own.  Big tiles keep their registers (the epilogue latency is amortised over hundreds of MFMAs there).
+    constexpr bool PRE = !SK && (C::TN * C::TM <= 8);
+    float4 bias_pre[PRE ? C::TN : 1];
+    float4 res1_pre[PRE ? C::TN : 1][PRE ? C::TM : 1];
+    if constexpr (PRE) {
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i) {
+            int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            n = n < d.N ? n : 0;
+            bias_pre[i] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) {
+                int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+                m = m < d.M ? m : d.M - 1;
+                res1_pre[i][j] = d.res1 ? *reinterpret_cast<const float4*>(d.res1 + (size_t)m * d.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+
     // fragment read offsets (bytes within a stage), constant per lane
     const int frow = lane & 15, fq = lane >> 4;
     const int fswz = swz_of_row<C::BK>(frow);
@@ -276,7 +298,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         for (int i = 0; i < C::TN; ++i) {
             const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
+            if constexpr (PRE) { if (n < N) b4 = bias_pre[i]; }
+            else if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
 #pragma unroll
             for (int j = 0; j < C::TM; ++j) {
                 acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
@@ -407,13 +430,19 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
             if (!mv || n >= N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (d.bias) {
-                const float4 b4 = *reinterpret_cast<const float4*>(d.bias + n);
+            if constexpr (PRE) {
+                const float4 b4 = bias_pre[i], r4 = res1_pre[i][j];   // zeros when absent; same (acc + bias) + res1 order as the other branch
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
-            }
-            if (d.res1) {
-                const float4 r4 = *reinterpret_cast<const float4*>(d.res1 + orow + n);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            } else {
+                if (d.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(d.bias + n);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (d.res1) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(d.res1 + orow + n);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
             }
             if (d.res2 && d.res2_h) {
                 const float4 a00 = *reinterpret_cast<const float4*>(d.res2 + up00 + n), a01 = *reinterpret_cast<const float4*>(d.res2 + up01 + n);
