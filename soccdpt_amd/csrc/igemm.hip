@@ -157,16 +157,18 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 
     // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
     // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
-    // its own.  Big tiles keep their registers (the epilogue latency is amortised over hundreds of MFMAs there).
+    // its own.  Big tiles prefetch only the bias (their residual rows would cost 64 registers).
     constexpr bool PRE = !SK && (C::TN * C::TM <= 8);
-    float4 bias_pre[PRE ? C::TN : 1];
+    constexpr bool PREB = !SK;   // the bias alone is cheap enough (TN x 4 registers) for every tile size: 128x128 convs 338 -> 323 us
+    float4 bias_pre[PREB ? C::TN : 1];
     float4 res1_pre[PRE ? C::TN : 1][PRE ? C::TM : 1];
-    if constexpr (PRE) {
+    if constexpr (PREB) {
 #pragma unroll
         for (int i = 0; i < C::TN; ++i) {
             int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
             n = n < d.N ? n : 0;
             bias_pre[i] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PRE)
 #pragma unroll
             for (int j = 0; j < C::TM; ++j) {
                 int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         for (int i = 0; i < C::TN; ++i) {
             const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if constexpr (PRE) { if (n < N) b4 = bias_pre[i]; }
+            if constexpr (PREB) { if (n < N) b4 = bias_pre[i]; }
             else if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
 #pragma unroll
             for (int j = 0; j < C::TM; ++j) {
@@ -435,7 +437,10 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             } else {
-                if (d.bias) {
+                if constexpr (PREB) {
+                    const float4 b4 = bias_pre[i];
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                } else if (d.bias) {
                     const float4 b4 = *reinterpret_cast<const float4*>(d.bias + n);
                     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
                 }
