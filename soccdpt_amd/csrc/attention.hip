@@ -70,16 +70,25 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         return (size_t)(b * res + sy) * res + sx;
     };
 
-    // ---- stage Q-hat (own query rows only), K-hat, V^T ----
+    // ---- stage Q-hat (own query rows only), K-hat, V^T: all loads of the thread are requested first (one memory latency) ----
+    constexpr int STG = (A::N * 4) / A::THREADS;
+    uint4 qld[STG], kld[STG], vld[STG];
 #pragma unroll
-    for (int it = 0; it < (A::N * 4) / A::THREADS; ++it) {
+    for (int it = 0; it < STG; ++it) {
         const int idx = it * A::THREADS + tid;
         const int p = idx >> 2, c = idx & 3;
         const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
         const bool own_q = QS == 1 || (p / (A::N / QS)) == qh;  // uniform over the 4 lanes of a token
-        const uint4 qv = own_q ? *reinterpret_cast<const uint4*>(src) : make_uint4(0u, 0u, 0u, 0u);
-        const uint4 kv = *reinterpret_cast<const uint4*>(src + C);
-        const uint4 vv = *reinterpret_cast<const uint4*>(src + 2 * C);
+        qld[it] = own_q ? *reinterpret_cast<const uint4*>(src) : make_uint4(0u, 0u, 0u, 0u);
+        kld[it] = *reinterpret_cast<const uint4*>(src + C);
+        vld[it] = *reinterpret_cast<const uint4*>(src + 2 * C);
+    }
+#pragma unroll
+    for (int it = 0; it < STG; ++it) {
+        const int idx = it * A::THREADS + tid;
+        const int p = idx >> 2, c = idx & 3;
+        const bool own_q = QS == 1 || (p / (A::N / QS)) == qh;
+        const uint4 qv = qld[it], kv = kld[it], vv = vld[it];
         const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
         float qf[8], kf[8];
         float qs = 0.f, ks = 0.f;
