@@ -297,19 +297,32 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
             pc = vcm[e];
         }
     }
-    if (!valid) return;
     const size_t n0 = (size_t)u * P.Wc + v0;
-    if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
-    if (P.seg_up) {
+    if (valid) {
+        if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
+        if (P.seg_up) {
 #pragma unroll
-        for (int c = 0; c < C; ++c)
-            *reinterpret_cast<float4*>(P.seg_up + ((size_t)b * C + c) * npix + n0) = make_float4(sem[c][0], sem[c][1], sem[c][2], sem[c][3]);
+            for (int c = 0; c < C; ++c)
+                *reinterpret_cast<float4*>(P.seg_up + ((size_t)b * C + c) * npix + n0) = make_float4(sem[c][0], sem[c][1], sem[c][2], sem[c][3]);
+        }
     }
     if (P.points) {
-        float4* o = reinterpret_cast<float4*>(P.points + ((size_t)b * npix + n0) * 3);
-        o[0] = make_float4(pt[0][0], pt[0][1], pt[0][2], pt[1][0]);
-        o[1] = make_float4(pt[1][1], pt[1][2], pt[2][0], pt[2][1]);
-        o[2] = make_float4(pt[2][2], pt[3][0], pt[3][1], pt[3][2]);
+        // a thread's 4 points are 48 contiguous bytes: written directly, each of the 3 store instructions of a wave touches every third
+        // 16-byte slot.  Through LDS the workgroup's 12 KB leave as three fully contiguous 4 KB sweeps instead.
+        __shared__ float4 s_pts[3 * 256];
+        if (valid) {
+            s_pts[3 * threadIdx.x + 0] = make_float4(pt[0][0], pt[0][1], pt[0][2], pt[1][0]);
+            s_pts[3 * threadIdx.x + 1] = make_float4(pt[1][1], pt[1][2], pt[2][0], pt[2][1]);
+            s_pts[3 * threadIdx.x + 2] = make_float4(pt[2][2], pt[3][0], pt[3][1], pt[3][2]);
+        }
+        __syncthreads();
+        const int nf4 = ((vhi - vlo) / 4) * 3;   // float4 slots of this row segment
+        float4* o = reinterpret_cast<float4*>(P.points + ((size_t)b * npix + (size_t)u * P.Wc + vlo) * 3);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const int idx = k * 256 + (int)threadIdx.x;
+            if (idx < nf4) o[idx] = s_pts[idx];
+        }
     }
 }
 
