@@ -299,11 +299,12 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
     }
     const size_t n0 = (size_t)u * P.Wc + v0;
     if (valid) {
-        if (P.inv_up) *reinterpret_cast<float4*>(P.inv_up + (size_t)b * npix + n0) = make_float4(iv[0], iv[1], iv[2], iv[3]);
+        typedef __attribute__((ext_vector_type(4))) float v4f;
+        if (P.inv_up) __builtin_nontemporal_store(v4f{iv[0], iv[1], iv[2], iv[3]}, reinterpret_cast<v4f*>(P.inv_up + (size_t)b * npix + n0));
         if (P.seg_up) {
 #pragma unroll
             for (int c = 0; c < C; ++c)
-                *reinterpret_cast<float4*>(P.seg_up + ((size_t)b * C + c) * npix + n0) = make_float4(sem[c][0], sem[c][1], sem[c][2], sem[c][3]);
+                __builtin_nontemporal_store(v4f{sem[c][0], sem[c][1], sem[c][2], sem[c][3]}, reinterpret_cast<v4f*>(P.seg_up + ((size_t)b * C + c) * npix + n0));
         }
     }
     if (P.points) {
@@ -321,7 +322,11 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const int idx = k * 256 + (int)threadIdx.x;
-            if (idx < nf4) o[idx] = s_pts[idx];
+            if (idx < nf4) {
+                typedef __attribute__((ext_vector_type(4))) float v4f;
+                const float4 q = s_pts[idx];
+                __builtin_nontemporal_store(v4f{q.x, q.y, q.z, q.w}, reinterpret_cast<v4f*>(o + idx));
+            }
         }
     }
 }
