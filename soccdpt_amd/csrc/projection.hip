@@ -338,7 +338,10 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const uint32_t* __restr
         const size_t n = q * 4;
         const uint32_t wv = bits[n >> 5] >> (n & 31);
         const float4 val = make_float4((float)(wv & 1u), (float)((wv >> 1) & 1u), (float)((wv >> 2) & 1u), (float)((wv >> 3) & 1u));
-        for (int b = 0; b < B; ++b) *reinterpret_cast<float4*>(occ + (size_t)b * ncell + n) = val;
+        for (int b = 0; b < B; ++b) {   // write-once 25 MB rows: streamed past the caches
+            typedef __attribute__((ext_vector_type(4))) float v4f;
+            __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(occ + (size_t)b * ncell + n));
+        }
     }
 }
 
