@@ -282,7 +282,7 @@ int soccdpt_op_mlp_ln(const void* x_op, float* x_f32, const void* w1, const floa
     std::string err;
     if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16) return fail(nullptr, "soccdpt_op_mlp_ln: 16-bit operand modes only");
     if (launch_mlp_ln(static_cast<const bf16_t*>(x_op), x_f32, static_cast<const bf16_t*>(w1), b1, static_cast<const bf16_t*>(w2), b2, ln_g, ln_b,
-                      static_cast<bf16_t*>(x_op_out), static_cast<bf16_t*>(halo), precision == SOCCDPT_PREC_F16, M, C, H, W, (hipStream_t)stream, err))
+                      static_cast<bf16_t*>(x_op_out), static_cast<bf16_t*>(halo), precision == SOCCDPT_PREC_F16, M, C, H, W, 0, (hipStream_t)stream, err))
         return fail(nullptr, err);
     return 0;
 }

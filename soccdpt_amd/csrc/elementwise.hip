@@ -141,7 +141,7 @@ template <int VPL, bool F16>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                           int C, int residual, int res /*spatial size for halo*/) {
+                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -169,10 +169,13 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
         q += d * d;
     }
     const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
-    size_t hoff = 0;
-    if (halo || halo_f32) {
+    size_t hoff = 0, boff = (size_t)row * C;
+    if (halo || halo_f32 || merge) {
         const int hw = res * res, b = row / hw, r = row - b * hw, yy = r / res, xx = r - yy * res;
         hoff = ((size_t)(b * (res + 2) + yy + 1) * (res + 2) + xx + 1) * C;
+        // merge: the operand copy goes straight into the PatchMerging layout [B][res/2][res/2][4C], channel block (yy&1) + 2*(xx&1)
+        // (timm order x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]): the gather kernel before the reduction GEMM disappears
+        if (merge) boff = (((size_t)(b * (res / 2) + yy / 2) * (res / 2) + xx / 2) * 4 + (yy & 1) + 2 * (xx & 1)) * C;
     }
 #pragma unroll
     for (int t = 0; t < VPL; ++t) {
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
             if (residual) o += xr[t];
             xf[(size_t)row * C + c] = o;
             const bf16_t ob = f2h<F16>(o);
-            if (xb) xb[(size_t)row * C + c] = ob;
+            if (xb) xb[boff + c] = ob;
             if (halo) halo[hoff + c] = ob;
             if (halo_f32) halo_f32[hoff + c] = o;
         }
@@ -190,13 +193,14 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
 }
 
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, hipStream_t st, std::string& err) {
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err) {
+    if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
-        if (hf) hipLaunchKernelGGL((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res);  \
-        else hipLaunchKernelGGL((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res);    \
+        if (hf) hipLaunchKernelGGL((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
+        else hipLaunchKernelGGL((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
     } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);

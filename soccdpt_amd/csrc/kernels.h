@@ -23,7 +23,7 @@ inline int check_launch(const char* what, std::string& err) {
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
                        int hf, int B, int S, int C0, hipStream_t st, std::string& err);
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, hipStream_t st, std::string& err);
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err);
 int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err);
 int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
                     int w, int H, int W, int C, hipStream_t st, std::string& err);
@@ -67,7 +67,7 @@ int launch_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd,
 // mlp_fused.hip: x <- x + LN(fc2(GELU(fc1(x_op)))) in one launch for the narrow stages (C = 96 / 128 / 192 / 256), 16-bit operands
 bool mlp_ln_supported(int C);
 int launch_mlp_ln(const bf16_t* xop, float* xf, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, const float* g, const float* be,
-                  bf16_t* xop_out, bf16_t* halo, int hf, int M, int C, int H, int W, hipStream_t st, std::string& err);
+                  bf16_t* xop_out, bf16_t* halo, int hf, int M, int C, int H, int W, int merge, hipStream_t st, std::string& err);
 
 // adam.hip: fused multi-tensor Adam (host arrays of device pointers)
 int launch_adam(int n_tensors, float* const* params, const float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,

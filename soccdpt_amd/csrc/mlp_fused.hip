@@ -51,7 +51,7 @@ template <class K, bool F16>
 __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __restrict__ xop, float* __restrict__ xf, const uint16_t* __restrict__ w1,
                                                             const float* __restrict__ b1, const uint16_t* __restrict__ w2, const float* __restrict__ b2,
                                                             const float* __restrict__ g, const float* __restrict__ be, uint16_t* __restrict__ xop_out,
-                                                            uint16_t* __restrict__ halo, int M, int H, int W) {
+                                                            uint16_t* __restrict__ halo, int M, int H, int W, int merge) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int C = K::C, HID = 4 * C, NCH = HID / K::HC;
     char* const Xs = smem;
@@ -194,12 +194,14 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
         const float rstd = rsqrtf(sq / (float)C + 1e-5f);
         if (m >= M) continue;
         const size_t orow = (size_t)m * C;
-        size_t hrow = 0;
-        if (halo) {
+        size_t hrow = 0, brow = orow;
+        if (halo || merge) {
             const int hw = H * W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / W, x = rem - y * W;
             hrow = ((size_t)(b * (H + 2) + y + 1) * (W + 2) + x + 1) * C;
+            // merge: operand copy in the PatchMerging layout [B][H/2][W/2][4C], channel block (y&1) + 2*(x&1) (elementwise.hip, ln_residual)
+            if (merge) brow = (((size_t)(b * (H / 2) + y / 2) * (W / 2) + x / 2) * 4 + (y & 1) + 2 * (x & 1)) * C;
         }
 #pragma unroll
         for (int i = 0; i < K::TN2; ++i) {
@@ -215,7 +217,7 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
             uint2 p;
             p.x = pack_h2<F16>(o[0], o[1]);
             p.y = pack_h2<F16>(o[2], o[3]);
-            if (xop_out) *reinterpret_cast<uint2*>(xop_out + orow + n) = p;
+            if (xop_out) *reinterpret_cast<uint2*>(xop_out + brow + n) = p;
             if (halo) *reinterpret_cast<uint2*>(halo + hrow + n) = p;
         }
     }
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
 
 template <class K, bool F16>
 int launch_one(const uint16_t* xop, float* xf, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* g, const float* be,
-               uint16_t* xop_out, uint16_t* halo, int M, int H, int W, hipStream_t st, std::string& err) {
+               uint16_t* xop_out, uint16_t* halo, int M, int H, int W, int merge, hipStream_t st, std::string& err) {
     static bool attr_done = false;
     if (!attr_done) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_kernel<K, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
@@ -231,7 +233,7 @@ int launch_one(const uint16_t* xop, float* xf, const uint16_t* w1, const float* 
         attr_done = true;
     }
     hipLaunchKernelGGL((mlp_ln_kernel<K, F16>), dim3((unsigned)((M + K::BM - 1) / K::BM)), dim3(K::THREADS), K::LDS, st, xop, xf, w1, b1, w2, b2, g, be,
-                       xop_out, halo, M, H, W);
+                       xop_out, halo, M, H, W, merge);
     return check_launch("mlp_ln", err);
 }
 
@@ -240,13 +242,14 @@ int launch_one(const uint16_t* xop, float* xf, const uint16_t* w1, const float* 
 bool mlp_ln_supported(int C) { return C == 96 || C == 128 || C == 192 || C == 256; }
 
 int launch_mlp_ln(const bf16_t* xop, float* xf, const bf16_t* w1, const float* b1, const bf16_t* w2, const float* b2, const float* g, const float* be,
-                  bf16_t* xop_out, bf16_t* halo, int hf, int M, int C, int H, int W, hipStream_t st, std::string& err) {
+                  bf16_t* xop_out, bf16_t* halo, int hf, int M, int C, int H, int W, int merge, hipStream_t st, std::string& err) {
     if (!xop || !xf || !w1 || !b1 || !w2 || !b2 || !g || !be || M < 1) { err = "mlp_ln: bad arguments"; return 1; }
-    if (halo && (H <= 0 || W <= 0 || M % (H * W) != 0)) { err = "mlp_ln: halo output needs the token grid"; return 1; }
+    if ((halo || merge) && (H <= 0 || W <= 0 || M % (H * W) != 0)) { err = "mlp_ln: halo / merged output needs the token grid"; return 1; }
+    if (merge && ((H & 1) || (W & 1) || !xop_out || xop_out == xop)) { err = "mlp_ln: merged operand layout needs an even token grid and a separate output"; return 1; }
 #define MLP_CASE(CC, NB)                                                                                                              \
     case CC:                                                                                                                          \
-        return hf ? launch_one<MlpCfg<CC, NB>, true>(xop, xf, w1, b1, w2, b2, g, be, xop_out, halo, M, H, W, st, err)                 \
-                  : launch_one<MlpCfg<CC, NB>, false>(xop, xf, w1, b1, w2, b2, g, be, xop_out, halo, M, H, W, st, err)
+        return hf ? launch_one<MlpCfg<CC, NB>, true>(xop, xf, w1, b1, w2, b2, g, be, xop_out, halo, M, H, W, merge, st, err)                 \
+                  : launch_one<MlpCfg<CC, NB>, false>(xop, xf, w1, b1, w2, b2, g, be, xop_out, halo, M, H, W, merge, st, err)
     switch (C) {
         MLP_CASE(96, 1);
         MLP_CASE(128, 1);

@@ -437,8 +437,10 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                            W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), HF, B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
+        bool merged = false;   // the stage's last block wrote its operand copy straight into the PatchMerging layout (w.hbuf)
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
+            const bool to_merge = !F32 && s < 3 && j == a.depths[s] - 1;
             IgemmDesc d;
             d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_op = w.qkv;
             RUN(gemm(d));
@@ -457,14 +459,15 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 d.out_f32 = w.y;
                 RUN(gemm(d));
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, st, err)); }
+                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, 0, st, err)); }
             }
             if (!F32 && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
                 const bool hook = (j == a.hooks[s]);
                 PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
                 RUN(launch_mlp_ln(static_cast<const bf16_t*>(w.xb), w.xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
-                                  bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(w.xb), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, HF, M, C, res, res,
-                                  st, err));
+                                  bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, HF,
+                                  M, C, res, res, to_merge ? 1 : 0, st, err));
+                merged = to_merge;
                 continue;
             }
             d = IgemmDesc();
@@ -482,20 +485,21 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
               const bool hook = (j == a.hooks[s]);
-              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb),
+              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb),
                                      (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, HF, M, C,
-                                     1, res, st, err)); }
+                                     1, res, to_merge ? 1 : 0, st, err));
+              merged = to_merge; }
             }
         }
         if (s < 3) {
-            { PROF("merge_gather", 0.0, (double)M * C * 4.0);
+            if (!merged) { PROF("merge_gather", 0.0, (double)M * C * 4.0);
               RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, es, st, err)); }
             IgemmDesc d;
             d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
             RUN(gemm(d));
             { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
               RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M / 4, 2 * C, 0,
-                                     res / 2, st, err)); }
+                                     res / 2, 0, st, err)); }
         }
     }
     // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------

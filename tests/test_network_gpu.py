@@ -388,7 +388,9 @@ def test_fused_mlp_matches_unfused_path(gpu_device, model_type, backbone, img, m
         outs.append((inv.clone(), eng.workspace_tensor(2, "seg_logits").clone(), eng.workspace_tensor(2, "feat0").clone(), eng.launch_count()))
         del m
     (inv0, seg0, f0, n0), (inv1, seg1, f1, n1) = outs
-    assert n1 == n0 - 2                      # two stage-0 blocks x (fc1, fc2 with the LayerNorm epilogue) -> two blocks x one launch
+    # two stage-0 blocks x (fc1, fc2 with the LayerNorm epilogue) -> two blocks x one launch, and the fused kernel of the stage's last
+    # block writes its operand copy straight into the PatchMerging layout (no gather launch)
+    assert n1 == n0 - 3
     assert _rel_l2(f1, f0) < 2e-3            # bf16 / same-rounding paths: differences come from the last-ulp LayerNorm statistics flipping roundings
     # downstream the flipped bf16 roundings spread like any other operand rounding (each path is 3e-3 from the fp32 oracle)
     assert _rel_l2(inv1, inv0) < 5e-3 and _rel_l2(seg1, seg0) < 5e-3
