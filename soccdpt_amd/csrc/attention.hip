@@ -497,11 +497,12 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
             for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, acc[rg]);
             mt = fmaxf(mt, __shfl_xor(mt, 32));
             const float mn = fmaxf(m, mt);
-            const float alpha = __expf(m - mn);
+            const float mnl = mn * 1.4426950408889634f;   // exp(s - mn) = 2^(s*log2e - mn*log2e): one v_fma + one v_exp per logit
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, 1.4426950408889634f, -mnl));
             float psum = 0.f;
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
-                acc[rg] = __expf(acc[rg] - mn);
+                acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], 1.4426950408889634f, -mnl));
                 psum += acc[rg];
                 o[rg] *= alpha;
             }
