@@ -552,7 +552,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
                                         "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
-                                        "igemm_bf16_32x64x128_s3"};
+                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -579,11 +579,15 @@ static int pick_cfg(const IgemmDesc& d) {
     // (tools/autotune_network.py, profiles/r01j_autotune_in_network_*.txt).  In the real launch sequence weights and activations
     // arrive cold, and tiles that keep TWO workgroups per CU (128x128x64 s2, 256x128x32 s3, 64x64) beat the one-workgroup-per-CU
     // tiles (128x256x64, 256x256x64) that win a warm repeated-launch benchmark: the second workgroup hides the cold misses.
-    if (d.res2_h && b128 >= 384) return 1;  // sampled-residual epilogue (4 gathers per output)
+    // Long-K 3x3 convs onto N >= 256 that land on 128x128 tiles: the 8-wave variant (64x32 per wave, 16 waves per CU instead of 8) hides
+    // the LDS-fragment / MFMA-issue stalls better -- 64^2 RCU convs 229 -> 209 us, base_384 96^2 convs 548 -> 475 us in the network; the
+    // N = 128 depth-head conv and K <= 1152 keep the 4-wave tile (97 vs 106 us, 78 vs 82 us).
+    const int c128 = (d.taps == 9 && d.N >= 256 && K >= 1536) ? 21 : 1;
+    if (d.res2_h && b128 >= 384) return c128;  // sampled-residual epilogue (4 gathers per output)
     if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return 16;   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
     // short K, many output tiles (qkv / fc1 / proj / merge): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
     if (K <= 1024 && b64 >= 512) return 4;
-    if (b128 >= 256) return 1;
+    if (b128 >= 256) return c128;
     // small grids: halve the M tile (2x the workgroups) and use 128-deep k-tiles (half the barriers: 8-15 % over a 64-deep
     // 6-stage ring).  A two-stage variant and a wider use of 32-row tiles both win warm and lose in the network (doubled weight
     // re-reads): 3712 -> 3580 frames/s, reverted.
@@ -641,7 +645,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || id == 21) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if (id == 20 && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
@@ -665,6 +669,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
+        case 21: return launch_cfg<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
         case 20: return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
     }
     err = "igemm: unknown configuration id";
