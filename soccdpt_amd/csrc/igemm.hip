@@ -579,10 +579,10 @@ static int pick_cfg(const IgemmDesc& d) {
     // (tools/autotune_network.py, profiles/r01j_autotune_in_network_*.txt).  In the real launch sequence weights and activations
     // arrive cold, and tiles that keep TWO workgroups per CU (128x128x64 s2, 256x128x32 s3, 64x64) beat the one-workgroup-per-CU
     // tiles (128x256x64, 256x256x64) that win a warm repeated-launch benchmark: the second workgroup hides the cold misses.
-    // Long-K 3x3 convs onto N >= 256 that land on 128x128 tiles: the 8-wave variant (64x32 per wave, 16 waves per CU instead of 8) hides
-    // the LDS-fragment / MFMA-issue stalls better -- 64^2 RCU convs 229 -> 209 us, base_384 96^2 convs 548 -> 475 us in the network; the
-    // N = 128 depth-head conv and K <= 1152 keep the 4-wave tile (97 vs 106 us, 78 vs 82 us).
-    const int c128 = (d.taps == 9 && d.N >= 256 && K >= 1536) ? 21 : 1;
+    // Long-K 3x3 convs that land on 128x128 tiles: the 8-wave variant (64x32 per wave, 16 waves per CU instead of 8) hides the
+    // LDS-fragment / MFMA-issue stalls better -- 64^2 RCU convs 229 -> 209 us, depth-head conv 104 -> 92 us, base_384 96^2 convs
+    // 548 -> 475 us in the network (old / new library alternated inside one GPU call); K <= 1152 keeps the 4-wave tile (78 vs 82 us).
+    const int c128 = (d.taps == 9 && K >= 1536) ? 21 : 1;
     if (d.res2_h && b128 >= 384) return c128;  // sampled-residual epilogue (4 gathers per output)
     if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return 16;   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
     // short K, many output tiles (qkv / fc1 / proj / merge): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
