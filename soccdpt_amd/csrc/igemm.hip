@@ -552,7 +552,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
                                         "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
-                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8"};
+                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8", "igemm_bf16_32x64x128_s3_w8", "igemm_bf16_64x64x64_s4_w8", "igemm_bf16_128x128x32_s3_w8"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -574,7 +574,7 @@ static int pick_cfg(const IgemmDesc& d) {
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long K = (long)d.taps * d.Cin;
     const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128), b64 = cdiv(d.M, 64) * cdiv(d.N, 64);
-    if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 15 : 4;  // C = 96: layer1_rn (128x256x32) / stage-0 Linear layers (64x64x32)
+    if (!k64) return (d.taps == 9 && b128 >= 384 && d.N % 256 == 0) ? 24 : 4;  // C = 96: layer1_rn (128x128x32, 8 waves) / stage-0 Linear layers (64x64x32)
     // The rules below were re-derived from IN-NETWORK timings of every candidate at every launch site of both models
     // (tools/autotune_network.py, profiles/r01j_autotune_in_network_*.txt).  In the real launch sequence weights and activations
     // arrive cold, and tiles that keep TWO workgroups per CU (128x128x64 s2, 256x128x32 s3, 64x64) beat the one-workgroup-per-CU
@@ -591,9 +591,9 @@ static int pick_cfg(const IgemmDesc& d) {
     // small grids: halve the M tile (2x the workgroups) and use 128-deep k-tiles (half the barriers: 8-15 % over a 64-deep
     // 6-stage ring).  A two-stage variant and a wider use of 32-row tiles both win warm and lose in the network (doubled weight
     // re-reads): 3712 -> 3580 frames/s, reverted.
-    if (d.Cin % 128 == 0 && ((b64 < 256 && K >= 384) || (b64 <= 128 && K >= 256))) return 20;
+    if (d.Cin % 128 == 0 && ((b64 < 256 && K >= 384) || (b64 <= 128 && K >= 256))) return 22;   // (4-wave form: 20, kept for split-K)
     if ((b64 < 256 && K >= 1536) || (b64 < 128 && K >= 768)) return 14;
-    return 2;  // 64x64: 4x the blocks of 128x128
+    return 23;  // 64x64 (8 waves; the 4-wave form is configuration 2): 4x the blocks of 128x128
 }
 
 int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words) {
@@ -645,8 +645,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || id == 21) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
-    if (id == 20 && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
@@ -670,6 +670,9 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
         case 21: return launch_cfg<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
+        case 22: return launch_cfg<Cfg<32, 64, 128, 2, 4, 3>>(d, stream, err);   // 8 waves, 16x16 per wave: the small-grid long-K launches are latency chains,
+        case 23: return launch_cfg<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
+        case 24: return launch_cfg<Cfg<128, 128, 32, 2, 4, 3>>(d, stream, err);  // 8 waves, 64x32 per wave, 32-deep k-tiles (C = 96: layer1_rn 43 -> 34 us)
         case 20: return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
     }
     err = "igemm: unknown configuration id";

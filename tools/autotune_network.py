@@ -44,12 +44,12 @@ sites = eng.sites()
 total_base = sum(base.values())
 print(f"{model_type} B={B}: {len(sites)} distinct igemm shapes, {sum(s['launches'] for s in sites) // (REPS + 0)} launches profiled, "
       f"{total_base:.0f} us of igemm per forward with the heuristic")
-K64 = [2, 1, 13, 10, 14, 8, 6, 20, 21]
-K32 = [4, 9, 19, 15, 16] + [int(c) for c in os.environ.get('AUTOTUNE_EXTRA', '').split(',') if c]
+K64 = [2, 1, 13, 10, 14, 8, 6, 20, 21, 22, 23]
+K32 = [4, 9, 19, 15, 16, 24] + [int(c) for c in os.environ.get('AUTOTUNE_EXTRA', '').split(',') if c]
 results = []
 for s in sites:
     Cin = s["K"] // s["taps"]
-    cands = [c for c in (K64 if Cin % 64 == 0 else []) + K32 if not (c == 20 and Cin % 128)]
+    cands = [c for c in (K64 if Cin % 64 == 0 else []) + K32 if not (c in (20, 22) and Cin % 128)]
     if s["N"] <= 32 or s["M"] < int(os.environ.get('AUTOTUNE_MIN_M', '0')):
         continue
     row = {"auto": (s["cfg"], base[s["site"]])}
