@@ -584,7 +584,7 @@ static int pick_cfg(const IgemmDesc& d) {
     // 548 -> 475 us in the network (old / new library alternated inside one GPU call); K <= 1152 keeps the 4-wave tile (78 vs 82 us).
     const int c128 = (d.taps == 9 && K >= 1536) ? 21 : 1;
     if (d.res2_h && b128 >= 384) return c128;  // sampled-residual epilogue (4 gathers per output)
-    if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return 16;   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
+    if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return (d.taps == 9 && K >= 1536) ? 21 : 16;   // head-sized problems: 256x128x32, or the 8-wave 128x128x64 for the long-K 3x3 (seg head 159 -> 152 us)   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
     // short K, many output tiles (qkv / fc1 / proj / merge): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
     if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 256) return c128;
