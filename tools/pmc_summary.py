@@ -7,13 +7,16 @@ import collections, csv, json, re, sys
 def family(kernel_name: str) -> str:
     """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
     n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
-    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), \d+, \d+, (\d+)>, ([\w ]+), (true|false), (true|false)>", n)
+    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>, ([\w ]+), (true|false), (true|false)>", n)
     if m:
-        t = m.group(5)
+        t = m.group(7)
         if t == "float":
-            return f"igemm_f32_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(4)}"
-        return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(4)}" + ("_splitk" if m.group(7) == "true" else "")
-    for prefix, fam in (("window_attention", "window_attention"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
+            return f"igemm_f32_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(6)}"
+        # 8-wave forms of tiles that also exist with 4 waves carry a _w8 suffix in igemm.hip's kCfgNames
+        w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("32", "64"), ("64", "64"))
+        return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") +
+                ("_splitk" if m.group(9) == "true" else ""))
+    for prefix, fam in (("window_attention", "window_attention"), ("mlp_ln_kernel", "mlp_ln_fused"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
                         ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
                         ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail")):
         if n.startswith(prefix):
