@@ -367,7 +367,9 @@ struct AttnGenCfg {
     static constexpr int N = WS * WS;
     static constexpr int NT = (N + 31) / 32;
     static constexpr int NPAD = NT * 32;
-    static constexpr int THREADS = 256;
+    // 24x24 windows need 111 KB of LDS (one workgroup per CU): 8 waves, so that every SIMD has two waves to overlap the online
+    // softmax (VALU) of one query block with the MFMAs / LDS reads of another; the 12x12 windows (37 KB) keep 4 waves
+    static constexpr int THREADS = WS >= 24 ? 512 : 256;
     static constexpr int VT_STRIDE = NPAD * 2 + 8;
     static constexpr int KS_OFF = NPAD * 64, VT_OFF = 2 * NPAD * 64;
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
@@ -375,7 +377,7 @@ struct AttnGenCfg {
 
 // QS: query split as in window_attention_kernel (each workgroup stages all keys / values, owns 1/QS of the 32-query blocks).
 template <int WS, bool F16, int QS>
-__global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
+__global__ __launch_bounds__(AttnGenCfg<WS>::THREADS) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                      const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
                                                                      int shift, int heads) {
     using A = AttnGenCfg<WS>;
@@ -451,7 +453,7 @@ __global__ __launch_bounds__(256) void window_attention_flash_kernel(const bf16_
     const int r32 = lane & 31, h = lane >> 5;
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     constexpr int HALF = WS / 2;
-    for (int qb = qb_lo + wave; qb < qb_hi; qb += 4) {
+    for (int qb = qb_lo + wave; qb < qb_hi; qb += A::THREADS / 64) {
         const int qrow = qb * 32 + r32;
         const int qcl = qrow < A::N ? qrow : A::N - 1;
         const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
@@ -713,7 +715,7 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
 #undef FLASH_ATTR
             attr_done = true;
         }
-#define FLASH(W, H, Q) hipLaunchKernelGGL((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(256), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+#define FLASH(W, H, Q) hipLaunchKernelGGL((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
         if (ws == 24 && blocks < 256) { if (hf) FLASH(24, true, 2); else FLASH(24, false, 2); }   // too few (window, head) pairs: split the queries
         else if (ws == 24) { if (hf) FLASH(24, true, 1); else FLASH(24, false, 1); }
         else { if (hf) FLASH(12, true, 1); else FLASH(12, false, 1); }
