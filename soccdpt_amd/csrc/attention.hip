@@ -367,9 +367,10 @@ struct AttnGenCfg {
     static constexpr int N = WS * WS;
     static constexpr int NT = (N + 31) / 32;
     static constexpr int NPAD = NT * 32;
-    // 24x24 windows need 111 KB of LDS (one workgroup per CU): 8 waves, so that every SIMD has two waves to overlap the online
-    // softmax (VALU) of one query block with the MFMAs / LDS reads of another; the 12x12 windows (37 KB) keep 4 waves
-    static constexpr int THREADS = WS >= 24 ? 512 : 256;
+    // 24x24 windows need 111 KB of LDS (one workgroup per CU): 16 waves, so that every SIMD has four waves to overlap the online
+    // softmax (VALU) of one query block with the MFMAs / LDS reads of others (4 waves: 1.43 ms per base_384 forward, 8: 0.98, 16: 0.85);
+    // the 12x12 windows (37 KB, four workgroups per CU) keep 4 waves
+    static constexpr int THREADS = WS >= 24 ? 1024 : 256;
     static constexpr int VT_STRIDE = NPAD * 2 + 8;
     static constexpr int KS_OFF = NPAD * 64, VT_OFF = 2 * NPAD * 64;
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
