@@ -582,10 +582,13 @@ static int pick_cfg(const IgemmDesc& d) {
     // Long-K 3x3 convs that land on 128x128 tiles: the 8-wave variant (64x32 per wave, 16 waves per CU instead of 8) hides the
     // LDS-fragment / MFMA-issue stalls better -- 64^2 RCU convs 229 -> 209 us, depth-head conv 104 -> 92 us, base_384 96^2 convs
     // 548 -> 475 us in the network (old / new library alternated inside one GPU call); K <= 1152 keeps the 4-wave tile (78 vs 82 us).
-    const int c128 = (d.taps == 9 && K >= 1536) ? 21 : 1;
+    const int c128 = (d.taps == 9 && K >= 1152) ? 21 : 1;
     if (d.res2_h && b128 >= 384) return c128;  // sampled-residual epilogue (4 gathers per output)
     if (d.N % 256 == 0 && cdiv(d.M, 256) * (d.N / 256) >= 448) return (d.taps == 9 && K >= 1536) ? 21 : 16;   // head-sized problems: 256x128x32, or the 8-wave 128x128x64 for the long-K 3x3 (seg head 159 -> 152 us)   // head-sized convs: 256x128 tiles, 32-deep, 3 stages
     // short K, many output tiles (qkv / fc1 / proj / merge): write-heavy; 32-deep k-tiles halve the LDS footprint -> 5 blocks per CU
+    // plain Linear layers / 1x1 convs with many 128x128 tiles and no GELU epilogue (qkv, out_conv): the 8-wave 128x128 tile again
+    // (base_384 stage-2 qkv, 18 launches: 412 -> 338 us in the network; with the GELU epilogue of fc1 it loses to 64x64x32)
+    if (d.taps == 1 && d.act != ACT_GELU && K >= 128 && K <= 1024 && b128 >= 384) return 21;
     if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 256) return c128;
     // small grids: halve the M tile (2x the workgroups) and use 128-deep k-tiles (half the barriers: 8-15 % over a 64-deep
