@@ -1,4 +1,8 @@
-"""Which tile configuration makes the eager 2-stream seg output deviate?  Forces tiles per shape with tune_set and counts mismatches."""
+"""Reproducer of the packed-f32 problem recorded in DESIGN.md section 4: with the library built WITH packed-f32 VALU ops
+(`make -C soccdpt_amd/csrc clean all NOPK=`), the eager two-stream seg output deviates from the single-stream one as soon as the
+seg-head conv of the other sub-batch runs on 64x64 / 128x128 tiles next to conv1x1_c3_kernel; with the shipped build (no packed ops)
+every variant reports 0.  Forces tiles per shape with tune_set and counts mismatching elements per variant.
+usage: python tools/race_bisect.py [M,N,K,taps,cfg ...]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
