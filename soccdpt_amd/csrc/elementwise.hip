@@ -192,11 +192,77 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
     }
 }
 
+// Same, for C % 256 == 0 (C = 256 / 512 / 768 / 1024): a lane owns float4 groups (16-byte loads and stores, a quarter of the memory
+// instructions; base_384's 47 launches per forward are mostly these widths).
+template <int V4, bool F16>  // float4 groups per lane = C / 256
+__global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __restrict__ y, const float* __restrict__ g,
+                                                              const float* __restrict__ beta, float* __restrict__ xf,
+                                                              bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
+                                                              int C, int residual, int res, int merge) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float4* yr = reinterpret_cast<const float4*>(y + (size_t)row * C);
+    const float4* xr4 = reinterpret_cast<const float4*>(xf + (size_t)row * C);
+    float4 v[V4], xr[V4], gg[V4], bb[V4];
+#pragma unroll
+    for (int t = 0; t < V4; ++t) {
+        const int c4 = lane + 64 * t;
+        v[t] = yr[c4];
+        xr[t] = residual ? xr4[c4] : make_float4(0.f, 0.f, 0.f, 0.f);
+        gg[t] = reinterpret_cast<const float4*>(g)[c4];
+        bb[t] = reinterpret_cast<const float4*>(beta)[c4];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < V4; ++t) s += (v[t].x + v[t].y) + (v[t].z + v[t].w);
+    const float mean = wave_sum(s) / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int t = 0; t < V4; ++t) {
+        v[t].x -= mean; v[t].y -= mean; v[t].z -= mean; v[t].w -= mean;
+        q += (v[t].x * v[t].x + v[t].y * v[t].y) + (v[t].z * v[t].z + v[t].w * v[t].w);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)C + 1e-5f);
+    size_t hoff = 0, boff = (size_t)row * C;
+    if (halo || halo_f32 || merge) {
+        const int hw = res * res, b = row / hw, r = row - b * hw, yy = r / res, xx = r - yy * res;
+        hoff = ((size_t)(b * (res + 2) + yy + 1) * (res + 2) + xx + 1) * C;
+        if (merge) boff = (((size_t)(b * (res / 2) + yy / 2) * (res / 2) + xx / 2) * 4 + (yy & 1) + 2 * (xx & 1)) * C;
+    }
+#pragma unroll
+    for (int t = 0; t < V4; ++t) {
+        const int c = 4 * (lane + 64 * t);
+        float4 o;
+        o.x = v[t].x * rstd * gg[t].x + bb[t].x + xr[t].x;
+        o.y = v[t].y * rstd * gg[t].y + bb[t].y + xr[t].y;
+        o.z = v[t].z * rstd * gg[t].z + bb[t].z + xr[t].z;
+        o.w = v[t].w * rstd * gg[t].w + bb[t].w + xr[t].w;
+        *reinterpret_cast<float4*>(xf + (size_t)row * C + c) = o;
+        uint2 ob;
+        ob.x = pack_h2<F16>(o.x, o.y);
+        ob.y = pack_h2<F16>(o.z, o.w);
+        if (xb) *reinterpret_cast<uint2*>(xb + boff + c) = ob;
+        if (halo) *reinterpret_cast<uint2*>(halo + hoff + c) = ob;
+        if (halo_f32) *reinterpret_cast<float4*>(halo_f32 + hoff + c) = o;
+    }
+}
+
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
                        int C, int residual, int res, int merge, hipStream_t st, std::string& err) {
     if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
+    if (C % 256 == 0 && C <= 1024) {
+#define LN4_CASE(V)                                                                                                                       \
+    do {                                                                                                                                  \
+        if (hf) hipLaunchKernelGGL((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
+        else hipLaunchKernelGGL((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
+    } while (0)
+        switch (C / 256) { case 1: LN4_CASE(1); break; case 2: LN4_CASE(2); break; case 3: LN4_CASE(3); break; default: LN4_CASE(4); break; }
+#undef LN4_CASE
+        return check_launch("ln_residual", err);
+    }
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
         if (hf) hipLaunchKernelGGL((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
