@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--precision", choices=["bf16", "f16", "f32"], default="bf16",
                     help="bf16: bf16 MFMA operands (BASELINE config); f16: IEEE fp16 operands, same kernels and MFMA rate, "
                          "meets the 1e-3 tolerance; f32: exact-f32 parity mode (1/16 MFMA rate)")
-    ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: no gain)")
+    ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: slower than eager)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
@@ -218,6 +218,27 @@ def main():
                                   "note": "same forward with fp16 instead of bf16 MFMA operands (f32 accumulate); depth / logits / features "
                                           "within 1e-3 rel-L2 of the fp32 CPU oracle, bf16 is at 3e-3"}
         del net16
+
+    # ---- the same workload dealt to two concurrent sub-batches on internal streams (soccdpt_set_streams(2), eager): bitwise the same
+    # outputs (tests/test_network_gpu.py), faster because the latency-bound launches of one half overlap the other half's.  Reported
+    # beside `value`, which stays on one stream so that the per-kernel durations behind `roofline` are those of kernels running alone.
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and args.streams == 1 and B >= 2:
+        with contextlib.redirect_stdout(io.StringIO()):
+            net2 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=2,
+                              model_type=args.model_type, precision=0)
+        net2.load_state_dict(sd, strict=False)
+        net2 = net2.eval().to(dev)
+        for _ in range(args.warmup):
+            out = net2(x)
+        torch.cuda.synchronize()
+        t4 = time.perf_counter()
+        for _ in range(args.steps):
+            out = net2(x)
+        torch.cuda.synchronize()
+        e2 = time.perf_counter() - t4
+        result["two_streams"] = {"value": round(B * args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
+                                 "note": "same forward, batch dealt to 2 concurrent sub-batches on internal streams (bench.py --streams 2 makes it the timed mode)"}
+        del net2
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, rank 0 at N = 1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
