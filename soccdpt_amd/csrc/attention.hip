@@ -370,7 +370,7 @@ struct AttnGenCfg {
     // 24x24 windows need 111 KB of LDS (one workgroup per CU): 16 waves, so that every SIMD has four waves to overlap the online
     // softmax (VALU) of one query block with the MFMAs / LDS reads of others (4 waves: 1.43 ms per base_384 forward, 8: 0.98, 16: 0.85);
     // the 12x12 windows (37 KB, four workgroups per CU) keep 4 waves
-    static constexpr int THREADS = WS >= 24 ? 1024 : 256;
+    static constexpr int THREADS = WS >= 24 ? 1024 : (WS == 16 ? 512 : 256);   // 16x16: 8 query blocks, one per wave
     static constexpr int VT_STRIDE = NPAD * 2 + 8;
     static constexpr int KS_OFF = NPAD * 64, VT_OFF = 2 * NPAD * 64;
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
@@ -698,11 +698,17 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
     const int nw = res / ws;
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
     if (ws == 16) {
-        using A = AttnCfg<16>;
-#define ATT16(H, Q) hipLaunchKernelGGL((window_attention_kernel<16, H, Q>), dim3(blocks * Q), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
-        if (blocks < 512) { if (hf) ATT16(true, 2); else ATT16(false, 2); }   // too few (window, head) pairs to fill 256 CUs evenly: split the queries
-        else { if (hf) ATT16(true, 1); else ATT16(false, 1); }
-#undef ATT16
+        // 16x16 windows run the online-softmax kernel too: holding all 8 score tiles of a query block (the kernel above) costs 192-404
+        // registers per lane = one or two waves per SIMD; tile-at-a-time softmax needs 127, and with 8 waves per workgroup (one query
+        // block each) the CU keeps 16 waves busy: 0.184 -> 0.165 ms of attention per tiny_256 forward.
+        static bool attr16 = false;
+        if (!attr16) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
+            attr16 = true;
+        }
+        if (hf) hipLaunchKernelGGL((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else hipLaunchKernelGGL((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 8) {
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
