@@ -219,8 +219,9 @@ def main():
                                           "within 1e-3 rel-L2 of the fp32 CPU oracle, bf16 is at 3e-3"}
         del net16
 
-    # ---- the same workload dealt to two concurrent sub-batches on internal streams (soccdpt_set_streams(2), eager): bitwise the same
-    # outputs (tests/test_network_gpu.py), faster because the latency-bound launches of one half overlap the other half's.  Reported
+    # ---- the same workload dealt to two concurrent sub-batches on internal streams (soccdpt_set_streams(2), eager): bit for bit the
+    # result of running the two sub-batches one after the other (tools/multistream_split_check.py; equal to the whole-batch result too
+    # unless the sub-batch size flips a split-K decision, which moves last bits), faster because the latency-bound launches of one half overlap the other half's.  Reported
     # beside `value`, which stays on one stream so that the per-kernel durations behind `roofline` are those of kernels running alone.
     if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and args.streams == 1 and B >= 2:
         with contextlib.redirect_stdout(io.StringIO()):

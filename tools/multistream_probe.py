@@ -2,6 +2,9 @@
 host synchronisation, over many inputs; counts output elements of the multi-stream results that differ from the single-stream one.
 Co-residency of different kernels only happens in these modes; this probe found the packed-f32 problem recorded in DESIGN.md
 section 4 (seg output of the eager two-stream mode) and is the check to run after any kernel or schedule change.
+Note: the comparison is against the WHOLE batch on one stream, so it only reads 0 when the sub-batches take the same tile / split-K
+decisions as the whole batch (tiny_256 at B = 4 / 8, base_384 at B = 4); where they do not (base_384 at B = 8) use
+tools/multistream_split_check.py, which compares against the same sub-batches run one after the other.
 usage: python tools/multistream_probe.py [model_type] [bf16|f16|f32] [streams] [B] [n_inputs]"""
 import os, sys, tempfile
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
