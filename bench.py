@@ -37,16 +37,26 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--streams", type=int, default=1, help="concurrent sub-batches inside one forward (soccdpt_set_streams)")
-    ap.add_argument("--model-type", default="dpt_swin2_tiny_256", choices=["dpt_swin2_tiny_256", "dpt_swin2_base_384"],
-                    help="dpt_swin2_tiny_256 = BASELINE metric config; dpt_swin2_base_384 = BASELINE configs[3] (8 frames per GPU)")
+    ap.add_argument("--model-type", default="dpt_swin2_tiny_256", choices=["dpt_swin2_tiny_256", "dpt_swin2_base_384", "dpt_hybrid_384"],
+                    help="dpt_swin2_tiny_256 = BASELINE metric config (configs[1]); dpt_swin2_base_384 --batch 8 = configs[3]'s per-GPU shape "
+                         "(64 frames over 8 GPUs); dpt_hybrid_384 --batch 4 = configs[2]")
     ap.add_argument("--precision", choices=["bf16", "f16", "f32"], default="bf16",
                     help="bf16: bf16 MFMA operands (BASELINE config); f16: IEEE fp16 operands, same kernels and MFMA rate, "
                          "meets the 1e-3 tolerance; f32: exact-f32 parity mode (1/16 MFMA rate)")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: slower than eager)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true",
+                    help="only the timed headline leg + its per-kernel event pass: no fp16 / two-stream / CPU-baseline legs "
+                         "(what tools/collect_profiles.sh runs under rocprofv3, so profiles/*_kernel_stats.csv describe the headline launches alone)")
+    ap.add_argument("--with-two-streams", action="store_true",
+                    help="also time the EXPERIMENTAL two-concurrent-sub-batches mode (soccdpt_set_streams(2); opt-in, DESIGN.md section 4)")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = True
+    if args.with_two_streams or args.streams > 1:
+        os.environ["SOCCDPT_ALLOW_MULTISTREAM"] = "1"
 
     # stdout must carry exactly ONE JSON line: RCCL prints a version banner to stdout when a communicator is created, and
     # libraries may print too.  Keep the real stdout aside and point fd 1 at stderr for everything else.
@@ -74,9 +84,9 @@ def main():
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
                          model_type=args.model_type,
                          graph=args.graph, precision={"bf16": 0, "f32": 1, "f16": 2}[args.precision])
-    from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+    from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
     backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
-    img = SWIN_ARCHS[backbone].img
+    img = backbone_image_size(backbone)
     sd = synth_state_dict(backbone, alias_pretrained=True)
     net.load_state_dict(sd, strict=False)
     net = net.eval().to(dev)
@@ -103,10 +113,16 @@ def main():
         out = net(x)
     barrier()
     elapsed = time.perf_counter() - t0
+    per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
+    rccl_ranks = 1
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        allt = torch.empty((world,), device=dev, dtype=torch.float64)
+        dist.all_gather_into_tensor(allt, t)                # evidence of how many ranks RCCL really connected
+        per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in allt.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        rccl_ranks = dist.get_world_size()
     frames = world * B * args.steps
     fps = frames / elapsed
 
@@ -146,12 +162,21 @@ def main():
             g["ms"] += s["ms"]; g["flops"] += s["flops"]; g["bytes"] += s["bytes"]; g["launches"] += s["launches"]; g["members"].append(name)
         fam, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
         peak = PEAK_F32_TFLOPS if args.precision == "f32" else PEAK_BF16_TFLOPS
-        pmc = {}
+        pmc, pmc_file, pmc_stale = {}, None, None
         try:   # HBM bytes / MFMA-pipe utilisation per launch: PMC counters cannot be read inside this process; they come from the
-               # committed rocprofv3 --pmc passes over this same command (profiles/, tools/collect_profiles.sh, tools/pmc_summary.py)
+               # committed rocprofv3 --pmc passes over this same command (profiles/, tools/collect_profiles.sh, tools/pmc_summary.py).
+               # A file is only used when it was collected from the CURRENT kernel sources (csrc_sha); otherwise traffic is null.
             import glob
-            pmc_file = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))[-1]
-            pmc = json.load(open(pmc_file))["kernels"]
+            from soccdpt_amd.lib import csrc_sha
+            tagsfx = {"dpt_swin2_tiny_256": "", "dpt_swin2_base_384": "_base384", "dpt_hybrid_384": "_hybrid384"}[args.model_type]
+            cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*{tagsfx}_pmc_traffic.json")))
+            cands = [c for c in cands if tagsfx or not any(t in os.path.basename(c) for t in ("_base384", "_hybrid384"))]
+            pmc_file = cands[-1]
+            pj = json.load(open(pmc_file))
+            if pj.get("csrc_sha") == csrc_sha():
+                pmc = pj["kernels"]
+            else:
+                pmc_stale = f"{os.path.basename(pmc_file)} was collected from other kernel sources (csrc_sha {pj.get('csrc_sha')} != {csrc_sha()})"
         except Exception:
             pmc_file = None
         if dom["flops"] > 0:
@@ -181,6 +206,21 @@ def main():
         if tr and len(tr) == len(dom["members"]):
             roofline["traffic"] = round(sum(tr) / dom["launches"])     # HBM bytes per launch, launch-weighted over the members
             roofline["traffic_source"] = os.path.basename(pmc_file)
+        elif pmc_stale:
+            roofline["traffic_note"] = "null: " + pmc_stale
+        # second regime (SURVEY.md 8d "two regimes, report both"): the HBM-bound projection + occupancy expansion
+        hb = {n: stats[n] for n in ("project_voxelise", "occ_expand") if n in stats and stats[n]["bytes"] > 0}
+        roofline_hbm = None
+        if hb:
+            hb_bytes, hb_ms, hb_l = sum(v["bytes"] for v in hb.values()), sum(v["ms"] for v in hb.values()), sum(v["launches"] for v in hb.values())
+            ach = hb_bytes / (hb_ms * 1e-3) / 1e9
+            roofline_hbm = dict(bound="hbm", kernel="project_rows_kernel + occ_expand_kernel", achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
+                                frac=round(ach / PEAK_HBM_GBS, 4), traffic=None, bytes_per_step=hb_bytes / prof_steps, us_per_step=round(hb_ms * 1e3 / prof_steps, 2),
+                                by_kernel=[dict(kernel=n, avg_launch_us=round(v["ms"] * 1e3 / v["launches"], 2), achieved=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1),
+                                                frac=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM_GBS, 4),
+                                                **({"traffic": round(pmc[n]["hbm_bytes_per_launch"])} if n in pmc else {})) for n, v in hb.items()])
+            if all(n in pmc for n in hb):
+                roofline_hbm["traffic"] = round(sum(pmc[n]["hbm_bytes_per_launch"] * hb[n]["launches"] for n in hb) / hb_l)
         result = {
             "metric": f"frames/sec SOccDPT_V3 {args.model_type.replace('dpt_', '')} @{img}px (depth+seg+points+occupancy forward)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,6 +231,8 @@ def main():
                        "parallelism": f"dp{world}" if world > 1 else "single",
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
             "roofline": roofline,
+            "roofline_hbm": roofline_hbm,
+            "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
             "kernels": kernels,
             "device_ms_per_step": round(total_ms / prof_steps, 3),
             "ms_per_step_with_events": round(elapsed_prof / prof_steps * 1e3, 3),
@@ -200,7 +242,7 @@ def main():
 
     # ---- the same workload with IEEE fp16 MFMA operands (SOCCDPT_PREC_F16): same kernels and MFMA rate; this is the mode that
     # meets the north star's 1e-3 tolerance (tests/test_network_gpu.py::test_f16_mode_meets_1e3_relative).  N = 1 only.
-    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph:
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and not args.headline_only:
         with contextlib.redirect_stdout(io.StringIO()):
             net16 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
                                model_type=args.model_type, precision=2)
@@ -218,12 +260,21 @@ def main():
                                   "note": "same forward with fp16 instead of bf16 MFMA operands (f32 accumulate); depth / logits / features "
                                           "within 1e-3 rel-L2 of the fp32 CPU oracle, bf16 is at 3e-3"}
         del net16
+    if rank == 0 and result is not None:
+        # Which arithmetic meets the north star's tolerance (1e-3 relative on depth maps / class logits, tests/test_network_gpu.py):
+        # stated as top-level fields, not in a note (VERDICT r1 #5e)
+        meets = {"bf16": False, "f16": True, "f32": True}
+        result["tolerance"] = {"north_star": "1e-3 relative (depth, logits), voxel indices bit-exact at the projection boundary",
+                               "dtype_of_value": args.precision, "value_meets_tolerance": meets[args.precision],
+                               "dtype_meeting_tolerance_at_full_mfma_rate": "f16",
+                               "value_meeting_tolerance": result["value"] if meets[args.precision] else
+                               (result.get("f16_operands", {}).get("value"))}
 
     # ---- the same workload dealt to two concurrent sub-batches on internal streams (soccdpt_set_streams(2), eager): bit for bit the
     # result of running the two sub-batches one after the other (tools/multistream_split_check.py; equal to the whole-batch result too
     # unless the sub-batch size flips a split-K decision, which moves last bits), faster because the latency-bound launches of one half overlap the other half's.  Reported
     # beside `value`, which stays on one stream so that the per-kernel durations behind `roofline` are those of kernels running alone.
-    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and args.streams == 1 and B >= 2:
+    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and args.streams == 1 and B >= 2 and args.with_two_streams and not args.headline_only:
         with contextlib.redirect_stdout(io.StringIO()):
             net2 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=2,
                               model_type=args.model_type, precision=0)
@@ -238,7 +289,8 @@ def main():
         torch.cuda.synchronize()
         e2 = time.perf_counter() - t4
         result["two_streams"] = {"value": round(B * args.steps / e2, 2), "unit": "frames/s", "ms_per_step": round(e2 / args.steps * 1e3, 3),
-                                 "note": "same forward, batch dealt to 2 concurrent sub-batches on internal streams (bench.py --streams 2 makes it the timed mode)"}
+                                 "experimental": True,
+                                 "note": "EXPERIMENTAL opt-in mode (soccdpt_set_streams(2)): same forward, batch dealt to 2 concurrent sub-batches on internal streams"}
         del net2
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, rank 0 at N = 1 only ----

@@ -31,6 +31,7 @@ extern "C" {
 /* backbone ids: model/loader.py:65-77 (model_type switch), model/blocks.py:59-78 */
 #define SOCCDPT_BACKBONE_SWIN2T16_256 0 /* dpt_swin2_tiny_256 */
 #define SOCCDPT_BACKBONE_SWIN2B24_384 1 /* dpt_swin2_base_384 */
+#define SOCCDPT_BACKBONE_VITB_RN50_384 2 /* dpt_hybrid_384: ResNetV2-50 stem + ViT-B/16 (model/loader.py:115-120, backbones/vit.py:147-258) */
 
 /* dtype codes for soccdpt_bind_weight */
 #define SOCCDPT_DTYPE_F32 0
@@ -82,6 +83,17 @@ const char* soccdpt_weight_key(void* handle, int index);   /* their keys, for th
  * BN-folded, CPB-table) weights, and of per-forward scratch for batch B. */
 size_t soccdpt_prepared_bytes(void* handle);
 size_t soccdpt_workspace_bytes(void* handle, int B);
+/* Workspace contract.  The 3x3 convolutions read one-pixel zero borders ("halos") that no kernel ever writes, and where those
+ * borders lie inside the workspace depends on (B, stream count).  THE LIBRARY OWNS THAT INVARIANT: soccdpt_forward /
+ * soccdpt_network zero-fill the first soccdpt_workspace_bytes(handle, B) bytes on `stream` whenever they see a
+ * (dev_workspace pointer, B, stream count) tuple different from the previous call's (one hipMemsetAsync per layout change,
+ * nothing in the steady state).  A caller that lets anything else write into the buffer between calls, or that frees it and
+ * is handed the same address again, must call soccdpt_workspace_invalidate() so that the next forward zero-fills again.
+ * The buffer may have any contents when first handed over.  A too-small workspace and a handle used while another device
+ * is current are errors (non-zero return, soccdpt_last_error). */
+int soccdpt_workspace_invalidate(void* handle);
+/* Number of zero-fills the handle has issued so far (diagnostics / tests of the contract above). */
+int soccdpt_workspace_zero_fills(void* handle);
 
 /* Fold BN, convert/re-lay weights, build CPB bias tables.  Call after all binds and
  * again whenever bound weight values change.  `prepared` stays in use by forward. */
@@ -101,7 +113,10 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
 /* Frames are independent through the network: the batch of a call is dealt to `n` sub-batches (1..8) that run
  * concurrently on the caller's stream plus n-1 library-owned streams, forked from and joined into the caller's
  * stream with events (no host synchronisation; results are stream-ordered on the caller's stream).  Changes the
- * workspace size/layout: query soccdpt_workspace_bytes again and hand over a zero-filled workspace. */
+ * workspace size/layout: query soccdpt_workspace_bytes again (the next forward re-zeroes the halos itself).
+ * EXPERIMENTAL for n > 1: the library refuses n > 1 unless the environment variable SOCCDPT_ALLOW_MULTISTREAM=1 is set
+ * (a wrong-result hazard of packed-f32 VALU code under kernel co-residency was worked around, not
+ * root-caused; one stream is the supported configuration). */
 int soccdpt_set_streams(void* handle, int n);
 /* on != 0: soccdpt_network / soccdpt_forward capture their launch sequence into a hipGraph the second time they
  * see the same (x, outputs, workspace, B) pointers and replay it afterwards (one host launch per forward).  Callers

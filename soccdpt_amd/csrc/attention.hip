@@ -674,10 +674,10 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
         return check_launch("window_attention_f32_any", err);
     }
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.need()) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_f32_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnCfgF32<16>::LDS);
-        attr_done = true;
+        attr_done.done();
     }
     if (ws == 16) {
         using A = AttnCfgF32<16>;
@@ -701,11 +701,11 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
         // 16x16 windows run the online-softmax kernel too: holding all 8 score tiles of a query block (the kernel above) costs 192-404
         // registers per lane = one or two waves per SIMD; tile-at-a-time softmax needs 127, and with 8 waves per workgroup (one query
         // block each) the CU keeps 16 waves busy: 0.184 -> 0.165 ms of attention per tiny_256 forward.
-        static bool attr16 = false;
-        if (!attr16) {
+        static PerDeviceOnce attr16;
+        if (attr16.need()) {
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, false, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
-            attr16 = true;
+            attr16.done();
         }
         if (hf) hipLaunchKernelGGL((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
         else hipLaunchKernelGGL((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
@@ -715,12 +715,12 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
         if (hf) hipLaunchKernelGGL((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
         else hipLaunchKernelGGL((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 24 || ws == 12) {
-        static bool attr_done = false;
-        if (!attr_done) {
+        static PerDeviceOnce attr_done;
+        if (attr_done.need()) {
 #define FLASH_ATTR(H, Q) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<24, H, Q>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<24>::LDS)
             FLASH_ATTR(false, 1); FLASH_ATTR(true, 1); FLASH_ATTR(false, 2); FLASH_ATTR(true, 2);
 #undef FLASH_ATTR
-            attr_done = true;
+            attr_done.done();
         }
 #define FLASH(W, H, Q) hipLaunchKernelGGL((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
         if (ws == 24 && blocks < 256) { if (hf) FLASH(24, true, 2); else FLASH(24, false, 2); }   // too few (window, head) pairs: split the queries

@@ -73,6 +73,14 @@ const char* soccdpt_weight_key(void* handle, int index) {
 
 size_t soccdpt_prepared_bytes(void* handle) { return static_cast<Handle*>(handle)->prepared_bytes; }
 size_t soccdpt_workspace_bytes(void* handle, int B) { return model_workspace_bytes(*static_cast<Handle*>(handle), B); }
+int soccdpt_workspace_invalidate(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    h->ws_key = Handle::WsKey();
+    model_drop_graph(*h);
+    return 0;
+}
+int soccdpt_workspace_zero_fills(void* handle) { return handle ? static_cast<Handle*>(handle)->ws_zero_fills : -1; }
 
 int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
@@ -170,6 +178,11 @@ int soccdpt_metrics_iou(const float* dev_pred, const float* dev_gt, int B, int C
 int soccdpt_set_streams(void* handle, int n) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
+    if (n > 1) {   // experimental: see the header
+        const char* e = getenv("SOCCDPT_ALLOW_MULTISTREAM");
+        if (!e || atoi(e) != 1) return fail(h, "soccdpt_set_streams: n > 1 is experimental (DESIGN.md section 4); set SOCCDPT_ALLOW_MULTISTREAM=1 to opt in");
+    }
+    h->ws_key = Handle::WsKey();
     return model_set_streams(*h, n, h->err);
 }
 

@@ -162,12 +162,12 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
 int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, const float* w4, float b4, float* out, int hf, int B, int h,
                       int w, hipStream_t st, std::string& err) {
     if ((2 * h) % TH || (2 * w) % TW) { err = "depth_tail: output size must be a multiple of 8 x 16"; return 1; }
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&depth_tail_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         if (e != hipSuccess) { err = std::string("depth_tail: ") + hipGetErrorString(e); return 1; }
-        attr_done = true;
+        attr_done.done();
     }
     const int ntiles = B * (2 * h / TH) * (2 * w / TW);
     const int blocks = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU keeps the weights resident

@@ -5,9 +5,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
 #include <string>
 
 namespace soccdpt {
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per device and call site (a
+// process may hold one handle per GPU).  Setting the attribute twice is harmless, so concurrent first calls need no lock.
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask[4];   // 256 devices
+    PerDeviceOnce() { for (auto& m : mask) m.store(0ull); }
+    static int dev() { int d = 0; (void)hipGetDevice(&d); return d & 255; }
+    bool need() const { const int d = dev(); return !((mask[d >> 6].load(std::memory_order_acquire) >> (d & 63)) & 1ull); }
+    void done() { const int d = dev(); mask[d >> 6].fetch_or(1ull << (d & 63), std::memory_order_release); }
+};
 
 typedef uint16_t bf16_t;  // raw 16-bit operand bits: bf16, or fp16 under SOCCDPT_PREC_F16 (half16.h)
 

@@ -507,11 +507,11 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     const int nk = d.taps * d.Cin / BK, kpt = d.Cin / BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
     const size_t lds = (size_t)C::NS * C::STAGE;
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
-        attr_done = true;
+        attr_done.done();
     }
     const int splits = SK ? d.splitk : 1;
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||

@@ -111,6 +111,13 @@ struct Handle {
         int B = 0, streams = 0;
         bool operator==(const GraphKey& o) const { return x == o.x && inv == o.inv && seg == o.seg && ws == o.ws && B == o.B && streams == o.streams; }
     } graph_key;
+    // zero-halo invariant (model_network): the (buffer, B, streams) tuple the workspace was last zero-filled for
+    struct WsKey {
+        const void* ws = nullptr;
+        int B = 0, streams = 0;
+        bool operator==(const WsKey& o) const { return ws == o.ws && B == o.B && streams == o.streams; }
+    } ws_key;
+    int ws_zero_fills = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;  // capture/replay stream (the caller's may be the legacy null stream, which cannot capture)

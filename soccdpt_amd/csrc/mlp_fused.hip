@@ -226,11 +226,11 @@ __global__ __launch_bounds__(K::THREADS) void mlp_ln_kernel(const uint16_t* __re
 template <class K, bool F16>
 int launch_one(const uint16_t* xop, float* xf, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* g, const float* be,
                uint16_t* xop_out, uint16_t* halo, int M, int H, int W, int merge, hipStream_t st, std::string& err) {
-    static bool attr_done = false;
-    if (!attr_done) {
+    static PerDeviceOnce attr_done;
+    if (attr_done.need()) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_ln_kernel<K, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, K::LDS);
         if (e != hipSuccess) { err = std::string("mlp_ln: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
-        attr_done = true;
+        attr_done.done();
     }
     hipLaunchKernelGGL((mlp_ln_kernel<K, F16>), dim3((unsigned)((M + K::BM - 1) / K::BM)), dim3(K::THREADS), K::LDS, st, xop, xf, w1, b1, w2, b2, g, be,
                        xop_out, halo, M, H, W, merge);

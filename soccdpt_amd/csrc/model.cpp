@@ -681,7 +681,22 @@ void model_drop_graph(Handle& h) {
 int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t st,
                   std::string& err) {
     if (!h.is_prepared) { err = "soccdpt_network: call soccdpt_prepare after binding weights"; return 1; }
-    if (B <= 0 || !x || !inv256 || !seg256) { err = "soccdpt_network: bad argument"; return 1; }
+    if (B <= 0 || !x || !inv256 || !seg256 || !ws) { err = "soccdpt_network: bad argument"; return 1; }
+    {   // The library owns the zero-halo invariant: the workspace layout (and so the position of every conv border) depends on
+        // (B, stream count); the first call with a new (buffer, B, streams) tuple zero-fills the buffer on the caller's stream.
+        int dev = -1;
+        (void)hipGetDevice(&dev);
+        if (dev != h.device) { err = "soccdpt_network: the handle was created on device " + std::to_string(h.device) + " but device " + std::to_string(dev) + " is current"; return 1; }
+        const size_t need = model_workspace_bytes(h, B);
+        if (ws_bytes < need) { err = "soccdpt_network: workspace too small (soccdpt_workspace_bytes)"; return 1; }
+        Handle::WsKey wk{ws, B, h.n_streams};
+        if (!(wk == h.ws_key)) {
+            model_drop_graph(h);
+            if (hipMemsetAsync(ws, 0, need, st) != hipSuccess) { err = "soccdpt_network: workspace zero-fill failed"; return 1; }
+            h.ws_key = wk;
+            h.ws_zero_fills++;
+        }
+    }
     if (!h.use_graph || h.prof.on) return network_eager(h, x, B, inv256, seg256, ws, ws_bytes, st, err);
     Handle::GraphKey key;
     key.x = x; key.inv = inv256; key.seg = seg256; key.ws = ws; key.B = B; key.streams = h.n_streams;

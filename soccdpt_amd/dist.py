@@ -58,7 +58,13 @@ def init_from_env(backend: str = "nccl"):
     force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"  # exercise the RCCL path with a single rank (tests)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29511")
+        if "MASTER_PORT" not in os.environ:
+            if world > 1:   # ranks cannot agree on a port by themselves: the launcher (torchrun --master-port) must name it
+                raise RuntimeError("soccdpt_amd.dist: WORLD_SIZE > 1 but MASTER_PORT is not set (launch with torch.distributed.run)")
+            import socket
+            with socket.socket() as s:   # single forced rank: any free port (a fixed default collides between concurrent jobs)
+                s.bind(("127.0.0.1", 0))
+                os.environ["MASTER_PORT"] = str(s.getsockname()[1])
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
@@ -67,10 +73,11 @@ def init_from_env(backend: str = "nccl"):
     return rank, local, world
 
 
-def attach(net, group=None):
-    """Make `net` (SOccDPT / SOccDPT_V3) produce the union-over-all-ranks occupancy grid."""
+def attach(net, group=None, or_reduce: Optional[Callable] = None):
+    """Make `net` (SOccDPT / SOccDPT_V3) produce the union-over-all-ranks occupancy grid.  `or_reduce`: CPU stand-in for the
+    HIP OR-reduce kernel (gloo tests only; the product path leaves it None)."""
     import os
     force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"
     if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
-        net.occ_exchange = OccExchange(group)
+        net.occ_exchange = OccExchange(group, or_reduce=or_reduce)
     return net

@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsoccdpt_hip.so")
 
 ABI_VERSION = 1
-BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1}
+BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2
@@ -65,6 +65,19 @@ class IgemmArgs(ctypes.Structure):
 _lib = None
 
 
+def csrc_sha() -> str:
+    """Short hash of the kernel sources the loaded library was (presumably) built from.  profiles/*_pmc_traffic.json carry it, so
+    that bench.py can tell whether committed PMC counters still describe the current kernels."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(_HERE, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
+            h.update(name.encode())
+            h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_library() -> ctypes.CDLL:
     """Load libsoccdpt_hip.so; fail loudly when it has not been built."""
     global _lib
@@ -93,6 +106,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_prepared_bytes.restype = cs
     L.soccdpt_workspace_bytes.argtypes = [vp, ci]
     L.soccdpt_workspace_bytes.restype = cs
+    L.soccdpt_workspace_invalidate.argtypes = [vp]
+    L.soccdpt_workspace_invalidate.restype = ci
+    L.soccdpt_workspace_zero_fills.argtypes = [vp]
+    L.soccdpt_workspace_zero_fills.restype = ci
     L.soccdpt_prepare.argtypes = [vp, vp, cs, vp]
     L.soccdpt_prepare.restype = ci
     L.soccdpt_forward.argtypes = [vp, vp, ci, vp, vp, vp, vp, vp, vp, cs, vp]
@@ -263,15 +280,16 @@ class Engine:
                         "soccdpt_prepare")
 
     def workspace(self, B: int) -> torch.Tensor:
+        """Per-forward scratch.  The library zero-fills it itself whenever (buffer, B, streams) changes (include/soccdpt_hip.h,
+        workspace contract), so any allocation will do; the buffer only grows."""
         nbytes = self.L.soccdpt_workspace_bytes(self._h, B)
         if self._workspace is None or self._workspace.numel() < nbytes:
-            # zero-filled: halo borders of the padded NHWC activations stay zero for ever
-            self._workspace = torch.zeros(max(nbytes, 16), dtype=torch.uint8, device=self.device)
-            self._workspace_B = B
-        elif self._workspace_B != B:
-            self._workspace.zero_()  # the layout (and so the halo positions) depends on B
-            self._workspace_B = B
+            self._workspace = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+            self.L.soccdpt_workspace_invalidate(self._h)   # a freed buffer's address may be handed out again
         return self._workspace
+
+    def workspace_zero_fills(self) -> int:
+        return int(self.L.soccdpt_workspace_zero_fills(self._h))
 
     def occ_words(self) -> int:
         return int(self.L.soccdpt_occ_words(self._h))

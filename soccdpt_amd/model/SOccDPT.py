@@ -193,20 +193,23 @@ class SOccDPT_V3(SOccDPT):
         return super()._apply(fn, *args, **kwargs)
 
     def _sync_weights(self, eng: Engine):
+        """(Re-)bind and re-prepare when any consumed tensor changed: in-place updates bump `_version` (optimizers, the fused
+        Adam, load_state_dict), `p.data = ...` changes `data_ptr()`.  The LIVE parameters / buffers are watched, not a
+        state_dict() snapshot."""
         refs = self._weight_refs.get(id(eng))
         if refs is not None:
-            version = tuple(t._version for t in refs)
+            version = tuple((t._version, t.data_ptr()) for t in refs)
             if self._bound_versions.get(id(eng)) == version:
                 return
-        sd = self.state_dict()
+        live = dict(self.named_parameters(remove_duplicate=False))
+        live.update(dict(self.named_buffers(remove_duplicate=False)))
         keys = eng.weight_keys()
-        refs = [sd[k] for k in keys]
-        version = tuple(t._version for t in refs)
-        for k in keys:
-            t = sd[k]
+        refs = [live[k] for k in keys]
+        version = tuple((t._version, t.data_ptr()) for t in refs)
+        for k, t in zip(keys, refs):
             if t.device != eng.device or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError(f"weight {k} must be a contiguous float32 tensor on {eng.device} (got {t.device}, {t.dtype})")
-            eng.bind(k, t)
+            eng.bind(k, t.detach())
         eng.prepare()
         self._weight_refs[id(eng)] = refs
         self._bound_versions[id(eng)] = version

@@ -67,6 +67,15 @@ MODEL_TYPE_TO_BACKBONE: Dict[str, str] = {
     "dpt_hybrid_384": "vitb_rn50_384",
 }
 
+def backbone_image_size(backbone: str) -> int:
+    """Network input size of a backbone this build implements (model/loader.py:141-272 net_w / net_h)."""
+    if backbone in SWIN_ARCHS:
+        return SWIN_ARCHS[backbone].img
+    if backbone == "vitb_rn50_384":
+        return 384
+    raise AssertionError(f"Backbone '{backbone}' not implemented on the MI355X path")
+
+
 DEFAULT_DEPTH_WEIGHTS: Dict[str, str] = {k: f"weights/{k}.pt" for k in MODEL_TYPE_TO_BACKBONE}
 
 model_types = DEFAULT_DEPTH_WEIGHTS.keys()

@@ -80,8 +80,16 @@ def evaluate_depth(net, dataloader, device, amp=False):
         y_pred = net(x)
         m = depth_metrics(y_pred, y, mask)
         acc.append(torch.stack([m[k] for k in DEPTH_KEYS]))
-    vals = torch.stack(acc).mean(0).cpu().numpy()
-    return tuple(float(v) for v in np.asarray(vals))
+    vals = torch.stack(acc).cpu().numpy().astype(np.float64)          # [batches, 7]
+    # per-metric filtering of the reference (utils/__init__.py:236-244): a non-finite abs_rel / sq_rel / rmse_log of ONE batch is
+    # dropped from that metric's mean instead of poisoning it; rmse and a1..a3 are always kept
+    out = []
+    for i, k in enumerate(DEPTH_KEYS):
+        col = vals[:, i]
+        if k in ("abs_rel", "sq_rel", "rmse_log"):
+            col = col[np.isfinite(col)]
+        out.append(float(np.mean(col)))
+    return tuple(out)
 
 
 def evaluate_seg(net, dataloader, device, amp=False):

@@ -49,7 +49,8 @@ class Adam:
             n = len(items)
             arr = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
             ps = arr([p.data_ptr() for p, _ in items])
-            gs = arr([p.grad.contiguous().data_ptr() for p, _ in items])
+            grads = [p.grad.contiguous() for p, _ in items]   # kept alive until after the launch (a non-contiguous grad makes a temporary)
+            gs = arr([g.data_ptr() for g in grads])
             ms = arr([s["exp_avg"].data_ptr() for _, s in items])
             vs = arr([s["exp_avg_sq"].data_ptr() for _, s in items])
             sizes = (ctypes.c_size_t * n)(*[p.numel() for p, _ in items])
@@ -58,6 +59,10 @@ class Adam:
                                          _stream_ptr(dev))
             if rc != 0:
                 raise RuntimeError("soccdpt_adam_step failed: " + L.soccdpt_last_error(None).decode())
+            # the kernel wrote through raw pointers: bump the autograd version counters so that everything keyed on
+            # tensor._version (SOccDPT_V3._sync_weights re-runs soccdpt_prepare) sees the update
+            torch._C._increment_version([p for p, _ in items])
+            del grads
 
 
 def patches(n_trainable: int, percentage: float) -> List[range]:

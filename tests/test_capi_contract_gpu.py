@@ -1,0 +1,85 @@
+"""GPU: contracts of the C ABI that a non-Python caller relies on (include/soccdpt_hip.h, "Workspace contract"; VERDICT r1 #8 /
+ADVICE r1): the library, not the caller, keeps the zero-halo invariant of the workspace; errors are returned, never silent."""
+import ctypes
+import os
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def model(gpu_device):
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True)
+    m.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
+    return m.eval().to(gpu_device)
+
+
+def _raw_network(eng, x, ws):
+    B, S = x.shape[0], x.shape[2]
+    inv = torch.empty((B, S, S), device=x.device)
+    seg = torch.empty((B, 3, S, S), device=x.device)
+    rc = eng.L.soccdpt_network(eng._h, x.data_ptr(), B, inv.data_ptr(), seg.data_ptr(), ws.data_ptr(), ws.numel(),
+                               torch.cuda.current_stream(x.device).cuda_stream)
+    return rc, inv, seg
+
+
+def test_library_owns_the_zero_halo_invariant(model, gpu_device):
+    """A caller-provided buffer full of garbage, reused across batch sizes, gives the same results as fresh zeroed buffers."""
+    from soccdpt_amd.utils.synth import synth_input
+    eng = model._engine(gpu_device)
+    model._sync_weights(eng)
+    x3 = synth_input(3, seed0=50).to(gpu_device)
+    ref = {}
+    for B in (2, 3):
+        inv, seg = model.network(x3[:B])
+        ref[B] = (inv.clone(), seg.clone())
+    need = max(eng.L.soccdpt_workspace_bytes(eng._h, B) for B in (2, 3))
+    ws = torch.full((need,), 0xFF, dtype=torch.uint8, device=gpu_device)      # NaN patterns in every halo
+    fills0 = eng.workspace_zero_fills()
+    for B in (2, 3, 2, 2):
+        rc, inv, seg = _raw_network(eng, x3[:B].contiguous(), ws)
+        torch.cuda.synchronize()
+        assert rc == 0, eng.L.soccdpt_last_error(eng._h)
+        assert torch.equal(inv, ref[B][0]) and torch.equal(seg, ref[B][1]), B
+    assert eng.workspace_zero_fills() - fills0 == 3          # one per layout change (2, 3, 2), none for the repeated call
+    # somebody scribbles over the buffer: the caller says so, the library re-zeroes
+    ws.fill_(0x7F)
+    assert eng.L.soccdpt_workspace_invalidate(eng._h) == 0
+    rc, inv, seg = _raw_network(eng, x3[:2].contiguous(), ws)
+    torch.cuda.synchronize()
+    assert rc == 0 and torch.equal(inv, ref[2][0])
+
+
+def test_errors_are_returned(model, gpu_device):
+    from soccdpt_amd.utils.synth import synth_input
+    eng = model._engine(gpu_device)
+    model._sync_weights(eng)
+    x = synth_input(2, seed0=51).to(gpu_device)
+    need = eng.L.soccdpt_workspace_bytes(eng._h, 2)
+    small = torch.empty((need // 2,), dtype=torch.uint8, device=gpu_device)
+    rc, _, _ = _raw_network(eng, x, small)
+    assert rc != 0 and b"workspace too small" in eng.L.soccdpt_last_error(eng._h)
+    # the experimental multi-stream mode is opt-in
+    old = os.environ.pop("SOCCDPT_ALLOW_MULTISTREAM", None)
+    try:
+        assert eng.L.soccdpt_set_streams(eng._h, 2) != 0
+        assert b"experimental" in eng.L.soccdpt_last_error(eng._h)
+        assert eng.L.soccdpt_set_streams(eng._h, 1) == 0
+    finally:
+        if old is not None:
+            os.environ["SOCCDPT_ALLOW_MULTISTREAM"] = old
+    # unknown backbone id / wrong ABI version are refused at creation
+    cfg = type(eng.cfg)()
+    ctypes.memmove(ctypes.byref(cfg), ctypes.byref(eng.cfg), ctypes.sizeof(cfg))
+    cfg.backbone = 99
+    h = ctypes.c_void_p()
+    assert eng.L.soccdpt_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+    cfg.backbone = 0
+    cfg.abi_version = 12345
+    assert eng.L.soccdpt_create(ctypes.byref(cfg), ctypes.byref(h)) != 0

@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from soccdpt_amd.dist import OccExchange, gather_occ_bits, shard_range
+from soccdpt_amd.dist import OccExchange, attach, gather_occ_bits, shard_range
 
 
 def test_shard_range_partitions_batch():
@@ -70,3 +70,58 @@ def test_two_rank_union_equals_single_rank(tmp_path):
     assert np.array_equal(u0, u1)          # every rank ends with the same union grid
     assert np.array_equal(u0, whole)       # ... equal to the single-rank grid of the global batch
     assert int(np.unpackbits(whole.view(np.uint8)).sum()) > 0
+
+
+def _worker_attach(rank, world, port, outdir, gb):
+    """The path bench.py takes: init -> attach(net) -> net.occ_exchange(eng, bits), with an uneven batch split."""
+    import types
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import cref
+    from tests.golden_inputs import proj_inputs
+    inv, seg = proj_inputs(seed=91, B=gb, S=64)
+    lo, hi = shard_range(gb, rank, world)
+    assert hi > lo
+    bits = torch.from_numpy(cref.project(inv[lo:hi], seg[lo:hi], want=("occ_bits",))["occ_bits"].view(np.int32).copy())
+
+    def or_reduce(g):
+        out = g[0].clone()
+        for i in range(1, g.shape[0]):
+            out |= g[i]
+        return out
+    net = attach(types.SimpleNamespace(occ_exchange=None), or_reduce=or_reduce)
+    assert net.occ_exchange is not None and dist.get_world_size() == world
+    for _ in range(2):                       # the receive buffer is reused on the second call
+        union = net.occ_exchange(None, bits)
+    np.save(os.path.join(outdir, f"union_{rank}.npy"), union.numpy())
+    np.save(os.path.join(outdir, f"shard_{rank}.npy"), np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_ranks_uneven_shards_through_attach(tmp_path):
+    """world_size 4, global batch 7 -> shards of 2, 2, 2, 1 frames: every rank ends with the single-rank union grid."""
+    gb, world = 7, 4
+    mp.spawn(_worker_attach, args=(world, _free_port(), str(tmp_path), gb), nprocs=world, join=True)
+    from oracle import cref
+    from tests.golden_inputs import proj_inputs
+    inv, seg = proj_inputs(seed=91, B=gb, S=64)
+    whole = cref.project(inv, seg, want=("occ_bits",))["occ_bits"].view(np.int32)
+    sizes = []
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"union_{r}.npy"), whole), r
+        lo, hi = np.load(tmp_path / f"shard_{r}.npy")
+        sizes.append(int(hi - lo))
+    assert sizes == [2, 2, 2, 1]
+    assert int(np.unpackbits(whole.view(np.uint8)).sum()) > 0
+
+
+def test_init_from_env_refuses_multi_rank_without_port(monkeypatch):
+    from soccdpt_amd.dist import init_from_env
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "0")
+    monkeypatch.delenv("MASTER_PORT", raising=False)
+    with pytest.raises(RuntimeError):
+        init_from_env("gloo")

@@ -40,7 +40,8 @@ def test_synth_state_dict_loads_strict_enough(net):
     shapes = v3_state_shapes("swin2t16_256")
     for k, shp in shapes.items():
         assert tuple(sd[k].shape) == tuple(shp)
-    assert sum(v.numel() for k, v in sd.items() if k.startswith("depth_net.pretrained")) == 28_347_154 or True
+    # timm swinv2_tiny_window16_256: 28,347,154 parameters including the 1000-class head
+    assert sum(v.numel() for k, v in sd.items() if k.startswith("depth_net.pretrained")) == 28_347_154
 
 
 def test_api_surface(net):
@@ -86,9 +87,17 @@ def test_oracle_decoder_matches_golden(golden_dir):
         with torch.no_grad():
             inv, p1 = R.dpt_decoder(sd, feats)
             seg = R.seg_head(sd, p1, sig)
-        np.testing.assert_allclose(inv.numpy(), g["inv256"], rtol=1e-4, atol=1e-6)
-        np.testing.assert_allclose(seg.numpy(), g["seg256"], rtol=1e-4, atol=1e-5)
-        np.testing.assert_allclose(p1[0, ::16, ::8, ::8].numpy(), g["path1_sample"], rtol=1e-4, atol=1e-4)
+        # The fixture holds the REFERENCE's outputs, generated with 8 intra-op threads (oracle/make_golden.py); with the same
+        # thread count oneDNN / MKL split the work identically and the oracle must reproduce them BIT FOR BIT (that is the claim
+        # "decoder + heads pinned").  On a host that cannot give 8 threads only round-off-level agreement can be checked.
+        if torch.get_num_threads() == 8 and (os.cpu_count() or 1) >= 8:
+            assert np.array_equal(inv.numpy(), g["inv256"]), name
+            assert np.array_equal(seg.numpy(), g["seg256"]), name
+            assert np.array_equal(p1[0, ::16, ::8, ::8].numpy(), g["path1_sample"]), name
+        else:  # pragma: no cover
+            np.testing.assert_allclose(inv.numpy(), g["inv256"], rtol=1e-5, atol=1e-7)
+            np.testing.assert_allclose(seg.numpy(), g["seg256"], rtol=1e-5, atol=1e-6)
+            np.testing.assert_allclose(p1[0, ::16, ::8, ::8].numpy(), g["path1_sample"], rtol=1e-5, atol=1e-5)
 
 
 def test_oracle_encoder_regression(golden_dir):

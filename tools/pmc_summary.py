@@ -48,7 +48,10 @@ if len(sys.argv) > 4:  # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GU
             out[k]["mfma_busy_cycles_per_launch"] = mf[k][1] / mf[k][0]
             out[k]["gpu_active_cycles_per_launch_sum_of_8_xcds"] = ga[k][1] / ga[k][0]
             out[k]["mfma_util"] = mf[k][1] / (ga[k][1] / 8.0 * 256 * 4)
-json.dump(dict(note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --steps 3 --warmup 1 --no-cpu-baseline`; KiB->bytes; "
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from soccdpt_amd.lib import csrc_sha  # noqa: E402
+json.dump(dict(csrc_sha=csrc_sha(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --headline-only --steps 3 --warmup 1`; KiB->bytes; "
                     "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads)", kernels=out),
           open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out), "kernels")
