@@ -9,12 +9,13 @@ Pinning status
 * decoder + heads + projection: pinned bit-for-bit against the reference's own
   code run in the build container (``oracle/make_golden.py``; fixtures in
   ``tests/golden/``).
-* Swin-V2 encoder: **parity unpinned** at the timm boundary.  The arithmetic
+* Swin-V2 and ViT-hybrid encoders: **parity unpinned** at the timm boundary (the hybrid's adapters -- pos-embed resize, readout
+  projection, hooks / unflatten / reassemble convs -- ARE the reference's code and are pinned by fixtures).  The arithmetic
   lives in ``timm==0.6.12`` (``/root/reference/requirements.txt:12``), which is
   neither vendored nor installed; the reference has no tests or golden vectors.
   The restatement below follows the published Swin-V2 algorithm as called from
   ``SOccDPT/model/backbones/swin2.py:24-30`` and is cross-checked against the
-  independent HF ``transformers`` ``Swinv2Model`` (tests/test_oracle_encoder.py).
+  independent HF ``transformers`` ports (``Swinv2Model``, DPT hybrid; tests/test_oracle_encoder.py, oracle/hf_crosscheck.py).
 
 Every function cites the reference file:line it follows (paths relative to
 ``/root/reference/SOccDPT``).  The state-dict key layout is the reference's
@@ -64,10 +65,34 @@ ARCHS: Dict[str, SwinArch] = {
     "swin2b24_384": SwinArch(384, 4, 128, (2, 2, 18, 2), (4, 8, 16, 32), 24, (12, 12, 12, 6), (1, 1, 17, 1)),
 }
 
-MODEL_TYPE_TO_BACKBONE = {  # model/loader.py:65-77
+MODEL_TYPE_TO_BACKBONE = {  # model/loader.py:65-77,115-120
     "dpt_swin2_tiny_256": "swin2t16_256",
     "dpt_swin2_base_384": "swin2b24_384",
+    "dpt_hybrid_384": "vitb_rn50_384",
 }
+
+
+@dataclass(frozen=True)
+class HybridArch:
+    """timm 0.6.12 `vit_base_resnet50_384` (= vit_base_r50_s16_384) as created by backbones/vit.py:244-258: ResNetV2 (3, 4, 9)
+    stem/stages with weight-standardised SAME-padded convolutions + GroupNorm(32), 1x1 projection to 768, 12 pre-norm ViT-B blocks
+    over 24 x 24 + 1 tokens; hooks [0, 1, 8, 11] (model/dpt.py:86), reassemble channels [256, 512, 768, 768] (model/blocks.py:103-112)."""
+    img: int = 384
+    embed: int = 768
+    depth: int = 12
+    heads: int = 12
+    stem: int = 64
+    layers: Tuple[int, ...] = (3, 4, 9)
+    hooks: Tuple[int, ...] = (0, 1, 8, 11)
+    features: Tuple[int, ...] = (256, 512, 768, 768)
+    patch: int = 16
+
+    @property
+    def grid(self) -> int:
+        return self.img // self.patch
+
+
+HYBRID = HybridArch()
 
 
 # ----------------------------------------------------------------------------
@@ -198,6 +223,133 @@ def swin_encoder(sd: Dict[str, Tensor], x: Tensor, arch: SwinArch, pfx: str = "d
         if s < len(arch.depths) - 1:
             t = patch_merging(sd, f"{pfx}layers.{s}.downsample.", t, res)
             res //= 2
+    return outs
+
+
+# ----------------------------------------------------------------------------
+# ViT-hybrid encoder.  PARITY UNPINNED at the timm boundary, like the Swin-V2 encoder: the ResNetV2
+# and VisionTransformer arithmetic lives in timm==0.6.12 (requirements.txt:12; call site backbones/vit.py:244-258), not vendored,
+# not installable; restated from the published architectures and cross-checked against HF transformers' independent port
+# (DPT hybrid = BiT backbone + ViT; oracle/hf_crosscheck.py, tests/test_oracle_encoder.py).  The ADAPTERS around it are the
+# reference's own code and are pinned by fixtures generated from it (oracle/make_golden.py): forward_flex / _resize_pos_embed
+# (backbones/vit.py:23-85), forward_adapted_unflatten + ProjectReadout + act_postprocess (backbones/utils.py:27-40,84-133,
+# backbones/vit.py:147-231).  backbones/vit.py:181-182,222-223 are broken in the snapshot (`_ = nn.Sequential(...)` followed by
+# exec("...=value")): the evident upstream-MiDaS intent `value = nn.Sequential(...)` is followed.
+# ----------------------------------------------------------------------------
+def pad_same(x: Tensor, k: int, s: int, value: float = 0.0) -> Tensor:
+    """TF-style SAME padding (timm padding.pad_same): total = max((ceil(i/s)-1)*s + k - i, 0), the extra pixel goes right/bottom."""
+    ih, iw = x.shape[-2:]
+    ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
+    pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
+    if ph > 0 or pw > 0:
+        x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2], value=value)
+    return x
+
+
+def std_conv_same(x: Tensor, w: Tensor, stride: int = 1, eps: float = 1e-8) -> Tensor:
+    """timm StdConv2dSame(bias=False, eps=1e-8): per-output-channel weight standardisation (biased variance, evaluated through
+    F.batch_norm exactly like timm) and 'SAME' padding -- static symmetric padding when stride == 1, dynamic TF padding otherwise."""
+    k = w.shape[-1]
+    ws = F.batch_norm(w.reshape(1, w.shape[0], -1), None, None, training=True, momentum=0.0, eps=eps).reshape_as(w)
+    if stride == 1:
+        return F.conv2d(x, ws, None, 1, (k - 1) // 2)
+    return F.conv2d(pad_same(x, k, stride), ws, None, stride, 0)
+
+
+def group_norm_act(x: Tensor, w: Tensor, b: Tensor, relu: bool = True) -> Tensor:
+    """timm GroupNormAct(num_groups=32, eps=1e-5) (+ ReLU)."""
+    y = F.group_norm(x, 32, w, b, 1e-5)
+    return F.relu(y) if relu else y
+
+
+def resnetv2_bottleneck(sd, p: str, x: Tensor, stride: int) -> Tensor:
+    """timm resnetv2.Bottleneck (non-pre-activation, the ViT-hybrid form): 1x1 -> GN+ReLU -> 3x3 (stride) -> GN+ReLU -> 1x1 -> GN,
+    shortcut = GN(1x1 stride conv) on the first block of a stage, ReLU after the sum."""
+    sc = x
+    if p + "downsample.conv.weight" in sd:
+        sc = std_conv_same(x, sd[p + "downsample.conv.weight"], stride)
+        sc = group_norm_act(sc, sd[p + "downsample.norm.weight"], sd[p + "downsample.norm.bias"], relu=False)
+    y = std_conv_same(x, sd[p + "conv1.weight"])
+    y = group_norm_act(y, sd[p + "norm1.weight"], sd[p + "norm1.bias"])
+    y = std_conv_same(y, sd[p + "conv2.weight"], stride)
+    y = group_norm_act(y, sd[p + "norm2.weight"], sd[p + "norm2.bias"])
+    y = std_conv_same(y, sd[p + "conv3.weight"])
+    y = group_norm_act(y, sd[p + "norm3.weight"], sd[p + "norm3.bias"], relu=False)
+    return F.relu(y + sc)
+
+
+def resnetv2_backbone(sd, p: str, x: Tensor, arch: HybridArch = HYBRID) -> List[Tensor]:
+    """timm ResNetV2(layers=(3,4,9), preact=False, stem_type='same', conv_layer=StdConv2dSame(eps=1e-8)): outputs of the three stages
+    ([B,256,96,96], [B,512,48,48], [B,1024,24,24] at 384 x 384)."""
+    y = std_conv_same(x, sd[p + "stem.conv.weight"], 2)
+    y = group_norm_act(y, sd[p + "stem.norm.weight"], sd[p + "stem.norm.bias"])
+    y = F.max_pool2d(pad_same(y, 3, 2, value=float("-inf")), 3, 2)     # MaxPool2dSame
+    outs = []
+    for s, depth in enumerate(arch.layers):
+        for j in range(depth):
+            y = resnetv2_bottleneck(sd, f"{p}stages.{s}.blocks.{j}.", y, stride=(2 if (s > 0 and j == 0) else 1))
+        outs.append(y)
+    return outs
+
+
+def resize_pos_embed(posemb: Tensor, gs_h: int, gs_w: int, start_index: int = 1) -> Tensor:
+    """backbones/vit.py:23-41 (_resize_pos_embed)."""
+    tok, grid = posemb[:, :start_index], posemb[0, start_index:]
+    gs_old = int(math.sqrt(len(grid)))
+    grid = grid.reshape(1, gs_old, gs_old, -1).permute(0, 3, 1, 2)
+    grid = F.interpolate(grid, size=(gs_h, gs_w), mode="bilinear")
+    grid = grid.permute(0, 2, 3, 1).reshape(1, gs_h * gs_w, -1)
+    return torch.cat([tok, grid], dim=1)
+
+
+def vit_block(sd, p: str, x: Tensor, heads: int) -> Tensor:
+    """timm vision_transformer.Block (pre-norm, LayerNorm eps 1e-6, no layer-scale, erf GELU)."""
+    B, N, C = x.shape
+    h = F.layer_norm(x, (C,), sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6)
+    qkv = F.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"]).reshape(B, N, 3, heads, C // heads).permute(2, 0, 3, 1, 4)
+    q, k, v = qkv[0], qkv[1], qkv[2]
+    a = (q @ k.transpose(-2, -1)) * ((C // heads) ** -0.5)
+    a = a.softmax(dim=-1)
+    h = (a @ v).transpose(1, 2).reshape(B, N, C)
+    x = x + F.linear(h, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"])
+    h = F.layer_norm(x, (C,), sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6)
+    h = F.gelu(F.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"]))
+    return x + F.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"])
+
+
+def project_readout(sd, p: str, x: Tensor, start_index: int = 1) -> Tensor:
+    """backbones/utils.py:27-40 ProjectReadout: Linear(2C, C) + GELU on cat(token, cls)."""
+    readout = x[:, 0].unsqueeze(1).expand_as(x[:, start_index:])
+    feats = torch.cat((x[:, start_index:], readout), -1)
+    return F.gelu(F.linear(feats, sd[p + "project.0.weight"], sd[p + "project.0.bias"]))
+
+
+def hybrid_encoder(sd: Dict[str, Tensor], x: Tensor, arch: HybridArch = HYBRID, pfx: str = "depth_net.pretrained.") -> List[Tensor]:
+    """forward_vit -> forward_adapted_unflatten(pretrained, x, "forward_flex") (backbones/vit.py:19-85, backbones/utils.py:84-133)
+    with hooks on patch_embed.backbone.stages[0,1] and blocks[8,11] (vit.py:164-171).  Returns the four NCHW maps handed to
+    scratch.layerN_rn: [B,256,96,96], [B,512,48,48], [B,768,24,24], [B,768,12,12]."""
+    B, _, H, W = x.shape
+    m = pfx + "model."
+    stages = resnetv2_backbone(sd, m + "patch_embed.backbone.", x, arch)
+    gh, gw = H // arch.patch, W // arch.patch
+    pos = resize_pos_embed(sd[m + "pos_embed"], gh, gw)
+    t = F.conv2d(stages[-1], sd[m + "patch_embed.proj.weight"], sd[m + "patch_embed.proj.bias"]).flatten(2).transpose(1, 2)
+    t = torch.cat((sd[m + "cls_token"].expand(B, -1, -1), t), dim=1) + pos            # no_embed_class=False: cat first, then add
+    hooked = {}
+    for i in range(arch.depth):
+        t = vit_block(sd, f"{m}blocks.{i}.", t, arch.heads)
+        if i in arch.hooks[2:]:
+            hooked[i] = t
+    # (the final model.norm is dead on this path: both hooks fire before it)
+    l1, l2 = stages[0], stages[1]                                   # act_postprocess1/2 = Identity x 3 (vit.py:179-182)
+    outs = [l1, l2]
+    for n, hk in ((3, arch.hooks[2]), (4, arch.hooks[3])):
+        ap = f"{pfx}act_postprocess{n}."
+        y = project_readout(sd, ap + "0.", hooked[hk]).transpose(1, 2).reshape(B, arch.embed, gh, gw)   # [0:2] + unflatten
+        y = F.conv2d(y, sd[ap + "3.weight"], sd[ap + "3.bias"])                                           # Conv2d(768, features[s], 1)
+        if n == 4:
+            y = F.conv2d(y, sd[ap + "4.weight"], sd[ap + "4.bias"], stride=2, padding=1)                  # Conv2d(768, 768, 3, 2, 1)
+        outs.append(y)
     return outs
 
 
@@ -369,8 +521,7 @@ def points_to_occupancy(points: Tensor, sem: Tensor, cfg: ProjConfig = ProjConfi
 # ----------------------------------------------------------------------------
 def soccdpt_v3_network(sd, x: Tensor, backbone: str = "swin2t16_256", sigmoid: bool = True):
     """Encoder + decoder + heads only: (inv_depth [B,H,W], seg [B,C,H,W], path_1)."""
-    arch = ARCHS[backbone]
-    layers = swin_encoder(sd, x, arch)
+    layers = hybrid_encoder(sd, x) if backbone == "vitb_rn50_384" else swin_encoder(sd, x, ARCHS[backbone])
     inv, p1 = dpt_decoder(sd, layers)
     seg = seg_head(sd, p1, sigmoid)
     return inv, seg, p1

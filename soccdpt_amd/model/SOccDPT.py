@@ -22,7 +22,7 @@ from .base_model import BaseModel
 from .blocks import Interpolate
 from .dpt import DPTDepthModel
 from .scaled_tanh import ScaledTanh
-from .spec import DEFAULT_DEPTH_WEIGHTS, MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS, model_types  # noqa: F401
+from .spec import DEFAULT_DEPTH_WEIGHTS, HYBRID_ARCHS, MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS, backbone_image_size, model_types  # noqa: F401
 
 # /root/reference/SOccDPT/datasets/bdd_helper.py:53-56
 DATASET_BASE = "~/Datasets/Depth_Dataset_Bengaluru"
@@ -87,7 +87,7 @@ class SOccDPT(BaseModel):
 
     # -- engine plumbing --
     def _engine_backbone(self) -> str:
-        return self.backbone if self.backbone in SWIN_ARCHS else "swin2t16_256"
+        return self.backbone if (self.backbone in SWIN_ARCHS or self.backbone in HYBRID_ARCHS) else "swin2t16_256"
 
     def _sigmoid_flag(self) -> bool:
         return True
@@ -220,9 +220,9 @@ class SOccDPT_V3(SOccDPT):
         if self.training:
             raise RuntimeError("the MI355X path implements the eval-mode forward; call net.eval() "
                                "(patch-wise training is the next scope row, SURVEY.md §8f)")
-        arch = SWIN_ARCHS[self._engine_backbone()]
-        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == arch.img and x.shape[3] == arch.img, \
-            f"expected x [B,3,{arch.img},{arch.img}], got {tuple(x.shape)}"
+        img = backbone_image_size(self._engine_backbone())
+        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, \
+            f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
         eng = self._engine(x.device)
         self._sync_weights(eng)
         dev = x.device

@@ -5,7 +5,8 @@ convolutions with fused ReLU / bias / residual epilogues, bilinear resize) runs 
 import torch.nn as nn
 
 from .backbones.swin2 import _make_pretrained_swin2b24_384, _make_pretrained_swin2t16_256
-from .spec import SWIN_ARCHS
+from .backbones.vit import _make_pretrained_vitb_rn50_384
+from .spec import HYBRID_ARCHS, SWIN_ARCHS
 
 
 class _Holder(nn.Module):
@@ -19,10 +20,13 @@ def _make_encoder(backbone, features, use_pretrained, groups=1, expand=False, ex
         pretrained = _make_pretrained_swin2t16_256(use_pretrained, hooks=hooks)
     elif backbone == "swin2b24_384":
         pretrained = _make_pretrained_swin2b24_384(use_pretrained, hooks=hooks)
+    elif backbone == "vitb_rn50_384":
+        pretrained = _make_pretrained_vitb_rn50_384(use_pretrained, hooks=hooks, use_vit_only=use_vit_only, use_readout=use_readout)
     else:
         print(f"Backbone '{backbone}' not implemented")
         assert False, f"Backbone '{backbone}' not implemented on the MI355X path"
-    scratch = _make_scratch(SWIN_ARCHS[backbone].dims(), features, groups=groups, expand=expand)
+    arch = HYBRID_ARCHS[backbone] if backbone in HYBRID_ARCHS else SWIN_ARCHS[backbone]
+    scratch = _make_scratch(arch.dims(), features, groups=groups, expand=expand)
     return pretrained, scratch
 
 

@@ -3,7 +3,7 @@ import torch.nn as nn
 
 from .base_model import BaseModel
 from .blocks import FeatureFusionBlock_custom, Interpolate, _make_encoder
-from .spec import SWIN_ARCHS
+from .spec import HYBRID_ARCHS, SWIN_ARCHS
 
 
 def _make_fusion_block(features, use_bn, size=None):
@@ -15,12 +15,12 @@ class DPT(BaseModel):
     def __init__(self, head, features=256, backbone="swin2t16_256", readout="project", channels_last=False,
                  use_bn=False, return_features=False, **kwargs):
         super().__init__()
-        assert backbone in SWIN_ARCHS, f"Backbone '{backbone}' not implemented on the MI355X path"
+        assert backbone in SWIN_ARCHS or backbone in HYBRID_ARCHS, f"Backbone '{backbone}' not implemented on the MI355X path"
         assert features == 256 and not use_bn
         self.channels_last = channels_last
         self.return_features = return_features
         self.backbone = backbone
-        hooks = list(SWIN_ARCHS[backbone].hooks)
+        hooks = list((HYBRID_ARCHS[backbone] if backbone in HYBRID_ARCHS else SWIN_ARCHS[backbone]).hooks)   # model/dpt.py:51-89
         self.pretrained, self.scratch = _make_encoder(backbone, features, False, groups=1, expand=False,
                                                       exportable=False, hooks=hooks, use_readout=readout)
         self.number_layers = 4

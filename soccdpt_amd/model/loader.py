@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 from .base_model import BaseModel
-from .spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+from .spec import HYBRID_ARCHS, MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
 from .transforms import InputTransform
 
 
@@ -43,7 +43,7 @@ def load_transforms(model_type: str = "dpt_large_384", height: int = 0, square: 
         print(f"model_type '{model_type}' not implemented")
         assert False, f"model_type '{model_type}' not implemented"
     backbone = MODEL_TYPE_TO_BACKBONE[model_type]
-    size = SWIN_ARCHS[backbone].img if backbone in SWIN_ARCHS else 384
+    size = SWIN_ARCHS[backbone].img if backbone in SWIN_ARCHS else (HYBRID_ARCHS[backbone].img if backbone in HYBRID_ARCHS else 384)
     net_w = net_h = size
     keep_aspect_ratio = False if backbone in SWIN_ARCHS else (not square)
     if height != 0:

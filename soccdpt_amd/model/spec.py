@@ -71,8 +71,8 @@ def backbone_image_size(backbone: str) -> int:
     """Network input size of a backbone this build implements (model/loader.py:141-272 net_w / net_h)."""
     if backbone in SWIN_ARCHS:
         return SWIN_ARCHS[backbone].img
-    if backbone == "vitb_rn50_384":
-        return 384
+    if backbone in HYBRID_ARCHS:
+        return HYBRID_ARCHS[backbone].img
     raise AssertionError(f"Backbone '{backbone}' not implemented on the MI355X path")
 
 
@@ -124,7 +124,98 @@ def encoder_param_shapes(arch: SwinV2Arch) -> "OrderedDict[str, Tuple[int, ...]]
     return p
 
 
-def scratch_param_shapes(arch: SwinV2Arch, features: int = 256) -> "OrderedDict[str, Tuple[int, ...]]":
+@dataclass(frozen=True)
+class HybridArch:
+    """timm 0.6.12 vit_base_resnet50_384 as the reference creates it (/root/reference/SOccDPT/model/backbones/vit.py:244-258);
+    hooks /root/reference/SOccDPT/model/dpt.py:86, reassemble channels /root/reference/SOccDPT/model/blocks.py:103-112."""
+    name: str = "vitb_rn50_384"
+    timm_name: str = "vit_base_resnet50_384"
+    img: int = 384
+    patch: int = 16
+    embed: int = 768
+    depth: int = 12
+    heads: int = 12
+    stem: int = 64
+    layers: Tuple[int, ...] = (3, 4, 9)
+    hooks: Tuple[int, ...] = (0, 1, 8, 11)
+    features: Tuple[int, ...] = (256, 512, 768, 768)
+
+    @property
+    def grid(self) -> int:
+        return self.img // self.patch
+
+    def dims(self) -> List[int]:
+        return list(self.features)
+
+
+HYBRID_ARCHS: Dict[str, HybridArch] = {"vitb_rn50_384": HybridArch()}
+
+
+def hybrid_param_shapes(arch: HybridArch) -> "OrderedDict[str, Tuple[int, ...]]":
+    """Parameters of `pretrained` for vitb_rn50_384 in registration order: `model.*` (timm VisionTransformer with a HybridEmbed:
+    own parameters cls_token / pos_embed first, then patch_embed.backbone (ResNetV2: stem, stages), patch_embed.proj, blocks, norm,
+    head), then act_postprocess3 / act_postprocess4 (backbones/vit.py:183-229; 1 and 2 are parameter-free Identity stacks)."""
+    p: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
+    E = arch.embed
+    n_tok = arch.grid * arch.grid + 1
+    p["model.cls_token"] = (1, 1, E)
+    p["model.pos_embed"] = (1, n_tok, E)
+    bb = "model.patch_embed.backbone."
+    p[bb + "stem.conv.weight"] = (arch.stem, 3, 7, 7)
+    p[bb + "stem.norm.weight"] = (arch.stem,)
+    p[bb + "stem.norm.bias"] = (arch.stem,)
+    prev = arch.stem
+    for s, depth in enumerate(arch.layers):
+        out = 256 << s
+        mid = out // 4
+        for j in range(depth):
+            b = f"{bb}stages.{s}.blocks.{j}."
+            if j == 0:
+                p[b + "downsample.conv.weight"] = (out, prev, 1, 1)
+                p[b + "downsample.norm.weight"] = (out,)
+                p[b + "downsample.norm.bias"] = (out,)
+            p[b + "conv1.weight"] = (mid, prev, 1, 1)
+            p[b + "norm1.weight"] = (mid,)
+            p[b + "norm1.bias"] = (mid,)
+            p[b + "conv2.weight"] = (mid, mid, 3, 3)
+            p[b + "norm2.weight"] = (mid,)
+            p[b + "norm2.bias"] = (mid,)
+            p[b + "conv3.weight"] = (out, mid, 1, 1)
+            p[b + "norm3.weight"] = (out,)
+            p[b + "norm3.bias"] = (out,)
+            prev = out
+    p["model.patch_embed.proj.weight"] = (E, prev, 1, 1)
+    p["model.patch_embed.proj.bias"] = (E,)
+    for i in range(arch.depth):
+        b = f"model.blocks.{i}."
+        p[b + "norm1.weight"] = (E,)
+        p[b + "norm1.bias"] = (E,)
+        p[b + "attn.qkv.weight"] = (3 * E, E)
+        p[b + "attn.qkv.bias"] = (3 * E,)
+        p[b + "attn.proj.weight"] = (E, E)
+        p[b + "attn.proj.bias"] = (E,)
+        p[b + "norm2.weight"] = (E,)
+        p[b + "norm2.bias"] = (E,)
+        p[b + "mlp.fc1.weight"] = (4 * E, E)
+        p[b + "mlp.fc1.bias"] = (4 * E,)
+        p[b + "mlp.fc2.weight"] = (E, 4 * E)
+        p[b + "mlp.fc2.bias"] = (E,)
+    p["model.norm.weight"] = (E,)
+    p["model.norm.bias"] = (E,)
+    p["model.head.weight"] = (1000, E)
+    p["model.head.bias"] = (1000,)
+    for n in (3, 4):
+        a = f"act_postprocess{n}."
+        p[a + "0.project.0.weight"] = (E, 2 * E)
+        p[a + "0.project.0.bias"] = (E,)
+        p[a + "3.weight"] = (arch.features[n - 1], E, 1, 1)
+        p[a + "3.bias"] = (arch.features[n - 1],)
+    p["act_postprocess4.4.weight"] = (arch.features[3], arch.features[3], 3, 3)
+    p["act_postprocess4.4.bias"] = (arch.features[3],)
+    return p
+
+
+def scratch_param_shapes(arch, features: int = 256) -> "OrderedDict[str, Tuple[int, ...]]":
     """depth_net.scratch.* (blocks.py:139-193, dpt.py:133-140,199-219)."""
     p: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
     for i, c in enumerate(arch.dims()):
@@ -162,10 +253,15 @@ def seg_head_param_shapes(features: int = 256, num_classes: int = 3) -> "Ordered
 def v3_state_shapes(backbone: str, features: int = 256, num_classes: int = 3) -> "OrderedDict[str, Tuple[int, ...]]":
     """All V3 tensors under the reference's canonical prefixes (without the
     duplicate `pretrained.model.*` aliases)."""
-    arch = SWIN_ARCHS[backbone]
     out: "OrderedDict[str, Tuple[int, ...]]" = OrderedDict()
-    for k, v in encoder_param_shapes(arch).items():
-        out["depth_net.pretrained.model." + k] = v
+    if backbone in HYBRID_ARCHS:
+        arch = HYBRID_ARCHS[backbone]
+        for k, v in hybrid_param_shapes(arch).items():
+            out["depth_net.pretrained." + k] = v
+    else:
+        arch = SWIN_ARCHS[backbone]
+        for k, v in encoder_param_shapes(arch).items():
+            out["depth_net.pretrained.model." + k] = v
     for k, v in scratch_param_shapes(arch, features).items():
         out["depth_net.scratch." + k] = v
     for k, v in seg_head_param_shapes(features, num_classes).items():

@@ -173,3 +173,54 @@ def test_patchwise_schedule_matches_reference():
         assert [int(p.requires_grad) for p in net.parameters()] == ref["after"]
     with pytest.raises(AssertionError):
         PatchWiseInplace(torch.nn.Linear(2, 2).requires_grad_(False), 0.5)     # nothing trainable
+
+
+# ---------------- dpt_hybrid_384 (BASELINE configs[2]) ----------------
+@pytest.fixture(scope="module")
+def net_hybrid(tmp_path_factory):
+    import contextlib
+    import io
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import write_synth_calib
+    calib = write_synth_calib(str(tmp_path_factory.mktemp("calib_h") / "calib.yaml"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        return SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type="dpt_hybrid_384")
+
+
+def test_hybrid_state_dict_layout_matches_reference(net_hybrid, golden_dir):
+    """named_parameters() order and state-dict keys of the dpt_hybrid_384 model == what the reference's own module tree gives
+    (tests/golden/param_order_hybrid.json, recorded by oracle/make_golden.py from the reference's DPT / act_postprocess / seg_head
+    modules around a timm-named encoder stand-in)."""
+    import json
+    g = json.load(open(os.path.join(golden_dir, "param_order_hybrid.json")))
+    assert [n for n, _ in net_hybrid.named_parameters()] == g["named_parameters"]
+    assert list(net_hybrid.state_dict().keys()) == g["state_dict_keys"]
+    sd = synth_state_dict("vitb_rn50_384", alias_pretrained=True)
+    r = net_hybrid.load_state_dict(sd, strict=False)
+    assert not r.unexpected_keys and all("num_batches_tracked" in k for k in r.missing_keys)
+    assert net_hybrid.depth_net.backbone == "vitb_rn50_384"
+    # timm vit_base_r50_s16_384: 98.95 M parameters with the 1000-class head; + 2 readout projections + 3 reassemble convs
+    n_model = sum(v.numel() for k, v in sd.items() if k.startswith("depth_net.pretrained.model."))
+    assert n_model == 98_950_952, n_model
+
+
+def test_oracle_hybrid_matches_golden(golden_dir):
+    """oracle hybrid forward == the reference's own forward_vit / forward_adapted_unflatten / ProjectReadout / DPT.forward / seg head /
+    projection outputs at 384 x 384 (fixture from oracle/make_golden.py; the timm ResNetV2 / ViT arithmetic inside is unpinned)."""
+    import numpy as np
+    from oracle import soccdpt_ref as R
+    from soccdpt_amd.utils.synth import synth_input
+    torch.set_num_threads(8)
+    g = np.load(os.path.join(golden_dir, "hybrid_B1_tanh.npz"))
+    sd = synth_state_dict("vitb_rn50_384")
+    x = synth_input(1, size=384, seed0=int(g["seed"]))
+    with torch.no_grad():
+        layers = R.hybrid_encoder(sd, x)
+        inv, seg, p1 = R.soccdpt_v3_network(sd, x, backbone="vitb_rn50_384", sigmoid=False)
+    exact = torch.get_num_threads() == 8 and (os.cpu_count() or 1) >= 8
+    cmp = (lambda a, b: np.array_equal(a, b)) if exact else (lambda a, b: np.allclose(a, b, rtol=1e-5, atol=1e-6))
+    for i, l in enumerate(layers):
+        assert cmp(l[0, ::16, ::3, ::3].numpy(), g[f"layer{i + 1}_sample"]), i
+    assert cmp(inv.numpy(), g["inv384"])
+    assert cmp(seg[0, :, ::4, ::4].numpy(), g["seg384_sample"])
+    assert cmp(p1[0, ::16, ::12, ::12].numpy(), g["path1_sample"])

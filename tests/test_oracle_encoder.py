@@ -25,3 +25,20 @@ def test_swin_encoder_matches_hf_swinv2(backbone, img, tol):
         assert a.shape == b.shape
         err = float((a - b).abs().max() / b.abs().max())
         assert err < tol, (backbone, s, err)
+
+
+def test_hybrid_encoder_matches_hf_dpt_hybrid():
+    """vitb_rn50_384 (BASELINE configs[2]): ResNetV2 stem / stages (weight-standardised SAME convs, GroupNorm, -inf padded max-pool),
+    ViT-B blocks over 577 tokens, 'project' readout and the reassemble convs against HF's DPT-hybrid port, same weights."""
+    from oracle.hf_crosscheck import hybrid_hf_features
+    torch.set_num_threads(8)
+    sd = synth_state_dict("vitb_rn50_384")
+    x = synth_input(1, size=384, seed0=6)
+    with torch.no_grad():
+        mine = R.hybrid_encoder(sd, x)
+    theirs = hybrid_hf_features(sd, x)
+    assert [tuple(t.shape) for t in mine] == [(1, 256, 96, 96), (1, 512, 48, 48), (1, 768, 24, 24), (1, 768, 12, 12)]
+    for s, (a, b) in enumerate(zip(theirs, mine)):
+        assert a.shape == b.shape
+        err = float((a - b).abs().max() / b.abs().max())
+        assert err < 2e-5, (s, err)
