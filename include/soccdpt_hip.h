@@ -266,8 +266,30 @@ typedef struct soccdpt_igemm_args {
     uint32_t* sk_count;
     size_t sk_part_floats; /* capacity of sk_part in floats  */
     size_t sk_count_words; /* capacity of sk_count in words */
+    /* generalised addressing (the ViT-hybrid encoder's convolutions and read-out projection; zeros = the plain forms above):
+     * conv mode reads input pixel (y*stride + ky - pad, x*stride + kx - pad) of an NHWC image [B][Hi + 2*in_halo][Wi + 2*in_halo][Cin];
+     * conv_general == 0 keeps stride 1 / pad 1 / in_halo 1 / Hi = H / Wi = W.  gather1: taps == 1 with conv addressing (strided 1x1).
+     * Row groups (plain mode): row m at x + (m / grp_rows) * grp_stride + grp_off + (m % grp_rows) * ldx; columns k >= seg2_k come from the
+     * per-group row x + (m / grp_rows) * grp_stride + seg2_off + (k - seg2_k)  (cat(token, class token) of ProjectReadout,
+     * model/backbones/utils.py:27-40). */
+    int32_t conv_general, stride, pad, in_halo, Hi, Wi, gather1;
+    int32_t grp_rows, grp_off, seg2_k, seg2_off;
+    int64_t grp_stride;
+    /* GroupNorm statistics of the raw output (timm GroupNormAct after every StdConv2dSame of the ResNetV2 stem / stages): gn_stats
+     * [M / gn_hw][N / gn_cpg][2] = {mean, 1/sqrt(var + 1e-5)} per (sample, group); gn_part: (M / 64) * (N / gn_cpg) * 2 floats of scratch,
+     * gn_count: M / gn_hw zero words (left zero).  NULL = off. */
+    float* gn_stats;
+    float* gn_part;
+    uint32_t* gn_count;
+    int32_t gn_cpg, gn_hw;
+    size_t gn_part_floats, gn_count_words;
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
+
+/* Global softmax attention of one ViT block (timm vision_transformer.Attention between the qkv and proj Linear layers; created by
+ * model/backbones/vit.py:248): qkv [B*N][3*heads*64] -> out [B*N][heads*64] = softmax(q k^T / 8) v per (sample, head); elements
+ * bf16 / f32 / fp16 by `precision`.  N <= 608 (dpt_hybrid_384: N = 577). */
+int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, int B, int N, int heads, void* stream);
 
 /* Swin-V2 cosine window attention of one block (timm WindowAttention + shift/partition/reverse):
  * qkv [B*res*res][3*heads*32] -> out [B*res*res][heads*32], elements bf16 / f32 / fp16 by `precision` (SOCCDPT_PREC_*).  cpb_table [(2ws-1)^2][heads] f32 is

@@ -331,8 +331,21 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     d.splitk = a->splitk > 1 ? a->splitk : 1; d.sk_part = a->sk_part; d.sk_count = a->sk_count;
     d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words;
+    if (a->conv_general) { d.stride = a->stride; d.pad = a->pad; d.in_halo = a->in_halo; d.Hi = a->Hi; d.Wi = a->Wi; d.gather1 = a->gather1; }
+    d.grp_rows = a->grp_rows; d.grp_off = a->grp_off; d.grp_stride = a->grp_stride; d.seg2_k = a->seg2_k; d.seg2_off = a->seg2_off;
+    d.gn_stats = a->gn_stats; d.gn_part = a->gn_part; d.gn_count = a->gn_count; d.gn_cpg = a->gn_cpg; d.gn_hw = a->gn_hw;
+    d.gn_part_floats = a->gn_part_floats; d.gn_count_words = a->gn_count_words;
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, int B, int N, int heads, void* stream) {
+    std::string err;
+    if (!dev_qkv || !dev_out) return fail(nullptr, "soccdpt_op_vit_attention: null argument");
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F32 && precision != SOCCDPT_PREC_F16)
+        return fail(nullptr, "soccdpt_op_vit_attention: unknown precision");
+    if (launch_vit_attention(dev_qkv, dev_out, precision, B, N, heads, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;
 }
 

@@ -43,6 +43,21 @@ struct IgemmDesc {
     // plain mode: row m at X + m*ldx.  conv mode (taps == 9): X is a Halo image [B][H+2][W+2][Cin], M = B*H*W
     int ldx = 0;
     int H = 0, W = 0;
+    // Generalised conv addressing (taps == 9, or taps == 1 with gather1 != 0: a strided 1x1 convolution).  Output pixel (y, x) of the
+    // H x W map reads input pixel (y*stride + ky - pad, x*stride + kx - pad) of an NHWC image [B][Hi + 2*in_halo][Wi + 2*in_halo][Cin]
+    // (in_halo = 1: zero-haloed; every tap must stay inside the haloed image -- checked by launch_igemm).  Defaults = the stride-1
+    // pad-1 convolution of a halo image.  stride 2 / pad 0 on a halo image is timm's dynamic 'SAME' 3x3 (the extra pixel right / bottom),
+    // stride 2 / pad 1 is nn.Conv2d(k=3, s=2, p=1) (/root/reference/SOccDPT/model/backbones/vit.py:196-202).
+    int stride = 1, pad = 1, in_halo = 1;
+    int Hi = 0, Wi = 0;   // input map size; 0 = H, W
+    int gather1 = 0;
+    // Plain-mode row groups: row m lives at X + (m / grp_rows) * grp_stride + grp_off + (m % grp_rows) * ldx  (grp_rows == 0: m * ldx).
+    // The ViT token matrix [B][577][768] read without its class-token rows is grp_rows = 576, grp_stride = 577*768, grp_off = 768.
+    int grp_rows = 0, grp_off = 0;
+    long long grp_stride = 0;
+    // Second A segment: columns k >= seg2_k come from the PER-GROUP row X + (m / grp_rows) * grp_stride + seg2_off + (k - seg2_k):
+    // cat(token, class token) @ W^T of ProjectReadout (/root/reference/SOccDPT/model/backbones/utils.py:27-40) without the cat.
+    int seg2_k = 0, seg2_off = 0;
     // ---- epilogue: v = acc (+bias[n]) (+res1[m][n]) (+res2[m][n]); act; stores ----
     const float* bias = nullptr;
     const float* res1 = nullptr;  // f32 [M][N]
@@ -73,6 +88,17 @@ struct IgemmDesc {
     unsigned* sk_count = nullptr;
     size_t sk_part_floats = 0, sk_count_words = 0;  // capacities, validated by launch_igemm
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
+    // GroupNorm statistics of the raw output (the ST instantiation): with gn_stats != nullptr the epilogue also reduces sum / sum of
+    // squares of v over every (sample, group of gn_cpg consecutive channels): per-tile partials go to gn_part ((M / BM) * (N / gn_cpg) * 2
+    // floats), the LAST workgroup of a sample to arrive (gn_count[b], zero at rest) adds them in tile order in f64 -- deterministic --
+    // and writes gn_stats[(b * (N / gn_cpg) + g) * 2] = {mean, 1 / sqrt(var + gn_eps)} (biased variance, torch.nn.GroupNorm).
+    // gn_hw = pixels per sample (M = B * gn_hw; must be a multiple of the M tile).
+    float* gn_stats = nullptr;
+    float* gn_part = nullptr;
+    unsigned* gn_count = nullptr;
+    int gn_cpg = 0, gn_hw = 0;
+    float gn_eps = 1e-5f;
+    size_t gn_part_floats = 0, gn_count_words = 0;   // capacities, validated by launch_igemm
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);

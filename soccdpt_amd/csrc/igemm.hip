@@ -62,7 +62,9 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // tile to d.sk_part[split][M][N], and the LAST workgroup to arrive at the tile (a counter in d.sk_count, left at 0 again) sums
 // the splitk partials in split order -- deterministic, no float atomics -- and runs the epilogue.  No workgroup ever waits
 // for another one.  For long-K problems whose output grid cannot fill the 256 CUs (coarse decoder levels, stage-3 fc2).
-template <class C, typename T, bool LN, bool SK = false>
+// ST: GroupNorm statistics of the raw output (d.gn_stats): per-tile per-group partial sums, finished by the last workgroup of each
+// sample (same fence-free sc1 exchange as SK).  ResNetV2 stages of the ViT-hybrid encoder (csrc/hybrid.hip applies the normalisation).
+template <class C, typename T, bool LN, bool SK = false, bool ST = false>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = C::BM, BN = C::BN;
@@ -92,26 +94,35 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     const int nt = bid % ntiles, mt = bid / ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
     const int Ktot = d.taps * d.Cin;
-    const int Wp = d.W + 2;
+    const int Wp = d.W + 2;                 // OUTPUT halo geometry (out_halo / ln_halo stores)
+    const bool conv_addr = d.taps == 9 || d.gather1;
+    const int Wpi = (d.Wi ? d.Wi : d.W) + 2 * d.in_halo, Hpi = (d.Hi ? d.Hi : d.H) + 2 * d.in_halo;   // INPUT image geometry
 
     // ---- per-thread staging sources (element offsets) ----
-    uint32_t x_off[C::X_LOADS], w_off[C::W_LOADS];
+    uint32_t x_off[C::X_LOADS], x_off2[C::X_LOADS], w_off[C::W_LOADS];
 #pragma unroll
     for (int i = 0; i < C::X_LOADS; ++i) {
         const int cid = i * C::THREADS + tid;
         const int row = cid / C::CPR, c = cid % C::CPR;
         int m = m0 + row;
         m = m < d.M ? m : d.M - 1;
-        uint32_t base;
-        if (d.taps == 9) {
+        uint32_t base, base2 = 0;
+        if (conv_addr) {
             const int hw = d.H * d.W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / d.W, x = rem - y * d.W;
-            base = (uint32_t)(((b * (d.H + 2) + y) * Wp + x) * d.Cin);
+            base = (uint32_t)(((b * Hpi + y * d.stride + d.in_halo - d.pad) * Wpi + x * d.stride + d.in_halo - d.pad) * d.Cin);
+        } else if (d.grp_rows) {
+            const int g = m / d.grp_rows, r = m - g * d.grp_rows;
+            const uint32_t gb = (uint32_t)((long long)g * d.grp_stride);
+            base = gb + (uint32_t)d.grp_off + (uint32_t)r * (uint32_t)d.ldx;
+            base2 = gb + (uint32_t)d.seg2_off;
         } else {
             base = (uint32_t)m * (uint32_t)d.ldx;
         }
-        x_off[i] = base + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+        const uint32_t sw = (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+        x_off[i] = base + sw;
+        x_off2[i] = base2 - base;   // delta to the second-segment row (mod 2^32), added when the k-tile lies in the second segment
     }
 #pragma unroll
     for (int i = 0; i < C::W_LOADS; ++i) {
@@ -125,17 +136,21 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     auto stage = [&](int kt, int buf) {
         kt += kbase;
         uint32_t xk, wk = (uint32_t)kt * BK;  // elements of T
+        bool seg2 = false;
         if (d.taps == 9) {
             const int tap = kt / kpt, kc = kt - tap * kpt;
             const int ky = tap / 3, kx = tap - ky * 3;
-            xk = (uint32_t)((ky * Wp + kx) * d.Cin + kc * BK);
+            xk = (uint32_t)((ky * Wpi + kx) * d.Cin + kc * BK);
+        } else if (d.seg2_k && (int)wk >= d.seg2_k) {   // wave-uniform: the per-group row (ViT readout token)
+            seg2 = true;
+            xk = wk - (uint32_t)d.seg2_k;
         } else {
             xk = wk;
         }
         char* sb = smem + buf * C::STAGE;
 #pragma unroll
         for (int i = 0; i < C::X_LOADS; ++i) {
-            const T* g = Xp + x_off[i] + xk;
+            const T* g = Xp + (x_off[i] + (seg2 ? x_off2[i] : 0u)) + xk;   // a VALUE select: selecting between the two arrays demotes them (and d) to scratch
             char* l = sb + (i * C::THREADS + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -398,6 +413,13 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     float dot_part[C::TM];
 #pragma unroll
     for (int j = 0; j < C::TM; ++j) dot_part[j] = 0.f;
+    float gsum[ST ? C::TN : 1][4], gsq[ST ? C::TN : 1][4];   // ST: per-lane sums over this wave's pixel rows of its 4 channels per n-tile
+    if constexpr (ST) {
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gsum[i][r] = 0.f; gsq[i][r] = 0.f; }
+    }
 #pragma unroll
     for (int j = 0; j < C::TM; ++j) {
         const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
@@ -461,6 +483,10 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 const float4 r4 = *reinterpret_cast<const float4*>(d.res2 + orow + n);
                 v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
             }
+            if constexpr (ST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { gsum[i][r] += v[r]; gsq[i][r] = fmaf(v[r], v[r], gsq[i][r]); }
+            }
             float a[4];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -486,6 +512,69 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             }
         }
     }
+    if constexpr (ST) {
+        // ---- GroupNorm statistics.  (1) in-wave: the 16 lanes that share (lane >> 4) hold the same 4 channels of 16 different pixels.
+        // (2) per-channel sums of the WM wave rows meet in LDS (the staging ring is free after the barrier), (3) one thread per group adds
+        // its gn_cpg channels in a fixed order and publishes the tile's partial with an L2-bypassing store, (4) the last workgroup of the
+        // sample to arrive adds the tile partials in tile order in f64 and writes {mean, rstd}.  Fixed orders everywhere: bitwise
+        // reproducible; no workgroup waits for another one.
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = gsum[i][r], q = gsq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                gsum[i][r] = a; gsq[i][r] = q;
+            }
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+        __syncthreads();
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = wn * C::TN * 16 + i * 16 + (lane >> 4) * 4 + r;
+                    red[(wm * BN + ch) * 2] = gsum[i][r];
+                    red[(wm * BN + ch) * 2 + 1] = gsq[i][r];
+                }
+        }
+        __syncthreads();
+        const int cpg = d.gn_cpg, G = N / cpg, gpt = BN / cpg;   // groups in total / per n-tile
+        if (tid < gpt && n0 + tid * cpg < N) {
+            float a = 0.f, q = 0.f;
+            for (int c = 0; c < cpg; ++c)
+#pragma unroll
+                for (int w = 0; w < C::WM; ++w) { a += red[(w * BN + tid * cpg + c) * 2]; q += red[(w * BN + tid * cpg + c) * 2 + 1]; }
+            float* pp = d.gn_part + ((size_t)mt * G + n0 / cpg + tid) * 2;
+            __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tps = d.gn_hw / BM;                 // M tiles per sample (host: gn_hw % BM == 0)
+        const int sample = mt / tps;
+        unsigned* arrival = reinterpret_cast<unsigned*>(smem) + 2 * C::WM * BN;
+        if (tid == 0) *arrival = __hip_atomic_fetch_add(d.gn_count + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*arrival == (unsigned)(tps * ntiles) - 1u) {
+            if (tid == 0) __hip_atomic_store(d.gn_count + sample, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (int g = tid; g < G; g += C::THREADS) {
+                double a = 0.0, q = 0.0;
+                for (int t = 0; t < tps; ++t) {
+                    const float* pp = d.gn_part + ((size_t)(sample * tps + t) * G + g) * 2;
+                    a += (double)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q += (double)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const double cnt = (double)d.gn_hw * cpg;
+                const double mean = a / cnt;
+                double var = q / cnt - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                d.gn_stats[((size_t)sample * G + g) * 2] = (float)mean;
+                d.gn_stats[((size_t)sample * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+            }
+        }
+    }
     if (d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
 #pragma unroll
         for (int j = 0; j < C::TM; ++j) {
@@ -499,24 +588,33 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }  // generic epilogue
 }
 
-template <class C, typename T, bool LN = false, bool SK = false>
+template <class C, typename T, bool LN = false, bool SK = false, bool ST = false>
 static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (LN != (d.ln_g != nullptr)) { err = "igemm: this configuration has no fused-LayerNorm instantiation"; return 1; }
     if (SK != (d.splitk > 1)) { err = "igemm: this configuration has no split-K instantiation"; return 1; }
+    if (ST != (d.gn_stats != nullptr)) { err = "igemm: this configuration has no GroupNorm-statistics instantiation"; return 1; }
     constexpr int BK = C::ROWB / (int)sizeof(T);
     const int nk = d.taps * d.Cin / BK, kpt = d.Cin / BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
     const size_t lds = (size_t)C::NS * C::STAGE;
+    if constexpr (ST) {
+        const int G = d.gn_cpg > 0 ? d.N / d.gn_cpg : 0;
+        if (!d.gn_part || !d.gn_count || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
+            (size_t)mtiles * G * 2 > d.gn_part_floats || (size_t)(d.M / d.gn_hw) > d.gn_count_words || (size_t)(2 * C::WM * C::BN + 1) * 4 > lds) {
+            err = "igemm: bad GroupNorm-statistics descriptor (pixels per sample must be a multiple of the M tile)";
+            return 1;
+        }
+    }
     static PerDeviceOnce attr_done;
     if (attr_done.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done.done();
     }
     const int splits = SK ? d.splitk : 1;
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
                (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
-    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK, ST>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;
@@ -531,6 +629,12 @@ template <class C>
 static int launch_cfg_sk(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.splitk <= 1) return launch_cfg<C>(d, stream, err);
     return d.f16 ? launch_cfg_t<C, f16_t, false, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, true>(d, stream, err);
+}
+// configurations that also carry the GroupNorm-statistics epilogue
+template <class C>
+static int launch_cfg_st(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (!d.gn_stats) return launch_cfg<C>(d, stream, err);
+    return d.f16 ? launch_cfg_t<C, f16_t, false, false, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, true>(d, stream, err);
 }
 // configurations that also carry the fused-LayerNorm epilogue (one n-tile covers the row)
 template <class C>
@@ -556,6 +660,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
+    if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
     if (d.N <= 32) return 2;
     const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -569,6 +674,11 @@ static int pick_cfg(const IgemmDesc& d) {
     // launches), then by rocprofv3 device durations of repeated launches (tools/igemm_tune.py; warm caches flatter big
     // one-workgroup-per-CU tiles and tiles that re-read weights), finally by timing every candidate inside the forward.
     if (d.tune >= 0) return d.tune;
+    if (d.gn_stats) {   // GroupNorm-statistics epilogue: instantiated for 128x128x64 (8 waves), 64x64x64 (8 waves) and 64x64x32
+        if (!k64) return 4;
+        const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+        return (d.gn_hw % 128 == 0 && d.gn_cpg <= 128 && t128 >= 256) ? 21 : 23;
+    }
     if (d.splitk > 1) return d.Cin % 128 == 0 ? 20 : 14;  // the split-K instantiations: 32(M) x 64(N) tiles
     if (d.N <= 32) return 5;
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
@@ -604,7 +714,7 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     // and loads: the 8 XCD L2s are not coherent with each other inside a kernel), about one kernel floor.  It only pays for the
     // longest K on the smallest grid: layer4_rn (M=512, N=256, K=6912) 30.9 -> 18.3 us at 4 splits; K=2304..3456 on 64..256
     // tiles and the stage-3 Linear layers (K <= 3072) are break-even or slower and stay unsplit.
-    if (d.f32 || d.ln_g || d.out_dot || d.N <= 32 || d.Cin % 64 != 0 || d.tune >= 0) return 1;
+    if (d.f32 || d.ln_g || d.out_dot || d.gn_stats || d.seg2_k || d.N <= 32 || d.Cin % 64 != 0 || d.tune >= 0) return 1;
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long nk = (long)d.taps * d.Cin / 64, blocks = cdiv(d.M, 32) * cdiv(d.N, 64);
     if (blocks > 128 || nk < 96 || (size_t)blocks > count_words) return 1;
@@ -633,16 +743,25 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.N % 4 != 0) { err = "igemm: N must be a multiple of 4"; return 1; }
     if (d.Cin % 32 != 0) { err = "igemm: Cin must be a multiple of 32"; return 1; }
     if (d.taps != 1 && d.taps != 9) { err = "igemm: taps must be 1 or 9"; return 1; }
-    if (d.taps == 9 && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
+    if ((d.taps == 9 || d.gather1) && (d.H <= 0 || d.W <= 0 || d.M % (d.H * d.W) != 0)) { err = "igemm: bad conv geometry"; return 1; }
+    if (d.taps == 9 || d.gather1) {   // every tap of every output pixel must stay inside the (haloed) input image
+        const int Hi = d.Hi ? d.Hi : d.H, Wi = d.Wi ? d.Wi : d.W, k = d.taps == 9 ? 3 : 1;
+        const int lo = d.in_halo - d.pad, hiy = (d.H - 1) * d.stride + k - 1 + lo, hix = (d.W - 1) * d.stride + k - 1 + lo;
+        if (d.stride < 1 || lo < 0 || hiy >= Hi + 2 * d.in_halo || hix >= Wi + 2 * d.in_halo) { err = "igemm: conv taps leave the input image"; return 1; }
+    }
+    if (d.seg2_k && (d.taps != 1 || d.gather1 || !d.grp_rows || d.seg2_k % 128 != 0 || d.seg2_k >= d.Cin)) { err = "igemm: bad second-segment descriptor"; return 1; }
+    if (d.grp_rows && (d.taps != 1 || d.gather1)) { err = "igemm: row groups are a plain-mode feature"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         switch (pick_cfg_f32(d)) {
-            case 0: return d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, true>(d, stream, err)
+            case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, false, false, true>(d, stream, err)
+                         : d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, true>(d, stream, err)
                                   : launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float>(d, stream, err);
-            case 1: return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
+            case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, true>(d, stream, err)
+                                      : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
             default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, float>(d, stream, err);
         }
     }
@@ -653,10 +772,10 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
-        case 1: return launch_cfg<Cfg<128, 128, 64, 2, 2, 2>>(d, stream, err);
-        case 2: return launch_cfg<Cfg<64, 64, 64, 2, 2, 4>>(d, stream, err);
+        case 1: return launch_cfg_st<Cfg<128, 128, 64, 2, 2, 2>>(d, stream, err);
+        case 2: return launch_cfg_st<Cfg<64, 64, 64, 2, 2, 4>>(d, stream, err);
         case 3: return launch_cfg<Cfg<128, 128, 32, 2, 2, 4>>(d, stream, err);
-        case 4: return launch_cfg<Cfg<64, 64, 32, 2, 2, 4>>(d, stream, err);
+        case 4: return launch_cfg_st<Cfg<64, 64, 32, 2, 2, 4>>(d, stream, err);
         case 5: return launch_cfg<Cfg<128, 32, 64, 4, 1, 4>>(d, stream, err);
         case 6: return launch_cfg<Cfg<256, 128, 64, 4, 2, 2>>(d, stream, err);
         case 7: return launch_cfg<Cfg<256, 128, 64, 4, 2, 3>>(d, stream, err);
@@ -672,11 +791,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
-        case 21: return launch_cfg<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
+        case 21: return launch_cfg_st<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
         case 22: return launch_cfg<Cfg<32, 64, 128, 2, 4, 3>>(d, stream, err);   // 8 waves, 16x16 per wave: the small-grid long-K launches are latency chains,
-        case 23: return launch_cfg<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
+        case 23: return launch_cfg_st<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
         case 24: return launch_cfg<Cfg<128, 128, 32, 2, 4, 3>>(d, stream, err);  // 8 waves, 64x32 per wave, 32-deep k-tiles (C = 96: layer1_rn 43 -> 34 us)
-        case 20: return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
+        case 20: return d.gn_stats ? launch_cfg_st<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err) : launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
     }
     err = "igemm: unknown configuration id";
     return 1;

@@ -19,9 +19,19 @@ struct Arch {
     int heads[4] = {3, 6, 12, 24};
     int pretrained_window[4] = {0, 0, 0, 0};
     int hooks[4] = {1, 1, 5, 1};
+    // ViT-hybrid (vitb_rn50_384; /root/reference/SOccDPT/model/backbones/vit.py:147-258, model/blocks.py:103-112): ResNetV2 (3, 4, 9) stem +
+    // 12 ViT-B blocks; the reassembled pyramid is [256, 512, 768, 768] channels at 1/4, 1/8, 1/16, 1/32 of the input
+    bool hybrid = false;
+    int vit_depth = 12, vit_heads = 12, vit_dim = 768, stem_ch = 64;
+    int rn_layers[3] = {3, 4, 9};
+    int vit_hooks[2] = {8, 11};
     int grid() const { return img / patch; }
     int dim(int s) const { return embed << s; }
     int res(int s) const { return grid() >> s; }
+    // feature pyramid handed to scratch.layerN_rn (level l = 0 finest)
+    int fdim(int l) const { return hybrid ? (l == 0 ? 256 : l == 1 ? 512 : 768) : dim(l); }
+    int fres(int l) const { return hybrid ? (img / 4) >> l : res(l); }
+    int out_res() const { return img; }   // network output resolution (4 * fres(0))
     int ws(int s) const { return res(s) < window ? res(s) : window; }
     int shift(int s, int j) const { return (j % 2 == 0 || res(s) <= window) ? 0 : window / 2; }
 };

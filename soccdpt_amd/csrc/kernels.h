@@ -74,6 +74,34 @@ int launch_adam(int n_tensors, float* const* params, const float* const* grads, 
                 const size_t* sizes, double lr, double beta1, double beta2, double eps, double weight_decay, int step, hipStream_t st,
                 std::string& err);
 
+// hybrid.hip: non-GEMM kernels of the ViT-hybrid encoder (dpt_hybrid_384).  out_mode: operand format written, 0 bf16 / 1 fp16 / 2 f32
+int launch_ws_conv_w(const float* w, void* out, int out_mode, int Cout, int Cin, int k, int Kpad, float eps, hipStream_t st, std::string& err);
+int launch_stem_im2col(const float* x, void* A, int out_mode, int B, int S, hipStream_t st, std::string& err);
+struct GnApplyArgs {
+    const float* raw = nullptr;      // [M][C] f32 convolution output
+    const float* stats = nullptr;    // [B][C/cpg][2] {mean, rstd} (igemm ST epilogue)
+    const float *gamma = nullptr, *beta = nullptr;
+    const float *raw2 = nullptr, *stats2 = nullptr, *gamma2 = nullptr, *beta2 = nullptr;   // projection shortcut: + GN2(raw2)
+    const float* res = nullptr;      // identity shortcut: + res [M][C]
+    float* out_f32 = nullptr;        // [M][C]
+    void* out_op = nullptr;          // [M][C] operand type
+    void* out_halo = nullptr;        // [B][H+2][W+2][C] operand type (zero halo untouched)
+    int relu = 1;
+    size_t M = 0;
+    int HW = 0, W = 0, C = 0, cpg = 0;
+};
+int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::string& err);
+int launch_gn_relu_maxpool(const float* raw, const float* stats, const float* gamma, const float* beta, void* out, int out_mode, int B, int Hi, int C, int cpg,
+                           hipStream_t st, std::string& err);
+int launch_vit_tokens_ln(const float* y, const float* cls, const float* pos, float* xf, const float* g, const float* be, void* xb, int out_mode, int B, int ntok,
+                         int C, float eps, hipStream_t st, std::string& err);
+int launch_ln_rows(float* xf, const float* g, const float* be, void* xb, int out_mode, int rows, int C, float eps, hipStream_t st, std::string& err);
+int launch_pos_embed_resize(const float* pos, float* out, int g0, int g, int C, hipStream_t st, std::string& err);
+
+// vit_attention.hip: global softmax attention of a ViT block (timm Attention.forward): qkv [B*N][3*heads*64] -> out [B*N][heads*64],
+// softmax(q k^T / 8) v per (sample, head), N tokens (577 for dpt_hybrid_384).  prec: SOCCDPT_PREC_* of qkv / out.
+int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err);
+
 // attention.hip
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);

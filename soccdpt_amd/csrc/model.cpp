@@ -27,7 +27,30 @@ struct RcuW {
     const void *w1, *w2;
     const float *b1, *b2;
 };
+// ViT-hybrid encoder (dpt_hybrid_384): ResNetV2 bottleneck, ViT block
+struct RnBlockW {
+    const void *ds_w = nullptr, *c1_w = nullptr, *c2_w = nullptr, *c3_w = nullptr;   // weight-standardised, tap-major, operand type
+    const float *ds_g = nullptr, *ds_b = nullptr, *n1_g = nullptr, *n1_b = nullptr, *n2_g = nullptr, *n2_b = nullptr, *n3_g = nullptr, *n3_b = nullptr;
+    int cin = 0, cout = 0, mid = 0, stride = 1;
+    bool proj = false;
+};
+struct VitBlockW {
+    const void *qkv_w, *proj_w, *fc1_w, *fc2_w;
+    const float *qkv_b, *proj_b, *fc1_b, *fc2_b, *n1_g, *n1_b, *n2_g, *n2_b;
+};
+struct HybridW {
+    const void* stem_w = nullptr;          // [64][160]
+    const float *stem_g = nullptr, *stem_b = nullptr;
+    std::vector<std::vector<RnBlockW>> stages;
+    const void* pe_w = nullptr;
+    const float *pe_b = nullptr, *cls = nullptr;
+    float* pos = nullptr;                  // position embedding at the run-time grid ([1 + g*g][768])
+    std::vector<VitBlockW> blocks;
+    const void *ro_w[2] = {nullptr, nullptr}, *pp_w[2] = {nullptr, nullptr}, *pp4_w = nullptr;
+    const float *ro_b[2] = {nullptr, nullptr}, *pp_b[2] = {nullptr, nullptr}, *pp4_b = nullptr;
+};
 struct Prepared {
+    HybridW hy;
     std::vector<std::vector<BlockW>> blocks;  // [stage][block]
     MergeW merge[3];
     const void* layer_rn[4];
@@ -76,6 +99,9 @@ void add_w(Handle& h, const std::string& key, std::vector<int64_t> shape) {
 }
 
 const std::string ENC = "depth_net.pretrained.model.";
+const std::string HYB = "depth_net.pretrained.";
+std::string rnblk(int s, int j) { return ENC + "patch_embed.backbone.stages." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
+std::string vitblk(int i) { return ENC + "blocks." + std::to_string(i) + "."; }
 const std::string SCR = "depth_net.scratch.";
 
 std::string blk(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
@@ -101,7 +127,92 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, HF, Cout, Cin, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    {
+    const int OM = F32 ? 2 : HF;   // operand format code of hybrid.hip
+    // weight-standardised convolution weight (timm StdConv2dSame, eps 1e-8), tap-major [Cout][Kpad]
+    auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad) -> const void* {
+        const size_t n = (size_t)Cout * Kpad;
+        void* p = F32 ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        if (run && launch_ws_conv_w(W(key), p, OM, Cout, Cin, k, Kpad, 1e-8f, st, err)) return nullptr;
+        return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
+    };
+    if (a.hybrid) {
+        HybridW hw;
+        const std::string bb = ENC + "patch_embed.backbone.";
+        {   // The stem runs in exact f32 in EVERY precision mode: weight standardisation makes each filter zero-mean, so the large DC level
+            // of the reference's un-normalised inputs (pixel values up to 509, SURVEY.md 3.4: no /255) cancels exactly in f32 and only the
+            // small pixel-to-pixel variation survives -- 16-bit operand rounding of either side (absolute error ~1 on the pixels, a
+            // non-zero filter sum after rounding) is as large as that signal (measured: stage-0 features 3.5e-2 off in bf16, 2.4e-3 in fp16).
+            float* p = ar.take<float>((size_t)a.stem_ch * 160);
+            if (run && launch_ws_conv_w(W(bb + "stem.conv.weight"), p, 2, a.stem_ch, 3, 7, 160, 1e-8f, st, err)) return 1;
+            hw.stem_w = run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
+        }
+        if (run) { if (!hw.stem_w) return 1; hw.stem_g = W(bb + "stem.norm.weight"); hw.stem_b = W(bb + "stem.norm.bias"); }
+        int prev = a.stem_ch;
+        hw.stages.assign(3, {});
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int cout = 256 << s3, mid = cout / 4;
+            for (int j = 0; j < a.rn_layers[s3]; ++j) {
+                const std::string b = rnblk(s3, j);
+                RnBlockW bw;
+                bw.cin = prev; bw.cout = cout; bw.mid = mid; bw.proj = (j == 0); bw.stride = (j == 0 && s3 > 0) ? 2 : 1;
+                if (bw.proj) bw.ds_w = wsw(b + "downsample.conv.weight", cout, prev, 1, prev);
+                bw.c1_w = wsw(b + "conv1.weight", mid, prev, 1, prev);
+                bw.c2_w = wsw(b + "conv2.weight", mid, mid, 3, 9 * mid);
+                bw.c3_w = wsw(b + "conv3.weight", cout, mid, 1, mid);
+                if (run) {
+                    if ((bw.proj && !bw.ds_w) || !bw.c1_w || !bw.c2_w || !bw.c3_w) return 1;
+                    if (bw.proj) { bw.ds_g = W(b + "downsample.norm.weight"); bw.ds_b = W(b + "downsample.norm.bias"); }
+                    bw.n1_g = W(b + "norm1.weight"); bw.n1_b = W(b + "norm1.bias");
+                    bw.n2_g = W(b + "norm2.weight"); bw.n2_b = W(b + "norm2.bias");
+                    bw.n3_g = W(b + "norm3.weight"); bw.n3_b = W(b + "norm3.bias");
+                }
+                hw.stages[s3].push_back(bw);
+                prev = cout;
+            }
+        }
+        const int E = a.vit_dim, g = a.grid();
+        hw.pe_w = cvt(ENC + "patch_embed.proj.weight", (size_t)E * prev);
+        hw.pos = ar.take<float>((size_t)(1 + g * g) * E);
+        if (run) {
+            if (!hw.pe_w) return 1;
+            hw.pe_b = W(ENC + "patch_embed.proj.bias");
+            hw.cls = W(ENC + "cls_token");
+            const int g0 = 24;   // vit_base_resnet50_384: pos_embed is [1, 1 + 24*24, 768]
+            if (launch_pos_embed_resize(W(ENC + "pos_embed"), hw.pos, g0, g, E, st, err)) return 1;
+        }
+        for (int i = 0; i < a.vit_depth; ++i) {
+            const std::string b = vitblk(i);
+            VitBlockW vb{};
+            vb.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * E * E);
+            vb.proj_w = cvt(b + "attn.proj.weight", (size_t)E * E);
+            vb.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * E * E);
+            vb.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * E * E);
+            if (run) {
+                if (!vb.qkv_w || !vb.proj_w || !vb.fc1_w || !vb.fc2_w) return 1;
+                vb.qkv_b = W(b + "attn.qkv.bias"); vb.proj_b = W(b + "attn.proj.bias");
+                vb.fc1_b = W(b + "mlp.fc1.bias"); vb.fc2_b = W(b + "mlp.fc2.bias");
+                vb.n1_g = W(b + "norm1.weight"); vb.n1_b = W(b + "norm1.bias");
+                vb.n2_g = W(b + "norm2.weight"); vb.n2_b = W(b + "norm2.bias");
+            }
+            hw.blocks.push_back(vb);
+        }
+        for (int k = 0; k < 2; ++k) {
+            const std::string ap = HYB + "act_postprocess" + std::to_string(3 + k) + ".";
+            hw.ro_w[k] = cvt(ap + "0.project.0.weight", (size_t)E * 2 * E);
+            hw.pp_w[k] = cvt(ap + "3.weight", (size_t)a.fdim(2 + k) * E);
+            if (run) {
+                if (!hw.ro_w[k] || !hw.pp_w[k]) return 1;
+                hw.ro_b[k] = W(ap + "0.project.0.bias");
+                hw.pp_b[k] = W(ap + "3.bias");
+            }
+        }
+        hw.pp4_w = convw(HYB + "act_postprocess4.4.weight", a.fdim(3), a.fdim(3), nullptr);
+        if (run) {
+            if (!hw.pp4_w) return 1;
+            hw.pp4_b = W(HYB + "act_postprocess4.4.bias");
+            P->hy = hw;
+        }
+    } else {
         float* pw = ar.take<float>(48 * 128);
         if (run) {
             if (launch_patch_w(W(ENC + "patch_embed.proj.weight"), pw, a.embed, st, err)) return 1;
@@ -109,7 +220,7 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
     }
     if (run) P->blocks.assign(4, {});
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < 4 && !a.hybrid; ++s) {
         const int C = a.dim(s), H = a.heads[s], ws = a.ws(s);
         for (int j = 0; j < a.depths[s]; ++j) {
             const std::string b = blk(s, j);
@@ -148,7 +259,7 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     }
     const int F = h.cfg.features;
     for (int i = 0; i < 4; ++i) {
-        const void* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.dim(i), nullptr);
+        const void* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.fdim(i), nullptr);
         if (run) { if (!p) return 1; P->layer_rn[i] = p; }
     }
     for (int r = 1; r <= 4; ++r) {
@@ -197,6 +308,13 @@ struct Workspace {
     void *lrn_relu[4], *t_relu[4], *out_relu[4], *u[4];
     void *path1, *d1, *d1u, *s1;
     float* s2;
+    // ViT-hybrid encoder
+    void *hy_a0 = nullptr, *hy_xop = nullptr, *hy_t1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *hy_t2 = nullptr;
+    float *hy_r[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_xf = nullptr, *hy_stats[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_part = nullptr;
+    unsigned* hy_count = nullptr;
+    size_t hy_part_floats = 0;
+    float *vt_y = nullptr, *vt_xf = nullptr;
+    void *vt_xb = nullptr, *vt_qkv = nullptr, *vt_attn = nullptr, *vt_h = nullptr, *vt_tok[2] = {nullptr, nullptr}, *vt_ro = nullptr, *vt_pp4 = nullptr;
     float* sk_part;      // split-K partial tiles (igemm.h): kSplitKPartFloats floats
     unsigned* sk_count;  // split-K arrival counters: zero from workspace init, left zero by every launch
 };
@@ -208,18 +326,46 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
     const size_t es = F32 ? 4 : 2;
     auto op = [&](size_t elems) -> void* { return ar.take<char>(elems * es); };
-    w.xf = ar.take<float>(M0 * C0);
-    w.y = ar.take<float>(M0 * C0);
-    w.xb = F32 ? static_cast<void*>(w.xf) : op(M0 * C0);
-    w.qkv = op(M0 * 3 * C0);
-    w.attn = op(M0 * C0);
-    w.hbuf = op(M0 * 4 * C0);
+    if (a.hybrid) {
+        const int S = a.img, H1 = S / 2, H2 = S / 4, E = a.vit_dim, NT = G * G + 1;
+        w.hy_a0 = ar.take<float>((size_t)B * H1 * H1 * 160);       // f32 in every mode (see lay_out: the stem)
+        const size_t big = (size_t)B * H1 * H1 * a.stem_ch;     // = B * H2*H2 * 256: the largest raw convolution output
+        for (int i = 0; i < 4; ++i) w.hy_r[i] = ar.take<float>(big);
+        w.hy_xf = ar.take<float>(big);
+        w.hy_xop = op(big);
+        w.hy_t2 = op((size_t)B * H2 * H2 * 128);                 // widest plain mid tensor: 48^2 x 256 = 96^2 x 64 <= 96^2 x 128
+        // one zero-halo image per distinct (resolution, width) of a 3x3 conv input: the halo positions differ, a shared buffer
+        // would carry stale interior values of one geometry into the border of another
+        const int tr[5] = {H2, H2, H2 / 2, H2 / 2, H2 / 4}, tc[5] = {64, 128, 128, 256, 256};
+        for (int i = 0; i < 5; ++i) w.hy_t1[i] = op(Halo{tr[i], tr[i], tc[i]}.elems(B));
+        for (int i = 0; i < 4; ++i) w.hy_stats[i] = ar.take<float>((size_t)B * 32 * 2);
+        w.hy_part_floats = (size_t)B * H1 * H1;                  // (M / 64 tiles) x 32 groups x 2 at the stem's M = B * H1^2
+        w.hy_part = ar.take<float>(w.hy_part_floats);
+        w.hy_count = ar.take<unsigned>((size_t)B + 8);
+        w.vt_y = ar.take<float>((size_t)B * G * G * E);
+        w.vt_xf = ar.take<float>((size_t)B * NT * E);
+        w.vt_xb = op((size_t)B * NT * E);
+        w.vt_qkv = op((size_t)B * NT * 3 * E);
+        w.vt_attn = op((size_t)B * NT * E);
+        w.vt_h = op((size_t)B * NT * 4 * E);
+        for (int k = 0; k < 2; ++k) w.vt_tok[k] = op((size_t)B * NT * E);
+        w.vt_ro = op((size_t)B * G * G * E);
+        w.vt_pp4 = op(Halo{G, G, a.fdim(3)}.elems(B));
+        w.xf = w.y = nullptr; w.xb = w.qkv = w.attn = w.hbuf = nullptr;
+    } else {
+        w.xf = ar.take<float>(M0 * C0);
+        w.y = ar.take<float>(M0 * C0);
+        w.xb = F32 ? static_cast<void*>(w.xf) : op(M0 * C0);
+        w.qkv = op(M0 * 3 * C0);
+        w.attn = op(M0 * C0);
+        w.hbuf = op(M0 * 4 * C0);
+    }
     for (int s = 0; s < 4; ++s) {
-        Halo hl{a.res(s), a.res(s), a.dim(s)};
+        Halo hl{a.fres(s), a.fres(s), a.fdim(s)};
         w.feat[s] = op(hl.elems(B));
     }
     for (int l = 0; l < 4; ++l) {
-        const int r = a.res(l);
+        const int r = a.fres(l);
         const size_t M = (size_t)B * r * r;
         Halo hl{r, r, F};
         w.lrn_raw[l] = ar.take<float>(M * F);
@@ -231,7 +377,7 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
         w.out_relu[l] = op(hl.elems(B));
         w.u[l] = op(M * F);
     }
-    const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
+    const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     w.path1 = op(Halo{r1, r1, F}.elems(B));
     w.d1 = op((size_t)B * r1 * r1 * (F / 2));
     w.d1u = op(Halo{r0, r0, F / 2}.elems(B));
@@ -254,6 +400,8 @@ int model_init(Handle& h, std::string& err) {
         a.img = 384; a.embed = 128; a.window = 24;
         int d[4] = {2, 2, 18, 2}, hd[4] = {4, 8, 16, 32}, pw[4] = {12, 12, 12, 6}, hk[4] = {1, 1, 17, 1};
         for (int i = 0; i < 4; ++i) { a.depths[i] = d[i]; a.heads[i] = hd[i]; a.pretrained_window[i] = pw[i]; a.hooks[i] = hk[i]; }
+    } else if (h.cfg.backbone == SOCCDPT_BACKBONE_VITB_RN50_384) {
+        a.hybrid = true; a.img = 384; a.patch = 16;
     } else {
         err = "soccdpt_create: backbone not implemented on the HIP path";
         return 1;
@@ -261,11 +409,70 @@ int model_init(Handle& h, std::string& err) {
     h.arch = a;
     h.img = a.img;
     const int64_t C0 = a.embed;
+    if (a.hybrid) {
+        // timm 0.6.12 vit_base_resnet50_384 + the reference's act_postprocess3/4 (backbones/vit.py:183-229): SURVEY.md 8a row a4-H
+        const int64_t E = a.vit_dim, NT = (int64_t)a.grid() * a.grid() + 1;
+        add_w(h, ENC + "cls_token", {1, 1, E});
+        add_w(h, ENC + "pos_embed", {1, NT, E});
+        const std::string bb = ENC + "patch_embed.backbone.";
+        add_w(h, bb + "stem.conv.weight", {a.stem_ch, 3, 7, 7});
+        add_w(h, bb + "stem.norm.weight", {a.stem_ch});
+        add_w(h, bb + "stem.norm.bias", {a.stem_ch});
+        int64_t prev = a.stem_ch;
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int64_t cout = 256 << s3, mid = cout / 4;
+            for (int j = 0; j < a.rn_layers[s3]; ++j) {
+                const std::string b = rnblk(s3, j);
+                if (j == 0) {
+                    add_w(h, b + "downsample.conv.weight", {cout, prev, 1, 1});
+                    add_w(h, b + "downsample.norm.weight", {cout});
+                    add_w(h, b + "downsample.norm.bias", {cout});
+                }
+                add_w(h, b + "conv1.weight", {mid, prev, 1, 1});
+                add_w(h, b + "norm1.weight", {mid});
+                add_w(h, b + "norm1.bias", {mid});
+                add_w(h, b + "conv2.weight", {mid, mid, 3, 3});
+                add_w(h, b + "norm2.weight", {mid});
+                add_w(h, b + "norm2.bias", {mid});
+                add_w(h, b + "conv3.weight", {cout, mid, 1, 1});
+                add_w(h, b + "norm3.weight", {cout});
+                add_w(h, b + "norm3.bias", {cout});
+                prev = cout;
+            }
+        }
+        add_w(h, ENC + "patch_embed.proj.weight", {E, prev, 1, 1});
+        add_w(h, ENC + "patch_embed.proj.bias", {E});
+        for (int i = 0; i < a.vit_depth; ++i) {
+            const std::string b = vitblk(i);
+            add_w(h, b + "norm1.weight", {E});
+            add_w(h, b + "norm1.bias", {E});
+            add_w(h, b + "attn.qkv.weight", {3 * E, E});
+            add_w(h, b + "attn.qkv.bias", {3 * E});
+            add_w(h, b + "attn.proj.weight", {E, E});
+            add_w(h, b + "attn.proj.bias", {E});
+            add_w(h, b + "norm2.weight", {E});
+            add_w(h, b + "norm2.bias", {E});
+            add_w(h, b + "mlp.fc1.weight", {4 * E, E});
+            add_w(h, b + "mlp.fc1.bias", {4 * E});
+            add_w(h, b + "mlp.fc2.weight", {E, 4 * E});
+            add_w(h, b + "mlp.fc2.bias", {E});
+        }
+        for (int k = 0; k < 2; ++k) {
+            const std::string ap = HYB + "act_postprocess" + std::to_string(3 + k) + ".";
+            add_w(h, ap + "0.project.0.weight", {E, 2 * E});
+            add_w(h, ap + "0.project.0.bias", {E});
+            add_w(h, ap + "3.weight", {a.fdim(2 + k), E, 1, 1});
+            add_w(h, ap + "3.bias", {a.fdim(2 + k)});
+        }
+        add_w(h, HYB + "act_postprocess4.4.weight", {a.fdim(3), a.fdim(3), 3, 3});
+        add_w(h, HYB + "act_postprocess4.4.bias", {a.fdim(3)});
+    } else {
     add_w(h, ENC + "patch_embed.proj.weight", {C0, 3, a.patch, a.patch});
     add_w(h, ENC + "patch_embed.proj.bias", {C0});
     add_w(h, ENC + "patch_embed.norm.weight", {C0});
     add_w(h, ENC + "patch_embed.norm.bias", {C0});
-    for (int s = 0; s < 4; ++s) {
+    }
+    for (int s = 0; s < 4 && !a.hybrid; ++s) {
         const int64_t C = a.dim(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
             const std::string b = blk(s, j);
@@ -295,7 +502,7 @@ int model_init(Handle& h, std::string& err) {
         }
     }
     const int64_t F = h.cfg.features;
-    for (int i = 0; i < 4; ++i) add_w(h, SCR + "layer" + std::to_string(i + 1) + "_rn.weight", {F, a.dim(i), 3, 3});
+    for (int i = 0; i < 4; ++i) add_w(h, SCR + "layer" + std::to_string(i + 1) + "_rn.weight", {F, a.fdim(i), 3, 3});
     for (int r = 1; r <= 4; ++r) {
         const std::string b = SCR + "refinenet" + std::to_string(r) + ".";
         add_w(h, b + "out_conv.weight", {F, F, 1, 1});
@@ -368,12 +575,14 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
     };
     const int hk = h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 5 : 2);  // zero-halo NHWC: 2 bf16, 3 f32, 5 fp16
     for (int s = 0; s < 4; ++s)
-        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.res(s), a.res(s), a.dim(s)}.elems(B), hk, a.res(s), a.res(s), a.dim(s));
-    const int r1 = 2 * a.res(0);
+        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.fres(s), a.fres(s), a.fdim(s)}.elems(B), hk, a.fres(s), a.fres(s), a.fdim(s));
+    const int r1 = 2 * a.fres(0);
     if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
     if (n == "seg_feat") return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, hk == 3 ? 0 : hk - 1, r1, r1, h.cfg.features);  // seg head conv3x3 + BN + ReLU output
     if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
-    if (n == "xf") return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
+    if (n == "xf" && !a.hybrid) return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
+    if (n == "vit_tokens" && a.hybrid) return set(w.vt_xf, (size_t)B * (a.grid() * a.grid() + 1) * a.vit_dim, 0, 1, a.grid() * a.grid() + 1, a.vit_dim);  // residual stream after the last block
+    if (n == "rn_stage2" && a.hybrid) return set(w.hy_xf, (size_t)B * a.grid() * a.grid() * 1024, 0, a.grid(), a.grid(), 1024);                     // ResNetV2 output (stage 2)
     return 1;
 }
 
@@ -406,7 +615,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d) {
-        d.f32 = F32 ? 1 : 0; d.f16 = HF;
+        if (!d.f32) { d.f32 = F32 ? 1 : 0; d.f16 = HF; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
         const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps);
         if (!h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py)
             auto it = h.tune_by_shape.find(key);
@@ -431,6 +640,140 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         PROF(pname, igemm_flops(d), 0.0); return launch_igemm(d, st, err); };
 
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
+    if (a.hybrid) {
+        // ---------------- ViT-hybrid encoder (dpt_hybrid_384) ----------------
+        // forward_flex (/root/reference/SOccDPT/model/backbones/vit.py:44-85) + forward_adapted_unflatten (backbones/utils.py:84-133);
+        // launch for launch what oracle/soccdpt_ref.py hybrid_encoder() states.
+        const HybridW& Y = P.hy;
+        const int OM = F32 ? 2 : HF;
+        const int S = a.img, H1 = S / 2, H2 = S / 4;
+        // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
+        auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
+            d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part; d.gn_count = w.hy_count; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
+            d.gn_part_floats = w.hy_part_floats; d.gn_count_words = (size_t)B + 8;
+        };
+        auto gn = [&](GnApplyArgs g) {
+            PROF("gn_apply", 0.0, (double)g.M * g.C * (4.0 + (g.raw2 || g.res ? 4.0 : 0.0) + (g.out_f32 ? 4.0 : 0.0) + (g.out_op ? es : 0) + (g.out_halo ? es : 0)));
+            return launch_gn_apply(g, OM, st, err);
+        };
+        {   // stem: Conv 7x7 / 2 'SAME' (im2col + igemm) -> GroupNorm + ReLU -> MaxPool 3x3 / 2 'SAME'
+            { PROF("stem_im2col", 0.0, (double)B * S * S * 12.0 + (double)B * H1 * H1 * 160.0 * 4.0);
+              RUN(launch_stem_im2col(x, w.hy_a0, 2, B, S, st, err)); }
+            IgemmDesc d;
+            d.f32 = 1;
+            d.X = w.hy_a0; d.Wt = Y.stem_w; d.M = B * H1 * H1; d.N = a.stem_ch; d.Cin = 160; d.ldx = 160; d.out_f32 = w.hy_r[0];
+            with_stats(d, 0, a.stem_ch, H1 * H1);
+            RUN(gemm(d));
+            { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * es);
+              RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, OM, B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
+        }
+        int rcur = H2;
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const int nb = (int)Y.stages[s3].size();
+            for (int j = 0; j < nb; ++j) {
+                const RnBlockW& bw = Y.stages[s3][j];
+                const int rin = rcur, rout = rin / bw.stride;
+                const int Min = B * rin * rin, Mout = B * rout * rout;
+                // zero-halo image for this (resolution, width): see carve()
+                const int ti = s3 == 0 ? 0 : (s3 == 1 ? (j == 0 ? 1 : 2) : (j == 0 ? 3 : 4));
+                if (bw.proj) {   // shortcut: GN(1x1 stride-s conv)
+                    IgemmDesc d;
+                    d.X = w.hy_xop; d.Wt = bw.ds_w; d.M = Mout; d.N = bw.cout; d.Cin = bw.cin; d.out_f32 = w.hy_r[3];
+                    if (bw.stride == 1) { d.ldx = bw.cin; }
+                    else { d.gather1 = 1; d.stride = bw.stride; d.pad = 0; d.in_halo = 0; d.Hi = rin; d.Wi = rin; d.H = rout; d.W = rout; }
+                    with_stats(d, 3, bw.cout, rout * rout);
+                    RUN(gemm(d));
+                }
+                {   // conv1 1x1 -> GN + ReLU -> halo image
+                    IgemmDesc d;
+                    d.X = w.hy_xop; d.Wt = bw.c1_w; d.M = Min; d.N = bw.mid; d.Cin = bw.cin; d.ldx = bw.cin; d.out_f32 = w.hy_r[0];
+                    with_stats(d, 0, bw.mid, rin * rin);
+                    RUN(gemm(d));
+                    GnApplyArgs g;
+                    g.raw = w.hy_r[0]; g.stats = w.hy_stats[0]; g.gamma = bw.n1_g; g.beta = bw.n1_b; g.out_halo = w.hy_t1[ti];
+                    g.M = (size_t)Min; g.HW = rin * rin; g.W = rin; g.C = bw.mid; g.cpg = bw.mid / 32;
+                    RUN(gn(g));
+                }
+                {   // conv2 3x3 (stride on this conv; 'SAME': pad 1 at stride 1, the extra pixel right / bottom at stride 2) -> GN + ReLU
+                    IgemmDesc d;
+                    d.X = w.hy_t1[ti]; d.Wt = bw.c2_w; d.M = Mout; d.N = bw.mid; d.Cin = bw.mid; d.taps = 9; d.H = rout; d.W = rout; d.Hi = rin; d.Wi = rin;
+                    d.stride = bw.stride; d.pad = bw.stride == 1 ? 1 : 0; d.in_halo = 1; d.out_f32 = w.hy_r[1];
+                    with_stats(d, 1, bw.mid, rout * rout);
+                    RUN(gemm(d));
+                    GnApplyArgs g;
+                    g.raw = w.hy_r[1]; g.stats = w.hy_stats[1]; g.gamma = bw.n2_g; g.beta = bw.n2_b; g.out_op = w.hy_t2;
+                    g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.mid; g.cpg = bw.mid / 32;
+                    RUN(gn(g));
+                }
+                {   // conv3 1x1 -> GN, + shortcut, ReLU: the new residual stream (f32) and its operand copy; hooked stages also as a halo image
+                    IgemmDesc d;
+                    d.X = w.hy_t2; d.Wt = bw.c3_w; d.M = Mout; d.N = bw.cout; d.Cin = bw.mid; d.ldx = bw.mid; d.out_f32 = w.hy_r[2];
+                    with_stats(d, 2, bw.cout, rout * rout);
+                    RUN(gemm(d));
+                    GnApplyArgs g;
+                    g.raw = w.hy_r[2]; g.stats = w.hy_stats[2]; g.gamma = bw.n3_g; g.beta = bw.n3_b;
+                    if (bw.proj) { g.raw2 = w.hy_r[3]; g.stats2 = w.hy_stats[3]; g.gamma2 = bw.ds_g; g.beta2 = bw.ds_b; }
+                    else g.res = w.hy_xf;
+                    g.out_f32 = w.hy_xf; g.out_op = w.hy_xop;
+                    if (j == nb - 1 && s3 < 2) g.out_halo = w.feat[s3];   // hooks on patch_embed.backbone.stages[0], [1] (vit.py:164-167)
+                    g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.cout; g.cpg = bw.cout / 32;
+                    RUN(gn(g));
+                }
+                rcur = rout;
+            }
+        }
+        // ---- ViT-B over g*g + 1 tokens ----
+        const int E = a.vit_dim, G = a.grid(), NT = G * G + 1, Mt = B * NT, Mp = B * G * G;
+        {
+            IgemmDesc d;
+            d.X = w.hy_xop; d.Wt = Y.pe_w; d.M = Mp; d.N = E; d.Cin = 1024; d.ldx = 1024; d.bias = Y.pe_b; d.out_f32 = w.vt_y;
+            RUN(gemm(d));
+            PROF("vit_tokens_ln", 0.0, (double)Mt * E * (8.0 + 4.0 + es));
+            RUN(launch_vit_tokens_ln(w.vt_y, Y.cls, Y.pos, w.vt_xf, Y.blocks[0].n1_g, Y.blocks[0].n1_b, w.vt_xb, OM, B, NT, E, 1e-6f, st, err));
+        }
+        for (int i = 0; i < a.vit_depth; ++i) {
+            const VitBlockW& vb = Y.blocks[i];
+            IgemmDesc d;
+            d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b; d.out_op = w.vt_qkv;
+            RUN(gemm(d));
+            { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * es);
+              RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, h.cfg.precision, B, NT, a.vit_heads, st, err)); }
+            d = IgemmDesc();
+            d.X = w.vt_attn; d.Wt = vb.proj_w; d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = vb.proj_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;   // x += attn (in place)
+            RUN(gemm(d));
+            { PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + es));
+              RUN(launch_ln_rows(w.vt_xf, vb.n2_g, vb.n2_b, w.vt_xb, OM, Mt, E, 1e-6f, st, err)); }
+            d = IgemmDesc();
+            d.X = w.vt_xb; d.Wt = vb.fc1_w; d.M = Mt; d.N = 4 * E; d.Cin = E; d.ldx = E; d.bias = vb.fc1_b; d.act = ACT_GELU; d.out_op = w.vt_h;
+            RUN(gemm(d));
+            d = IgemmDesc();
+            d.X = w.vt_h; d.Wt = vb.fc2_w; d.M = Mt; d.N = E; d.Cin = 4 * E; d.ldx = 4 * E; d.bias = vb.fc2_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;      // x += mlp (in place)
+            for (int k = 0; k < 2; ++k)
+                if (i == a.vit_hooks[k]) d.out_op = w.vt_tok[k];   // hooks on blocks[8], blocks[11] (vit.py:168-171): operand copy for the readout GEMM
+            RUN(gemm(d));
+            if (i + 1 < a.vit_depth) {
+                PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + es));
+                RUN(launch_ln_rows(w.vt_xf, Y.blocks[i + 1].n1_g, Y.blocks[i + 1].n1_b, w.vt_xb, OM, Mt, E, 1e-6f, st, err));
+            }
+        }
+        // ---- act_postprocess3 / 4: ProjectReadout (cat(token, cls) @ W^T + GELU, the cat never materialises) -> Conv1x1 (-> Conv3x3 / 2) ----
+        for (int k = 0; k < 2; ++k) {
+            IgemmDesc d;
+            d.X = w.vt_tok[k]; d.Wt = Y.ro_w[k]; d.M = Mp; d.N = E; d.Cin = 2 * E; d.ldx = E; d.bias = Y.ro_b[k]; d.act = ACT_GELU; d.out_op = w.vt_ro;
+            d.grp_rows = G * G; d.grp_stride = (long long)NT * E; d.grp_off = E; d.seg2_k = E; d.seg2_off = 0;
+            RUN(gemm(d));
+            d = IgemmDesc();
+            d.X = w.vt_ro; d.Wt = Y.pp_w[k]; d.M = Mp; d.N = a.fdim(2 + k); d.Cin = E; d.ldx = E; d.bias = Y.pp_b[k]; d.H = G; d.W = G;
+            d.out_op = k == 0 ? w.feat[2] : w.vt_pp4; d.out_halo = 1;
+            RUN(gemm(d));
+            if (k == 1) {
+                d = IgemmDesc();
+                d.X = w.vt_pp4; d.Wt = Y.pp4_w; d.M = B * (G / 2) * (G / 2); d.N = a.fdim(3); d.Cin = a.fdim(3); d.taps = 9; d.H = G / 2; d.W = G / 2; d.Hi = G; d.Wi = G;
+                d.stride = 2; d.pad = 1; d.in_halo = 1; d.bias = Y.pp4_b; d.out_op = w.feat[3]; d.out_halo = 1;
+                RUN(gemm(d));
+            }
+        }
+    } else {
     // ---------------- encoder ----------------
     { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
@@ -502,6 +845,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                                      res / 2, 0, st, err)); }
         }
     }
+    }   // Swin-V2 encoder
     // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------
     auto conv = [&](const void* X, int Cin, const void* Wt, int N, int r) {
         IgemmDesc d;
@@ -509,9 +853,9 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         return d;
     };
     for (int l = 3; l >= 0; --l) {
-        const int r = a.res(l), M = B * r * r;
+        const int r = a.fres(l), M = B * r * r;
         {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd bf16 halo (RCU conv1 input)
-            IgemmDesc d = conv(w.feat[l], a.dim(l), P.layer_rn[l], F, r);
+            IgemmDesc d = conv(w.feat[l], a.fdim(l), P.layer_rn[l], F, r);
             d.out_f32 = w.lrn_raw[l]; d.out_op = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
             RUN(gemm(d));
         }
@@ -524,7 +868,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             RUN(gemm(d));
             d = conv(w.t_relu[l], F, u1.w2, F, r);
             d.bias = u1.b2; d.res1 = w.lrn_raw[l];
-            d.res2 = w.oc[l + 1]; d.res2_h = a.res(l + 1); d.res2_w = a.res(l + 1);  // bilinear(out_conv output of the coarser level), on the fly
+            d.res2 = w.oc[l + 1]; d.res2_h = a.fres(l + 1); d.res2_w = a.fres(l + 1);  // bilinear(out_conv output of the coarser level), on the fly
             d.out_f32 = w.out_raw[l]; d.out_op = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
             RUN(gemm(d));
             fused_raw = w.out_raw[l];
@@ -549,7 +893,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                                    2 * r, 2 * r, F, st, err)); }
     }
     // ---------------- heads ----------------
-    const int r1 = 2 * a.res(0), r0 = 4 * a.res(0);
+    const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     {
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
         d.bias = P.d0_b; d.out_op = w.d1;

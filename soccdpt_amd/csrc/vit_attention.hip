@@ -1,0 +1,252 @@
+// Global multi-head softmax attention of a ViT block for gfx950 (dpt_hybrid_384: 12 heads x 64, 24*24 + 1 = 577 tokens).
+//
+// Replaces timm 0.6.12 vision_transformer.Attention.forward between the qkv and proj Linear layers (created by
+// /root/reference/SOccDPT/model/backbones/vit.py:248, run from forward_flex vit.py:79-80; restated in oracle/soccdpt_ref.py vit_block):
+//     attn = softmax(q k^T * d^-0.5);  out = attn v          per (sample, head)
+// Design (CDNA4), the same decomposition as the Swin-V2 online-softmax kernel (attention.hip) with d = 64 and no bias:
+//  * one workgroup per (sample, head, query part): K (row-major, 16-byte chunks XOR-swizzled -> conflict-free ds_read_b128) and V^T
+//    ([d][token], 8-byte row pad) of the whole sequence are staged ONCE in LDS (2 x 78 KB of the CU's 160 KB), each of the 4 waves then
+//    walks the key tiles for its own 32-query block: Q stays in registers (read straight from HBM, the 2^-3 softmax scale folded in
+//    exactly), nothing is re-staged per tile and no barrier sits in the main loop;
+//  * S^T = K Q^T with v_mfma_f32_32x32x16 ("swapped" product): a lane owns one query column, so the running max / sum are lane-local
+//    plus one exchange with the other half-wave, and the exponentiated accumulator is directly the B operand of O^T = V^T P^T;
+//  * the sequence length is prime (577): the last key tile is masked arithmetically, padded V rows are zero, padded query rows are
+//    computed and not stored.
+#include "../../include/soccdpt_hip.h"
+#include "half16.h"
+#include "kernels.h"
+
+namespace soccdpt {
+namespace {
+
+typedef __attribute__((ext_vector_type(4))) short h16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int D = 64;            // head dimension
+constexpr int KROW = D * 2;      // bytes per K row in LDS
+
+template <bool F16>
+__global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int NPAD, int heads, int QS) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int VT_STRIDE = NPAD * 2 + 8;
+    char* Ks = smem;
+    char* Vt = smem + (size_t)NPAD * KROW;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * D;
+    int bid = blockIdx.x;
+    const int part = bid % QS;
+    bid /= QS;
+    const int head = bid % heads;
+    const int b = bid / heads;
+    const int NT = NPAD / 32;
+    const int QB0 = (NT + QS - 1) / QS;
+    const int qb_lo = part * QB0, qb_hi = (qb_lo + QB0) < NT ? (qb_lo + QB0) : NT;
+    const uint16_t* base = qkv + (size_t)b * N * (3 * C) + head * D;
+
+    // ---- stage K and V^T of the whole sequence: thread = (token, 16-byte chunk of 8 d) ----
+    for (int idx = tid; idx < NPAD * 8; idx += 256) {
+        const int p = idx >> 3, c = idx & 7;
+        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
+        if (p < N) {
+            const uint16_t* src = base + (size_t)p * (3 * C) + c * 8;
+            kv = *reinterpret_cast<const uint4*>(src + C);
+            vv = *reinterpret_cast<const uint4*>(src + 2 * C);
+        }
+        *reinterpret_cast<uint4*>(Ks + p * KROW + ((c ^ (p & 7)) * 16)) = kv;
+        const uint32_t vu[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+        }
+    }
+    __syncthreads();
+
+    const int r32 = lane & 31, h = lane >> 5;
+    constexpr float LOG2E = 1.4426950408889634f;
+    for (int qb = qb_lo + wave; qb < qb_hi; qb += 4) {
+        const int qrow = qb * 32 + r32;
+        const int qcl = qrow < N ? qrow : N - 1;
+        // Q fragment: B operand, lane (query r32, half h) holds d = 16 ks + 8 h + j; scaled by d^-0.5 = 2^-3 (exact in bf16 / fp16)
+        h16x8 qfrag[4];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const uint4 q4 = *reinterpret_cast<const uint4*>(base + (size_t)qcl * (3 * C) + ks * 16 + 8 * h);
+            const uint32_t qu[4] = {q4.x, q4.y, q4.z, q4.w};
+            h16x8 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                f[2 * j] = (short)f2h<F16>(h_lo<F16>(qu[j]) * 0.125f);
+                f[2 * j + 1] = (short)f2h<F16>(h_hi<F16>(qu[j]) * 0.125f);
+            }
+            qfrag[ks] = f;
+        }
+        float m = -3.0e38f, l = 0.f;
+        f32x16 o0, o1;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) { o0[rg] = 0.f; o1[rg] = 0.f; }
+#pragma unroll 1
+        for (int t = 0; t < NT; ++t) {
+            f32x16 acc;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+            const int krow = t * 32 + r32;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const h16x8 kfrag = *reinterpret_cast<const h16x8*>(Ks + krow * KROW + (((ks * 2 + h) ^ (krow & 7)) * 16));
+                acc = mfma_32x32x16<F16>(kfrag, qfrag[ks], acc);
+            }
+            if (t == NT - 1) {   // keys beyond the sequence: excluded from max, sum and P V
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int key = t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                    if (key >= N) acc[rg] = -3.0e38f;
+                }
+            }
+            float mt = acc[0];
+#pragma unroll
+            for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, acc[rg]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float mnl = mn * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mnl));
+            float psum = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], LOG2E, -mnl));
+                psum += acc[rg];
+                o0[rg] *= alpha;
+                o1[rg] *= alpha;
+            }
+            l = l * alpha + psum;
+            m = mn;
+#pragma unroll
+            for (int st = 0; st < 2; ++st) {
+                h16x8 pb;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(acc[8 * st + j]);
+                // element j of this lane half is key 32t + 16st + 8(j>>2) + 4h + (j&3): V^T is read in the same k order
+                const int koff = (t * 32 + st * 16 + 4 * h) * 2;
+                {
+                    const char* vrow = Vt + r32 * VT_STRIDE + koff;
+                    const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
+                    const h16x4 v1 = *reinterpret_cast<const h16x4*>(vrow + 16);
+                    const h16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o0 = mfma_32x32x16<F16>(vf, pb, o0);
+                }
+                {
+                    const char* vrow = Vt + (32 + r32) * VT_STRIDE + koff;
+                    const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
+                    const h16x4 v1 = *reinterpret_cast<const h16x4*>(vrow + 16);
+                    const h16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                    o1 = mfma_32x32x16<F16>(vf, pb, o1);
+                }
+            }
+        }
+        l += __shfl_xor(l, 32);
+        if (qrow < N) {   // lane owns query column r32; accumulator register rg is d = (rg&3) + 8(rg>>2) + 4h (+32 for o1)
+            const float inv = 1.0f / l;
+            uint16_t* orow = out + ((size_t)b * N + qrow) * C + head * D;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 p0, p1;
+                p0.x = pack_h2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv);
+                p0.y = pack_h2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                p1.x = pack_h2<F16>(o1[4 * g] * inv, o1[4 * g + 1] * inv);
+                p1.y = pack_h2<F16>(o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+                *reinterpret_cast<uint2*>(orow + 8 * g + 4 * h) = p0;
+                *reinterpret_cast<uint2*>(orow + 32 + 8 * g + 4 * h) = p1;
+            }
+        }
+    }
+}
+
+// Exact-f32 variant (SOCCDPT_PREC_F32, the parity mode; not a throughput kernel): one thread owns one query (q and the output row in
+// registers), keys are staged 64 at a time in LDS and read by broadcast, online softmax in f32.
+__global__ __launch_bounds__(64) void vit_attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int heads) {
+    __shared__ float Ks[64][D + 1];
+    __shared__ float Vs[64][D + 1];
+    const int C = heads * D, nqb = (N + 63) / 64;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb;
+    bid /= nqb;
+    const int head = bid % heads;
+    const int b = bid / heads;
+    const int tid = threadIdx.x;
+    const float* base = qkv + (size_t)b * N * (3 * C) + head * D;
+    const int q = qb * 64 + tid;
+    const int qc = q < N ? q : N - 1;
+    float qh[D], o[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) { qh[d] = base[(size_t)qc * (3 * C) + d] * 0.125f; o[d] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        __syncthreads();
+        {   // stage 64 keys: 16 threads x float4 per row
+            for (int idx = tid; idx < 64 * 16; idx += 64) {
+                const int kr = idx >> 4, c4 = (idx & 15) * 4;
+                const int k = k0 + kr;
+                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
+                if (k < N) {
+                    kv = *reinterpret_cast<const float4*>(base + (size_t)k * (3 * C) + C + c4);
+                    vv = *reinterpret_cast<const float4*>(base + (size_t)k * (3 * C) + 2 * C + c4);
+                }
+                Ks[kr][c4] = kv.x; Ks[kr][c4 + 1] = kv.y; Ks[kr][c4 + 2] = kv.z; Ks[kr][c4 + 3] = kv.w;
+                Vs[kr][c4] = vv.x; Vs[kr][c4 + 1] = vv.y; Vs[kr][c4 + 2] = vv.z; Vs[kr][c4 + 3] = vv.w;
+            }
+        }
+        __syncthreads();
+        const int nk = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < nk; ++kk) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < D; ++d) s = fmaf(qh[d], Ks[kk][d], s);
+            const float mn = fmaxf(m, s);
+            const float alpha = __expf(m - mn), p = __expf(s - mn);
+            l = l * alpha + p;
+#pragma unroll
+            for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[kk][d], o[d] * alpha);
+            m = mn;
+        }
+    }
+    if (q < N) {
+        const float inv = 1.0f / l;
+        float* orow = out + ((size_t)b * N + q) * C + head * D;
+#pragma unroll
+        for (int d = 0; d < D; d += 4) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    }
+}
+
+}  // namespace
+
+int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err) {
+    if (B <= 0 || N <= 0 || heads <= 0) { err = "vit_attention: bad geometry"; return 1; }
+    if (prec == SOCCDPT_PREC_F32) {
+        const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64));
+        hipLaunchKernelGGL(vit_attention_f32_kernel, dim3(blocks), dim3(64), 0, st, static_cast<const float*>(qkv), static_cast<float*>(out), N, heads);
+        return check_launch("vit_attention_f32", err);
+    }
+    const int NPAD = (N + 31) / 32 * 32, NT = NPAD / 32;
+    const size_t lds = (size_t)NPAD * KROW + (size_t)D * (NPAD * 2 + 8);
+    if (lds > 160 * 1024) { err = "vit_attention: sequence too long for the LDS-resident K / V^T form (max 608 tokens)"; return 1; }
+    // query split: enough workgroups to cover the 256 CUs, at most one 32-query block per wave and workgroup
+    int QS = (256 + B * heads - 1) / (B * heads);
+    QS = QS < 1 ? 1 : (QS > NT ? NT : QS);
+    const int per = (NT + QS - 1) / QS;
+    QS = (NT + per - 1) / per;    // drop empty parts
+    static PerDeviceOnce attr_done;
+    if (attr_done.need()) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attention_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(&vit_attention_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) { err = std::string("vit_attention: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
+        attr_done.done();
+    }
+    const unsigned blocks = (unsigned)(B * heads * QS);
+    if (prec == SOCCDPT_PREC_F16)
+        hipLaunchKernelGGL(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+    else
+        hipLaunchKernelGGL(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+    return check_launch("vit_attention", err);
+}
+
+}  // namespace soccdpt

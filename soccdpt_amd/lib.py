@@ -59,6 +59,12 @@ class IgemmArgs(ctypes.Structure):
         ("tune", ctypes.c_int32), ("precision", ctypes.c_int32),
         ("splitk", ctypes.c_int32), ("sk_part", ctypes.c_void_p), ("sk_count", ctypes.c_void_p),
         ("sk_part_floats", ctypes.c_size_t), ("sk_count_words", ctypes.c_size_t),
+        ("conv_general", ctypes.c_int32), ("stride", ctypes.c_int32), ("pad", ctypes.c_int32), ("in_halo", ctypes.c_int32),
+        ("Hi", ctypes.c_int32), ("Wi", ctypes.c_int32), ("gather1", ctypes.c_int32),
+        ("grp_rows", ctypes.c_int32), ("grp_off", ctypes.c_int32), ("seg2_k", ctypes.c_int32), ("seg2_off", ctypes.c_int32),
+        ("grp_stride", ctypes.c_int64),
+        ("gn_stats", ctypes.c_void_p), ("gn_part", ctypes.c_void_p), ("gn_count", ctypes.c_void_p),
+        ("gn_cpg", ctypes.c_int32), ("gn_hw", ctypes.c_int32), ("gn_part_floats", ctypes.c_size_t), ("gn_count_words", ctypes.c_size_t),
     ]
 
 
@@ -162,6 +168,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_profile_collect.restype = ci
     L.soccdpt_op_igemm.argtypes = [ctypes.POINTER(IgemmArgs), vp]
     L.soccdpt_op_igemm.restype = ci
+    L.soccdpt_op_vit_attention.argtypes = [vp, vp, ci, ci, ci, ci, vp]
+    L.soccdpt_op_vit_attention.restype = ci
     L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.soccdpt_op_window_attention.restype = ci
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
@@ -396,16 +404,31 @@ class Engine:
 
 
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
-             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None, splitk=1, sk_part=None, sk_count=None):
-    """Kernel-level entry (tests): one implicit-GEMM launch on the current stream."""
+             act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None, splitk=1, sk_part=None, sk_count=None,
+             conv=None, gather1=0, grp_rows=0, grp_off=0, grp_stride=0, seg2_k=0, seg2_off=0, gn_stats=None, gn_part=None, gn_count=None, gn_cpg=0, gn_hw=0):
+    """Kernel-level entry (tests): one implicit-GEMM launch on the current stream.  conv = dict(stride, pad, in_halo, Hi, Wi) selects
+    the generalised convolution addressing."""
     L = load_library()
+    c = conv or {}
     a = IgemmArgs(_ptr(x), _ptr(wt), M, N, Cin, taps, ldx, H, W, _ptr(bias), _ptr(res1), _ptr(res2), act, _ptr(out_f32),
                   act_on_f32, _ptr(out_bf16), out_halo, _ptr(dot_w), float(dot_b), _ptr(out_dot), tune,
                   int(precision) if precision is not None else (PREC_F32 if f32 else PREC_BF16), int(splitk), _ptr(sk_part), _ptr(sk_count),
-                  0 if sk_part is None else sk_part.numel(), 0 if sk_count is None else sk_count.numel())
+                  0 if sk_part is None else sk_part.numel(), 0 if sk_count is None else sk_count.numel(),
+                  1 if conv else 0, c.get("stride", 1), c.get("pad", 1), c.get("in_halo", 1), c.get("Hi", 0), c.get("Wi", 0), int(gather1),
+                  int(grp_rows), int(grp_off), int(seg2_k), int(seg2_off), int(grp_stride),
+                  _ptr(gn_stats), _ptr(gn_part), _ptr(gn_count), int(gn_cpg), int(gn_hw),
+                  0 if gn_part is None else gn_part.numel(), 0 if gn_count is None else gn_count.numel())
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_vit_attention(qkv, out, B, N, heads, precision=PREC_BF16):
+    """Kernel-level entry (tests): softmax(q k^T / 8) v of one ViT block on the current stream."""
+    L = load_library()
+    rc = L.soccdpt_op_vit_attention(_ptr(qkv), _ptr(out), int(precision), B, N, heads, _stream_ptr(qkv.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_vit_attention failed: " + L.soccdpt_last_error(None).decode())
 
 
 def op_input_transform_u8(frames: torch.Tensor, Hd: int, Wd: int, mean=(0.5, 0.5, 0.5), std=(0.5, 0.5, 0.5)) -> torch.Tensor:

@@ -9,7 +9,7 @@ import os, sys, tempfile, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from soccdpt_amd.model.SOccDPT import SOccDPT_V3
-from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, SWIN_ARCHS
+from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
 from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
 
 model_type = sys.argv[1] if len(sys.argv) > 1 else "dpt_swin2_tiny_256"
@@ -17,7 +17,7 @@ B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 prec = {"bf16": 0, "f16": 2}[sys.argv[3] if len(sys.argv) > 3 else "bf16"]
 dev = torch.device("cuda:0")
 backbone = MODEL_TYPE_TO_BACKBONE[model_type]
-img = SWIN_ARCHS[backbone].img
+img = backbone_image_size(backbone)
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type=model_type, precision=prec)
 net.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
