@@ -699,6 +699,9 @@ static int pick_cfg(const IgemmDesc& d) {
     // plain Linear layers / 1x1 convs with many 128x128 tiles and no GELU epilogue (qkv, out_conv): the 8-wave 128x128 tile again
     // (base_384 stage-2 qkv, 18 launches: 412 -> 338 us in the network; with the GELU epilogue of fc1 it loses to 64x64x32)
     if (d.taps == 1 && d.act != ACT_GELU && K >= 128 && K <= 1024 && b128 >= 384) return 21;
+    // ViT-B Linear layers of dpt_hybrid_384 (M = B * 577, K = 768): 128x128 tiles already pay from 256 tiles on, GELU epilogue or not
+    // (in-network, B = 4: qkv 350 -> 261 us, fc1 452 -> 320 us per 12 launches; profiles/r02e_autotune_in_network_hybrid384.txt)
+    if (d.taps == 1 && K >= 768 && K <= 1024 && b128 >= 256) return 21;
     if (K <= 1024 && b64 >= 512) return 4;
     if (b128 >= 256) return c128;
     // small grids: halve the M tile (2x the workgroups) and use 128-deep k-tiles (half the barriers: 8-15 % over a 64-deep
