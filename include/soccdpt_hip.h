@@ -283,6 +283,8 @@ typedef struct soccdpt_igemm_args {
     uint32_t* gn_count;
     int32_t gn_cpg, gn_hw;
     size_t gn_part_floats, gn_count_words;
+    uint64_t* stamps; /* diagnostics: 4 s_memrealtime stamps (100 MHz) per workgroup (entry, first k-tile landed, main loop done, stores
+                         done); NULL = off (tools/igemm_stamps.py) */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 

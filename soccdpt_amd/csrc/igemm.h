@@ -99,9 +99,15 @@ struct IgemmDesc {
     int gn_cpg = 0, gn_hw = 0;
     float gn_eps = 1e-5f;
     size_t gn_part_floats = 0, gn_count_words = 0;   // capacities, validated by launch_igemm
+    // diagnostics (tools/igemm_stamps.py): when non-null every workgroup writes 4 s_memrealtime stamps (100 MHz) -- entry, first k-tile
+    // landed, main loop done, epilogue done -- to stamps[4 * blockIdx.x ..]; the values are never read by the kernel
+    unsigned long long* stamps = nullptr;
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);
+// conv8p.hip: phase-interleaved big-tile 3x3 convolution (configuration ids 30 / 31 / 32 = 256x256 / 128x256 / 256x128 pixels x channels)
+bool conv8p_supported(const IgemmDesc& d, int variant);
+int launch_conv8p(const IgemmDesc& d, int variant, hipStream_t stream, std::string& err);
 // Split factor the heuristic would use for this problem (1 = none) given scratch for `part_floats` floats / `count_words` tiles.
 int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words);
 constexpr size_t kSplitKPartFloats = 2u << 20;  // 8 MB of f32 partials per workspace: splitk * M * N <= this

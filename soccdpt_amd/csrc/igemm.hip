@@ -76,6 +76,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
+    if (d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware bijective remap: consecutive logical tiles -> same XCD (blocks b, b+8 share one)
     int bid = blockIdx.x;
@@ -225,6 +226,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     for (int kt = 0; kt < nk; ++kt) {
         wait_tile(kt);
         __builtin_amdgcn_s_barrier();
+        if (kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
         const char* sb = smem + (kt % C::NS) * C::STAGE;
 #pragma unroll
@@ -261,6 +263,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }
 
     const int N = d.N;
+    if (d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SK) {
         // Cross-workgroup exchange WITHOUT fences: a release/acquire fence at agent scope writes back / invalidates the whole
         // per-XCD L2 on gfx950 (measured: ~30 us per split).  Instead every partial is stored and loaded with agent-scope
@@ -575,6 +578,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             }
         }
     }
+    if (d.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) d.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
     if (d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
 #pragma unroll
         for (int j = 0; j < C::TM; ++j) {
@@ -656,7 +664,10 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x32_s3", "igemm_bf16_128x256x64_s2", "igemm_bf16_64x64x64_s6",
                                         "igemm_bf16_64x64x64_s8", "igemm_bf16_64x128x64_s4", "igemm_bf16_32x64x64_s6", "igemm_bf16_128x256x32_s3",
                                         "igemm_bf16_256x128x32_s3", "igemm_bf16_128x256x32_s4", "igemm_bf16_256x256x32_s3", "igemm_bf16_64x128x32_s4",
-                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8", "igemm_bf16_32x64x128_s3_w8", "igemm_bf16_64x64x64_s4_w8", "igemm_bf16_128x128x32_s3_w8"};
+                                        "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8", "igemm_bf16_32x64x128_s3_w8", "igemm_bf16_64x64x64_s4_w8", "igemm_bf16_128x128x32_s3_w8",
+                                        "igemm_bf16_cfg25", "igemm_bf16_cfg26", "igemm_bf16_cfg27", "igemm_bf16_cfg28", "igemm_bf16_cfg29",
+                                        "conv8p_bf16_256x256x64", "conv8p_bf16_128x256x64", "conv8p_bf16_256x128x64", "conv8p_var33", "conv8p_var34", "conv8p_var35", "conv8p_var36",
+                                        "conv8p_var37", "conv8p_var38", "conv8p_var39"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
@@ -770,6 +781,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
+    if (id >= 30 && id <= 39) return launch_conv8p(d, id - 30, stream, err);
     if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }

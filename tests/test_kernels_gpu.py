@@ -345,3 +345,42 @@ def test_mlp_ln_fused(gpu_device, M, C, prec, hook):
     op_mlp_ln(xop2, got2, w1, b1, w2, b2, lg, lb, x_op_out=xop2, precision=pr)
     torch.cuda.synchronize()
     assert torch.equal(got2, got) and torch.equal(xop2, out_op)
+
+
+# ---------------- conv8p.hip: phase-interleaved big-tile 3x3 convolution (configuration ids 30 / 31 / 32) ----------------
+@pytest.mark.parametrize("tune,Cout", [(30, 256), (31, 256), (32, 128), (30, 512), (32, 256)])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv8p_matches_torch(gpu_device, tune, Cout, prec):
+    """256x256 / 128x256 / 256x128 tiles with the staggered read / matrix intervals: ragged M (1600 and 2 x 50 x 50 pixels are no tile
+    multiples), 18 k-tiles (Cin 128) and 36 (Cin 256), every epilogue path (bias, two residuals, ReLU, f32 + halo operand stores), and
+    repeated launches (a staging / fragment-read race would show as a sporadic wrong tile)."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, op_igemm
+    dt = torch.bfloat16 if prec == "bf16" else torch.float16
+    P = PREC_BF16 if prec == "bf16" else PREC_F16
+    for B, H, Cin in ((1, 40, 128), (2, 50, 256)):
+        g = torch.Generator().manual_seed(tune * 100 + H)
+        x = torch.randn(B, Cin, H, H, generator=g).to(dt).to(gpu_device)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dt).to(gpu_device)
+        bias = torch.randn(Cout, generator=g).to(gpu_device)
+        res1 = torch.randn(B, H, H, Cout, generator=g).to(gpu_device)
+        res2 = torch.randn(B, H, H, Cout, generator=g).to(gpu_device)
+        ref = F.conv2d(x.float(), w.float(), bias, padding=1).permute(0, 2, 3, 1)
+        full = ref + res1 + res2
+        xh = torch.zeros(B, H + 2, H + 2, Cin, dtype=dt, device=gpu_device)
+        xh[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+        wt = w.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+        out = torch.empty(B, H, H, Cout, device=gpu_device)
+        outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=dt, device=gpu_device)
+        for rep in range(4):
+            out.fill_(-7.0)
+            op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, res1=res1, res2=res2, act=1, out_f32=out, out_bf16=outh, out_halo=1,
+                     tune=tune, precision=P)
+            torch.cuda.synchronize()
+            torch.testing.assert_close(out, full, rtol=1e-4, atol=2e-4, msg=f"tune={tune} rep={rep}")
+        torch.testing.assert_close(outh[:, 1:-1, 1:-1].float(), F.relu(full), rtol=1e-2, atol=1e-2)
+        assert float(outh[:, 0].abs().max()) == 0 and float(outh[:, :, 0].abs().max()) == 0 and float(outh[:, -1].abs().max()) == 0
+        # bit-identical to the 128 x 128 tile: same k order per output element (k-tiles of 64, two MFMA k-steps each)
+        o2 = torch.empty_like(out)
+        op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, res1=res1, res2=res2, act=1, out_f32=o2, tune=21, precision=P)
+        torch.cuda.synchronize()
+        assert torch.equal(o2, out), f"tune={tune}: differs from configuration 21"
