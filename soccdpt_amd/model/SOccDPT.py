@@ -245,6 +245,17 @@ class SOccDPT_V3(SOccDPT):
         self.last_occ_bits = bits
         return self._shape_outputs(inv_up, seg_up, points, occ)
 
+    def train_forward(self, x: torch.Tensor):
+        """Train-mode forward that keeps what the backward needs (BatchNorm batch statistics + Dropout in the seg head, saved activations).
+        Not built yet: SURVEY.md 8f #1 / rows a14, f#1."""
+        raise NotImplementedError("the network's train-mode forward / backward kernels are not built yet (conv dgrad / wgrad, attention, LayerNorm, "
+                                  "GELU, bilinear backward, train-mode BatchNorm + Dropout: SURVEY.md 8f #1); the criterion, its output gradients, the "
+                                  "fused Adam and the patch-wise schedule are (soccdpt_amd.scripts.train_SOccDPT --forward_only walks them)")
+
+    def backward(self, d_inv: torch.Tensor, d_seg: torch.Tensor):
+        """Gradients of every trainable parameter from d loss / d (inv_depth, segmentation): see train_forward."""
+        return self.train_forward(None)
+
     def network(self, x: torch.Tensor):
         """Stage-level: encoder + decoder + heads only -> (inv_depth [B,S,S], segmentation [B,C,S,S])."""
         eng = self._engine(x.device)
