@@ -97,7 +97,10 @@ def main():
 
     def barrier():
         if dist.is_initialized():
-            dist.barrier(device_ids=[local])
+            if dist.get_backend() == "nccl":
+                dist.barrier(device_ids=[local])
+            else:
+                dist.barrier()      # SOCCDPT_DIST_REHEARSAL=1 (gloo; see soccdpt_amd/dist.py)
         torch.cuda.synchronize()
 
     # clock / allocator pre-warm (untimed, in addition to the W warm-up steps): a GPU that has just been handed over from another
@@ -116,8 +119,9 @@ def main():
     per_rank_ms = [round(elapsed / args.steps * 1e3, 3)]
     rccl_ranks = 1
     if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        allt = torch.empty((world,), device=dev, dtype=torch.float64)
+        cdev = dev if dist.get_backend() == "nccl" else torch.device("cpu")
+        t = torch.tensor([elapsed], device=cdev, dtype=torch.float64)
+        allt = torch.empty((world,), device=cdev, dtype=torch.float64)
         dist.all_gather_into_tensor(allt, t)                # evidence of how many ranks RCCL really connected
         per_rank_ms = [round(float(v) / args.steps * 1e3, 3) for v in allt.cpu()]
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,7 +232,7 @@ def main():
             "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
             "config": {"workload": f"SOccDPT_V3 {args.model_type} full forward, compute_occ=True, camera 1920x1080",
                        "batch_per_gpu": B, "global_batch": B * world, "image": img, "streams_per_gpu": args.streams, "hip_graph": args.graph,
-                       "parallelism": f"dp{world}" if world > 1 else "single",
+                       "parallelism": f"dp{world}" if world > 1 else "single", "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
@@ -320,7 +324,7 @@ def main():
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(result) + "\n").encode())
     if dist.is_initialized():
-        dist.barrier(device_ids=[local])
+        barrier()
         dist.destroy_process_group()
 
 

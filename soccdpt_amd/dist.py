@@ -22,13 +22,26 @@ def shard_range(global_batch: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def rehearsal() -> bool:
+    """SOCCDPT_DIST_REHEARSAL=1: run the N-rank code path of bench.py / attach() on a box with FEWER GPUs than ranks -- backend gloo, rank r on
+    device r % device_count -- so that the sharding, barrier, timing and exchange plumbing can be exercised before an 8-GPU run.  RCCL itself is
+    not involved (it refuses two ranks on one device); the product configuration is backend "nccl", one rank per GPU."""
+    import os
+    return os.environ.get("SOCCDPT_DIST_REHEARSAL", "0") == "1"
+
+
 def gather_occ_bits(bits: torch.Tensor, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """All-gather the packed local grids: [words] int32 -> [world, words] int32 (same device).  `out`: reusable flat buffer."""
     world = dist.get_world_size(group)
     n = world * bits.numel()
     flat = out if (out is not None and out.numel() == n and out.device == bits.device and out.dtype == bits.dtype) else \
         torch.empty((n,), dtype=bits.dtype, device=bits.device)
-    dist.all_gather_into_tensor(flat, bits.contiguous().reshape(-1), group=group)
+    if bits.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal only: gloo moves host memory
+        host = torch.empty((n,), dtype=bits.dtype)
+        dist.all_gather_into_tensor(host, bits.detach().cpu().contiguous().reshape(-1), group=group)
+        flat.copy_(host)
+    else:
+        dist.all_gather_into_tensor(flat, bits.contiguous().reshape(-1), group=group)
     return flat.reshape(world, bits.numel())
 
 
@@ -56,6 +69,9 @@ def init_from_env(backend: str = "nccl"):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"  # exercise the RCCL path with a single rank (tests)
+    if rehearsal():
+        backend = "gloo"
+        local = local % max(torch.cuda.device_count(), 1)
     if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if "MASTER_PORT" not in os.environ:

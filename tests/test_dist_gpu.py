@@ -31,3 +31,23 @@ def test_rccl_exchange_single_rank_matches_plain_forward(gpu_device):
     assert r.returncode == 0, r.stderr[-2000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1].split()
     assert tuple(line[1:4]) == want
+
+
+def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
+    """The N > 1 path of bench.py (sharded frames, barrier + max-over-ranks timing, the packed-grid exchange, rank-0 JSON line) under
+    torch.distributed.run with TWO ranks on the one GPU of a test box: SOCCDPT_DIST_REHEARSAL=1 swaps RCCL for gloo (RCCL refuses two ranks
+    on one device), everything else is the code the 8-GPU scaling run executes.  The line must report both ranks and whole-job throughput."""
+    import json
+    env = dict(os.environ, SOCCDPT_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29553", bench, "--gpus", "2", "--steps", "5", "--warmup", "2", "--prewarm", "3", "--batch", "2"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]          # exactly ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and len(d["per_rank_ms_per_step"]) == 2
+    assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["config"]["dist_backend"] == "gloo"
+    assert abs(d["value"] - 4 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3      # whole-job frames / max-over-ranks time
+    assert "cpu_baseline" not in d                                                         # N = 1 only
