@@ -64,7 +64,9 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // for another one.  For long-K problems whose output grid cannot fill the 256 CUs (coarse decoder levels, stage-3 fc2).
 // ST: GroupNorm statistics of the raw output (d.gn_stats): per-tile per-group partial sums, finished by the last workgroup of each
 // sample (same fence-free sc1 exchange as SK).  ResNetV2 stages of the ViT-hybrid encoder (csrc/hybrid.hip applies the normalisation).
-template <class C, typename T, bool LN, bool SK = false, bool ST = false>
+// GEN: the generalised addressing (strided / un-haloed / gathered convolution, row groups, second A segment) and the diagnostics stamps.
+// A separate instantiation: carried by every launch they cost the Swin models 1.5 % of the forward (A/B in one GPU call, tools/ab_bench.sh).
+template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int BM = C::BM, BN = C::BN;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
-    if (d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+    if (GEN && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware bijective remap: consecutive logical tiles -> same XCD (blocks b, b+8 share one)
     int bid = blockIdx.x;
@@ -96,8 +98,9 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     const int m0 = mt * BM, n0 = nt * BN;
     const int Ktot = d.taps * d.Cin;
     const int Wp = d.W + 2;                 // OUTPUT halo geometry (out_halo / ln_halo stores)
-    const bool conv_addr = d.taps == 9 || d.gather1;
-    const int Wpi = (d.Wi ? d.Wi : d.W) + 2 * d.in_halo, Hpi = (d.Hi ? d.Hi : d.H) + 2 * d.in_halo;   // INPUT image geometry
+    const bool conv_addr = d.taps == 9 || (GEN && d.gather1);
+    const int Wpi = GEN ? (d.Wi ? d.Wi : d.W) + 2 * d.in_halo : d.W + 2;   // INPUT image geometry
+    const int Hpi = GEN ? (d.Hi ? d.Hi : d.H) + 2 * d.in_halo : d.H + 2;
 
     // ---- per-thread staging sources (element offsets) ----
     uint32_t x_off[C::X_LOADS], x_off2[C::X_LOADS], w_off[C::W_LOADS];
@@ -112,8 +115,9 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             const int hw = d.H * d.W;
             const int b = m / hw, rem = m - b * hw;
             const int y = rem / d.W, x = rem - y * d.W;
-            base = (uint32_t)(((b * Hpi + y * d.stride + d.in_halo - d.pad) * Wpi + x * d.stride + d.in_halo - d.pad) * d.Cin);
-        } else if (d.grp_rows) {
+            if constexpr (GEN) base = (uint32_t)(((b * Hpi + y * d.stride + d.in_halo - d.pad) * Wpi + x * d.stride + d.in_halo - d.pad) * d.Cin);
+            else base = (uint32_t)(((b * Hpi + y) * Wpi + x) * d.Cin);
+        } else if (GEN && d.grp_rows) {
             const int g = m / d.grp_rows, r = m - g * d.grp_rows;
             const uint32_t gb = (uint32_t)((long long)g * d.grp_stride);
             base = gb + (uint32_t)d.grp_off + (uint32_t)r * (uint32_t)d.ldx;
@@ -142,7 +146,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             const int tap = kt / kpt, kc = kt - tap * kpt;
             const int ky = tap / 3, kx = tap - ky * 3;
             xk = (uint32_t)((ky * Wpi + kx) * d.Cin + kc * BK);
-        } else if (d.seg2_k && (int)wk >= d.seg2_k) {   // wave-uniform: the per-group row (ViT readout token)
+        } else if (GEN && d.seg2_k && (int)wk >= d.seg2_k) {   // wave-uniform: the per-group row (ViT readout token)
             seg2 = true;
             xk = wk - (uint32_t)d.seg2_k;
         } else {
@@ -151,7 +155,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         char* sb = smem + buf * C::STAGE;
 #pragma unroll
         for (int i = 0; i < C::X_LOADS; ++i) {
-            const T* g = Xp + (x_off[i] + (seg2 ? x_off2[i] : 0u)) + xk;   // a VALUE select: selecting between the two arrays demotes them (and d) to scratch
+            const T* g = Xp + (x_off[i] + ((GEN && seg2) ? x_off2[i] : 0u)) + xk;   // a VALUE select: selecting between the two arrays demotes them (and d) to scratch
             char* l = sb + (i * C::THREADS + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     for (int kt = 0; kt < nk; ++kt) {
         wait_tile(kt);
         __builtin_amdgcn_s_barrier();
-        if (kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (GEN && kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
         const char* sb = smem + (kt % C::NS) * C::STAGE;
 #pragma unroll
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }
 
     const int N = d.N;
-    if (d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if (GEN && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
     if constexpr (SK) {
         // Cross-workgroup exchange WITHOUT fences: a release/acquire fence at agent scope writes back / invalidates the whole
         // per-XCD L2 on gfx950 (measured: ~30 us per split).  Instead every partial is stored and loaded with agent-scope
@@ -578,7 +582,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             }
         }
     }
-    if (d.stamps) {
+    if (GEN && d.stamps) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         if (tid == 0) d.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
@@ -596,8 +600,14 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     }  // generic epilogue
 }
 
-template <class C, typename T, bool LN = false, bool SK = false, bool ST = false>
+// does the descriptor use what only the GEN instantiations implement?
+static bool need_gen(const IgemmDesc& d) {
+    return d.stride != 1 || d.pad != 1 || d.in_halo != 1 || d.Hi || d.Wi || d.gather1 || d.grp_rows || d.seg2_k || d.stamps;
+}
+
+template <class C, typename T, bool LN = false, bool SK = false, bool ST = false, bool GEN = false>
 static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (!GEN && need_gen(d)) { err = "igemm: this configuration has no generalised-addressing instantiation (use 2, 20 or a GroupNorm-statistics launch)"; return 1; }
     if (LN != (d.ln_g != nullptr)) { err = "igemm: this configuration has no fused-LayerNorm instantiation"; return 1; }
     if (SK != (d.splitk > 1)) { err = "igemm: this configuration has no split-K instantiation"; return 1; }
     if (ST != (d.gn_stats != nullptr)) { err = "igemm: this configuration has no GroupNorm-statistics instantiation"; return 1; }
@@ -615,14 +625,14 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     }
     static PerDeviceOnce attr_done;
     if (attr_done.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK, ST>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK, ST, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done.done();
     }
     const int splits = SK ? d.splitk : 1;
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
                (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
-    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK, ST>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK, ST, GEN>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;
@@ -642,7 +652,14 @@ static int launch_cfg_sk(const IgemmDesc& d, hipStream_t stream, std::string& er
 template <class C>
 static int launch_cfg_st(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (!d.gn_stats) return launch_cfg<C>(d, stream, err);
-    return d.f16 ? launch_cfg_t<C, f16_t, false, false, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, true>(d, stream, err);
+    return d.f16 ? launch_cfg_t<C, f16_t, false, false, true, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, true, true>(d, stream, err);
+}
+// configurations 2 and 20 also carry the generalised addressing without statistics (and 20 with split-K)
+template <class C>
+static int launch_cfg_gen(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (d.gn_stats) return launch_cfg_st<C>(d, stream, err);
+    if (!need_gen(d)) return launch_cfg<C>(d, stream, err);
+    return d.f16 ? launch_cfg_t<C, f16_t, false, false, false, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, false, true>(d, stream, err);
 }
 // configurations that also carry the fused-LayerNorm epilogue (one n-tile covers the row)
 template <class C>
@@ -672,6 +689,7 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
 static int pick_cfg_f32(const IgemmDesc& d) {
     if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
+    if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
     if (d.N <= 32) return 2;
     const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
@@ -689,6 +707,11 @@ static int pick_cfg(const IgemmDesc& d) {
         if (!k64) return 4;
         const long t128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
         return (d.gn_hw % 128 == 0 && d.gn_cpg <= 128 && t128 >= 256) ? 21 : 23;
+    }
+    if (need_gen(d)) {   // generalised addressing without statistics (ViT read-out projection, Conv2d(3, 2, 1) of act_postprocess4): configurations 2 / 20
+        if (d.splitk > 1) return 20;
+        const long t64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+        return (d.Cin % 128 == 0 && t64 < 256) ? 20 : 2;
     }
     if (d.splitk > 1) return d.Cin % 128 == 0 ? 20 : 14;  // the split-K instantiations: 32(M) x 64(N) tiles
     if (d.N <= 32) return 5;
@@ -729,6 +752,7 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     // longest K on the smallest grid: layer4_rn (M=512, N=256, K=6912) 30.9 -> 18.3 us at 4 splits; K=2304..3456 on 64..256
     // tiles and the stage-3 Linear layers (K <= 3072) are break-even or slower and stay unsplit.
     if (d.f32 || d.ln_g || d.out_dot || d.gn_stats || d.seg2_k || d.N <= 32 || d.Cin % 64 != 0 || d.tune >= 0) return 1;
+    if (need_gen(d) && d.Cin % 128 != 0) return 1;   // split-K with generalised addressing exists for the 128-deep tile only
     auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
     const long nk = (long)d.taps * d.Cin / 64, blocks = cdiv(d.M, 32) * cdiv(d.N, 64);
     if (blocks > 128 || nk < 96 || (size_t)blocks > count_words) return 1;
@@ -771,11 +795,12 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         switch (pick_cfg_f32(d)) {
-            case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, false, false, true>(d, stream, err)
+            case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, false, false, true, true>(d, stream, err)
                          : d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, true>(d, stream, err)
                                   : launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float>(d, stream, err);
-            case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, true>(d, stream, err)
-                                      : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
+            case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, true, true>(d, stream, err)
+                         : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, false, true>(d, stream, err)
+                                       : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
             default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, float>(d, stream, err);
         }
     }
@@ -788,7 +813,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     switch (id) {
         case 0: return launch_cfg<Cfg<128, 128, 64, 2, 2, 4>>(d, stream, err);
         case 1: return launch_cfg_st<Cfg<128, 128, 64, 2, 2, 2>>(d, stream, err);
-        case 2: return launch_cfg_st<Cfg<64, 64, 64, 2, 2, 4>>(d, stream, err);
+        case 2: return launch_cfg_gen<Cfg<64, 64, 64, 2, 2, 4>>(d, stream, err);
         case 3: return launch_cfg<Cfg<128, 128, 32, 2, 2, 4>>(d, stream, err);
         case 4: return launch_cfg_st<Cfg<64, 64, 32, 2, 2, 4>>(d, stream, err);
         case 5: return launch_cfg<Cfg<128, 32, 64, 4, 1, 4>>(d, stream, err);
@@ -810,7 +835,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 22: return launch_cfg<Cfg<32, 64, 128, 2, 4, 3>>(d, stream, err);   // 8 waves, 16x16 per wave: the small-grid long-K launches are latency chains,
         case 23: return launch_cfg_st<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
         case 24: return launch_cfg<Cfg<128, 128, 32, 2, 4, 3>>(d, stream, err);  // 8 waves, 64x32 per wave, 32-deep k-tiles (C = 96: layer1_rn 43 -> 34 us)
-        case 20: return d.gn_stats ? launch_cfg_st<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err) : launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
+        case 20:
+            if (d.gn_stats || (need_gen(d) && d.splitk <= 1)) return launch_cfg_gen<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);
+            if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, f16_t, false, true, false, true>(d, stream, err)
+                                          : launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, bf16_t, false, true, false, true>(d, stream, err);
+            return launch_cfg_sk<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);  // 128-deep k-tiles: half the barriers of the long-K small-grid launches
     }
     err = "igemm: unknown configuration id";
     return 1;

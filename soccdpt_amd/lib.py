@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoccdpt_hip.so")
+LIB_PATH = os.environ.get("SOCCDPT_LIB_PATH") or os.path.join(_HERE, "libsoccdpt_hip.so")   # override: A/B of two builds in one GPU call (tools/ab_bench.sh)
 
 ABI_VERSION = 1
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}

@@ -1,6 +1,7 @@
 """Where does a small GEMM launch spend its time?  Per-workgroup s_memrealtime stamps (igemm.h: IgemmDesc::stamps) of the encoder's
 latency-bound Linear layers: dispatch spread (first to last workgroup entry), time to the first landed k-tile, main loop, epilogue, and
-the launch's wall span -- the numbers behind DESIGN.md's "every kernel costs >= 4.4 us" floor.
+the launch's wall span -- the numbers behind DESIGN.md's "every kernel costs >= 4.4 us" floor.  Stamps live in the generalised-addressing
+instantiations only (configurations 2 = 64x64x64 and 20 = 32x64x128, 4 waves), which is what these launches then run on.
     python tools/igemm_stamps.py"""
 import math, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
