@@ -7,7 +7,7 @@ import collections, csv, json, re, sys
 def family(kernel_name: str) -> str:
     """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
     n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
-    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>, ([\w ]+), (true|false), (true|false)>", n)
+    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)   # LN, SK[, ST, GEN]
     if m:
         t = m.group(7)
         if t == "float":
