@@ -300,6 +300,22 @@ int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, 
 int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
                                 float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, void* stream);
 
+/* ---- training step: replaces `masks_pred = net(images)` in train mode + `grad_scaler.scale(loss).backward()`
+ * (scripts/train_SOccDPT.py:360-393) for the encoder + decoder + heads (model/SOccDPT.py:660-685, model/dpt.py:142-232).
+ * SOCCDPT_PREC_F32 handles with a Swin-V2 backbone only; weights are read as bound (no soccdpt_prepare needed: they change every step).
+ * soccdpt_bind_grad: `dev_grad` (same shape as the weight, f32) receives d loss / d weight -- WRITTEN, not accumulated -- on every
+ * soccdpt_train_backward; NULL unbinds (the weight is frozen and its weight-gradient GEMM is skipped: model/loss.py:110-152).
+ * soccdpt_train_forward: train-mode forward (seg head BatchNorm on batch statistics, running buffers bound as "seg_head.1.running_mean/var"
+ * updated in place with momentum 0.1; Dropout(dropout_p) with a counter-based mask from `seed`); keeps every activation the backward needs
+ * in the workspace.  soccdpt_train_backward: d_inv [B,S,S], d_seg [B,C,S,S] -> bound gradients; must follow a soccdpt_train_forward on the
+ * same workspace and B. */
+int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad);
+size_t soccdpt_train_workspace_bytes(void* handle, int B);
+int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_inv, float* dev_seg, void* dev_workspace, size_t workspace_bytes,
+                          float dropout_p, uint32_t seed, void* stream);
+int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float* dev_d_inv, const float* dev_d_seg, void* dev_workspace,
+                           size_t workspace_bytes, void* stream);
+
 /* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
  * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "seg_logits" (seg head before up-sampling/activation, f32 [B,2G,2G,3]), "xf" (final stage tokens f32).
  * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC, 4 = fp16 plain, 5 = fp16 zero-halo NHWC.  Returns non-zero for unknown names. */

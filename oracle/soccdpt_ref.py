@@ -126,7 +126,7 @@ def relative_position_index(ws: int) -> Tensor:
 
 def cpb_bias(sd: Dict[str, Tensor], pfx: str, ws: int, pretrained_ws: int, heads: int) -> Tensor:
     """16*sigmoid(cpb_mlp(coords))[rel_index] -> [heads, N, N]."""
-    tab = cpb_coords_table(ws, pretrained_ws)
+    tab = cpb_coords_table(ws, pretrained_ws).to(sd[pfx + "cpb_mlp.0.weight"].dtype)   # (f64 runs: the gradient-noise reference of the training tests)
     h = F.relu(F.linear(tab, sd[pfx + "cpb_mlp.0.weight"], sd[pfx + "cpb_mlp.0.bias"]))
     t = F.linear(h, sd[pfx + "cpb_mlp.2.weight"])  # [(2ws-1)^2, heads]
     idx = relative_position_index(ws).reshape(-1)
@@ -170,7 +170,7 @@ def window_attention(sd, pfx, x: Tensor, res: int, ws: int, shift: int, heads: i
     attn = attn + cpb_bias(sd, pfx, ws, pretrained_ws, heads).unsqueeze(0)
     mask = shift_attn_mask(res, ws, shift)
     if mask is not None:
-        attn = attn.reshape(B, nw * nw, heads, N, N) + mask[None, :, None]
+        attn = attn.reshape(B, nw * nw, heads, N, N) + mask.to(attn.dtype)[None, :, None]
         attn = attn.reshape(-1, heads, N, N)
     attn = torch.softmax(attn, dim=-1)
     out = (attn @ v).transpose(1, 2).reshape(-1, N, C)
@@ -400,19 +400,22 @@ def dpt_decoder(sd, layers: Sequence[Tensor], pfx: str = "depth_net.scratch.") -
     return h.squeeze(1), p1
 
 
-def seg_logits(sd, feats: Tensor, pfx: str = "seg_head.") -> Tensor:
-    """Class logits of the seg head at half resolution: Conv3x3 -> BN(eval) -> ReLU -> Dropout(eval) -> Conv1x1
-    (model/SOccDPT.py:660-671), i.e. seg_head before Interpolate and the activation."""
+def seg_logits(sd, feats: Tensor, pfx: str = "seg_head.", training: bool = False, dropout_p: float = 0.0) -> Tensor:
+    """Class logits of the seg head at half resolution: Conv3x3 -> BN -> ReLU -> Dropout -> Conv1x1
+    (model/SOccDPT.py:660-671), i.e. seg_head before Interpolate and the activation.  training=True is nn.Module.train():
+    BatchNorm2d normalises with batch statistics and updates running_mean / running_var in place (momentum 0.1), Dropout(dropout_p) is live."""
     h = F.conv2d(feats, sd[pfx + "0.weight"], padding=1)
     h = F.batch_norm(h, sd[pfx + "1.running_mean"], sd[pfx + "1.running_var"],
-                     sd[pfx + "1.weight"], sd[pfx + "1.bias"], False, 0.1, 1e-5)
+                     sd[pfx + "1.weight"], sd[pfx + "1.bias"], training, 0.1, 1e-5)
     h = F.relu(h)
+    if training and dropout_p > 0.0:
+        h = F.dropout(h, dropout_p, True)
     return F.conv2d(h, sd[pfx + "4.weight"], sd[pfx + "4.bias"])
 
 
-def seg_head(sd, feats: Tensor, sigmoid: bool, pfx: str = "seg_head.") -> Tensor:
-    """Eval-mode seg head (model/SOccDPT.py:660-674; ScaledTanh model/scaled_tanh.py:4-10)."""
-    h = seg_logits(sd, feats, pfx)
+def seg_head(sd, feats: Tensor, sigmoid: bool, pfx: str = "seg_head.", training: bool = False, dropout_p: float = 0.0) -> Tensor:
+    """Seg head (model/SOccDPT.py:660-674; ScaledTanh model/scaled_tanh.py:4-10); eval mode unless training=True."""
+    h = seg_logits(sd, feats, pfx, training, dropout_p)
     h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
     if sigmoid:
         return torch.sigmoid(h)
@@ -519,11 +522,14 @@ def points_to_occupancy(points: Tensor, sem: Tensor, cfg: ProjConfig = ProjConfi
 # ----------------------------------------------------------------------------
 # Whole forward (model/SOccDPT.py:681-685)
 # ----------------------------------------------------------------------------
-def soccdpt_v3_network(sd, x: Tensor, backbone: str = "swin2t16_256", sigmoid: bool = True):
-    """Encoder + decoder + heads only: (inv_depth [B,H,W], seg [B,C,H,W], path_1)."""
+def soccdpt_v3_network(sd, x: Tensor, backbone: str = "swin2t16_256", sigmoid: bool = True, training: bool = False,
+                       dropout_p: float = 0.0):
+    """Encoder + decoder + heads only: (inv_depth [B,H,W], seg [B,C,H,W], path_1).  training=True: the train-mode forward the
+    reference's training loop differentiates (scripts/train_SOccDPT.py:360-393) -- torch autograd over this function is the
+    gradient oracle of tests/test_train_step_gpu.py."""
     layers = hybrid_encoder(sd, x) if backbone == "vitb_rn50_384" else swin_encoder(sd, x, ARCHS[backbone])
     inv, p1 = dpt_decoder(sd, layers)
-    seg = seg_head(sd, p1, sigmoid)
+    seg = seg_head(sd, p1, sigmoid, training=training, dropout_p=dropout_p)
     return inv, seg, p1
 
 

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "internal.h"
+#include "train.h"
 #include "kernels.h"
 
 using namespace soccdpt;
@@ -93,6 +94,36 @@ int soccdpt_network(void* handle, const float* dev_x, int B, float* dev_inv256, 
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
     return model_network(*h, dev_x, B, dev_inv256, dev_seg256, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !key) return fail(h, "soccdpt_bind_grad: null argument");
+    auto it = h->index.find(key);
+    if (it == h->index.end()) return fail(h, std::string("soccdpt_bind_grad: unknown key: ") + key);
+    h->weights[it->second].grad = dev_grad;
+    return 0;
+}
+size_t soccdpt_train_workspace_bytes(void* handle, int B) { return handle && B > 0 ? train_workspace_bytes(*static_cast<Handle*>(handle), B) : 0; }
+int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_inv, float* dev_seg, void* dev_workspace, size_t workspace_bytes,
+                          float dropout_p, uint32_t seed, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (!dev_x || !dev_inv || !dev_seg) return fail(h, "soccdpt_train_forward: null argument");
+    if (!(dropout_p >= 0.f && dropout_p < 1.f)) return fail(h, "soccdpt_train_forward: dropout_p must be in [0, 1)");
+    h->train_key = Handle::TrainKey();
+    if (train_forward(*h, dev_x, B, dev_inv, dev_seg, dev_workspace, workspace_bytes, dropout_p, seed, (hipStream_t)stream, h->err)) return 1;
+    h->train_key.ws = dev_workspace; h->train_key.B = B; h->train_key.dropout_p = dropout_p;
+    return 0;
+}
+int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float* dev_d_inv, const float* dev_d_seg, void* dev_workspace,
+                           size_t workspace_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (!dev_d_inv || !dev_d_seg) return fail(h, "soccdpt_train_backward: null argument");
+    if (h->train_key.ws != dev_workspace || h->train_key.B != B || !dev_workspace)
+        return fail(h, "soccdpt_train_backward: no soccdpt_train_forward ran on this workspace with this batch size");
+    return train_backward(*h, dev_x, B, dev_d_inv, dev_d_seg, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
 }
 
 int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, int B, int in_h, int in_w, float* dev_inv_up,

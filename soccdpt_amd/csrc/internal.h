@@ -40,6 +40,7 @@ struct WeightSlot {
     std::string key;
     std::vector<int64_t> shape;
     const float* ptr = nullptr;
+    float* grad = nullptr;   // gradient destination of the training step (soccdpt_bind_grad); nullptr = frozen
     size_t numel() const {
         size_t n = 1;
         for (auto d : shape) n *= (size_t)d;
@@ -128,6 +129,12 @@ struct Handle {
         bool operator==(const WsKey& o) const { return ws == o.ws && B == o.B && streams == o.streams; }
     } ws_key;
     int ws_zero_fills = 0;
+    // training step (train.cpp): what the last soccdpt_train_forward ran with, checked by soccdpt_train_backward
+    struct TrainKey {
+        const void* ws = nullptr;
+        int B = 0;
+        float dropout_p = 0.f;
+    } train_key;
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;  // capture/replay stream (the caller's may be the legacy null stream, which cannot capture)

@@ -1,0 +1,44 @@
+// Launchers of train.hip (backward / train-mode forward kernels, exact f32) and the training entry points of train_step.cpp.
+#pragma once
+#include "internal.h"
+#include "kernels.h"
+
+namespace soccdpt {
+
+int tr_transpose(const float* in, float* out, int R, int C, hipStream_t st, std::string& err);
+int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err);
+int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
+int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
+int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
+int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);
+int tr_relu_bwd(const float* dy, const float* ref, const float* add, float* dx, size_t n, hipStream_t st, std::string& err);
+int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, float* dx, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_gelu_bwd(const float* dy, const float* pre, float* dx, size_t n, hipStream_t st, std::string& err);
+int tr_ln_bwd(const float* y, const float* g, const float* dout, float* dy, float* xhat, int M, int C, float eps, hipStream_t st, std::string& err);
+int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
+int tr_bn_stats(const float* sum, const float* sumsq, float* stats, float* rmean, float* rvar, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err);
+int tr_bn_relu_dropout_fwd(const float* x, const float* stats, const float* gamma, const float* beta, float* out, uint8_t* keep, size_t M, int C, float p, uint32_t seed, hipStream_t st, std::string& err);
+int tr_bn_relu_dropout_bwd_pre(const float* dout, const float* out, const uint8_t* keep, float* dz, size_t n, float p, hipStream_t st, std::string& err);
+int tr_bn_bwd(const float* dz, const float* x, const float* stats, const float* gamma, const float* dbeta, const float* dgamma, float* dx, size_t M, int C, hipStream_t st, std::string& err);
+int tr_bn_xhat(const float* x, const float* stats, float* xh, size_t M, int C, hipStream_t st, std::string& err);
+int tr_smallk_fwd(const float* x, const float* w, const float* bias, float* out, size_t M, int C, int K, hipStream_t st, std::string& err);
+int tr_smallk_dgrad(const float* dl, const float* w, float* dx, size_t M, int C, int K, hipStream_t st, std::string& err);
+int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, size_t M, int C, int K, hipStream_t st, std::string& err);
+int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err);
+int tr_depth_tail_fwd(const float* e, const float* w4, const float* b4, float* inv, size_t M, int K, hipStream_t st, std::string& err);
+int tr_depth_tail_bwd(const float* dinv, const float* inv, const float* e, const float* w4, float* de, float* rowterm, size_t M, int K, hipStream_t st, std::string& err);
+int tr_merge_scatter(const float* dg, float* dx, int B, int R, int C, hipStream_t st, std::string& err);
+int tr_patch_im2col(const float* x, float* out, int B, int S, hipStream_t st, std::string& err);
+int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream_t st, std::string& err);
+int tr_attention_bwd(const float* qkv, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
+int tr_attn_param_grads(const float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err);
+int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err);
+
+// train_step.cpp: SOccDPT_V3 training step (model/SOccDPT.py:660-685 in train mode + autograd), SOCCDPT_PREC_F32 only
+size_t train_workspace_bytes(Handle& h, int B);
+int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t st, std::string& err);
+int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err);
+
+}  // namespace soccdpt

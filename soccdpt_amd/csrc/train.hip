@@ -1,0 +1,965 @@
+// Backward (and train-mode forward) kernels of the SOccDPT_V3 training step for gfx950, exact-f32 (SOCCDPT_PREC_F32).
+//
+// What autograd does for the reference in scripts/train_SOccDPT.py:390-393 (`grad_scaler.scale(loss).backward()`) over
+// model/SOccDPT.py:660-685, model/dpt.py:142-232, model/blocks.py:391-497 and timm's SwinTransformerV2 blocks.  GEMM-shaped gradients
+// (dgrad of every Linear / convolution, wgrad of every weight) run on the f32 MFMA igemm (igemm.hip) over operands these kernels lay out:
+//   dX = dY W            -> igemm(X = dY, Wt = W^T)                      (transpose_kernel; conv: flipped tap-major weights + zero-haloed dY)
+//   dW = dY^T X          -> igemm(X = dY^T [N][M], Wt = X^T [K][M])      (transpose_kernel; conv: im2colT_kernel builds [9C][M])
+// Everything else here is an elementwise / row / column-reduction kernel, deterministic (no float atomics): fixed-order tree reductions.
+#include "kernels.h"
+
+namespace soccdpt {
+namespace {
+
+constexpr float LN100 = 4.605170185988092f;
+
+// ---------------- layout ----------------
+// [R][C] -> [C][R], 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+    __shared__ float t[32][33];
+    const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: column block of `in`, by: row block
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = by + i, c = bx + tx;
+        t[i][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = bx + i, r = by + tx;
+        if (c < C && r < R) out[(size_t)c * R + r] = t[tx][i];
+    }
+}
+
+// zero-haloed NHWC image [B][H+2][W+2][C] -> im2col^T [(tap*C + c)][m], m = (b, y, x): the Wt operand of the 3x3 wgrad GEMM
+__global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C) {
+    __shared__ float t[32][33];
+    const size_t M = (size_t)B * H * W;
+    const int tap = blockIdx.z, ky = tap / 3, kx = tap % 3;
+    const size_t m0 = (size_t)blockIdx.y * 32;
+    const int c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) {
+        const size_t m = m0 + i;
+        float v = 0.f;
+        if (m < M && c0 + tx < C) {
+            const int b = (int)(m / ((size_t)H * W)), r = (int)(m - (size_t)b * H * W), y = r / W, x = r - y * W;
+            v = halo[(((size_t)b * (H + 2) + y + ky) * (W + 2) + x + kx) * C + c0 + tx];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i;
+        const size_t m = m0 + tx;
+        if (c < C && m < M) out[((size_t)tap * C + c) * M + m] = t[tx][i];
+    }
+}
+
+// W [N][C][3][3] -> Wd [C][2-ky][2-kx][N] (tap-major, flipped): Wt operand of the 3x3 dgrad (a convolution of dY with the rotated filter)
+__global__ void conv_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int C) {
+    const size_t n = (size_t)N * C * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int nn = (int)(i % N);
+        size_t r = i / N;
+        const int tap = (int)(r % 9), c = (int)(r / 9);
+        out[i] = w[((size_t)nn * C + c) * 9 + (8 - tap)];
+    }
+}
+
+// dW tap-major [N][9][C] -> parameter layout [N][C][3][3]
+__global__ void wgrad_permute_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C) {
+    const size_t n = (size_t)N * C * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9);
+        size_t r = i / 9;
+        const int c = (int)(r % C), nn = (int)(r / C);
+        out[i] = in[((size_t)nn * 9 + tap) * C + c];
+    }
+}
+
+// plain [B][H][W][C] <-> halo [B][H+2][W+2][C]
+__global__ void to_halo_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H), b = (int)(r / H);
+        out[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = in[i];
+    }
+}
+// out[i] (+)= halo interior
+__global__ void from_halo_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C, int accumulate) {
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H), b = (int)(r / H);
+        const float v = halo[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c];
+        out[i] = accumulate ? out[i] + v : v;
+    }
+}
+
+// ---------------- reductions ----------------
+// column sums of [M][N] (bias gradients, LayerNorm gamma / beta gradients): out[n] = sum_m a[m][n] (* b[m][n] when b != nullptr).
+// Two deterministic stages: 64 row-chunks per column block, then their sum in chunk order.
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part, size_t M, int N, int chunks) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (n >= N) return;
+    const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
+    float s = 0.f;
+    for (size_t m = lo; m < hi; ++m) s += b ? a[m * N + n] * b[m * N + n] : a[m * N + n];
+    part[(size_t)ch * N + n] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int chunks, int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
+// ---------------- elementwise ----------------
+__global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {   // y += x
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
+}
+// dX = dY * (ref > 0)  (+ add), ref = the forward value whose ReLU was taken (plain layout)
+__global__ void relu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ ref, const float* __restrict__ add, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = ref[i] > 0.f ? dy[i] : 0.f;
+        if (add) v += add[i];
+        dx[i] = v;
+    }
+}
+// same with `ref` in zero-halo layout [B][H+2][W+2][C] (the saved post-ReLU operand images of the decoder)
+__global__ void relu_bwd_halo_kernel(const float* __restrict__ dy, const float* __restrict__ ref_halo, const float* __restrict__ add, float* __restrict__ dx, int B, int H, int W,
+                                     int C) {
+    const size_t n = (size_t)B * H * W * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % W);
+        r /= W;
+        const int y = (int)(r % H), b = (int)(r / H);
+        float v = ref_halo[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] > 0.f ? dy[i] : 0.f;
+        if (add) v += add[i];
+        dx[i] = v;
+    }
+}
+// d/dx gelu(x) (erf form), dX = dY * gelu'(pre)
+__global__ void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = pre[i];
+        const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+        const float pdf = 0.3989422804014327f * expf(-0.5f * x * x);
+        dx[i] = dy[i] * (cdf + x * pdf);
+    }
+}
+
+// LayerNorm backward, one wave per row: out = LN(y) * g + b.  dy = rstd * (g*dout - mean(g*dout) - xhat * mean(g*dout*xhat)).
+// Also writes xhat (for the gamma gradient: colsum(dout * xhat)); dy may alias dout.
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ y, const float* __restrict__ g, const float* dout, float* dy, float* __restrict__ xhat_out,
+                                                     int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* yr = y + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += yr[c];
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = yr[c] - mean; q += d * d; }
+    for (int o = 1; o < 64; o <<= 1) q += __shfl_xor(q, o);
+    const float rstd = rsqrtf(q / (float)C + eps);
+    float a = 0.f, bsum = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (yr[c] - mean) * rstd, gd = g[c] * dout[(size_t)row * C + c];
+        a += gd;
+        bsum += gd * xh;
+    }
+    for (int o = 1; o < 64; o <<= 1) { a += __shfl_xor(a, o); bsum += __shfl_xor(bsum, o); }
+    a /= (float)C;
+    bsum /= (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (yr[c] - mean) * rstd, gd = g[c] * dout[(size_t)row * C + c];
+        if (xhat_out) xhat_out[(size_t)row * C + c] = xh;
+        dy[(size_t)row * C + c] = rstd * (gd - a - xh * bsum);
+    }
+}
+
+// bilinear x(H/h) align_corners=True backward, NHWC: dlo[b][y][x][c] = sum over the high-res pixels that sample (y, x) of weight * dhi.
+// Gather form (deterministic): a low-res row y is touched by high-res rows Y with floor(Y*sy) in {y-1, y}.
+__global__ void bilinear_bwd_kernel(const float* __restrict__ dhi, float* __restrict__ dlo, int B, int h, int w, int H, int W, int C, int accumulate) {
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const size_t n = (size_t)B * h * w * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h), b = (int)(r / h);
+        // candidate high-res rows: Y*sy in (y-1, y+1)
+        int Y0 = sy > 0.f ? (int)ceilf(((float)y - 1.0f) / sy) : 0, Y1 = sy > 0.f ? (int)floorf(((float)y + 1.0f) / sy) : H - 1;
+        int X0 = sx > 0.f ? (int)ceilf(((float)x - 1.0f) / sx) : 0, X1 = sx > 0.f ? (int)floorf(((float)x + 1.0f) / sx) : W - 1;
+        Y0 = Y0 < 0 ? 0 : Y0; X0 = X0 < 0 ? 0 : X0; Y1 = Y1 > H - 1 ? H - 1 : Y1; X1 = X1 > W - 1 ? W - 1 : X1;
+        float acc = 0.f;
+        for (int Y = Y0; Y <= Y1; ++Y) {
+            const float fy = sy * (float)Y;
+            const int y0 = (int)fy, y1 = y0 + (y0 < h - 1);
+            const float ly = fy - (float)y0;
+            float wy = 0.f;
+            if (y0 == y) wy += 1.f - ly;
+            if (y1 == y) wy += ly;
+            if (wy == 0.f) continue;
+            for (int X = X0; X <= X1; ++X) {
+                const float fx = sx * (float)X;
+                const int x0 = (int)fx, x1 = x0 + (x0 < w - 1);
+                const float lx = fx - (float)x0;
+                float wx = 0.f;
+                if (x0 == x) wx += 1.f - lx;
+                if (x1 == x) wx += lx;
+                if (wx != 0.f) acc += wy * wx * dhi[(((size_t)b * H + Y) * W + X) * C + c];
+            }
+        }
+        dlo[i] = accumulate ? dlo[i] + acc : acc;
+    }
+}
+
+// ---------------- seg head (train mode) ----------------
+// BatchNorm2d with batch statistics over [M][C] (NHWC rows): stats[c] = {mean, invstd}; y = relu(gamma * xhat + beta) * keep / (1 - p);
+// running_mean / running_var updated like nn.BatchNorm2d(momentum 0.1, unbiased variance).  Deterministic: colsum kernels feed bn_stats.
+__global__ void bn_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float* __restrict__ stats, float* running_mean,
+                                float* running_var, int C, size_t M, float eps, float momentum) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const double mean = (double)sum[c] / (double)M;
+    double var = (double)sumsq[c] / (double)M - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    stats[2 * c] = (float)mean;
+    stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)M / (double)(M > 1 ? M - 1 : 1));
+    }
+}
+__device__ __forceinline__ uint32_t hash_u32(uint32_t x) {   // counter-based dropout mask (not torch's generator: the mask is saved, parity tests use p = 0)
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__global__ void bn_relu_dropout_fwd_kernel(const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                           const float* __restrict__ beta, float* __restrict__ out, uint8_t* __restrict__ keep, size_t M, int C, float p,
+                                           uint32_t seed) {
+    const size_t n = M * C;
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        float v = (x[i] - stats[2 * c]) * stats[2 * c + 1] * gamma[c] + beta[c];
+        v = v > 0.f ? v : 0.f;
+        uint8_t k = 1;
+        if (p > 0.f) {
+            const uint32_t r = hash_u32((uint32_t)i * 0x9E3779B9U + seed);
+            k = ((float)(r >> 8) * (1.0f / 16777216.0f)) >= p;
+        }
+        keep[i] = k;
+        out[i] = k ? v * inv_keep : 0.f;
+    }
+}
+// d(pre-activation of the BN affine): dz = dout * keep/(1-p) * (out > 0)   (out = relu(...) * keep / (1-p), so out > 0 <=> relu passed and kept)
+__global__ void bn_relu_dropout_bwd_pre_kernel(const float* __restrict__ dout, const float* __restrict__ out, const uint8_t* __restrict__ keep, float* __restrict__ dz, size_t n, float p) {
+    const float inv_keep = p > 0.f ? 1.f / (1.f - p) : 1.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dz[i] = (keep[i] && out[i] > 0.f) ? dout[i] * inv_keep : 0.f;
+}
+// dx = gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); sums[c] = {sum dz, sum dz*xhat} from the colsum kernels (= dbeta, dgamma)
+__global__ void bn_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ x, const float* __restrict__ stats, const float* __restrict__ gamma,
+                              const float* __restrict__ dbeta, const float* __restrict__ dgamma, float* __restrict__ dx, size_t M, int C) {
+    const size_t n = M * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float xh = (x[i] - stats[2 * c]) * stats[2 * c + 1];
+        dx[i] = gamma[c] * stats[2 * c + 1] * (dz[i] - dbeta[c] / (float)M - xh * dgamma[c] / (float)M);
+    }
+}
+// xhat for the gamma gradient of BatchNorm
+__global__ void bn_xhat_kernel(const float* __restrict__ x, const float* __restrict__ stats, float* __restrict__ xh, size_t M, int C) {
+    const size_t n = M * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        xh[i] = (x[i] - stats[2 * c]) * stats[2 * c + 1];
+    }
+}
+
+// Conv2d(C, K, 1) with tiny K (seg head: 3 classes): forward logits[m][k] = x[m][:] . w[k][:] + b[k]; backward dx[m][c] = sum_k dl[m][k] w[k][c]
+__global__ __launch_bounds__(256) void smallk_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ out,
+                                                         size_t M, int C, int K) {
+    const int lane = threadIdx.x & 63;
+    const size_t row = (size_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += x[row * C + c] * w[(size_t)k * C + c];
+        for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+        if (lane == 0) out[row * K + k] = s + (bias ? bias[k] : 0.f);
+    }
+}
+__global__ void smallk_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, float* __restrict__ dx, size_t M, int C, int K) {
+    const size_t n = M * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const size_t m = i / C;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += dl[m * K + k] * w[(size_t)k * C + c];
+        dx[i] = s;
+    }
+}
+// dW[k][c] = sum_m dl[m][k] x[m][c] via per-chunk partials (deterministic): part[ch][k][c]
+__global__ __launch_bounds__(256) void smallk_wgrad_part_kernel(const float* __restrict__ dl, const float* __restrict__ x, float* __restrict__ part, size_t M, int C, int K,
+                                                                int chunks) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    const int ch = blockIdx.y;
+    if (c >= C) return;
+    const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+        for (size_t m = lo; m < hi; ++m) s += dl[m * K + k] * x[m * C + c];
+        part[((size_t)ch * K + k) * C + c] = s;
+    }
+}
+
+// seg activation + x2 upsample: d logits_up[b][y][x][k] from d seg [B][K][S][S] (NCHW) and the saved output: ScaledTanh' = 2 y (1 - y), sigmoid' = y (1 - y)
+__global__ void seg_act_bwd_kernel(const float* __restrict__ dseg, const float* __restrict__ seg, float* __restrict__ dup, int B, int K, int S, int sigmoid) {
+    const size_t n = (size_t)B * S * S * K;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        size_t r = i / K;
+        const int x = (int)(r % S);
+        r /= S;
+        const int y = (int)(r % S), b = (int)(r / S);
+        const size_t j = (((size_t)b * K + k) * S + y) * S + x;
+        const float o = seg[j];
+        dup[i] = dseg[j] * (sigmoid ? o * (1.f - o) : 2.f * o * (1.f - o));
+    }
+}
+
+// depth head tail: inv = relu(sum_k relu(e[m][k]) * w4[k] + b4).  Forward (train) and backward: de[m][k] = dinv * (inv > 0) * w4[k] * (e > 0);
+// per-row terms for dw4 (colsum of dz * relu(e)) and db4 (sum dz) are written to rowterm[m][K+1].
+__global__ void depth_tail_fwd_kernel(const float* __restrict__ e, const float* __restrict__ w4, const float* __restrict__ b4, float* __restrict__ inv, size_t M, int K) {
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+        float s = b4[0];
+        for (int k = 0; k < K; ++k) s += fmaxf(e[m * K + k], 0.f) * w4[k];
+        inv[m] = fmaxf(s, 0.f);
+    }
+}
+__global__ void depth_tail_bwd_kernel(const float* __restrict__ dinv, const float* __restrict__ inv, const float* __restrict__ e, const float* __restrict__ w4,
+                                      float* __restrict__ de, float* __restrict__ rowterm, size_t M, int K) {
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+        const float dz = inv[m] > 0.f ? dinv[m] : 0.f;
+        for (int k = 0; k < K; ++k) {
+            const float ev = e[m * K + k];
+            de[m * K + k] = ev > 0.f ? dz * w4[k] : 0.f;
+            rowterm[m * (K + 1) + k] = dz * fmaxf(ev, 0.f);
+        }
+        rowterm[m * (K + 1) + K] = dz;
+    }
+}
+
+// ---------------- Swin-V2 pieces ----------------
+// PatchMerging gather backward: dg [B][R/2][R/2][4C] -> dx [B][R][R][C] (every token belongs to exactly one block: a permutation)
+__global__ void merge_scatter_kernel(const float* __restrict__ dg, float* __restrict__ dx, int B, int R, int C) {
+    const size_t n = (size_t)B * R * R * C;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        size_t r = i / C;
+        const int x = (int)(r % R);
+        r /= R;
+        const int y = (int)(r % R), b = (int)(r / R);
+        const int blk = (y & 1) + 2 * (x & 1);   // timm order x[0::2,0::2], x[1::2,0::2], x[0::2,1::2], x[1::2,1::2]
+        dx[i] = dg[((((size_t)b * (R / 2) + y / 2) * (R / 2) + x / 2) * 4 + blk) * C + c];
+    }
+}
+// patch embedding: x [B][3][S][S] -> patches [M][64] (k = c*16 + ky*4 + kx as in proj.weight [C0][3][4][4]; columns 48..63 zero)
+__global__ void patch_im2col_kernel(const float* __restrict__ x, float* __restrict__ out, int B, int S) {
+    const int G = S / 4;
+    const size_t n = (size_t)B * G * G * 64;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int k = (int)(i & 63);
+        size_t r = i >> 6;
+        const int gx = (int)(r % G);
+        r /= G;
+        const int gy = (int)(r % G), b = (int)(r / G);
+        float v = 0.f;
+        if (k < 48) {
+            const int c = k >> 4, ky = (k >> 2) & 3, kx = k & 3;
+            v = x[(((size_t)b * 3 + c) * S + gy * 4 + ky) * S + gx * 4 + kx];
+        }
+        out[i] = v;
+    }
+}
+// [N][64] -> [N][48] (drop the zero padding of the patch weight gradient) or the reverse with zero fill
+__global__ void pad_cols_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int cin, int cout) {
+    const size_t n = (size_t)N * cout;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cout), r = (int)(i / cout);
+        out[i] = c < cin ? in[(size_t)r * cin + c] : 0.f;
+    }
+}
+
+// Cosine window attention backward, one workgroup (64 threads) per (sample, window, head, 64-query block); one thread = one query.
+//   q^ = scale * q/|q|, k^ = k/|k|, S = q^ k^T + bias(rel) + mask, P = softmax(S), O = P v
+// Pass A (this kernel, per query): recompute the row statistics, then for every key: p, dP = dO . v, dS = p (dP - sum_j p_j dP_j);
+//   accumulates dq^ (registers), and writes dS to a [.., N, N] scratch for pass B (per key) -- deterministic, no atomics.
+// The bias-table and logit-scale gradients are reduced from that scratch by their own kernels.
+__global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
+                                                        const float* __restrict__ scale, float* __restrict__ dS_out, float* __restrict__ dqkv,
+                                                        float* __restrict__ dscale_part, int res, int ws, int shift, int heads) {
+    __shared__ float Kh[64][33];
+    __shared__ float Vs[64][33];
+    const int N = ws * ws, nqb = (N + 63) / 64;
+    const int C = heads * 32, nw = res / ws;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb;
+    bid /= nqb;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const int widx = (b * nw + wy) * nw + wx;
+    const int tid = threadIdx.x;
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / ws, c = p % ws;
+        int sy = wy * ws + r + shift, sx = wx * ws + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    const int q = qb * 64 + tid;
+    const bool qv = q < N;
+    const int qc = qv ? q : N - 1;
+    const int rq = qc / ws, cq = qc % ws;
+    const float sc = scale[head];
+    float qn[32], dOr[32], dqh[32];
+    float qnorm;
+    {
+        const float* src = qkv + token_row(qc) * (size_t)(3 * C) + head * 32;
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qn[d] = src[d]; ss += qn[d] * qn[d]; }
+        qnorm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qn[d] /= qnorm; dqh[d] = 0.f; }
+        const float* dsrc = dO + token_row(qc) * (size_t)C + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dOr[d] = dsrc[d];
+    }
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    const int half = ws / 2;
+    auto logit = [&](int kk, int k0) -> float {   // S[q][k0 + kk] from the staged k^ tile
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s = fmaf(qn[d], Kh[kk][d], s);
+        s *= sc;
+        const int k = k0 + kk, rk = k / ws, ck = k % ws;
+        s += table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
+        if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) s += -100.0f;
+        return s;
+    };
+    auto stage = [&](int k0) {
+        __syncthreads();
+        const int k = k0 + tid;
+        const int kc = k < N ? k : N - 1;
+        const float* src = qkv + token_row(kc) * (size_t)(3 * C) + head * 32;
+        float ss = 0.f;
+        float kr[32];
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { kr[d] = src[C + d]; ss += kr[d] * kr[d]; }
+        const float ki = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { Kh[tid][d] = kr[d] * ki; Vs[tid][d] = src[2 * C + d]; }
+        __syncthreads();
+    };
+    // pass 1: row max and sum
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        stage(k0);
+        const int nk = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < nk; ++kk) {
+            const float s = logit(kk, k0);
+            const float mn = fmaxf(m, s);
+            l = l * __expf(m - mn) + __expf(s - mn);
+            m = mn;
+        }
+    }
+    // pass 2: delta = sum_j p_j (dO . v_j)
+    float delta = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        stage(k0);
+        const int nk = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < nk; ++kk) {
+            const float p = __expf(logit(kk, k0) - m) / l;
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dp = fmaf(dOr[d], Vs[kk][d], dp);
+            delta += p * dp;
+        }
+    }
+    // pass 3: dS, dq^
+    float dsc = 0.f;
+    float* dSrow = dS_out + (((size_t)widx * heads + head) * N + qc) * N;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        stage(k0);
+        const int nk = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < nk; ++kk) {
+            const float p = __expf(logit(kk, k0) - m) / l;
+            float dp = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) dp = fmaf(dOr[d], Vs[kk][d], dp);
+            const float ds = p * (dp - delta);
+            if (qv) dSrow[k0 + kk] = ds;
+            float dot = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { dqh[d] = fmaf(ds, Kh[kk][d], dqh[d]); dot = fmaf(qn[d], Kh[kk][d], dot); }
+            dsc += ds * dot;      // d scale: S = scale * (qn . k^) + ...
+        }
+    }
+    if (qv) {
+        // dq^ is w.r.t. q^ = scale * qn: dqn = scale * dqh; dq = (dqn - qn (qn . dqn)) / |q|
+        float dotq = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dotq = fmaf(qn[d], dqh[d] * sc, dotq);
+        float* dst = dqkv + token_row(qc) * (size_t)(3 * C) + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dst[d] = (dqh[d] * sc - qn[d] * dotq) / qnorm;
+    }
+    // per-(window, head, query block) partial of d scale (reduced in fixed order by attn_scale_reduce_kernel)
+    dsc = qv ? dsc : 0.f;
+    for (int o = 1; o < 64; o <<= 1) dsc += __shfl_xor(dsc, o);
+    if (tid == 0) dscale_part[((size_t)widx * heads + head) * nqb + qb] = dsc;
+}
+
+// Pass B, one thread = one key: dv_k = sum_q P[q][k] dO_q needs P, so recompute it from dS?  No: P is recomputed from the logits with the
+// row statistics (stats[q] = {max, sum}) written by pass A2 below.  To keep this simple and exact, pass B re-derives P[q][k] itself per query tile:
+// dk^_k = sum_q dS[q][k] q^_q ; dv_k = sum_q P[q][k] dO_q.
+__global__ __launch_bounds__(64) void attn_bwd_k_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
+                                                        const float* __restrict__ scale, const float* __restrict__ dS_in, const float* __restrict__ rowstat,
+                                                        float* __restrict__ dqkv, int res, int ws, int shift, int heads) {
+    __shared__ float Qh[64][33];
+    __shared__ float dOs[64][33];
+    __shared__ float st_m[64], st_l[64];
+    const int N = ws * ws, nkb = (N + 63) / 64;
+    const int C = heads * 32, nw = res / ws;
+    int bid = blockIdx.x;
+    const int kb = bid % nkb;
+    bid /= nkb;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const int widx = (b * nw + wy) * nw + wx;
+    const int tid = threadIdx.x;
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / ws, c = p % ws;
+        int sy = wy * ws + r + shift, sx = wx * ws + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    const int k = kb * 64 + tid;
+    const bool kv = k < N;
+    const int kc = kv ? k : N - 1;
+    const int rk = kc / ws, ck = kc % ws;
+    const float sc = scale[head];
+    float kn[32], dkh[32], dv[32];
+    float knorm;
+    {
+        const float* src = qkv + token_row(kc) * (size_t)(3 * C) + head * 32 + C;
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { kn[d] = src[d]; ss += kn[d] * kn[d]; }
+        knorm = fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { kn[d] /= knorm; dkh[d] = 0.f; dv[d] = 0.f; }
+    }
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    const int half = ws / 2;
+    for (int q0 = 0; q0 < N; q0 += 64) {
+        __syncthreads();
+        {
+            const int q = q0 + tid;
+            const int qc = q < N ? q : N - 1;
+            const float* src = qkv + token_row(qc) * (size_t)(3 * C) + head * 32;
+            float ss = 0.f;
+            float qr[32];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { qr[d] = src[d]; ss += qr[d] * qr[d]; }
+            const float qi = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+            const float* dsrc = dO + token_row(qc) * (size_t)C + head * 32;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { Qh[tid][d] = qr[d] * qi; dOs[tid][d] = dsrc[d]; }
+            const float* rs = rowstat + (((size_t)widx * heads + head) * N + qc) * 2;
+            st_m[tid] = rs[0];
+            st_l[tid] = rs[1];
+        }
+        __syncthreads();
+        const int nq = (N - q0) < 64 ? (N - q0) : 64;
+        for (int qq = 0; qq < nq; ++qq) {
+            const int q = q0 + qq, rq = q / ws, cq = q % ws;
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s = fmaf(Qh[qq][d], kn[d], s);
+            s *= sc;
+            s += table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
+            if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) s += -100.0f;
+            const float p = __expf(s - st_m[qq]) / st_l[qq];
+            const float ds = dS_in[(((size_t)widx * heads + head) * N + q) * N + kc];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) {
+                dkh[d] = fmaf(ds * sc, Qh[qq][d], dkh[d]);     // dS/dk^ = scale * qn
+                dv[d] = fmaf(p, dOs[qq][d], dv[d]);
+            }
+        }
+    }
+    if (kv) {
+        float dotk = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) dotk = fmaf(kn[d], dkh[d], dotk);
+        float* dst = dqkv + token_row(kc) * (size_t)(3 * C) + head * 32;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) {
+            dst[C + d] = (dkh[d] - kn[d] * dotk) / knorm;
+            dst[2 * C + d] = dv[d];
+        }
+    }
+}
+
+// row statistics {max, sum exp} of every query (pass A of the forward recomputation, shared by attn_bwd_k_kernel)
+__global__ __launch_bounds__(64) void attn_rowstat_kernel(const float* __restrict__ qkv, const float* __restrict__ table, const float* __restrict__ scale,
+                                                          float* __restrict__ rowstat, int res, int ws, int shift, int heads) {
+    __shared__ float Kh[64][33];
+    const int N = ws * ws, nqb = (N + 63) / 64;
+    const int C = heads * 32, nw = res / ws;
+    int bid = blockIdx.x;
+    const int qb = bid % nqb;
+    bid /= nqb;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const int widx = (b * nw + wy) * nw + wx;
+    const int tid = threadIdx.x;
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / ws, c = p % ws;
+        int sy = wy * ws + r + shift, sx = wx * ws + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    const int q = qb * 64 + tid;
+    const int qc = q < N ? q : N - 1;
+    const int rq = qc / ws, cq = qc % ws;
+    const float sc = scale[head];
+    float qn[32];
+    {
+        const float* src = qkv + token_row(qc) * (size_t)(3 * C) + head * 32;
+        float ss = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) { qn[d] = src[d]; ss += qn[d] * qn[d]; }
+        const float qi = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+        for (int d = 0; d < 32; ++d) qn[d] *= qi;
+    }
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+    const int half = ws / 2;
+    float m = -3.0e38f, l = 0.f;
+    for (int k0 = 0; k0 < N; k0 += 64) {
+        __syncthreads();
+        {
+            const int k = k0 + tid;
+            const int kc = k < N ? k : N - 1;
+            const float* src = qkv + token_row(kc) * (size_t)(3 * C) + head * 32 + C;
+            float ss = 0.f;
+            float kr[32];
+#pragma unroll
+            for (int d = 0; d < 32; ++d) { kr[d] = src[d]; ss += kr[d] * kr[d]; }
+            const float ki = 1.0f / fmaxf(sqrtf(ss), 1e-12f);
+#pragma unroll
+            for (int d = 0; d < 32; ++d) Kh[tid][d] = kr[d] * ki;
+        }
+        __syncthreads();
+        const int nk = (N - k0) < 64 ? (N - k0) : 64;
+        for (int kk = 0; kk < nk; ++kk) {
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d) s = fmaf(qn[d], Kh[kk][d], s);
+            s *= sc;
+            const int k = k0 + kk, rk = k / ws, ck = k % ws;
+            s += table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
+            if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) s += -100.0f;
+            const float mn = fmaxf(m, s);
+            l = l * __expf(m - mn) + __expf(s - mn);
+            m = mn;
+        }
+    }
+    if (q < N) {
+        float* rs = rowstat + (((size_t)widx * heads + head) * N + q) * 2;
+        rs[0] = m;
+        rs[1] = l;
+    }
+}
+
+// d table[r][h] = sum over (window, q, k with rel(q, k) = r) dS: one thread per (r, h), fixed order
+__global__ void attn_table_grad_kernel(const float* __restrict__ dS, float* __restrict__ dtable, int nwin, int ws, int heads) {
+    const int T = 2 * ws - 1, N = ws * ws;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * T * heads) return;
+    const int h = i % heads, r = i / heads;
+    const int dr = r / T - (ws - 1), dc = r % T - (ws - 1);   // rq - rk, cq - ck
+    float s = 0.f;
+    for (int w = 0; w < nwin; ++w) {
+        const float* base = dS + ((size_t)w * heads + h) * N * N;
+        for (int rk = 0; rk < ws; ++rk) {
+            const int rq = rk + dr;
+            if (rq < 0 || rq >= ws) continue;
+            for (int ck = 0; ck < ws; ++ck) {
+                const int cq = ck + dc;
+                if (cq < 0 || cq >= ws) continue;
+                s += base[(size_t)(rq * ws + cq) * N + rk * ws + ck];
+            }
+        }
+    }
+    dtable[i] = s;
+}
+// logit_scale gradient: scale = exp(min(ls, ln 100)); d ls = scale * d scale when ls < ln 100
+__global__ void attn_scale_reduce_kernel(const float* __restrict__ part, const float* __restrict__ ls, float* __restrict__ dls, int nwin, int heads, int nqb) {
+    const int h = blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= heads) return;
+    float s = 0.f;
+    for (int w = 0; w < nwin; ++w)
+        for (int q = 0; q < nqb; ++q) s += part[((size_t)w * heads + h) * nqb + q];
+    const float l = ls[h];
+    dls[h] = l < LN100 ? s * __expf(l) : 0.f;
+}
+
+// continuous position bias MLP backward: table = 16 sigmoid(t), t = relu(coords W0^T + b0) W2^T.
+// dt = dtable * 16 s (1 - s) with s = table / 16; hidden recomputed.  Three small kernels (T^2 <= 2209 rows, 512 hidden).
+__global__ void cpb_dt_kernel(const float* __restrict__ dtable, const float* __restrict__ table, float* __restrict__ dt, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = table[i] * (1.0f / 16.0f);
+    dt[i] = dtable[i] * 16.0f * s * (1.0f - s);
+}
+__device__ __forceinline__ void cpb_coords(int r, int ws, int pws, float& c0, float& c1) {
+    const int T = 2 * ws - 1;
+    const float den = (float)((pws > 0 ? pws : ws) - 1);
+    float a = (float)(r / T - (ws - 1)) / den * 8.0f, b = (float)(r % T - (ws - 1)) / den * 8.0f;
+    const float inv = 1.0f / log2f(8.0f);
+    c0 = (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) * log2f(fabsf(a) + 1.0f) * inv;
+    c1 = (b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f)) * log2f(fabsf(b) + 1.0f) * inv;
+}
+// dW2[h][j] = sum_r dt[r][h] hid[r][j]
+__global__ void cpb_w2_grad_kernel(const float* __restrict__ dt, const float* __restrict__ w0, const float* __restrict__ b0, float* __restrict__ dw2, int ws, int pws, int heads) {
+    const int T2 = (2 * ws - 1) * (2 * ws - 1);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= heads * 512) return;
+    const int j = i % 512, h = i / 512;
+    float s = 0.f;
+    for (int r = 0; r < T2; ++r) {
+        float c0, c1;
+        cpb_coords(r, ws, pws, c0, c1);
+        const float hid = fmaxf(c0 * w0[2 * j] + c1 * w0[2 * j + 1] + b0[j], 0.f);
+        s += dt[(size_t)r * heads + h] * hid;
+    }
+    dw2[i] = s;
+}
+// dW0[j][0..1], db0[j]: d hid[r][j] = sum_h dt[r][h] W2[h][j] gated by relu
+__global__ void cpb_w0_grad_kernel(const float* __restrict__ dt, const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w2,
+                                   float* __restrict__ dw0, float* __restrict__ db0, int ws, int pws, int heads) {
+    const int T2 = (2 * ws - 1) * (2 * ws - 1);
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= 512) return;
+    float g0 = 0.f, g1 = 0.f, gb = 0.f;
+    for (int r = 0; r < T2; ++r) {
+        float c0, c1;
+        cpb_coords(r, ws, pws, c0, c1);
+        const float pre = c0 * w0[2 * j] + c1 * w0[2 * j + 1] + b0[j];
+        if (pre <= 0.f) continue;
+        float dh = 0.f;
+        for (int h = 0; h < heads; ++h) dh += dt[(size_t)r * heads + h] * w2[(size_t)h * 512 + j];
+        g0 += dh * c0;
+        g1 += dh * c1;
+        gb += dh;
+    }
+    dw0[2 * j] = g0;
+    dw0[2 * j + 1] = g1;
+    db0[j] = gb;
+}
+// q_bias / v_bias gradients from the qkv bias gradient [3C] (the k part has no parameter)
+__global__ void qv_bias_grad_kernel(const float* __restrict__ dqkv_bias, float* __restrict__ dq, float* __restrict__ dv, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C) return;
+    if (dq) dq[i] = dqkv_bias[i];
+    if (dv) dv[i] = dqkv_bias[2 * C + i];
+}
+
+inline unsigned gs_blocks(size_t n) {
+    size_t b = (n + 255) / 256;
+    return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
+}
+
+}  // namespace
+
+#define TK(name) return check_launch(name, err)
+
+int tr_transpose(const float* in, float* out, int R, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, out, R, C);
+    TK("transpose");
+}
+int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
+    const size_t M = (size_t)B * H * W;
+    hipLaunchKernelGGL(im2colT_kernel, dim3((C + 31) / 32, (unsigned)((M + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C);
+    TK("im2colT");
+}
+int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(conv_w_dgrad_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+    TK("conv_w_dgrad");
+}
+int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(wgrad_permute_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
+    TK("wgrad_permute");
+}
+int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(to_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+    TK("to_halo");
+}
+int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);
+    TK("from_halo");
+}
+// scratch: 64 * N floats
+int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err) {
+    const int chunks = M >= 4096 ? 64 : (M >= 64 ? 16 : 1);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
+    TK("colsum");
+}
+int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);
+    TK("axpy");
+}
+int tr_relu_bwd(const float* dy, const float* ref, const float* add, float* dx, size_t n, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, ref, add, dx, n);
+    TK("relu_bwd");
+}
+int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, float* dx, int B, int H, int W, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(relu_bwd_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, dy, ref_halo, add, dx, B, H, W, C);
+    TK("relu_bwd_halo");
+}
+int tr_gelu_bwd(const float* dy, const float* pre, float* dx, size_t n, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, pre, dx, n);
+    TK("gelu_bwd");
+}
+int tr_ln_bwd(const float* y, const float* g, const float* dout, float* dy, float* xhat, int M, int C, float eps, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, g, dout, dy, xhat, M, C, eps);
+    TK("ln_bwd");
+}
+int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
+    TK("bilinear_bwd");
+}
+int tr_bn_stats(const float* sum, const float* sumsq, float* stats, float* rmean, float* rvar, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sum, sumsq, stats, rmean, rvar, C, M, eps, momentum);
+    TK("bn_stats");
+}
+int tr_bn_relu_dropout_fwd(const float* x, const float* stats, const float* gamma, const float* beta, float* out, uint8_t* keep, size_t M, int C, float p, uint32_t seed,
+                           hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(bn_relu_dropout_fwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, gamma, beta, out, keep, M, C, p, seed);
+    TK("bn_relu_dropout_fwd");
+}
+int tr_bn_relu_dropout_bwd_pre(const float* dout, const float* out, const uint8_t* keep, float* dz, size_t n, float p, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(bn_relu_dropout_bwd_pre_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dout, out, keep, dz, n, p);
+    TK("bn_relu_dropout_bwd_pre");
+}
+int tr_bn_bwd(const float* dz, const float* x, const float* stats, const float* gamma, const float* dbeta, const float* dgamma, float* dx, size_t M, int C, hipStream_t st,
+              std::string& err) {
+    hipLaunchKernelGGL(bn_bwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dz, x, stats, gamma, dbeta, dgamma, dx, M, C);
+    TK("bn_bwd");
+}
+int tr_bn_xhat(const float* x, const float* stats, float* xh, size_t M, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(bn_xhat_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, xh, M, C);
+    TK("bn_xhat");
+}
+int tr_smallk_fwd(const float* x, const float* w, const float* bias, float* out, size_t M, int C, int K, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(smallk_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, w, bias, out, M, C, K);
+    TK("smallk_fwd");
+}
+int tr_smallk_dgrad(const float* dl, const float* w, float* dx, size_t M, int C, int K, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dl, w, dx, M, C, K);
+    TK("smallk_dgrad");
+}
+// scratch: 64 * K * C floats
+int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, size_t M, int C, int K, hipStream_t st, std::string& err) {
+    const int chunks = 64;
+    hipLaunchKernelGGL(smallk_wgrad_part_kernel, dim3((C + 255) / 256, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K * C + 255) / 256), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
+    TK("smallk_wgrad");
+}
+int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(seg_act_bwd_kernel, dim3(gs_blocks((size_t)B * S * S * K)), dim3(256), 0, st, dseg, seg, dup, B, K, S, sigmoid);
+    TK("seg_act_bwd");
+}
+int tr_depth_tail_fwd(const float* e, const float* w4, const float* b4, float* inv, size_t M, int K, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(depth_tail_fwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, e, w4, b4, inv, M, K);
+    TK("depth_tail_fwd");
+}
+int tr_depth_tail_bwd(const float* dinv, const float* inv, const float* e, const float* w4, float* de, float* rowterm, size_t M, int K, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M, K);
+    TK("depth_tail_bwd");
+}
+int tr_merge_scatter(const float* dg, float* dx, int B, int R, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(merge_scatter_kernel, dim3(gs_blocks((size_t)B * R * R * C)), dim3(256), 0, st, dg, dx, B, R, C);
+    TK("merge_scatter");
+}
+int tr_patch_im2col(const float* x, float* out, int B, int S, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(patch_im2col_kernel, dim3(gs_blocks((size_t)B * (S / 4) * (S / 4) * 64)), dim3(256), 0, st, x, out, B, S);
+    TK("patch_im2col");
+}
+int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(pad_cols_kernel, dim3(gs_blocks((size_t)N * cout)), dim3(256), 0, st, in, out, N, cin, cout);
+    TK("pad_cols");
+}
+// dS scratch: nwin * heads * N * N floats; rowstat: nwin * heads * N * 2; dscale_part: nwin * heads * nqb
+int tr_attention_bwd(const float* qkv, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* dqkv, int B, int res,
+                     int ws, int shift, int heads, hipStream_t st, std::string& err) {
+    const int nw = res / ws, N = ws * ws, nqb = (N + 63) / 64;
+    const unsigned blocks = (unsigned)(B * nw * nw * heads * nqb);
+    hipLaunchKernelGGL(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, rowstat, res, ws, shift, heads);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, dqkv, dscale_part, res, ws, shift, heads);
+    hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, dqkv, res, ws, shift, heads);
+    TK("attention_bwd");
+}
+int tr_attn_param_grads(const float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
+                        float* dt, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
+    const int T2 = (2 * ws - 1) * (2 * ws - 1), N = ws * ws, nqb = (N + 63) / 64;
+    hipLaunchKernelGGL(attn_table_grad_kernel, dim3((T2 * heads + 63) / 64), dim3(64), 0, st, dS, dtable, nwin, ws, heads);
+    hipLaunchKernelGGL(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
+    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(1), dim3(64), 0, st, dscale_part, ls, dls, nwin, heads, nqb);
+    if (dw2) hipLaunchKernelGGL(cpb_w2_grad_kernel, dim3((heads * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, dw2, ws, pws, heads);
+    if (dw0 || db0) hipLaunchKernelGGL(cpb_w0_grad_kernel, dim3(2), dim3(256), 0, st, dt, w0, b0, w2, dw0, db0, ws, pws, heads);
+    TK("attn_param_grads");
+}
+int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(qv_bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dqkv_bias, dq, dv, C);
+    TK("qv_bias_grad");
+}
+
+}  // namespace soccdpt

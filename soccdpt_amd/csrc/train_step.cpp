@@ -1,0 +1,581 @@
+// Training step of SOccDPT_V3 (Swin-V2 encoders): train-mode forward that keeps every activation the backward needs (the "tape"),
+// and the backward that autograd runs for the reference (scripts/train_SOccDPT.py:360-393 over model/SOccDPT.py:660-685, model/dpt.py:142-232,
+// model/blocks.py:391-497 and timm's SwinTransformerV2).  Exact f32 (SOCCDPT_PREC_F32): every GEMM-shaped gradient goes through the f32
+// MFMA igemm (igemm.hip), the rest through train.hip.  Train mode differs from eval in the seg head only (model/SOccDPT.py:660-671):
+// BatchNorm2d uses batch statistics and updates its running buffers, Dropout(0.1) is live; drop_path is 0 in the reference's encoders.
+//
+// Gradients are WRITTEN (not accumulated) to the buffers bound with soccdpt_bind_grad; a weight without a bound gradient is frozen and its
+// weight-gradient GEMM is skipped (the reference freezes / partially unfreezes the encoder: model/loss.py:110-152).
+#include "train.h"
+
+#include <cstring>
+
+namespace soccdpt {
+namespace {
+
+struct TArena {
+    char* base;
+    size_t off = 0;
+    explicit TArena(void* p) : base(static_cast<char*>(p)) {}
+    float* f(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += n * sizeof(float);
+        return p;
+    }
+};
+
+const std::string ENC = "depth_net.pretrained.model.";
+const std::string SCR = "depth_net.scratch.";
+std::string blk_key(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
+
+struct BlkT {
+    float *qkv_bias, *scale, *table, *bias_acc;
+    const float* xin;
+    float *qkv, *attn, *a_pre, *x1, *hpre, *hact, *m_pre, *xout;
+};
+
+struct Tape {
+    // encoder
+    float *patches, *pe_wpad, *pe_pre, *x0;
+    std::vector<BlkT> blk[4];
+    float *mg[3], *mr_pre[3], *mx[3];
+    float* feat[4];   // zero-halo
+    // decoder (level 0 = finest); *_relu / t1 / t2 are zero-halo images
+    float *lrn_raw[4], *lrn_relu[4], *t1[4], *out_raw[4], *out_relu[4], *t2[4], *u[4], *oc[4];
+    float *w_lrn[4], *w_rcu[4][2][2];
+    float *path1, *d1, *d1u, *e, *inv, *seg;
+    float *w_d0, *w_d2, *w_s0;
+    float *c_raw, *bn_stats, *r, *logits;
+    uint8_t* keep;
+    // halo zone [halo_lo, halo_hi): zero-filled at the start of every forward
+    size_t halo_lo = 0, halo_hi = 0;
+    // backward scratch
+    float *G[5], *GX, *GP, *DOC, *DF[4];
+    float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
+    float *dS, *rowstat, *dscale_part, *dtable, *dt;
+    size_t maxAct = 0;
+    float dropout_p = 0.f;
+};
+
+// One walk decides the layout; with base == nullptr it only measures.
+void carve(const Handle& h, int B, TArena& ar, Tape& T) {
+    const Arch& a = h.arch;
+    const int F = h.cfg.features, G = a.grid();
+    const size_t M0 = (size_t)B * G * G;
+    auto halo = [&](int r, int C) { return ar.f((size_t)B * (r + 2) * (r + 2) * C); };
+    // ---- halo zone ----
+    ar.f(0);
+    T.halo_lo = (ar.off + 255) & ~size_t(255);
+    for (int l = 0; l < 4; ++l) {
+        const int r = a.fres(l);
+        T.feat[l] = halo(r, a.fdim(l));
+        T.lrn_relu[l] = halo(r, F);
+        T.t1[l] = l < 3 ? halo(r, F) : nullptr;
+        T.out_relu[l] = l < 3 ? halo(r, F) : nullptr;
+        T.t2[l] = halo(r, F);
+    }
+    const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
+    T.path1 = halo(r1, F);
+    T.d1u = halo(r0, F / 2);
+    ar.f(0);
+    T.halo_hi = (ar.off + 255) & ~size_t(255);
+    // ---- encoder tape ----
+    T.patches = ar.f(M0 * 64);
+    T.pe_wpad = ar.f((size_t)a.embed * 64);
+    T.pe_pre = ar.f(M0 * a.embed);
+    T.x0 = ar.f(M0 * a.embed);
+    size_t maxAct = M0 * 64;
+    size_t maxDS = 0, maxStat = 0, maxTab = 0, maxPart = 0;
+    for (int s = 0; s < 4; ++s) {
+        const int C = a.dim(s), res = a.res(s), H = a.heads[s], ws = a.ws(s);
+        const size_t M = (size_t)B * res * res;
+        T.blk[s].assign(a.depths[s], BlkT{});
+        for (int j = 0; j < a.depths[s]; ++j) {
+            BlkT& b = T.blk[s][j];
+            b.qkv_bias = ar.f(3 * C);
+            b.scale = ar.f(H);
+            b.table = ar.f((size_t)(2 * ws - 1) * (2 * ws - 1) * H);
+            b.bias_acc = ar.f(attn_bias_elems(ws, H));
+            b.qkv = ar.f(M * 3 * C);
+            b.attn = ar.f(M * C);
+            b.a_pre = ar.f(M * C);
+            b.x1 = ar.f(M * C);
+            b.hpre = ar.f(M * 4 * C);
+            b.hact = ar.f(M * 4 * C);
+            b.m_pre = ar.f(M * C);
+            b.xout = ar.f(M * C);
+        }
+        maxAct = std::max(maxAct, M * 4 * C);
+        const size_t nwin = (size_t)B * (res / ws) * (res / ws), N = (size_t)ws * ws;
+        maxDS = std::max(maxDS, nwin * H * N * N);
+        maxStat = std::max(maxStat, nwin * H * N * 2);
+        maxPart = std::max(maxPart, nwin * H * ((N + 63) / 64));
+        maxTab = std::max(maxTab, (size_t)(2 * ws - 1) * (2 * ws - 1) * H);
+        if (s < 3) {
+            T.mg[s] = ar.f(M * C);            // [M/4][4C]
+            T.mr_pre[s] = ar.f(M / 4 * 2 * C);
+            T.mx[s] = ar.f(M / 4 * 2 * C);
+        }
+    }
+    // ---- decoder tape ----
+    for (int l = 0; l < 4; ++l) {
+        const size_t M = (size_t)B * a.fres(l) * a.fres(l);
+        T.lrn_raw[l] = ar.f(M * F);
+        T.out_raw[l] = l < 3 ? ar.f(M * F) : nullptr;
+        T.u[l] = ar.f(M * F);
+        T.oc[l] = ar.f(M * F);
+        T.w_lrn[l] = ar.f((size_t)F * 9 * a.fdim(l));
+        for (int u = 0; u < 2; ++u)
+            for (int c = 0; c < 2; ++c) T.w_rcu[l][u][c] = ar.f((size_t)F * 9 * F);
+        maxAct = std::max(maxAct, M * F);
+    }
+    const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
+    T.d1 = ar.f(M1 * (F / 2));
+    T.e = ar.f(M0p * 32);
+    T.inv = ar.f(M0p);
+    T.seg = ar.f(M0p * 3);
+    T.w_d0 = ar.f((size_t)(F / 2) * 9 * F);
+    T.w_d2 = ar.f((size_t)32 * 9 * (F / 2));
+    T.w_s0 = ar.f((size_t)F * 9 * F);
+    T.c_raw = ar.f(M1 * F);
+    T.bn_stats = ar.f(2 * F);
+    T.r = ar.f(M1 * F);
+    T.logits = ar.f(M1 * 4);
+    T.keep = reinterpret_cast<uint8_t*>(ar.f((M1 * F + 3) / 4));
+    maxAct = std::max(maxAct, std::max(M1 * F, M0p * (size_t)(F / 2)));
+    maxAct = std::max(maxAct, M0p * 33);
+    T.maxAct = maxAct;
+    // ---- backward scratch ----
+    for (auto& g : T.G) g = ar.f(maxAct);
+    T.GX = ar.f(M0 * a.embed);            // the largest token-stream gradient (stage 0; later stages are smaller)
+    T.GP = ar.f(M1 * F);
+    T.DOC = ar.f((size_t)B * a.fres(0) * a.fres(0) * F);
+    for (int l = 0; l < 4; ++l) T.DF[l] = ar.f((size_t)B * a.fres(l) * a.fres(l) * a.fdim(l));
+    T.S_T1 = ar.f(maxAct);
+    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct));
+    T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)));
+    const size_t Cmax = a.dim(3);
+    T.S_wt = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
+    T.S_dw = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
+    T.S_col = ar.f(64 * std::max((size_t)4 * Cmax, (size_t)3 * F));
+    T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
+    T.dS = ar.f(maxDS);
+    T.rowstat = ar.f(maxStat);
+    T.dscale_part = ar.f(maxPart);
+    T.dtable = ar.f(maxTab);
+    T.dt = ar.f(maxTab);
+}
+
+struct Ctx {
+    Handle& h;
+    Tape& T;
+    int B;
+    hipStream_t st;
+    std::string& err;
+    const float* W(const std::string& key) const { return h.weights[h.index.at(key)].ptr; }
+    float* Gd(const std::string& key) const { return h.weights[h.index.at(key)].grad; }
+};
+
+#define TRY(call) do { if (call) return 1; } while (0)
+
+int gemm(Ctx& c, IgemmDesc d) {
+    d.f32 = 1;
+    return launch_igemm(d, c.st, c.err);
+}
+
+int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what) {
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c.st);
+    if (e != hipSuccess) { c.err = std::string(what) + ": " + hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+// y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
+int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
+    Tape& T = c.T;
+    if (dX_out) {
+        TRY(tr_transpose(W, T.S_wt, N, K, c.st, c.err));   // [K][N]
+        IgemmDesc d;
+        d.X = dY; d.Wt = T.S_wt; d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
+        TRY(gemm(c, d));
+    }
+    if (dW) {
+        TRY(tr_transpose(dY, T.S_T1, (int)M, N, c.st, c.err));   // [N][M]
+        TRY(tr_transpose(X, T.S_T2, (int)M, K, c.st, c.err));    // [K][M]
+        IgemmDesc d;
+        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = K; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = dW;
+        TRY(gemm(c, d));
+    }
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+    return 0;
+}
+
+// y = conv3x3(Xhalo, W) + b backward.  dY plain [B*r*r][N], Xhalo [B][r+2][r+2][C], W [N][C][3][3].
+int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db) {
+    Tape& T = c.T;
+    const int B = c.B;
+    const size_t M = (size_t)B * r * r;
+    if (dX_out) {
+        const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * sizeof(float);
+        hipError_t e = hipMemsetAsync(T.S_halo, 0, hb, c.st);
+        if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+        TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
+        TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err));   // [C][9][N], rotated
+        IgemmDesc d;
+        d.X = T.S_halo; d.Wt = T.S_wt; d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
+        TRY(gemm(c, d));
+    }
+    if (dW) {
+        TRY(tr_transpose(dY, T.S_T1, (int)M, N, c.st, c.err));          // [N][M]
+        TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, c.st, c.err));        // [9C][M]
+        IgemmDesc d;
+        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = T.S_dw;
+        TRY(gemm(c, d));
+        TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+    }
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+    return 0;
+}
+
+// out = LN(y) g + b backward: d y -> dy; gamma / beta gradients
+int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta) {
+    TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, 1e-5f, c.st, c.err));
+    if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, M, C, 0, c.st, c.err));
+    if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, M, C, 0, c.st, c.err));
+    return 0;
+}
+
+IgemmDesc conv_desc(const void* X, int Cin, const void* Wt, int N, int r, int B) {
+    IgemmDesc d;
+    d.X = X; d.Wt = Wt; d.M = B * r * r; d.N = N; d.Cin = Cin; d.taps = 9; d.H = r; d.W = r;
+    return d;
+}
+
+bool any_grad(const Handle& h, const std::string& prefix) {
+    for (const auto& w : h.weights)
+        if (w.grad && w.key.compare(0, prefix.size(), prefix) == 0) return true;
+    return false;
+}
+
+int check_train(Handle& h, int B, const void* ws, size_t ws_bytes, std::string& err) {
+    if (h.cfg.precision != SOCCDPT_PREC_F32) { err = "soccdpt_train_*: the training step is built for SOCCDPT_PREC_F32 handles only"; return 1; }
+    if (h.arch.hybrid) { err = "soccdpt_train_*: the ViT-hybrid encoder has no backward yet (Swin-V2 encoders only)"; return 1; }
+    if (h.cfg.features != 256 || h.cfg.num_classes != 3) { err = "soccdpt_train_*: features must be 256 and num_classes 3"; return 1; }
+    if (B < 1 || !ws) { err = "soccdpt_train_*: bad arguments"; return 1; }
+    for (const auto& w : h.weights)
+        if (!w.ptr) { err = "soccdpt_train_*: weight not bound: " + w.key; return 1; }
+    if (ws_bytes < train_workspace_bytes(h, B)) { err = "soccdpt_train_*: workspace too small"; return 1; }
+    return 0;
+}
+
+}  // namespace
+
+size_t train_workspace_bytes(Handle& h, int B) {
+    TArena ar(nullptr);
+    Tape T;
+    carve(h, B, ar, T);
+    return ar.off + 256;
+}
+
+int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t st, std::string& err) {
+    if (check_train(h, B, ws, ws_bytes, err)) return 1;
+    const Arch& a = h.arch;
+    TArena ar(ws);
+    Tape T;
+    carve(h, B, ar, T);
+    T.dropout_p = dropout_p;
+    Ctx c{h, T, B, st, err};
+    const int F = h.cfg.features;
+    {
+        hipError_t e = hipMemsetAsync(static_cast<char*>(ws) + T.halo_lo, 0, T.halo_hi - T.halo_lo, st);
+        if (e != hipSuccess) { err = std::string("train_forward memset: ") + hipGetErrorString(e); return 1; }
+    }
+    // ---------------- encoder ----------------
+    const int G = a.grid(), C0 = a.embed;
+    const size_t M0 = (size_t)B * G * G;
+    TRY(tr_patch_im2col(x, T.patches, B, a.img, st, err));
+    TRY(tr_pad_cols(c.W(ENC + "patch_embed.proj.weight"), T.pe_wpad, C0, 48, 64, st, err));
+    {
+        IgemmDesc d;
+        d.X = T.patches; d.Wt = T.pe_wpad; d.M = (int)M0; d.N = C0; d.Cin = 64; d.ldx = 64; d.bias = c.W(ENC + "patch_embed.proj.bias"); d.out_f32 = T.pe_pre;
+        TRY(gemm(c, d));
+        TRY(launch_ln_residual(T.pe_pre, c.W(ENC + "patch_embed.norm.weight"), c.W(ENC + "patch_embed.norm.bias"), T.x0, nullptr, nullptr, nullptr, 0, (int)M0, C0, 0, G, 0,
+                               st, err));
+    }
+    const float* xcur = T.x0;
+    for (int s = 0; s < 4; ++s) {
+        const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
+        for (int j = 0; j < a.depths[s]; ++j) {
+            BlkT& b = T.blk[s][j];
+            const std::string k = blk_key(s, j);
+            b.xin = xcur;
+            TRY(launch_qkv_bias(c.W(k + "attn.q_bias"), c.W(k + "attn.v_bias"), b.qkv_bias, C, st, err));
+            TRY(launch_logit_scale(c.W(k + "attn.logit_scale"), b.scale, H, st, err));
+            TRY(launch_cpb_table(c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"), c.W(k + "attn.cpb_mlp.2.weight"), b.table, wsz, a.pretrained_window[s], H,
+                                 st, err));
+            TRY(launch_attn_bias(b.table, b.bias_acc, wsz, H, st, err));
+            IgemmDesc d;
+            d.X = b.xin; d.Wt = c.W(k + "attn.qkv.weight"); d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = b.qkv_bias; d.out_f32 = b.qkv;
+            TRY(gemm(c, d));
+            TRY(launch_window_attention_f32(b.qkv, b.bias_acc, b.table, b.scale, b.attn, B, res, wsz, a.shift(s, j), H, st, err));
+            d = IgemmDesc();
+            d.X = b.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "attn.proj.bias"); d.out_f32 = b.a_pre;
+            TRY(gemm(c, d));
+            TRY(copy_d2d(c, b.x1, b.xin, (size_t)M * C * 4, "train_forward copy"));
+            TRY(launch_ln_residual(b.a_pre, c.W(k + "norm1.weight"), c.W(k + "norm1.bias"), b.x1, nullptr, nullptr, nullptr, 0, M, C, 1, res, 0, st, err));
+            d = IgemmDesc();
+            d.X = b.x1; d.Wt = c.W(k + "mlp.fc1.weight"); d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "mlp.fc1.bias"); d.act = ACT_GELU;
+            d.out_f32 = b.hpre; d.out_op = b.hact;
+            TRY(gemm(c, d));
+            d = IgemmDesc();
+            d.X = b.hact; d.Wt = c.W(k + "mlp.fc2.weight"); d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = c.W(k + "mlp.fc2.bias"); d.out_f32 = b.m_pre;
+            TRY(gemm(c, d));
+            TRY(copy_d2d(c, b.xout, b.x1, (size_t)M * C * 4, "train_forward copy"));
+            TRY(launch_ln_residual(b.m_pre, c.W(k + "norm2.weight"), c.W(k + "norm2.bias"), b.xout, nullptr, nullptr, j == a.hooks[s] ? T.feat[s] : nullptr, 0, M, C, 1, res, 0,
+                                   st, err));
+            xcur = b.xout;
+        }
+        if (s < 3) {
+            const std::string dk = ENC + "layers." + std::to_string(s) + ".downsample.";
+            TRY(launch_merge_gather(xcur, T.mg[s], B, res, C, 4, st, err));
+            IgemmDesc d;
+            d.X = T.mg[s]; d.Wt = c.W(dk + "reduction.weight"); d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = T.mr_pre[s];
+            TRY(gemm(c, d));
+            TRY(launch_ln_residual(T.mr_pre[s], c.W(dk + "norm.weight"), c.W(dk + "norm.bias"), T.mx[s], nullptr, nullptr, nullptr, 0, M / 4, 2 * C, 0, res / 2, 0, st, err));
+            xcur = T.mx[s];
+        }
+    }
+    // ---------------- decoder ----------------
+    for (int l = 0; l < 4; ++l) {
+        TRY(launch_conv_w(c.W(SCR + "layer" + std::to_string(l + 1) + "_rn.weight"), nullptr, T.w_lrn[l], 1, 0, F, a.fdim(l), st, err));
+        const std::string rb = SCR + "refinenet" + std::to_string(l + 1) + ".";
+        for (int u = 0; u < 2; ++u) {
+            if (l == 3 && u == 0) continue;
+            const std::string ub = rb + "resConfUnit" + std::to_string(u + 1) + ".";
+            TRY(launch_conv_w(c.W(ub + "conv1.weight"), nullptr, T.w_rcu[l][u][0], 1, 0, F, F, st, err));
+            TRY(launch_conv_w(c.W(ub + "conv2.weight"), nullptr, T.w_rcu[l][u][1], 1, 0, F, F, st, err));
+        }
+    }
+    for (int l = 3; l >= 0; --l) {
+        const int r = a.fres(l), M = B * r * r;
+        const std::string rb = SCR + "refinenet" + std::to_string(l + 1) + ".";
+        {
+            IgemmDesc d = conv_desc(T.feat[l], a.fdim(l), T.w_lrn[l], F, r, B);
+            d.out_f32 = T.lrn_raw[l]; d.out_op = T.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            TRY(gemm(c, d));
+        }
+        const float* fused_raw = T.lrn_raw[l];
+        const float* fused_relu = T.lrn_relu[l];
+        if (l < 3) {
+            const std::string ub = rb + "resConfUnit1.";
+            IgemmDesc d = conv_desc(T.lrn_relu[l], F, T.w_rcu[l][0][0], F, r, B);
+            d.bias = c.W(ub + "conv1.bias"); d.act = ACT_RELU; d.out_op = T.t1[l]; d.out_halo = 1;
+            TRY(gemm(c, d));
+            d = conv_desc(T.t1[l], F, T.w_rcu[l][0][1], F, r, B);
+            d.bias = c.W(ub + "conv2.bias"); d.res1 = T.lrn_raw[l];
+            d.res2 = T.oc[l + 1]; d.res2_h = a.fres(l + 1); d.res2_w = a.fres(l + 1);
+            d.out_f32 = T.out_raw[l]; d.out_op = T.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
+            TRY(gemm(c, d));
+            fused_raw = T.out_raw[l];
+            fused_relu = T.out_relu[l];
+        }
+        {
+            const std::string ub = rb + "resConfUnit2.";
+            IgemmDesc d = conv_desc(fused_relu, F, T.w_rcu[l][1][0], F, r, B);
+            d.bias = c.W(ub + "conv1.bias"); d.act = ACT_RELU; d.out_op = T.t2[l]; d.out_halo = 1;
+            TRY(gemm(c, d));
+            d = conv_desc(T.t2[l], F, T.w_rcu[l][1][1], F, r, B);
+            d.bias = c.W(ub + "conv2.bias"); d.res1 = fused_raw; d.out_f32 = T.u[l];
+            TRY(gemm(c, d));
+        }
+        {
+            IgemmDesc d;
+            d.X = T.u[l]; d.Wt = c.W(rb + "out_conv.weight"); d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = c.W(rb + "out_conv.bias"); d.out_f32 = T.oc[l];
+            TRY(gemm(c, d));
+        }
+        if (l == 0) TRY(launch_bilinear(T.oc[0], 0, nullptr, nullptr, T.path1, 1, 0, B, r, r, 2 * r, 2 * r, F, st, err));
+    }
+    // ---------------- heads ----------------
+    const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
+    const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
+    TRY(launch_conv_w(c.W(SCR + "output_conv.0.weight"), nullptr, T.w_d0, 1, 0, F / 2, F, st, err));
+    TRY(launch_conv_w(c.W(SCR + "output_conv.2.weight"), nullptr, T.w_d2, 1, 0, 32, F / 2, st, err));
+    TRY(launch_conv_w(c.W("seg_head.0.weight"), nullptr, T.w_s0, 1, 0, F, F, st, err));
+    {
+        IgemmDesc d = conv_desc(T.path1, F, T.w_d0, F / 2, r1, B);
+        d.bias = c.W(SCR + "output_conv.0.bias"); d.out_f32 = T.d1;
+        TRY(gemm(c, d));
+        TRY(launch_bilinear(T.d1, 0, nullptr, nullptr, T.d1u, 1, 0, B, r1, r1, r0, r0, F / 2, st, err));
+        d = conv_desc(T.d1u, F / 2, T.w_d2, 32, r0, B);
+        d.bias = c.W(SCR + "output_conv.2.bias"); d.out_f32 = T.e;
+        TRY(gemm(c, d));
+        TRY(tr_depth_tail_fwd(T.e, c.W(SCR + "output_conv.4.weight"), c.W(SCR + "output_conv.4.bias"), T.inv, M0p, 32, st, err));
+        TRY(copy_d2d(c, inv, T.inv, M0p * 4, "train_forward inv"));
+    }
+    {
+        IgemmDesc d = conv_desc(T.path1, F, T.w_s0, F, r1, B);
+        d.out_f32 = T.c_raw;
+        TRY(gemm(c, d));
+        float* sum = T.S_vec;
+        float* sumsq = T.S_vec + F;
+        TRY(tr_colsum(T.c_raw, nullptr, sum, T.S_col, M1, F, 0, st, err));
+        TRY(tr_colsum(T.c_raw, T.c_raw, sumsq, T.S_col, M1, F, 0, st, err));
+        TRY(tr_bn_stats(sum, sumsq, T.bn_stats, const_cast<float*>(c.W("seg_head.1.running_mean")), const_cast<float*>(c.W("seg_head.1.running_var")), F, M1, 1e-5f, 0.1f, st,
+                        err));
+        TRY(tr_bn_relu_dropout_fwd(T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), c.W("seg_head.1.bias"), T.r, T.keep, M1, F, dropout_p, seed, st, err));
+        TRY(launch_seg_tail(T.r, 1, 0, c.W("seg_head.4.weight"), c.W("seg_head.4.bias"), T.logits, T.seg, B, r1, r1, h.cfg.sigmoid, st, err));
+        TRY(copy_d2d(c, seg, T.seg, M0p * 3 * 4, "train_forward seg"));
+    }
+    return 0;
+}
+
+int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err) {
+    if (check_train(h, B, ws, ws_bytes, err)) return 1;
+    (void)x;
+    const Arch& a = h.arch;
+    TArena ar(ws);
+    Tape T;
+    carve(h, B, ar, T);
+    T.dropout_p = h.train_key.dropout_p;
+    Ctx c{h, T, B, st, err};
+    const int F = h.cfg.features;
+    float** G = T.G;
+    const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
+    const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
+    const bool enc_train = any_grad(h, ENC);
+    // the block buffers are re-derived from the same walk as the forward's: xin pointers
+    {
+        const float* xcur = T.x0;
+        for (int s = 0; s < 4; ++s) {
+            for (auto& b : T.blk[s]) { b.xin = xcur; xcur = b.xout; }
+            if (s < 3) xcur = T.mx[s];
+        }
+    }
+    // ---------------- depth head ----------------
+    {
+        TRY(tr_depth_tail_bwd(d_inv, T.inv, T.e, c.W(SCR + "output_conv.4.weight"), G[0], G[1], M0p, 32, st, err));
+        float* dw4 = c.Gd(SCR + "output_conv.4.weight");
+        float* db4 = c.Gd(SCR + "output_conv.4.bias");
+        if (dw4 || db4) {
+            TRY(tr_colsum(G[1], nullptr, T.S_vec, T.S_col, M0p, 33, 0, st, err));
+            if (dw4) TRY(copy_d2d(c, dw4, T.S_vec, 32 * 4, "train_backward"));
+            if (db4) TRY(copy_d2d(c, db4, T.S_vec + 32, 4, "train_backward"));
+        }
+        TRY(conv3_bwd(c, G[0], T.d1u, c.W(SCR + "output_conv.2.weight"), r0, 32, F / 2, G[2], nullptr, c.Gd(SCR + "output_conv.2.weight"), c.Gd(SCR + "output_conv.2.bias")));
+        TRY(tr_bilinear_bwd(G[2], G[3], B, r1, r1, r0, r0, F / 2, 0, st, err));
+        TRY(conv3_bwd(c, G[3], T.path1, c.W(SCR + "output_conv.0.weight"), r1, F / 2, F, T.GP, nullptr, c.Gd(SCR + "output_conv.0.weight"), c.Gd(SCR + "output_conv.0.bias")));
+    }
+    // ---------------- seg head ----------------
+    {
+        TRY(tr_seg_act_bwd(d_seg, T.seg, G[0], B, 3, r0, h.cfg.sigmoid, st, err));
+        TRY(tr_bilinear_bwd(G[0], G[1], B, r1, r1, r0, r0, 3, 0, st, err));   // d logits [M1][3]
+        if (float* dw = c.Gd("seg_head.4.weight")) TRY(tr_smallk_wgrad(G[1], T.r, dw, T.S_col, M1, F, 3, st, err));
+        if (float* db = c.Gd("seg_head.4.bias")) {
+            // colsum needs N >= 1: three columns
+            TRY(tr_colsum(G[1], nullptr, db, T.S_col, M1, 3, 0, st, err));
+        }
+        TRY(tr_smallk_dgrad(G[1], c.W("seg_head.4.weight"), G[2], M1, F, 3, st, err));
+        TRY(tr_bn_relu_dropout_bwd_pre(G[2], T.r, T.keep, G[0], M1 * F, T.dropout_p, st, err));
+        TRY(tr_bn_xhat(T.c_raw, T.bn_stats, G[3], M1, F, st, err));
+        float* dbeta = T.S_vec;
+        float* dgamma = T.S_vec + F;
+        TRY(tr_colsum(G[0], nullptr, dbeta, T.S_col, M1, F, 0, st, err));
+        TRY(tr_colsum(G[0], G[3], dgamma, T.S_col, M1, F, 0, st, err));
+        if (float* p = c.Gd("seg_head.1.bias")) TRY(copy_d2d(c, p, dbeta, F * 4, "train_backward"));
+        if (float* p = c.Gd("seg_head.1.weight")) TRY(copy_d2d(c, p, dgamma, F * 4, "train_backward"));
+        TRY(tr_bn_bwd(G[0], T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), dbeta, dgamma, G[2], M1, F, st, err));
+        TRY(conv3_bwd(c, G[2], T.path1, c.W("seg_head.0.weight"), r1, F, F, T.GP, T.GP, c.Gd("seg_head.0.weight"), nullptr));
+    }
+    TRY(tr_bilinear_bwd(T.GP, T.DOC, B, a.fres(0), a.fres(0), r1, r1, F, 0, st, err));
+    // ---------------- decoder, fine -> coarse ----------------
+    for (int l = 0; l < 4; ++l) {
+        const int r = a.fres(l);
+        const size_t M = (size_t)B * r * r;
+        const std::string rb = SCR + "refinenet" + std::to_string(l + 1) + ".";
+        TRY(linear_bwd(c, T.DOC, T.u[l], c.W(rb + "out_conv.weight"), M, F, F, G[0], nullptr, c.Gd(rb + "out_conv.weight"), c.Gd(rb + "out_conv.bias")));
+        const float* fused_raw = l < 3 ? T.out_raw[l] : T.lrn_raw[l];
+        const float* fused_relu = l < 3 ? T.out_relu[l] : T.lrn_relu[l];
+        {
+            const std::string ub = rb + "resConfUnit2.";
+            TRY(conv3_bwd(c, G[0], T.t2[l], c.W(ub + "conv2.weight"), r, F, F, G[1], nullptr, c.Gd(ub + "conv2.weight"), c.Gd(ub + "conv2.bias")));
+            TRY(tr_relu_bwd_halo(G[1], T.t2[l], nullptr, G[1], B, r, r, F, st, err));
+            TRY(conv3_bwd(c, G[1], fused_relu, c.W(ub + "conv1.weight"), r, F, F, G[2], nullptr, c.Gd(ub + "conv1.weight"), c.Gd(ub + "conv1.bias")));
+            TRY(tr_relu_bwd(G[2], fused_raw, G[0], G[3], M * F, st, err));   // d fused_raw
+        }
+        const float* d_lrn = G[3];
+        if (l < 3) {
+            TRY(tr_bilinear_bwd(G[3], T.DOC, B, a.fres(l + 1), a.fres(l + 1), r, r, F, 0, st, err));   // gradient of the coarser level's out_conv output
+            const std::string ub = rb + "resConfUnit1.";
+            TRY(conv3_bwd(c, G[3], T.t1[l], c.W(ub + "conv2.weight"), r, F, F, G[1], nullptr, c.Gd(ub + "conv2.weight"), c.Gd(ub + "conv2.bias")));
+            TRY(tr_relu_bwd_halo(G[1], T.t1[l], nullptr, G[1], B, r, r, F, st, err));
+            TRY(conv3_bwd(c, G[1], T.lrn_relu[l], c.W(ub + "conv1.weight"), r, F, F, G[2], nullptr, c.Gd(ub + "conv1.weight"), c.Gd(ub + "conv1.bias")));
+            TRY(tr_relu_bwd(G[2], T.lrn_raw[l], G[3], G[0], M * F, st, err));
+            d_lrn = G[0];
+        }
+        const std::string lk = SCR + "layer" + std::to_string(l + 1) + "_rn.weight";
+        TRY(conv3_bwd(c, d_lrn, T.feat[l], c.W(lk), r, F, a.fdim(l), enc_train ? T.DF[l] : nullptr, nullptr, c.Gd(lk), nullptr));
+    }
+    if (!enc_train) return 0;
+    // ---------------- encoder, last stage -> first ----------------
+    bool have = false;   // GX holds a gradient
+    for (int s = 3; s >= 0; --s) {
+        const int C = a.dim(s), res = a.res(s), wsz = a.ws(s), H = a.heads[s];
+        const size_t M = (size_t)B * res * res;
+        for (int j = a.depths[s] - 1; j >= 0; --j) {
+            BlkT& b = T.blk[s][j];
+            const std::string k = blk_key(s, j);
+            if (j == a.hooks[s]) {
+                if (have) TRY(tr_axpy(T.GX, T.DF[s], M * C, st, err));
+                else TRY(copy_d2d(c, T.GX, T.DF[s], M * C * 4, "train_backward"));
+                have = true;
+            }
+            if (!have) continue;   // blocks after the last hooked one do not reach the outputs
+            // xout = x1 + LN2(m_pre)
+            TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), T.GX, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
+            TRY(linear_bwd(c, G[0], b.hact, c.W(k + "mlp.fc2.weight"), M, C, 4 * C, G[2], nullptr, c.Gd(k + "mlp.fc2.weight"), c.Gd(k + "mlp.fc2.bias")));
+            TRY(tr_gelu_bwd(G[2], b.hpre, G[2], M * 4 * C, st, err));
+            TRY(linear_bwd(c, G[2], b.x1, c.W(k + "mlp.fc1.weight"), M, 4 * C, C, G[3], T.GX, c.Gd(k + "mlp.fc1.weight"), c.Gd(k + "mlp.fc1.bias")));   // G3 = d x1
+            // x1 = xin + LN1(a_pre)
+            TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), G[3], G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
+            TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
+            TRY(tr_attention_bwd(b.qkv, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            {
+                float* dls = c.Gd(k + "attn.logit_scale");
+                float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
+                float* db0 = c.Gd(k + "attn.cpb_mlp.0.bias");
+                float* dw2 = c.Gd(k + "attn.cpb_mlp.2.weight");
+                if (dls || dw0 || db0 || dw2) {
+                    float* tmp0 = T.S_vec;               // 1024 + 512 floats of scratch when only some of the three are bound
+                    TRY(tr_attn_param_grads(T.dS, T.dscale_part, b.table, c.W(k + "attn.logit_scale"), c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"),
+                                            c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, dls, dw0 ? dw0 : (db0 ? tmp0 : nullptr), db0 ? db0 : (dw0 ? tmp0 + 1024 : nullptr),
+                                            dw2, B * (res / wsz) * (res / wsz), wsz, a.pretrained_window[s], H, st, err));
+                }
+            }
+            {
+                float* dq = c.Gd(k + "attn.q_bias");
+                float* dv = c.Gd(k + "attn.v_bias");
+                float* dbias = (dq || dv) ? T.S_vec : nullptr;
+                TRY(linear_bwd(c, G[4], b.xin, c.W(k + "attn.qkv.weight"), M, 3 * C, C, T.GX, G[3], c.Gd(k + "attn.qkv.weight"), dbias));
+                if (dbias) TRY(tr_qv_bias_grad(dbias, dq, dv, C, st, err));
+            }
+        }
+        if (!have) continue;
+        if (s > 0) {
+            // x_s = LN(reduction(gather(x_{s-1})))   (timm PatchMerging of Swin-V2: reduction then norm)
+            const int Cp = a.dim(s - 1);
+            const std::string dk = ENC + "layers." + std::to_string(s - 1) + ".downsample.";
+            TRY(ln_bwd(c, T.mr_pre[s - 1], c.W(dk + "norm.weight"), T.GX, G[0], G[1], M, C, c.Gd(dk + "norm.weight"), c.Gd(dk + "norm.bias")));
+            TRY(linear_bwd(c, G[0], T.mg[s - 1], c.W(dk + "reduction.weight"), M, C, 4 * Cp, G[2], nullptr, c.Gd(dk + "reduction.weight"), nullptr));
+            TRY(tr_merge_scatter(G[2], T.GX, B, a.res(s - 1), Cp, st, err));
+        } else {
+            const int C0 = a.embed;
+            TRY(ln_bwd(c, T.pe_pre, c.W(ENC + "patch_embed.norm.weight"), T.GX, G[0], G[1], M, C0, c.Gd(ENC + "patch_embed.norm.weight"), c.Gd(ENC + "patch_embed.norm.bias")));
+            float* dw = c.Gd(ENC + "patch_embed.proj.weight");
+            TRY(linear_bwd(c, G[0], T.patches, T.pe_wpad, M, C0, 64, nullptr, nullptr, dw ? T.S_dw + 65536 : nullptr, c.Gd(ENC + "patch_embed.proj.bias")));
+            if (dw) TRY(tr_pad_cols(T.S_dw + 65536, dw, C0, 64, 48, st, err));
+        }
+    }
+    return 0;
+}
+
+}  // namespace soccdpt

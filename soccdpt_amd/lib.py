@@ -124,6 +124,11 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_network.argtypes = [vp, vp, ci, vp, vp, vp, cs, vp]
     L.soccdpt_network.restype = ci
     L.soccdpt_project.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
+    L.soccdpt_bind_grad.argtypes = [vp, ctypes.c_char_p, vp]
+    L.soccdpt_train_workspace_bytes.argtypes = [vp, ci]
+    L.soccdpt_train_workspace_bytes.restype = cs
+    L.soccdpt_train_forward.argtypes = [vp, vp, ci, vp, vp, vp, cs, ctypes.c_float, ctypes.c_uint32, vp]
+    L.soccdpt_train_backward.argtypes = [vp, vp, ci, vp, vp, vp, cs, vp]
     L.soccdpt_project.restype = ci
     L.soccdpt_occ_or.argtypes = [vp, vp, vp, ci, vp]
     L.soccdpt_occ_or.restype = ci
@@ -345,6 +350,37 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_network(self._h, _ptr(x), B, _ptr(inv256), _ptr(seg256), ws.data_ptr(), ws.numel(),
                                                _stream_ptr(self.device)), "soccdpt_network")
+
+    # ---- training step (include/soccdpt_hip.h: soccdpt_train_*) ----
+    def bind_grad(self, key: str, g: Optional[torch.Tensor]):
+        """Gradient destination of one weight (written by train_backward); None freezes the weight."""
+        if g is not None:
+            assert g.device.type == "cuda" and g.dtype == torch.float32 and g.is_contiguous(), key
+        self._check(self.L.soccdpt_bind_grad(self._h, key.encode(), _ptr(g)), "soccdpt_bind_grad")
+        self._grads = getattr(self, "_grads", {})
+        self._grads[key] = g  # keep alive
+
+    def train_workspace(self, B: int) -> torch.Tensor:
+        nbytes = self.L.soccdpt_train_workspace_bytes(self._h, B)
+        cur = getattr(self, "_train_ws", None)
+        if cur is None or cur.numel() < nbytes:
+            self._train_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        return self._train_ws
+
+    def train_forward(self, x: torch.Tensor, inv: torch.Tensor, seg: torch.Tensor, dropout_p: float = 0.1, seed: int = 0):
+        B = x.shape[0]
+        ws = self.train_workspace(B)
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_train_forward(self._h, _ptr(x), B, _ptr(inv), _ptr(seg), ws.data_ptr(), ws.numel(), float(dropout_p),
+                                                     int(seed) & 0xFFFFFFFF, _stream_ptr(self.device)), "soccdpt_train_forward")
+
+    def train_backward(self, x: torch.Tensor, d_inv: torch.Tensor, d_seg: torch.Tensor):
+        B = x.shape[0]
+        ws = self.train_workspace(B)
+        assert d_inv.is_contiguous() and d_seg.is_contiguous() and d_inv.dtype == torch.float32 and d_seg.dtype == torch.float32
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_train_backward(self._h, _ptr(x), B, _ptr(d_inv), _ptr(d_seg), ws.data_ptr(), ws.numel(),
+                                                      _stream_ptr(self.device)), "soccdpt_train_backward")
 
     def forward(self, x: torch.Tensor, inv_up, seg_up, points, occ, occ_bits):
         B = x.shape[0]

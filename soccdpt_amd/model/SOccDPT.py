@@ -245,16 +245,77 @@ class SOccDPT_V3(SOccDPT):
         self.last_occ_bits = bits
         return self._shape_outputs(inv_up, seg_up, points, occ)
 
-    def train_forward(self, x: torch.Tensor):
-        """Train-mode forward that keeps what the backward needs (BatchNorm batch statistics + Dropout in the seg head, saved activations).
-        Not built yet: SURVEY.md 8f #1 / rows a14, f#1."""
-        raise NotImplementedError("the network's train-mode forward / backward kernels are not built yet (conv dgrad / wgrad, attention, LayerNorm, "
-                                  "GELU, bilinear backward, train-mode BatchNorm + Dropout: SURVEY.md 8f #1); the criterion, its output gradients, the "
-                                  "fused Adam and the patch-wise schedule are (soccdpt_amd.scripts.train_SOccDPT --forward_only walks them)")
+    def _bind_for_training(self, eng: Engine):
+        """Bind the LIVE parameters / buffers (the training step reads weights as bound: no prepare) and one gradient buffer per
+        trainable parameter; frozen parameters (requires_grad False: model/loss.py:110-152) are unbound and their weight-gradient
+        GEMMs skipped."""
+        live = dict(self.named_parameters(remove_duplicate=False))
+        live.update(dict(self.named_buffers(remove_duplicate=False)))
+        keys = eng.weight_keys()
+        state = self.__dict__.setdefault("_train_state", {})
+        st = state.setdefault(id(eng), {"ptrs": {}, "grads": {}, "req": {}})
+        for k in keys:
+            t = live[k]
+            if t.device != eng.device or t.dtype != torch.float32 or not t.is_contiguous():
+                raise RuntimeError(f"weight {k} must be a contiguous float32 tensor on {eng.device} (got {t.device}, {t.dtype})")
+            if st["ptrs"].get(k) != t.data_ptr():
+                eng.bind(k, t.detach())
+                st["ptrs"][k] = t.data_ptr()
+            req = bool(getattr(t, "requires_grad", False))
+            if st["req"].get(k) != req or (req and st["grads"][k].shape != t.shape):
+                st["grads"][k] = torch.zeros_like(t, requires_grad=False) if req else None
+                eng.bind_grad(k, st["grads"][k])
+                st["req"][k] = req
+        # the eval path prepares from the same tensors: make it re-prepare after training touched them
+        self._bound_versions.pop(id(eng), None)
+        return live, keys, st
+
+    def train_forward(self, x: torch.Tensor, seed: int = None):
+        """Train-mode forward (model/SOccDPT.py:660-685 under nn.Module.train(): BatchNorm2d of the seg head on batch statistics with its
+        running buffers updated, Dropout live) that keeps every activation the backward needs.  Returns (inv_depth [B,S,S],
+        segmentation [B,C,S,S]) at network resolution -- what SOccDPT_V3.forward hands to the up-sampling / criterion.  Exact f32
+        (precision=PREC_F32) and Swin-V2 encoders only; follow it with backward(d_inv, d_seg)."""
+        from ..lib import PREC_F32
+        if self.precision != PREC_F32:
+            raise RuntimeError("the training step is built for precision=PREC_F32 (exact-f32 MFMA); construct the model with it")
+        img = backbone_image_size(self._engine_backbone())
+        assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
+        eng = self._engine(x.device)
+        live, keys, st = self._bind_for_training(eng)
+        xin = x.detach().to(torch.float32).contiguous()
+        B = xin.shape[0]
+        inv = torch.empty((B, img, img), device=x.device)
+        seg = torch.empty((B, self.num_classes, img, img), device=x.device)
+        if seed is None:
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        eng.train_forward(xin, inv, seg, dropout_p=float(self.seg_head[3].p), seed=seed)
+        # BatchNorm bookkeeping that lives on the host side of nn.BatchNorm2d
+        bn = self.seg_head[1]
+        torch._C._increment_version([bn.running_mean, bn.running_var])
+        bn.num_batches_tracked += 1
+        self._train_x = (eng, xin)
+        return inv, seg
 
     def backward(self, d_inv: torch.Tensor, d_seg: torch.Tensor):
-        """Gradients of every trainable parameter from d loss / d (inv_depth, segmentation): see train_forward."""
-        return self.train_forward(None)
+        """d loss / d (inv_depth, segmentation) of the last train_forward -> .grad of every trainable parameter (accumulated like
+        autograd does when .grad is already populated).  Replaces loss.backward() of scripts/train_SOccDPT.py:390."""
+        if getattr(self, "_train_x", None) is None:
+            raise RuntimeError("backward() needs a train_forward() first")
+        eng, xin = self._train_x
+        live, keys, st = self._bind_for_training(eng)
+        eng.train_backward(xin, d_inv.detach().to(torch.float32).contiguous(), d_seg.detach().to(torch.float32).contiguous())
+        seen = set()
+        for k in keys:
+            g = st["grads"].get(k)
+            p = live[k]
+            if g is None or id(p) in seen:
+                continue
+            seen.add(id(p))
+            if p.grad is None:
+                p.grad = g
+            elif p.grad is not g:
+                p.grad.add_(g)
+        self._train_x = None
 
     def network(self, x: torch.Tensor):
         """Stage-level: encoder + decoder + heads only -> (inv_depth [B,S,S], segmentation [B,C,S,S])."""
