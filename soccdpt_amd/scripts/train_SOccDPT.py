@@ -5,12 +5,12 @@
 (:262-263), Adam (:311-318), ReduceLROnPlateau(min, patience 2) (:320-322), the `PatchWiseInplace` inner loop (:362-393), the criterion
 `loss_depth_w * SSI + loss_seg_w * BCE` (:323-338,380-386), one checkpoint per epoch (:437-449).
 
-What runs on MI355X today: the sweep / CLI surface, the schedule, the forward, the criterion WITH its gradient w.r.t. the network outputs
-(csrc/loss.hip) and the fused Adam (csrc/adam.hip).  What does not exist yet: the network's backward kernels (SURVEY.md 8f #1, rows a14 /
-f#1 -- conv dgrad / wgrad, attention / LayerNorm / GELU / bilinear backward, train-mode BatchNorm + Dropout).  Without `--forward_only` the
-script therefore stops at the first optimisation step with a NotImplementedError that says so; with `--forward_only` it walks the whole
-schedule (every patch of every batch of every epoch), evaluates the criterion and its output gradients, and skips backward + optimizer.
-There is no autograd / eager-PyTorch fallback for the missing part: the HIP library is the product.
+What runs on MI355X: all of it.  The train-mode forward and the network backward (csrc/train_step.cpp, csrc/train.hip: exact f32, Swin-V2
+encoders) sit behind `net.train_forward(x)` / `net.backward(d_inv, d_seg)`; the criterion and its gradient w.r.t. the network outputs are
+csrc/loss.hip, the optimizer is the fused Adam (csrc/adam.hip).  A frozen parameter (freeze / unfreeze helpers, PatchWiseInplace) has no
+gradient bound and its weight-gradient GEMM is skipped.  `--forward_only` walks the schedule with the eval-mode forward + criterion only
+(any operand precision, also dpt_hybrid_384, which has no backward yet).  There is no autograd / eager-PyTorch fallback: the HIP library is
+the product.
 
 Differences forced by the GPU box: wandb is absent -> the sweep is sampled locally (`method: random` with random.seed(0), `count` runs)
 and logging goes to stdout; the datasets are absent -> when `--base_path` does not exist a seeded synthetic set in the datasets' layout
@@ -160,6 +160,9 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
         model_kwargs["sigmoid"] = p["sigmoid"]
     calib = camera_intrinsics_yaml or write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     model_kwargs["camera_intrinsics_yaml"] = calib
+    if not forward_only:
+        from ..lib import PREC_F32
+        model_kwargs["precision"] = PREC_F32     # the training step (csrc/train_step.cpp) computes in exact f32, like the reference's amp=False runs
     net = load_model(arch=arch, model_kwargs=model_kwargs, device=torch.device("cpu"), model_path=p["load"] or None, model_type=model_type)
     net = net.to(device=device)
     freeze_pretrained_encoder(net)
@@ -182,11 +185,11 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
             mask_disp, mask_seg = mask_disp.to(device=device, dtype=torch.bool), mask_seg.to(device=device, dtype=torch.bool)
             for net_patch in PatchWiseInplace(net, p["patchwise_percentage"]):
                 if forward_only:
-                    net_patch.eval()     # the eval-mode kernels are what exists; BatchNorm batch statistics / Dropout belong to the missing part
+                    net_patch.eval()
                     inv, seg = net_patch.network(x)
                     net_patch.train()
                 else:
-                    inv, seg = net_patch.train_forward(x)      # raises: see the module docstring
+                    inv, seg = net_patch.train_forward(x)
                 out = training_loss(inv, seg, y_disp, mask_disp, y_seg, mask_seg, loss_depth_w, loss_seg_w,
                                     compute_scale_and_shift=p["compute_scale_and_shift"])
                 optimizer.zero_grad(set_to_none=True)
@@ -223,7 +226,7 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument("-c", "--checkpoint_dir", default=os.path.join(os.getcwd(), "checkpoints"), help="Directory to save checkpoints in")
     parser.add_argument("-b", "--base_path", default=os.path.expanduser("~/Datasets/Depth_Dataset_Bengaluru"), help="Base path to dataset")
     parser.add_argument("--sweep_json", required=True, help="Path to checkpoint to sweep json")
-    parser.add_argument("--forward_only", action="store_true", help="walk the schedule with forward + criterion only (the network backward is not built yet)")
+    parser.add_argument("--forward_only", action="store_true", help="walk the schedule with the eval-mode forward + criterion only (no backward / optimizer)")
     parser.add_argument("--max_steps", default=0, type=int, help="stop every run after this many batches (0 = all)")
     return parser
 

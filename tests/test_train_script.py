@@ -77,8 +77,8 @@ def test_freeze_unfreeze_is_index_based_like_the_reference(tmp_path):
 @pytest.mark.gpu
 def test_forward_only_schedule_walk_gpu(tmp_path, gpu_device):
     """BASELINE configs[4] shape: B = 3, encoder_percentage 0.5, patchwise_percentage 0.5 -> 2 patches per batch; forward + criterion (+ its
-    output gradients) run on the GPU for every patch, one checkpoint per epoch is written, and without --forward_only the script stops with
-    the NotImplementedError that names the missing backward."""
+    output gradients) run on the GPU for every patch and one checkpoint per epoch is written; without --forward_only the same schedule
+    trains (train-mode forward, backward, fused Adam) and moves only parameters that are unfrozen."""
     from soccdpt_amd.scripts.train_SOccDPT import build_parser, main
     sweep = _sweep_file(tmp_path, epochs=2, patchwise_percentage=0.5, val_percent=0.1)
     ck = tmp_path / "ck"
@@ -88,5 +88,48 @@ def test_forward_only_schedule_walk_gpu(tmp_path, gpu_device):
     assert (ck / "local_run_0" / "checkpoint_epoch_1.pth").exists()
     sd = torch.load(ck / "local_run_0" / "checkpoint_epoch_1.pth", map_location="cpu")
     assert "depth_net.scratch.refinenet1.out_conv.weight" in sd and "seg_head.4.bias" in sd
-    with pytest.raises(NotImplementedError):
-        main(build_parser().parse_args(argv))
+    ck2 = tmp_path / "ck_train"
+    argv[argv.index(str(ck))] = str(ck2)
+    hist = main(build_parser().parse_args(argv))
+    assert len(hist) == 1 and len(hist[0]) == 2 and all(h > 0 and h == h for h in hist[0])
+    sd2 = torch.load(ck2 / "local_run_0" / "checkpoint_epoch_1.pth", map_location="cpu")
+    moved = [k for k in sd if sd[k].is_floating_point() and not torch.equal(sd[k], sd2[k])]
+    assert "depth_net.scratch.refinenet1.out_conv.weight" in moved and "seg_head.4.bias" in moved and "seg_head.1.running_mean" in moved
+    # encoder_percentage 0.5 unfreezes the FIRST half of the encoder's parameter list (model/loss.py:124-152): the last stage stays frozen
+    assert "depth_net.pretrained.model.patch_embed.proj.weight" in moved
+    assert not any(k.startswith("depth_net.pretrained.model.layers.3.") for k in moved)
+
+
+@pytest.mark.gpu
+def test_training_reduces_the_loss_gpu(gpu_device):
+    """Eight optimisation steps on one fixed synthetic batch (train-mode forward -> SSI + BCE criterion -> backward -> fused Adam): the
+    loss falls.  The end-to-end check that the gradients point downhill through the whole stack."""
+    import os
+    import tempfile
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.scripts.train_SOccDPT import SyntheticDepthSegDataset, get_batch
+    from soccdpt_amd.utils.loss import training_loss
+    from soccdpt_amd.utils.optim import Adam
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
+    net.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
+    net = net.to(gpu_device).train()
+    ds = SyntheticDepthSegDataset(2, 256)
+    x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(ds, 2, 2)
+    x = x.to(gpu_device, torch.float32)
+    y_disp, y_seg = y_disp.to(gpu_device, torch.float32), y_seg.to(gpu_device, torch.float32)
+    mask_disp, mask_seg = mask_disp.to(gpu_device, torch.bool), mask_seg.to(gpu_device, torch.bool)
+    opt = Adam(net.parameters(), lr=1e-4)
+    losses = []
+    for step in range(8):
+        inv, seg = net.train_forward(x, seed=step)
+        out = training_loss(inv, seg, y_disp, mask_disp, y_seg, mask_seg, 0.5, 0.5, compute_scale_and_shift=True)
+        opt.zero_grad(set_to_none=True)
+        net.backward(out["d_inv"], out["d_seg"])
+        opt.step()
+        losses.append(float(out["loss"]))
+    print("losses:", [f"{v:.4f}" for v in losses])
+    assert all(v == v for v in losses)
+    assert losses[-1] < 0.9 * losses[0], losses
