@@ -794,6 +794,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
+        // split-K in f32: the weight-gradient GEMMs of the training step (K = pixels, a handful of output tiles; train_step.cpp picks the split)
+        if (d.splitk > 1) {
+            if (d.ln_g || d.gn_stats || need_gen(d) || d.out_dot) { err = "igemm: f32 split-K is a plain / 3x3 launch without LayerNorm, statistics or dot epilogues"; return 1; }
+            return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, true>(d, stream, err);
+        }
         switch (pick_cfg_f32(d)) {
             case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, false, false, true, true>(d, stream, err)
                          : d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, float, true>(d, stream, err)

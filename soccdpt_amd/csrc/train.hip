@@ -105,22 +105,42 @@ __global__ void from_halo_kernel(const float* __restrict__ halo, float* __restri
 
 // ---------------- reductions ----------------
 // column sums of [M][N] (bias gradients, LayerNorm gamma / beta gradients): out[n] = sum_m a[m][n] (* b[m][n] when b != nullptr).
-// Two deterministic stages: 64 row-chunks per column block, then their sum in chunk order.
+// Two deterministic stages: a block = 64 columns x 4 row phases over one chunk of rows (partials per chunk), then the chunks in order.
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part, size_t M, int N, int chunks) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
     const int ch = blockIdx.y;
-    if (n >= N) return;
     const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
     float s = 0.f;
-    for (size_t m = lo; m < hi; ++m) s += b ? a[m * N + n] * b[m * N + n] : a[m * N + n];
-    part[(size_t)ch * N + n] = s;
+    if (n < N)
+        for (size_t m = lo + ty; m < hi; m += 4) s += b ? a[m * N + n] * b[m * N + n] : a[m * N + n];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) part[(size_t)ch * N + n] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
 }
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int chunks, int accumulate) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// second stage: the chunk partials [chunks][N] summed in chunk order, 64 columns x 4 phases per block (phase p takes chunks p, p+4, ...)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int chunks, int accumulate) {
+    __shared__ float red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;
     float s = 0.f;
-    for (int c = 0; c < chunks; ++c) s += part[(size_t)c * N + n];
-    out[n] = accumulate ? out[n] + s : s;
+    if (n < N)
+        for (int c = ty; c < chunks; c += 4) s += part[(size_t)c * N + n];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < N) {
+        const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        out[n] = accumulate ? out[n] + v : v;
+    }
+}
+// sum over the leading axis of [R][n] with n large (attention logit gradients summed over windows): one thread per column
+__global__ void rowsum_kernel(const float* a, float* out, int R, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int r = 0; r < R; ++r) s += a[(size_t)r * n + i];
+        out[i] = s;
+    }
 }
 
 // ---------------- elementwise ----------------
@@ -317,18 +337,24 @@ __global__ void smallk_dgrad_kernel(const float* __restrict__ dl, const float* _
         dx[i] = s;
     }
 }
-// dW[k][c] = sum_m dl[m][k] x[m][c] via per-chunk partials (deterministic): part[ch][k][c]
+// dW[k][c] = sum_m dl[m][k] x[m][c] via per-chunk partials (deterministic): part[ch][k][c], K <= 4
 __global__ __launch_bounds__(256) void smallk_wgrad_part_kernel(const float* __restrict__ dl, const float* __restrict__ x, float* __restrict__ part, size_t M, int C, int K,
                                                                 int chunks) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
+    __shared__ float red[4][4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx;
     const int ch = blockIdx.y;
-    if (c >= C) return;
     const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
-    for (int k = 0; k < K; ++k) {
-        float s = 0.f;
-        for (size_t m = lo; m < hi; ++m) s += dl[m * K + k] * x[m * C + c];
-        part[((size_t)ch * K + k) * C + c] = s;
-    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C)
+        for (size_t m = lo + ty; m < hi; m += 4) {
+            const float xv = x[m * C + c];
+            for (int k = 0; k < K; ++k) s[k] += dl[m * K + k] * xv;
+        }
+    for (int k = 0; k < 4; ++k) red[ty][k][tx] = s[k];
+    __syncthreads();
+    if (ty == 0 && c < C)
+        for (int k = 0; k < K; ++k) part[((size_t)ch * K + k) * C + c] = (red[0][k][tx] + red[1][k][tx]) + (red[2][k][tx] + red[3][k][tx]);
 }
 
 // seg activation + x2 upsample: d logits_up[b][y][x][k] from d seg [B][K][S][S] (NCHW) and the saved output: ScaledTanh' = 2 y (1 - y), sigmoid' = y (1 - y)
@@ -717,41 +743,46 @@ __global__ __launch_bounds__(64) void attn_rowstat_kernel(const float* __restric
     }
 }
 
-// d table[r][h] = sum over (window, q, k with rel(q, k) = r) dS: one thread per (r, h), fixed order
-__global__ void attn_table_grad_kernel(const float* __restrict__ dS, float* __restrict__ dtable, int nwin, int ws, int heads) {
+// d table[r][h] = sum over (q, k with rel(q, k) = r) of dSsum[h][q][k], dSsum = dS summed over the windows (rowsum_kernel)
+__global__ void attn_table_grad_kernel(const float* __restrict__ dSsum, float* __restrict__ dtable, int ws, int heads) {
     const int T = 2 * ws - 1, N = ws * ws;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * T * heads) return;
     const int h = i % heads, r = i / heads;
     const int dr = r / T - (ws - 1), dc = r % T - (ws - 1);   // rq - rk, cq - ck
+    const float* base = dSsum + (size_t)h * N * N;
     float s = 0.f;
-    for (int w = 0; w < nwin; ++w) {
-        const float* base = dS + ((size_t)w * heads + h) * N * N;
-        for (int rk = 0; rk < ws; ++rk) {
-            const int rq = rk + dr;
-            if (rq < 0 || rq >= ws) continue;
-            for (int ck = 0; ck < ws; ++ck) {
-                const int cq = ck + dc;
-                if (cq < 0 || cq >= ws) continue;
-                s += base[(size_t)(rq * ws + cq) * N + rk * ws + ck];
-            }
+    for (int rk = 0; rk < ws; ++rk) {
+        const int rq = rk + dr;
+        if (rq < 0 || rq >= ws) continue;
+        for (int ck = 0; ck < ws; ++ck) {
+            const int cq = ck + dc;
+            if (cq < 0 || cq >= ws) continue;
+            s += base[(size_t)(rq * ws + cq) * N + rk * ws + ck];
         }
     }
     dtable[i] = s;
 }
 // logit_scale gradient: scale = exp(min(ls, ln 100)); d ls = scale * d scale when ls < ln 100
 __global__ void attn_scale_reduce_kernel(const float* __restrict__ part, const float* __restrict__ ls, float* __restrict__ dls, int nwin, int heads, int nqb) {
-    const int h = blockIdx.x * blockDim.x + threadIdx.x;
-    if (h >= heads) return;
+    __shared__ float red[256];
+    const int h = blockIdx.x;
     float s = 0.f;
-    for (int w = 0; w < nwin; ++w)
-        for (int q = 0; q < nqb; ++q) s += part[((size_t)w * heads + h) * nqb + q];
-    const float l = ls[h];
-    dls[h] = l < LN100 ? s * __expf(l) : 0.f;
+    for (int i = threadIdx.x; i < nwin * nqb; i += 256) s += part[((size_t)(i / nqb) * heads + h) * nqb + (i % nqb)];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float l = ls[h];
+        dls[h] = l < LN100 ? red[0] * __expf(l) : 0.f;
+    }
 }
 
 // continuous position bias MLP backward: table = 16 sigmoid(t), t = relu(coords W0^T + b0) W2^T.
-// dt = dtable * 16 s (1 - s) with s = table / 16; hidden recomputed.  Three small kernels (T^2 <= 2209 rows, 512 hidden).
+// dt = dtable * 16 s (1 - s) with s = table / 16; the hidden layer is recomputed into hid / dhid [(2ws-1)^2][512].
 __global__ void cpb_dt_kernel(const float* __restrict__ dtable, const float* __restrict__ table, float* __restrict__ dt, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -766,42 +797,49 @@ __device__ __forceinline__ void cpb_coords(int r, int ws, int pws, float& c0, fl
     c0 = (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)) * log2f(fabsf(a) + 1.0f) * inv;
     c1 = (b > 0.f ? 1.f : (b < 0.f ? -1.f : 0.f)) * log2f(fabsf(b) + 1.0f) * inv;
 }
-// dW2[h][j] = sum_r dt[r][h] hid[r][j]
-__global__ void cpb_w2_grad_kernel(const float* __restrict__ dt, const float* __restrict__ w0, const float* __restrict__ b0, float* __restrict__ dw2, int ws, int pws, int heads) {
+__global__ void cpb_hidden_kernel(const float* __restrict__ dt, const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w2,
+                                  float* __restrict__ hid, float* __restrict__ dhid, int ws, int pws, int heads) {
     const int T2 = (2 * ws - 1) * (2 * ws - 1);
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= heads * 512) return;
-    const int j = i % 512, h = i / 512;
-    float s = 0.f;
-    for (int r = 0; r < T2; ++r) {
-        float c0, c1;
-        cpb_coords(r, ws, pws, c0, c1);
-        const float hid = fmaxf(c0 * w0[2 * j] + c1 * w0[2 * j + 1] + b0[j], 0.f);
-        s += dt[(size_t)r * heads + h] * hid;
-    }
-    dw2[i] = s;
-}
-// dW0[j][0..1], db0[j]: d hid[r][j] = sum_h dt[r][h] W2[h][j] gated by relu
-__global__ void cpb_w0_grad_kernel(const float* __restrict__ dt, const float* __restrict__ w0, const float* __restrict__ b0, const float* __restrict__ w2,
-                                   float* __restrict__ dw0, float* __restrict__ db0, int ws, int pws, int heads) {
-    const int T2 = (2 * ws - 1) * (2 * ws - 1);
-    const int j = blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= 512) return;
-    float g0 = 0.f, g1 = 0.f, gb = 0.f;
-    for (int r = 0; r < T2; ++r) {
-        float c0, c1;
-        cpb_coords(r, ws, pws, c0, c1);
-        const float pre = c0 * w0[2 * j] + c1 * w0[2 * j + 1] + b0[j];
-        if (pre <= 0.f) continue;
-        float dh = 0.f;
+    if (i >= T2 * 512) return;
+    const int j = i & 511, r = i >> 9;
+    float c0, c1;
+    cpb_coords(r, ws, pws, c0, c1);
+    const float pre = c0 * w0[2 * j] + c1 * w0[2 * j + 1] + b0[j];
+    hid[i] = fmaxf(pre, 0.f);
+    float dh = 0.f;
+    if (pre > 0.f)
         for (int h = 0; h < heads; ++h) dh += dt[(size_t)r * heads + h] * w2[(size_t)h * 512 + j];
-        g0 += dh * c0;
-        g1 += dh * c1;
-        gb += dh;
+    dhid[i] = dh;
+}
+// out[o][j] = sum_r coef_o[r] * mat[r][j] for j < 512: grid (8, outputs), block = 64 columns x 4 row phases.
+//   mode 0 (dW2): coef_o[r] = dt[r][o], mat = hid.   mode 1 (dW0 / db0): o = 0, 1 -> coords, o = 2 -> 1; mat = dhid; out written as dw0[j][0..1], db0[j]
+__global__ __launch_bounds__(1024) void cpb_reduce_kernel(const float* __restrict__ mat, const float* __restrict__ dt, float* __restrict__ out0, float* __restrict__ out1,
+                                                         int ws, int pws, int heads, int mode) {
+    __shared__ float red[16][64];
+    const int T2 = (2 * ws - 1) * (2 * ws - 1);
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int j = blockIdx.x * 64 + tx, o = blockIdx.y;
+    float s = 0.f;
+    for (int r = ty; r < T2; r += 16) {
+        float coef;
+        if (mode == 0) coef = dt[(size_t)r * heads + o];
+        else {
+            float c0, c1;
+            cpb_coords(r, ws, pws, c0, c1);
+            coef = o == 0 ? c0 : (o == 1 ? c1 : 1.0f);
+        }
+        s += coef * mat[(size_t)r * 512 + j];
     }
-    dw0[2 * j] = g0;
-    dw0[2 * j + 1] = g1;
-    db0[j] = gb;
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0) {
+        float v = 0.f;
+        for (int p = 0; p < 16; ++p) v += red[p][tx];
+        if (mode == 0) out0[(size_t)o * 512 + j] = v;
+        else if (o < 2) { if (out0) out0[2 * j + o] = v; }
+        else if (out1) out1[j] = v;
+    }
 }
 // q_bias / v_bias gradients from the qkv bias gradient [3C] (the k part has no parameter)
 __global__ void qv_bias_grad_kernel(const float* __restrict__ dqkv_bias, float* __restrict__ dq, float* __restrict__ dv, int C) {
@@ -845,11 +883,14 @@ int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int 
     hipLaunchKernelGGL(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);
     TK("from_halo");
 }
-// scratch: 64 * N floats
+// scratch: up to 65536 + N floats
 int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err) {
-    const int chunks = M >= 4096 ? 64 : (M >= 64 ? 16 : 1);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 255) / 256, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
+    const int cb = (N + 63) / 64;
+    int chunks = 512 / cb;
+    if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
+    if (chunks < 1) chunks = 1;
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
     TK("colsum");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
@@ -906,11 +947,12 @@ int tr_smallk_dgrad(const float* dl, const float* w, float* dx, size_t M, int C,
     hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dl, w, dx, M, C, K);
     TK("smallk_dgrad");
 }
-// scratch: 64 * K * C floats
+// scratch: 256 * K * C floats (K <= 4)
 int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, size_t M, int C, int K, hipStream_t st, std::string& err) {
-    const int chunks = 64;
-    hipLaunchKernelGGL(smallk_wgrad_part_kernel, dim3((C + 255) / 256, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((K * C + 255) / 256), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
+    if (K > 4) { err = "smallk_wgrad: K > 4"; return 1; }
+    const int chunks = 256;
+    hipLaunchKernelGGL(smallk_wgrad_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
     TK("smallk_wgrad");
 }
 int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err) {
@@ -947,14 +989,22 @@ int tr_attention_bwd(const float* qkv, const float* dO, const float* table, cons
     hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, dqkv, res, ws, shift, heads);
     TK("attention_bwd");
 }
-int tr_attn_param_grads(const float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
-                        float* dt, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
+// dS is overwritten by its sum over the windows (first nwin = 1 slab); hid: 2 * (2ws-1)^2 * 512 floats of scratch
+int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
+                        float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
     const int T2 = (2 * ws - 1) * (2 * ws - 1), N = ws * ws, nqb = (N + 63) / 64;
-    hipLaunchKernelGGL(attn_table_grad_kernel, dim3((T2 * heads + 63) / 64), dim3(64), 0, st, dS, dtable, nwin, ws, heads);
-    hipLaunchKernelGGL(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
-    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(1), dim3(64), 0, st, dscale_part, ls, dls, nwin, heads, nqb);
-    if (dw2) hipLaunchKernelGGL(cpb_w2_grad_kernel, dim3((heads * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, dw2, ws, pws, heads);
-    if (dw0 || db0) hipLaunchKernelGGL(cpb_w0_grad_kernel, dim3(2), dim3(256), 0, st, dt, w0, b0, w2, dw0, db0, ws, pws, heads);
+    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb);
+    if (dw0 || db0 || dw2) {
+        const size_t n = (size_t)heads * N * N;
+        // in place: column i of slab 0 is read before it is written, the other slabs are only read
+        hipLaunchKernelGGL(rowsum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dS, dS, nwin, n);
+        hipLaunchKernelGGL(attn_table_grad_kernel, dim3((T2 * heads + 63) / 64), dim3(64), 0, st, dS, dtable, ws, heads);
+        hipLaunchKernelGGL(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
+        float* dhid = hid + (size_t)T2 * 512;
+        hipLaunchKernelGGL(cpb_hidden_kernel, dim3((T2 * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, w2, hid, dhid, ws, pws, heads);
+        if (dw2) hipLaunchKernelGGL(cpb_reduce_kernel, dim3(8, heads), dim3(1024), 0, st, hid, dt, dw2, (float*)nullptr, ws, pws, heads, 0);
+        if (dw0 || db0) hipLaunchKernelGGL(cpb_reduce_kernel, dim3(8, 3), dim3(1024), 0, st, dhid, dt, dw0, db0, ws, pws, heads, 1);
+    }
     TK("attn_param_grads");
 }
 int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err) {

@@ -29,6 +29,9 @@ const std::string ENC = "depth_net.pretrained.model.";
 const std::string SCR = "depth_net.scratch.";
 std::string blk_key(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
 
+constexpr size_t kTrainSkPartFloats = (size_t)8 << 20;   // 32 MB of f32 split-K partials
+constexpr size_t kTrainSkCountWords = 4096;
+
 struct BlkT {
     float *qkv_bias, *scale, *table, *bias_acc;
     const float* xin;
@@ -53,7 +56,9 @@ struct Tape {
     // backward scratch
     float *G[5], *GX, *GP, *DOC, *DF[4];
     float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
-    float *dS, *rowstat, *dscale_part, *dtable, *dt;
+    float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb;
+    float* sk_part;
+    unsigned* sk_count;
     size_t maxAct = 0;
     float dropout_p = 0.f;
 };
@@ -78,6 +83,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     T.path1 = halo(r1, F);
     T.d1u = halo(r0, F / 2);
+    T.sk_count = reinterpret_cast<unsigned*>(ar.f(kTrainSkCountWords));   // split-K arrival counters: zero at rest (zeroed with the halos)
     ar.f(0);
     T.halo_hi = (ar.off + 255) & ~size_t(255);
     // ---- encoder tape ----
@@ -158,13 +164,15 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     const size_t Cmax = a.dim(3);
     T.S_wt = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
     T.S_dw = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
-    T.S_col = ar.f(64 * std::max((size_t)4 * Cmax, (size_t)3 * F));
+    T.S_col = ar.f((size_t)1 << 20);
+    T.sk_part = ar.f(kTrainSkPartFloats);
     T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
     T.dS = ar.f(maxDS);
     T.rowstat = ar.f(maxStat);
     T.dscale_part = ar.f(maxPart);
     T.dtable = ar.f(maxTab);
     T.dt = ar.f(maxTab);
+    T.S_cpb = ar.f((size_t)2 * (2 * a.window - 1) * (2 * a.window - 1) * 512);
 }
 
 struct Ctx {
@@ -181,6 +189,22 @@ struct Ctx {
 
 int gemm(Ctx& c, IgemmDesc d) {
     d.f32 = 1;
+    return launch_igemm(d, c.st, c.err);
+}
+
+// Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
+// in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.
+int gemm_wgrad(Ctx& c, IgemmDesc d) {
+    d.f32 = 1;
+    const long tiles = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    const long nk = (long)d.taps * d.Cin / 32;
+    long S = (512 + tiles - 1) / tiles;
+    if (S > nk / 8) S = nk / 8;
+    if (S > 64) S = 64;
+    while (S > 1 && (size_t)S * d.M * d.N > kTrainSkPartFloats) --S;
+    if (S > 1 && (size_t)tiles <= kTrainSkCountWords) {
+        d.splitk = (int)S; d.sk_part = c.T.sk_part; d.sk_count = c.T.sk_count; d.sk_part_floats = kTrainSkPartFloats; d.sk_count_words = kTrainSkCountWords;
+    }
     return launch_igemm(d, c.st, c.err);
 }
 
@@ -204,7 +228,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
         TRY(tr_transpose(X, T.S_T2, (int)M, K, c.st, c.err));    // [K][M]
         IgemmDesc d;
         d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = K; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = dW;
-        TRY(gemm(c, d));
+        TRY(gemm_wgrad(c, d));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
     return 0;
@@ -230,7 +254,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, c.st, c.err));        // [9C][M]
         IgemmDesc d;
         d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = T.S_dw;
-        TRY(gemm(c, d));
+        TRY(gemm_wgrad(c, d));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
@@ -443,6 +467,16 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
     const bool enc_train = any_grad(h, ENC);
+    // Frozen prefixes (freeze helpers of model/loss.py, PatchWiseInplace): the gradient stops flowing where nothing upstream is trainable
+    bool lvl_own[4], lvl_side[4];   // level l: RCU2 / out_conv / anything coarser  |  RCU1 + layer_rn + encoder hook
+    for (int l = 0; l < 4; ++l) {
+        const std::string rb = SCR + "refinenet" + std::to_string(l + 1) + ".";
+        lvl_own[l] = any_grad(h, rb + "out_conv") || any_grad(h, rb + "resConfUnit2");
+        lvl_side[l] = enc_train || any_grad(h, rb + "resConfUnit1") || any_grad(h, SCR + "layer" + std::to_string(l + 1) + "_rn");
+    }
+    bool need_level[5];             // the gradient has to reach level l's out_conv output
+    need_level[4] = false;
+    for (int l = 3; l >= 0; --l) need_level[l] = lvl_own[l] || lvl_side[l] || need_level[l + 1];
     // the block buffers are re-derived from the same walk as the forward's: xin pointers
     {
         const float* xcur = T.x0;
@@ -463,7 +497,8 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         }
         TRY(conv3_bwd(c, G[0], T.d1u, c.W(SCR + "output_conv.2.weight"), r0, 32, F / 2, G[2], nullptr, c.Gd(SCR + "output_conv.2.weight"), c.Gd(SCR + "output_conv.2.bias")));
         TRY(tr_bilinear_bwd(G[2], G[3], B, r1, r1, r0, r0, F / 2, 0, st, err));
-        TRY(conv3_bwd(c, G[3], T.path1, c.W(SCR + "output_conv.0.weight"), r1, F / 2, F, T.GP, nullptr, c.Gd(SCR + "output_conv.0.weight"), c.Gd(SCR + "output_conv.0.bias")));
+        TRY(conv3_bwd(c, G[3], T.path1, c.W(SCR + "output_conv.0.weight"), r1, F / 2, F, need_level[0] ? T.GP : nullptr, nullptr, c.Gd(SCR + "output_conv.0.weight"),
+                      c.Gd(SCR + "output_conv.0.bias")));
     }
     // ---------------- seg head ----------------
     {
@@ -484,8 +519,9 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         if (float* p = c.Gd("seg_head.1.bias")) TRY(copy_d2d(c, p, dbeta, F * 4, "train_backward"));
         if (float* p = c.Gd("seg_head.1.weight")) TRY(copy_d2d(c, p, dgamma, F * 4, "train_backward"));
         TRY(tr_bn_bwd(G[0], T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), dbeta, dgamma, G[2], M1, F, st, err));
-        TRY(conv3_bwd(c, G[2], T.path1, c.W("seg_head.0.weight"), r1, F, F, T.GP, T.GP, c.Gd("seg_head.0.weight"), nullptr));
+        TRY(conv3_bwd(c, G[2], T.path1, c.W("seg_head.0.weight"), r1, F, F, need_level[0] ? T.GP : nullptr, T.GP, c.Gd("seg_head.0.weight"), nullptr));
     }
+    if (!need_level[0]) return 0;
     TRY(tr_bilinear_bwd(T.GP, T.DOC, B, a.fres(0), a.fres(0), r1, r1, F, 0, st, err));
     // ---------------- decoder, fine -> coarse ----------------
     for (int l = 0; l < 4; ++l) {
@@ -503,8 +539,13 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
             TRY(tr_relu_bwd(G[2], fused_raw, G[0], G[3], M * F, st, err));   // d fused_raw
         }
         const float* d_lrn = G[3];
-        if (l < 3) {
+        if (l < 3 && need_level[l + 1])
             TRY(tr_bilinear_bwd(G[3], T.DOC, B, a.fres(l + 1), a.fres(l + 1), r, r, F, 0, st, err));   // gradient of the coarser level's out_conv output
+        if (!lvl_side[l]) {
+            if (!need_level[l + 1]) return 0;
+            continue;
+        }
+        if (l < 3) {
             const std::string ub = rb + "resConfUnit1.";
             TRY(conv3_bwd(c, G[3], T.t1[l], c.W(ub + "conv2.weight"), r, F, F, G[1], nullptr, c.Gd(ub + "conv2.weight"), c.Gd(ub + "conv2.bias")));
             TRY(tr_relu_bwd_halo(G[1], T.t1[l], nullptr, G[1], B, r, r, F, st, err));
@@ -518,6 +559,17 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     if (!enc_train) return 0;
     // ---------------- encoder, last stage -> first ----------------
     bool have = false;   // GX holds a gradient
+    // trainable parameters at or before (stage s, block j) in forward order?  The walk ends below the earliest one.
+    auto trains_upto = [&](int s, int j) {
+        if (any_grad(h, ENC + "patch_embed.")) return true;
+        for (int t = 0; t <= s; ++t) {
+            if (t < s && any_grad(h, ENC + "layers." + std::to_string(t) + ".")) return true;
+            if (t == s)
+                for (int i = 0; i <= j; ++i)
+                    if (any_grad(h, blk_key(s, i))) return true;
+        }
+        return false;
+    };
     for (int s = 3; s >= 0; --s) {
         const int C = a.dim(s), res = a.res(s), wsz = a.ws(s), H = a.heads[s];
         const size_t M = (size_t)B * res * res;
@@ -530,6 +582,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
                 have = true;
             }
             if (!have) continue;   // blocks after the last hooked one do not reach the outputs
+            if (!trains_upto(s, j)) return 0;
             // xout = x1 + LN2(m_pre)
             TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), T.GX, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
             TRY(linear_bwd(c, G[0], b.hact, c.W(k + "mlp.fc2.weight"), M, C, 4 * C, G[2], nullptr, c.Gd(k + "mlp.fc2.weight"), c.Gd(k + "mlp.fc2.bias")));
@@ -544,12 +597,10 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
                 float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
                 float* db0 = c.Gd(k + "attn.cpb_mlp.0.bias");
                 float* dw2 = c.Gd(k + "attn.cpb_mlp.2.weight");
-                if (dls || dw0 || db0 || dw2) {
-                    float* tmp0 = T.S_vec;               // 1024 + 512 floats of scratch when only some of the three are bound
+                if (dls || dw0 || db0 || dw2)
                     TRY(tr_attn_param_grads(T.dS, T.dscale_part, b.table, c.W(k + "attn.logit_scale"), c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"),
-                                            c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, dls, dw0 ? dw0 : (db0 ? tmp0 : nullptr), db0 ? db0 : (dw0 ? tmp0 + 1024 : nullptr),
-                                            dw2, B * (res / wsz) * (res / wsz), wsz, a.pretrained_window[s], H, st, err));
-                }
+                                            c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, T.S_cpb, dls, dw0, db0, dw2, B * (res / wsz) * (res / wsz), wsz,
+                                            a.pretrained_window[s], H, st, err));
             }
             {
                 float* dq = c.Gd(k + "attn.q_bias");
@@ -560,6 +611,11 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
             }
         }
         if (!have) continue;
+        {   // anything trainable in patch_embed or stages < s (their blocks and PatchMerging)?
+            bool below = any_grad(h, ENC + "patch_embed.");
+            for (int t = 0; t < s; ++t) below = below || any_grad(h, ENC + "layers." + std::to_string(t) + ".");
+            if (!below) return 0;
+        }
         if (s > 0) {
             // x_s = LN(reduction(gather(x_{s-1})))   (timm PatchMerging of Swin-V2: reduction then norm)
             const int Cp = a.dim(s - 1);

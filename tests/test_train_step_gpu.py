@@ -144,3 +144,43 @@ def test_train_step_requires_f32(gpu_device):
     m = m.to(gpu_device).train()
     with pytest.raises(RuntimeError, match="PREC_F32"):
         m.train_forward(synth_input(1).to(gpu_device))
+
+
+def test_partial_freeze_matches_full_backward(gpu_device):
+    """PatchWiseInplace / unfreeze_pretrained_encoder_by_percentage leave arbitrary subsets trainable; the backward skips the weight
+    gradients of frozen tensors and stops where nothing upstream is trainable.  Every gradient it does produce must equal the one of the
+    all-trainable run bit for bit (same kernels, same order)."""
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _make(gpu_device)
+    m.train()
+    m.seg_head[3].p = 0.0
+    x = synth_input(1, seed0=8).to(gpu_device)
+    g = torch.Generator().manual_seed(4)
+    a = torch.randn((1, 256, 256), generator=g).to(gpu_device)
+    b = torch.randn((1, 3, 256, 256), generator=g).to(gpu_device)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    m.train_forward(x)
+    m.backward(a, b)
+    full = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    names = [k for k, _ in m.named_parameters()]
+    subsets = {
+        "seg head only": [k for k in names if k.startswith("seg_head.")],
+        "coarse decoder": [k for k in names if "refinenet4" in k or "refinenet3" in k or "layer4_rn" in k],
+        "encoder stage 2 block 3": [k for k in names if "layers.2.blocks.3." in k],
+        "every third tensor": names[::3],
+        "patch embedding": [k for k in names if "patch_embed" in k],
+    }
+    for label, keep in subsets.items():
+        keep = set(keep)
+        for k, p in m.named_parameters():
+            p.requires_grad_(k in keep)
+            p.grad = None
+        m.train_forward(x)
+        m.backward(a, b)
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if k in keep and k in full:
+                assert p.grad is not None and torch.equal(p.grad, full[k]), (label, k)
+            else:
+                assert p.grad is None, (label, k)
