@@ -315,6 +315,11 @@ int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_in
                           float dropout_p, uint32_t seed, void* stream);
 int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float* dev_d_inv, const float* dev_d_seg, void* dev_workspace,
                            size_t workspace_bytes, void* stream);
+/* Location of a saved activation / gradient inside the training workspace (tests, debugging): f32 [pixels][channels], NHWC order.
+ * "seg_conv" (seg_head.0 output), "seg_act" (after BatchNorm + ReLU + Dropout), "seg_logits", "depth_conv0", "depth_conv2", "lrn_raw<l>"
+ * (layer<l+1>_rn output), "fused_raw<l>" (RCU2 input of refinenet<l+1>, l < 3), "rcu2_out<l>", "fusion_out<l>" (out_conv output, before
+ * the resize), and after a backward "d_path1", "d_feat<l>" (gradient w.r.t. the hooked encoder map l).  Non-zero for unknown names. */
+int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems);
 
 /* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
  * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "seg_logits" (seg head before up-sampling/activation, f32 [B,2G,2G,3]), "xf" (final stage tokens f32).

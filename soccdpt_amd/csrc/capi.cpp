@@ -105,6 +105,11 @@ int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad) {
     return 0;
 }
 size_t soccdpt_train_workspace_bytes(void* handle, int B) { return handle && B > 0 ? train_workspace_bytes(*static_cast<Handle*>(handle), B) : 0; }
+int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !byte_offset || !elems) return 1;
+    return train_workspace_tensor(*h, B, name, byte_offset, elems);
+}
 int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_inv, float* dev_seg, void* dev_workspace, size_t workspace_bytes,
                           float dropout_p, uint32_t seed, void* stream) {
     Handle* h = static_cast<Handle*>(handle);

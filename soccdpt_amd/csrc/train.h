@@ -5,8 +5,8 @@
 
 namespace soccdpt {
 
-int tr_transpose(const float* in, float* out, int R, int C, hipStream_t st, std::string& err);
-int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err);
+int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
@@ -18,7 +18,7 @@ int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, f
 int tr_gelu_bwd(const float* dy, const float* pre, float* dx, size_t n, hipStream_t st, std::string& err);
 int tr_ln_bwd(const float* y, const float* g, const float* dout, float* dy, float* xhat, int M, int C, float eps, hipStream_t st, std::string& err);
 int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
-int tr_bn_stats(const float* sum, const float* sumsq, float* stats, float* rmean, float* rvar, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err);
+int tr_bn_stats(const float* x, float* stats, float* rmean, float* rvar, void* scratch, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err);
 int tr_bn_relu_dropout_fwd(const float* x, const float* stats, const float* gamma, const float* beta, float* out, uint8_t* keep, size_t M, int C, float p, uint32_t seed, hipStream_t st, std::string& err);
 int tr_bn_relu_dropout_bwd_pre(const float* dout, const float* out, const uint8_t* keep, float* dz, size_t n, float p, hipStream_t st, std::string& err);
 int tr_bn_bwd(const float* dz, const float* x, const float* stats, const float* gamma, const float* dbeta, const float* dgamma, float* dx, size_t M, int C, hipStream_t st, std::string& err);
@@ -38,6 +38,7 @@ int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStre
 
 // train_step.cpp: SOccDPT_V3 training step (model/SOccDPT.py:660-685 in train mode + autograd), SOCCDPT_PREC_F32 only
 size_t train_workspace_bytes(Handle& h, int B);
+int train_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems);
 int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t st, std::string& err);
 int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err);
 

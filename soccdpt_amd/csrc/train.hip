@@ -14,8 +14,8 @@ namespace {
 constexpr float LN100 = 4.605170185988092f;
 
 // ---------------- layout ----------------
-// [R][C] -> [C][R], 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C) {
+// [R][C] -> [C][Rp] (Rp >= R: rows padded with zeros up to the k-tile multiple the igemm needs), 32 x 32 tiles through LDS
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, int Rp) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: column block of `in`, by: row block
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -26,12 +26,12 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = bx + i, r = by + tx;
-        if (c < C && r < R) out[(size_t)c * R + r] = t[tx][i];
+        if (c < C && r < Rp) out[(size_t)c * Rp + r] = t[tx][i];
     }
 }
 
 // zero-haloed NHWC image [B][H+2][W+2][C] -> im2col^T [(tap*C + c)][m], m = (b, y, x): the Wt operand of the 3x3 wgrad GEMM
-__global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C) {
+__global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C, size_t Mp) {
     __shared__ float t[32][33];
     const size_t M = (size_t)B * H * W;
     const int tap = blockIdx.z, ky = tap / 3, kx = tap % 3;
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ 
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i;
         const size_t m = m0 + tx;
-        if (c < C && m < M) out[((size_t)tap * C + c) * M + m] = t[tx][i];
+        if (c < C && m < Mp) out[((size_t)tap * C + c) * Mp + m] = t[tx][i];
     }
 }
 
@@ -253,17 +253,40 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dhi, float* __rest
 // ---------------- seg head (train mode) ----------------
 // BatchNorm2d with batch statistics over [M][C] (NHWC rows): stats[c] = {mean, invstd}; y = relu(gamma * xhat + beta) * keep / (1 - p);
 // running_mean / running_var updated like nn.BatchNorm2d(momentum 0.1, unbiased variance).  Deterministic: colsum kernels feed bn_stats.
-__global__ void bn_stats_kernel(const float* __restrict__ sum, const float* __restrict__ sumsq, float* __restrict__ stats, float* running_mean,
-                                float* running_var, int C, size_t M, float eps, float momentum) {
+// Two passes in float64 (mean, then the centred second moment): the normalised values feed a ReLU, and a mean that is off by 1e-6 of
+// the spread flips the mask of the activations nearest zero -- each flip is an O(1) local gradient difference against autograd.
+// pass: 0 -> part[ch][c] = sum x;  1 -> part[ch][c] = sum (x - mean[c])^2   (block = 64 channels x 4 row phases, `chunks` row chunks)
+__global__ __launch_bounds__(256) void bn_moment_part_kernel(const float* __restrict__ x, const double* __restrict__ mean, double* __restrict__ part, size_t M, int C,
+                                                             int chunks, int pass) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + tx, ch = blockIdx.y;
+    const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
+    double s = 0.0;
+    if (c < C) {
+        const double mu = pass ? mean[c] : 0.0;
+        for (size_t m = lo + ty; m < hi; m += 4) {
+            const double v = (double)x[m * C + c] - mu;
+            s += pass ? v * v : v;
+        }
+    }
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && c < C) part[(size_t)ch * C + c] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+}
+// pass 0: mean[c];  pass 1: stats[c] = {mean, invstd} and the running buffers (momentum, unbiased variance) like nn.BatchNorm2d
+__global__ void bn_moment_final_kernel(const double* __restrict__ part, double* __restrict__ mean, float* __restrict__ stats, float* running_mean, float* running_var, int C,
+                                       size_t M, int chunks, float eps, float momentum, int pass) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
-    const double mean = (double)sum[c] / (double)M;
-    double var = (double)sumsq[c] / (double)M - mean * mean;
-    var = var > 0.0 ? var : 0.0;
-    stats[2 * c] = (float)mean;
+    double s = 0.0;
+    for (int k = 0; k < chunks; ++k) s += part[(size_t)k * C + c];
+    if (!pass) { mean[c] = s / (double)M; return; }
+    const double var = s / (double)M;
+    stats[2 * c] = (float)mean[c];
     stats[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
     if (running_mean) {
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean[c];
         running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)(var * (double)M / (double)(M > 1 ? M - 1 : 1));
     }
 }
@@ -858,13 +881,12 @@ inline unsigned gs_blocks(size_t n) {
 
 #define TK(name) return check_launch(name, err)
 
-int tr_transpose(const float* in, float* out, int R, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (R + 31) / 32), dim3(256), 0, st, in, out, R, C);
+int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose");
 }
-int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
-    const size_t M = (size_t)B * H * W;
-    hipLaunchKernelGGL(im2colT_kernel, dim3((C + 31) / 32, (unsigned)((M + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C);
+int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(im2colT_kernel, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT");
 }
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err) {
@@ -917,8 +939,15 @@ int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, in
     hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
     TK("bilinear_bwd");
 }
-int tr_bn_stats(const float* sum, const float* sumsq, float* stats, float* rmean, float* rvar, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(bn_stats_kernel, dim3((C + 255) / 256), dim3(256), 0, st, sum, sumsq, stats, rmean, rvar, C, M, eps, momentum);
+// scratch: (128 * C + C) doubles
+int tr_bn_stats(const float* x, float* stats, float* rmean, float* rvar, void* scratch, int C, size_t M, float eps, float momentum, hipStream_t st, std::string& err) {
+    const int chunks = 128;
+    double* part = static_cast<double*>(scratch);
+    double* mean = part + (size_t)chunks * C;
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(bn_moment_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, mean, part, M, C, chunks, pass);
+        hipLaunchKernelGGL(bn_moment_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, mean, stats, rmean, rvar, C, M, chunks, eps, momentum, pass);
+    }
     TK("bn_stats");
 }
 int tr_bn_relu_dropout_fwd(const float* x, const float* stats, const float* gamma, const float* beta, float* out, uint8_t* keep, size_t M, int C, float p, uint32_t seed,

@@ -158,8 +158,8 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.GP = ar.f(M1 * F);
     T.DOC = ar.f((size_t)B * a.fres(0) * a.fres(0) * F);
     for (int l = 0; l < 4; ++l) T.DF[l] = ar.f((size_t)B * a.fres(l) * a.fres(l) * a.fdim(l));
-    T.S_T1 = ar.f(maxAct);
-    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct));
+    T.S_T1 = ar.f(maxAct + 32 * 4 * (size_t)a.dim(3));
+    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 32 * 9 * (size_t)a.dim(3));
     T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)));
     const size_t Cmax = a.dim(3);
     T.S_wt = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
@@ -218,16 +218,17 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
     if (dX_out) {
-        TRY(tr_transpose(W, T.S_wt, N, K, c.st, c.err));   // [K][N]
+        TRY(tr_transpose(W, T.S_wt, N, K, N, c.st, c.err));   // [K][N]
         IgemmDesc d;
         d.X = dY; d.Wt = T.S_wt; d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
         TRY(gemm(c, d));
     }
     if (dW) {
-        TRY(tr_transpose(dY, T.S_T1, (int)M, N, c.st, c.err));   // [N][M]
-        TRY(tr_transpose(X, T.S_T2, (int)M, K, c.st, c.err));    // [K][M]
+        const int Mp = (int)((M + 31) / 32 * 32);                    // k-tile multiple; the padding rows are zero
+        TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));   // [N][Mp]
+        TRY(tr_transpose(X, T.S_T2, (int)M, K, Mp, c.st, c.err));    // [K][Mp]
         IgemmDesc d;
-        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = K; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = dW;
+        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = K; d.Cin = Mp; d.ldx = Mp; d.out_f32 = dW;
         TRY(gemm_wgrad(c, d));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
@@ -250,10 +251,11 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         TRY(gemm(c, d));
     }
     if (dW) {
-        TRY(tr_transpose(dY, T.S_T1, (int)M, N, c.st, c.err));          // [N][M]
-        TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, c.st, c.err));        // [9C][M]
+        const int Mp = (int)((M + 31) / 32 * 32);
+        TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));          // [N][Mp]
+        TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
         IgemmDesc d;
-        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = (int)M; d.ldx = (int)M; d.out_f32 = T.S_dw;
+        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = Mp; d.ldx = Mp; d.out_f32 = T.S_dw;
         TRY(gemm_wgrad(c, d));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }
@@ -293,6 +295,42 @@ int check_train(Handle& h, int B, const void* ws, size_t ws_bytes, std::string& 
 }
 
 }  // namespace
+
+// Named tape tensors for tests / debugging: f32, plain [rows][C] unless noted.
+int train_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems) {
+    if (h.arch.hybrid || B < 1 || !name) return 1;
+    char base[256];
+    TArena ar(base);   // a non-null base: offsets come out as pointer differences
+    Tape T;
+    carve(h, B, ar, T);
+    const Arch& a = h.arch;
+    const int F = h.cfg.features, r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
+    const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
+    const float* p = nullptr;
+    size_t n = 0;
+    const std::string k = name;
+    if (k == "seg_conv") { p = T.c_raw; n = M1 * F; }                 // seg_head.0 output (pre-BatchNorm)
+    else if (k == "seg_act") { p = T.r; n = M1 * F; }                 // after BatchNorm + ReLU + Dropout
+    else if (k == "seg_logits") { p = T.logits; n = M1 * 3; }
+    else if (k == "depth_conv2") { p = T.e; n = M0p * 32; }           // output_conv.2 output (pre-ReLU)
+    else if (k == "depth_conv0") { p = T.d1; n = M1 * (size_t)(F / 2); }
+    else if (k == "d_path1") { p = T.GP; n = M1 * F; }                // gradient w.r.t. path_1 (after the backward)
+    else {
+        for (int l = 0; l < 4 && !p; ++l) {
+            const size_t M = (size_t)B * a.fres(l) * a.fres(l);
+            const std::string sl = std::to_string(l);
+            if (k == "lrn_raw" + sl) { p = T.lrn_raw[l]; n = M * F; }
+            else if (k == "fusion_out" + sl) { p = T.oc[l]; n = M * F; }
+            else if (k == "rcu2_out" + sl) { p = T.u[l]; n = M * F; }
+            else if (k == "fused_raw" + sl && l < 3) { p = T.out_raw[l]; n = M * F; }
+            else if (k == "d_feat" + sl) { p = T.DF[l]; n = M * a.fdim(l); }
+        }
+    }
+    if (!p) return 1;
+    *byte_offset = (size_t)(reinterpret_cast<const char*>(p) - base);
+    *elems = n;
+    return 0;
+}
 
 size_t train_workspace_bytes(Handle& h, int B) {
     TArena ar(nullptr);
@@ -440,12 +478,8 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
         IgemmDesc d = conv_desc(T.path1, F, T.w_s0, F, r1, B);
         d.out_f32 = T.c_raw;
         TRY(gemm(c, d));
-        float* sum = T.S_vec;
-        float* sumsq = T.S_vec + F;
-        TRY(tr_colsum(T.c_raw, nullptr, sum, T.S_col, M1, F, 0, st, err));
-        TRY(tr_colsum(T.c_raw, T.c_raw, sumsq, T.S_col, M1, F, 0, st, err));
-        TRY(tr_bn_stats(sum, sumsq, T.bn_stats, const_cast<float*>(c.W("seg_head.1.running_mean")), const_cast<float*>(c.W("seg_head.1.running_var")), F, M1, 1e-5f, 0.1f, st,
-                        err));
+        TRY(tr_bn_stats(T.c_raw, T.bn_stats, const_cast<float*>(c.W("seg_head.1.running_mean")), const_cast<float*>(c.W("seg_head.1.running_var")), T.S_col, F, M1, 1e-5f,
+                        0.1f, st, err));
         TRY(tr_bn_relu_dropout_fwd(T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), c.W("seg_head.1.bias"), T.r, T.keep, M1, F, dropout_p, seed, st, err));
         TRY(launch_seg_tail(T.r, 1, 0, c.W("seg_head.4.weight"), c.W("seg_head.4.bias"), T.logits, T.seg, B, r1, r1, h.cfg.sigmoid, st, err));
         TRY(copy_d2d(c, seg, T.seg, M0p * 3 * 4, "train_forward seg"));

@@ -129,6 +129,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_train_workspace_bytes.restype = cs
     L.soccdpt_train_forward.argtypes = [vp, vp, ci, vp, vp, vp, cs, ctypes.c_float, ctypes.c_uint32, vp]
     L.soccdpt_train_backward.argtypes = [vp, vp, ci, vp, vp, vp, cs, vp]
+    L.soccdpt_train_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs)]
     L.soccdpt_project.restype = ci
     L.soccdpt_occ_or.argtypes = [vp, vp, vp, ci, vp]
     L.soccdpt_occ_or.restype = ci
@@ -366,6 +367,14 @@ class Engine:
         if cur is None or cur.numel() < nbytes:
             self._train_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         return self._train_ws
+
+    def train_tensor(self, B: int, name: str, channels: int) -> torch.Tensor:
+        """A saved activation / gradient of the training workspace as an f32 [pixels, channels] view (see soccdpt_train_workspace_tensor)."""
+        off, n = ctypes.c_size_t(), ctypes.c_size_t()
+        if self.L.soccdpt_train_workspace_tensor(self._h, B, name.encode(), ctypes.byref(off), ctypes.byref(n)) != 0:
+            raise KeyError(name)
+        ws = self.train_workspace(B)
+        return ws[off.value: off.value + 4 * n.value].view(torch.float32).view(-1, channels)
 
     def train_forward(self, x: torch.Tensor, inv: torch.Tensor, seg: torch.Tensor, dropout_p: float = 0.1, seed: int = 0):
         B = x.shape[0]

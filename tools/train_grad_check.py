@@ -1,7 +1,7 @@
 """Per-parameter gradient report of the HIP training step against torch autograd over the CPU oracle (the same comparison as
 tests/test_train_step_gpu.py, printed in network order so that the first wrong gradient walking backwards locates a bug).
 
-    python tools/train_grad_check.py [B] [sigmoid 0|1]
+    python tools/train_grad_check.py [B] [sigmoid 0|1] [model_type]
 """
 import os, sys, tempfile, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,25 +9,29 @@ import torch
 from oracle import soccdpt_ref as R
 from soccdpt_amd.lib import PREC_F32
 from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
 from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 sigmoid = bool(int(sys.argv[2])) if len(sys.argv) > 2 else False
+model_type = sys.argv[3] if len(sys.argv) > 3 else "dpt_swin2_tiny_256"
+backbone = MODEL_TYPE_TO_BACKBONE[model_type]
+S = backbone_image_size(backbone)
 dev = torch.device("cuda:0")
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
-m = SOccDPT_V3(sigmoid=sigmoid, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
-sd = synth_state_dict(alias_pretrained=True)
+m = SOccDPT_V3(sigmoid=sigmoid, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+sd = synth_state_dict(backbone, alias_pretrained=True)
 m.load_state_dict(sd, strict=False)
 m = m.to(dev).train()
 m.seg_head[3].p = 0.0
-x = synth_input(B, seed0=3)
+x = synth_input(B, size=S, seed0=3)
 g = torch.Generator().manual_seed(11)
-a = torch.randn((B, 256, 256), generator=g)
-b = torch.randn((B, 3, 256, 256), generator=g)
+a = torch.randn((B, S, S), generator=g)
+b = torch.randn((B, 3, S, S), generator=g)
 def oracle(dt):
     sd_o = {k: (v.clone().to(dt).requires_grad_(True) if v.is_floating_point() and "running_" not in k else (v.clone().to(dt) if v.is_floating_point() else v.clone()))
             for k, v in sd.items()}
-    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, x.to(dt), sigmoid=sigmoid, training=True)
+    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, x.to(dt), backbone=backbone, sigmoid=sigmoid, training=True)
     ((o_inv * a.to(dt)).sum() + (o_seg * b.to(dt)).sum()).backward()
     return sd_o, o_inv, o_seg
 t0 = time.time()
