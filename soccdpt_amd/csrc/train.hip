@@ -460,12 +460,13 @@ __global__ void pad_cols_kernel(const float* __restrict__ in, float* __restrict_
 
 // Cosine window attention backward, one workgroup (64 threads) per (sample, window, head, 64-query block); one thread = one query.
 //   q^ = scale * q/|q|, k^ = k/|k|, S = q^ k^T + bias(rel) + mask, P = softmax(S), O = P v
-// Pass A (this kernel, per query): recompute the row statistics, then for every key: p, dP = dO . v, dS = p (dP - sum_j p_j dP_j);
+// Pass A (this kernel, per query): with the row statistics of attn_rowstat_kernel and delta = dO . O, for every key: p, dP = dO . v, dS = p (dP - delta);
 //   accumulates dq^ (registers), and writes dS to a [.., N, N] scratch for pass B (per key) -- deterministic, no atomics.
 // The bias-table and logit-scale gradients are reduced from that scratch by their own kernels.
 __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
-                                                        const float* __restrict__ scale, float* __restrict__ dS_out, float* __restrict__ dqkv,
-                                                        float* __restrict__ dscale_part, int res, int ws, int shift, int heads) {
+                                                        const float* __restrict__ scale, const float* __restrict__ rowstat, const float* __restrict__ attn_out,
+                                                        float* __restrict__ dS_out, float* __restrict__ dqkv, float* __restrict__ dscale_part, int res, int ws, int shift,
+                                                        int heads) {
     __shared__ float Kh[64][33];
     __shared__ float Vs[64][33];
     const int N = ws * ws, nqb = (N + 63) / 64;
@@ -533,30 +534,15 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
         for (int d = 0; d < 32; ++d) { Kh[tid][d] = kr[d] * ki; Vs[tid][d] = src[2 * C + d]; }
         __syncthreads();
     };
-    // pass 1: row max and sum
-    float m = -3.0e38f, l = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
-        stage(k0);
-        const int nk = (N - k0) < 64 ? (N - k0) : 64;
-        for (int kk = 0; kk < nk; ++kk) {
-            const float s = logit(kk, k0);
-            const float mn = fmaxf(m, s);
-            l = l * __expf(m - mn) + __expf(s - mn);
-            m = mn;
-        }
-    }
-    // pass 2: delta = sum_j p_j (dO . v_j)
-    float delta = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
-        stage(k0);
-        const int nk = (N - k0) < 64 ? (N - k0) : 64;
-        for (int kk = 0; kk < nk; ++kk) {
-            const float p = __expf(logit(kk, k0) - m) / l;
-            float dp = 0.f;
+    // row statistics {max, sum exp} come from attn_rowstat_kernel; delta = sum_j p_j (dO . v_j) = dO . O with O the saved attention output
+    float m, l, delta = 0.f;
+    {
+        const float* rs = rowstat + (((size_t)widx * heads + head) * N + qc) * 2;
+        m = rs[0];
+        l = rs[1];
+        const float* orow = attn_out + token_row(qc) * (size_t)C + head * 32;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) dp = fmaf(dOr[d], Vs[kk][d], dp);
-            delta += p * dp;
-        }
+        for (int d = 0; d < 32; ++d) delta = fmaf(dOr[d], orow[d], delta);
     }
     // pass 3: dS, dq^
     float dsc = 0.f;
@@ -1009,12 +995,12 @@ int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream
     TK("pad_cols");
 }
 // dS scratch: nwin * heads * N * N floats; rowstat: nwin * heads * N * 2; dscale_part: nwin * heads * nqb
-int tr_attention_bwd(const float* qkv, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* dqkv, int B, int res,
-                     int ws, int shift, int heads, hipStream_t st, std::string& err) {
+int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part,
+                     float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err) {
     const int nw = res / ws, N = ws * ws, nqb = (N + 63) / 64;
     const unsigned blocks = (unsigned)(B * nw * nw * heads * nqb);
     hipLaunchKernelGGL(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, rowstat, res, ws, shift, heads);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, dqkv, dscale_part, res, ws, shift, heads);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, rowstat, attn_out, dS, dqkv, dscale_part, res, ws, shift, heads);
     hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, dqkv, res, ws, shift, heads);
     TK("attention_bwd");
 }
