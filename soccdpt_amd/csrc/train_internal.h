@@ -1,0 +1,122 @@
+// Shared declarations of the training step's translation units (train_step.cpp: Swin-V2 encoders, decoder, heads; train_hybrid_step.cpp: the
+// ViT-hybrid encoder).
+#pragma once
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "train.h"
+
+namespace soccdpt {
+namespace trn {
+
+struct TArena {
+    char* base;
+    size_t off = 0;
+    explicit TArena(void* p) : base(static_cast<char*>(p)) {}
+    float* f(size_t n) {
+        off = (off + 255) & ~size_t(255);
+        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
+        off += n * sizeof(float);
+        return p;
+    }
+};
+
+static const std::string ENC = "depth_net.pretrained.model.";
+static const std::string HYB = "depth_net.pretrained.";
+static const std::string SCR = "depth_net.scratch.";
+inline std::string blk_key(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
+
+constexpr size_t kTrainSkPartFloats = (size_t)8 << 20;   // 32 MB of f32 split-K partials
+constexpr size_t kTrainSkCountWords = 4096;
+
+struct BlkT {
+    float *qkv_bias, *scale, *table, *bias_acc;
+    const float* xin;
+    float *qkv, *attn, *a_pre, *x1, *hpre, *hact, *m_pre, *xout;
+};
+
+// ViT-hybrid encoder tape (train_hybrid_step.cpp)
+struct RnBlkT {
+    int cin, cout, mid, stride, rin, rout;
+    bool proj;
+    std::string key;
+    const float* xin;                           // [B*rin*rin][cin]
+    float *w_ds, *w_c1, *w_c2, *w_c3;           // standardised weights, tap-major
+    float *ds_raw, *ds_stats, *c1_raw, *c1_stats, *t1 /*halo*/, *c2_raw, *c2_stats, *t2, *c3_raw, *c3_stats, *out;
+};
+struct VitBlkT {
+    const float* xin;
+    float *ln1, *qkv, *attn, *x1, *ln2, *hpre, *hact, *xout;
+};
+struct HyTape {
+    float *a0, *w_stem, *stem_raw, *stem_stats, *pool;
+    uint8_t* pool_idx;
+    std::vector<RnBlkT> blk;
+    float *pe_y, *x0;
+    std::vector<VitBlkT> vb;
+    float *cat[2], *ro_pre[2], *ro_act[2], *pp4_in /*halo*/, *w_pp4;
+    float* gn_part;
+    unsigned* gn_count;
+    size_t gn_part_floats = 0;
+    float *GT, *GR, *xg, *rowstat;             // token-stream / residual-stream gradients, strided-shortcut operand, attention row statistics
+};
+
+struct Tape {
+    HyTape hy;
+    // encoder
+    float *patches, *pe_wpad, *pe_pre, *x0;
+    std::vector<BlkT> blk[4];
+    float *mg[3], *mr_pre[3], *mx[3];
+    float* feat[4];   // zero-halo
+    // decoder (level 0 = finest); *_relu / t1 / t2 are zero-halo images
+    float *lrn_raw[4], *lrn_relu[4], *t1[4], *out_raw[4], *out_relu[4], *t2[4], *u[4], *oc[4];
+    float *w_lrn[4], *w_rcu[4][2][2];
+    float *path1, *d1, *d1u, *e, *inv, *seg;
+    float *w_d0, *w_d2, *w_s0;
+    float *c_raw, *bn_stats, *r, *logits;
+    uint8_t* keep;
+    // halo zone [halo_lo, halo_hi): zero-filled at the start of every forward
+    size_t halo_lo = 0, halo_hi = 0;
+    // backward scratch
+    float *G[5], *GX, *GP, *DOC, *DF[4];
+    float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
+    float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb;
+    float* sk_part;
+    unsigned* sk_count;
+    size_t maxAct = 0;
+    float dropout_p = 0.f;
+};
+
+struct Ctx {
+    Handle& h;
+    Tape& T;
+    int B;
+    hipStream_t st;
+    std::string& err;
+    const float* W(const std::string& key) const { return h.weights[h.index.at(key)].ptr; }
+    float* Gd(const std::string& key) const { return h.weights[h.index.at(key)].grad; }
+};
+
+#define TRY(call) do { if (call) return 1; } while (0)
+
+#define TRY(call) do { if (call) return 1; } while (0)
+
+int gemm(Ctx& c, IgemmDesc d);
+int gemm_wgrad(Ctx& c, IgemmDesc d);
+int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what);
+// y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
+int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db);
+int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db);
+int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps = 1e-5f);
+IgemmDesc conv_desc(const void* X, int Cin, const void* Wt, int N, int r, int B);
+bool any_grad(const Handle& h, const std::string& prefix);
+
+// train_hybrid_step.cpp
+void hy_carve_halo(const Handle& h, int B, TArena& ar, Tape& T);   // inside the zero-filled zone
+void hy_carve(const Handle& h, int B, TArena& ar, Tape& T, size_t& maxAct);
+int hy_forward(Ctx& c, const float* x);       // fills T.feat[0..3]
+int hy_backward(Ctx& c);                       // consumes T.DF[0..3]
+
+}  // namespace trn
+}  // namespace soccdpt

@@ -6,62 +6,12 @@
 //
 // Gradients are WRITTEN (not accumulated) to the buffers bound with soccdpt_bind_grad; a weight without a bound gradient is frozen and its
 // weight-gradient GEMM is skipped (the reference freezes / partially unfreezes the encoder: model/loss.py:110-152).
-#include "train.h"
+#include "train_internal.h"
 
 #include <cstring>
 
 namespace soccdpt {
-namespace {
-
-struct TArena {
-    char* base;
-    size_t off = 0;
-    explicit TArena(void* p) : base(static_cast<char*>(p)) {}
-    float* f(size_t n) {
-        off = (off + 255) & ~size_t(255);
-        float* p = base ? reinterpret_cast<float*>(base + off) : nullptr;
-        off += n * sizeof(float);
-        return p;
-    }
-};
-
-const std::string ENC = "depth_net.pretrained.model.";
-const std::string SCR = "depth_net.scratch.";
-std::string blk_key(int s, int j) { return ENC + "layers." + std::to_string(s) + ".blocks." + std::to_string(j) + "."; }
-
-constexpr size_t kTrainSkPartFloats = (size_t)8 << 20;   // 32 MB of f32 split-K partials
-constexpr size_t kTrainSkCountWords = 4096;
-
-struct BlkT {
-    float *qkv_bias, *scale, *table, *bias_acc;
-    const float* xin;
-    float *qkv, *attn, *a_pre, *x1, *hpre, *hact, *m_pre, *xout;
-};
-
-struct Tape {
-    // encoder
-    float *patches, *pe_wpad, *pe_pre, *x0;
-    std::vector<BlkT> blk[4];
-    float *mg[3], *mr_pre[3], *mx[3];
-    float* feat[4];   // zero-halo
-    // decoder (level 0 = finest); *_relu / t1 / t2 are zero-halo images
-    float *lrn_raw[4], *lrn_relu[4], *t1[4], *out_raw[4], *out_relu[4], *t2[4], *u[4], *oc[4];
-    float *w_lrn[4], *w_rcu[4][2][2];
-    float *path1, *d1, *d1u, *e, *inv, *seg;
-    float *w_d0, *w_d2, *w_s0;
-    float *c_raw, *bn_stats, *r, *logits;
-    uint8_t* keep;
-    // halo zone [halo_lo, halo_hi): zero-filled at the start of every forward
-    size_t halo_lo = 0, halo_hi = 0;
-    // backward scratch
-    float *G[5], *GX, *GP, *DOC, *DF[4];
-    float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
-    float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb;
-    float* sk_part;
-    unsigned* sk_count;
-    size_t maxAct = 0;
-    float dropout_p = 0.f;
-};
+namespace trn {
 
 // One walk decides the layout; with base == nullptr it only measures.
 void carve(const Handle& h, int B, TArena& ar, Tape& T) {
@@ -84,15 +34,18 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.path1 = halo(r1, F);
     T.d1u = halo(r0, F / 2);
     T.sk_count = reinterpret_cast<unsigned*>(ar.f(kTrainSkCountWords));   // split-K arrival counters: zero at rest (zeroed with the halos)
+    if (a.hybrid) hy_carve_halo(h, B, ar, T);
     ar.f(0);
     T.halo_hi = (ar.off + 255) & ~size_t(255);
+    size_t maxAct = M0 * 64;
+    size_t maxDS = 0, maxStat = 0, maxTab = 0, maxPart = 0;
+    if (a.hybrid) hy_carve(h, B, ar, T, maxAct);
+    else {
     // ---- encoder tape ----
     T.patches = ar.f(M0 * 64);
     T.pe_wpad = ar.f((size_t)a.embed * 64);
     T.pe_pre = ar.f(M0 * a.embed);
     T.x0 = ar.f(M0 * a.embed);
-    size_t maxAct = M0 * 64;
-    size_t maxDS = 0, maxStat = 0, maxTab = 0, maxPart = 0;
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), H = a.heads[s], ws = a.ws(s);
         const size_t M = (size_t)B * res * res;
@@ -124,6 +77,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
             T.mx[s] = ar.f(M / 4 * 2 * C);
         }
     }
+    }
     // ---- decoder tape ----
     for (int l = 0; l < 4; ++l) {
         const size_t M = (size_t)B * a.fres(l) * a.fres(l);
@@ -153,17 +107,19 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     maxAct = std::max(maxAct, M0p * 33);
     T.maxAct = maxAct;
     // ---- backward scratch ----
+    const size_t Cmax0 = a.hybrid ? 1024 : (size_t)a.dim(3);
     for (auto& g : T.G) g = ar.f(maxAct);
-    T.GX = ar.f(M0 * a.embed);            // the largest token-stream gradient (stage 0; later stages are smaller)
+    T.GX = ar.f(a.hybrid ? 64 : M0 * a.embed);   // the largest token-stream gradient (stage 0; later stages are smaller)
     T.GP = ar.f(M1 * F);
     T.DOC = ar.f((size_t)B * a.fres(0) * a.fres(0) * F);
     for (int l = 0; l < 4; ++l) T.DF[l] = ar.f((size_t)B * a.fres(l) * a.fres(l) * a.fdim(l));
-    T.S_T1 = ar.f(maxAct + 32 * 4 * (size_t)a.dim(3));
-    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 32 * 9 * (size_t)a.dim(3));
+    T.S_T1 = ar.f(maxAct + 32 * 4 * Cmax0);
+    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 32 * 9 * Cmax0);
     T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)));
-    const size_t Cmax = a.dim(3);
-    T.S_wt = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
-    T.S_dw = ar.f(std::max((size_t)9 * F * F, 4 * Cmax * Cmax));
+    const size_t Cmax = a.hybrid ? 1024 : a.dim(3);
+    const size_t wmax = std::max(std::max((size_t)9 * F * F, 4 * Cmax * Cmax), a.hybrid ? (size_t)9 * 768 * 768 : 0);
+    T.S_wt = ar.f(wmax);
+    T.S_dw = ar.f(wmax);
     T.S_col = ar.f((size_t)1 << 20);
     T.sk_part = ar.f(kTrainSkPartFloats);
     T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
@@ -172,20 +128,8 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.dscale_part = ar.f(maxPart);
     T.dtable = ar.f(maxTab);
     T.dt = ar.f(maxTab);
-    T.S_cpb = ar.f((size_t)2 * (2 * a.window - 1) * (2 * a.window - 1) * 512);
+    T.S_cpb = ar.f(a.hybrid ? 64 : (size_t)2 * (2 * a.window - 1) * (2 * a.window - 1) * 512);
 }
-
-struct Ctx {
-    Handle& h;
-    Tape& T;
-    int B;
-    hipStream_t st;
-    std::string& err;
-    const float* W(const std::string& key) const { return h.weights[h.index.at(key)].ptr; }
-    float* Gd(const std::string& key) const { return h.weights[h.index.at(key)].grad; }
-};
-
-#define TRY(call) do { if (call) return 1; } while (0)
 
 int gemm(Ctx& c, IgemmDesc d) {
     d.f32 = 1;
@@ -265,8 +209,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
 }
 
 // out = LN(y) g + b backward: d y -> dy; gamma / beta gradients
-int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta) {
-    TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, 1e-5f, c.st, c.err));
+int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps) {
+    TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, eps, c.st, c.err));
     if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, M, C, 0, c.st, c.err));
     if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, M, C, 0, c.st, c.err));
     return 0;
@@ -286,7 +230,7 @@ bool any_grad(const Handle& h, const std::string& prefix) {
 
 int check_train(Handle& h, int B, const void* ws, size_t ws_bytes, std::string& err) {
     if (h.cfg.precision != SOCCDPT_PREC_F32) { err = "soccdpt_train_*: the training step is built for SOCCDPT_PREC_F32 handles only"; return 1; }
-    if (h.arch.hybrid) { err = "soccdpt_train_*: the ViT-hybrid encoder has no backward yet (Swin-V2 encoders only)"; return 1; }
+    if (h.arch.hybrid && h.arch.grid() != 24) { err = "soccdpt_train_*: the ViT-hybrid encoder trains at 384 x 384 (position embedding used as stored)"; return 1; }
     if (h.cfg.features != 256 || h.cfg.num_classes != 3) { err = "soccdpt_train_*: features must be 256 and num_classes 3"; return 1; }
     if (B < 1 || !ws) { err = "soccdpt_train_*: bad arguments"; return 1; }
     for (const auto& w : h.weights)
@@ -295,11 +239,12 @@ int check_train(Handle& h, int B, const void* ws, size_t ws_bytes, std::string& 
     return 0;
 }
 
-}  // namespace
+}  // namespace trn
+using namespace trn;
 
 // Named tape tensors for tests / debugging: f32, plain [rows][C] unless noted.
 int train_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems) {
-    if (h.arch.hybrid || B < 1 || !name) return 1;
+    if (B < 1 || !name) return 1;
     char base[256];
     TArena ar(base);   // a non-null base: offsets come out as pointer differences
     Tape T;
@@ -353,6 +298,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
         hipError_t e = hipMemsetAsync(static_cast<char*>(ws) + T.halo_lo, 0, T.halo_hi - T.halo_lo, st);
         if (e != hipSuccess) { err = std::string("train_forward memset: ") + hipGetErrorString(e); return 1; }
     }
+    if (a.hybrid) { TRY(hy_forward(c, x)); } else {
     // ---------------- encoder ----------------
     const int G = a.grid(), C0 = a.embed;
     const size_t M0 = (size_t)B * G * G;
@@ -407,6 +353,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             TRY(launch_ln_residual(T.mr_pre[s], c.W(dk + "norm.weight"), c.W(dk + "norm.bias"), T.mx[s], nullptr, nullptr, nullptr, 0, M / 4, 2 * C, 0, res / 2, 0, st, err));
             xcur = T.mx[s];
         }
+    }
     }
     // ---------------- decoder ----------------
     for (int l = 0; l < 4; ++l) {
@@ -501,7 +448,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     float** G = T.G;
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     const size_t M1 = (size_t)B * r1 * r1, M0p = (size_t)B * r0 * r0;
-    const bool enc_train = any_grad(h, ENC);
+    const bool enc_train = any_grad(h, HYB);   // "depth_net.pretrained.": the timm model and, for the hybrid, the act_postprocess read-outs
     // Frozen prefixes (freeze helpers of model/loss.py, PatchWiseInplace): the gradient stops flowing where nothing upstream is trainable
     bool lvl_own[4], lvl_side[4];   // level l: RCU2 / out_conv / anything coarser  |  RCU1 + layer_rn + encoder hook
     for (int l = 0; l < 4; ++l) {
@@ -513,7 +460,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     need_level[4] = false;
     for (int l = 3; l >= 0; --l) need_level[l] = lvl_own[l] || lvl_side[l] || need_level[l + 1];
     // the block buffers are re-derived from the same walk as the forward's: xin pointers
-    {
+    if (!a.hybrid) {
         const float* xcur = T.x0;
         for (int s = 0; s < 4; ++s) {
             for (auto& b : T.blk[s]) { b.xin = xcur; xcur = b.xout; }
@@ -592,6 +539,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         TRY(conv3_bwd(c, d_lrn, T.feat[l], c.W(lk), r, F, a.fdim(l), enc_train ? T.DF[l] : nullptr, nullptr, c.Gd(lk), nullptr));
     }
     if (!enc_train) return 0;
+    if (a.hybrid) return hy_backward(c);
     // ---------------- encoder, last stage -> first ----------------
     bool have = false;   // GX holds a gradient
     // trainable parameters at or before (stage s, block j) in forward order?  The walk ends below the earliest one.
