@@ -329,106 +329,165 @@ __global__ void tokens_to_patches_kernel(const float* __restrict__ dtok, float* 
     }
 }
 
-// ---------------- global softmax attention backward (timm vision_transformer.Attention, head dim 64) ----------------
-// qkv [B*N][3*H*64]; P = softmax(q k^T / 8); O = P v.  One thread = one query (kernels 1, 2) or one key (kernel 3); K / V / Q / dO tiles of 64
-// rows staged in LDS.  rowstat[b][h][q] = {max, sum exp, delta = dO . O}.
+// ---------------- global softmax attention, forward (train mode) and backward (timm vision_transformer.Attention, head dim 64) ----------------
+// qkv [B*N][3*H*64]; P = softmax(q k^T / 8); O = P v.  One thread = one query (forward, dq) or one key (dk, dv); the other axis is walked in
+// tiles of 64 rows staged in LDS.  A (sample, head) pair offers only ceil(N / 64) workgroups of one wave, so the walked axis is also dealt to
+// NSEG workgroups (tile t goes to segment t % NSEG) whose partial results a combine kernel merges in segment order (deterministic).
+// rowstat[b][h][q] = {max, sum exp} is written by the forward and reused by the backward.
 constexpr int VD = 64;
-__global__ __launch_bounds__(64) void vit_attn_rowstat_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ O,
-                                                              float* __restrict__ rowstat, int N, int heads) {
-    __shared__ float Ks[64][VD + 1];
+constexpr int NSEG = 8;
+__global__ __launch_bounds__(64) void vit_attn_fwd_seg_kernel(const float* __restrict__ qkv, float* __restrict__ part_o, float* __restrict__ part_ml, int N, int heads,
+                                                              int B) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][VD];
+    __shared__ __attribute__((aligned(16))) float Vs[64][VD];
     const int nqb = (N + 63) / 64, E = heads * VD;
     int bid = blockIdx.x;
+    const int seg = bid % NSEG;
+    bid /= NSEG;
     const int qb = bid % nqb;
     bid /= nqb;
     const int head = bid % heads, b = bid / heads;
     const int tid = threadIdx.x, q = qb * 64 + tid, qc = q < N ? q : N - 1;
-    float qr[VD];
+    float qr[VD], o[VD];
     const float* src = qkv + ((size_t)b * N + qc) * 3 * E + head * VD;
 #pragma unroll
-    for (int d = 0; d < VD; ++d) qr[d] = src[d] * 0.125f;
+    for (int d = 0; d < VD; ++d) { qr[d] = src[d] * 0.125f; o[d] = 0.f; }
     float m = -3.0e38f, l = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = seg * 64; k0 < N; k0 += 64 * NSEG) {
         __syncthreads();
-        {
-            const int k = k0 + tid, kc = k < N ? k : N - 1;
+        for (int i = 0; i < 64; ++i) {   // row i of the tile, lane = channel: coalesced global reads, conflict-free LDS writes
+            const int k = k0 + i, kc = k < N ? k : N - 1;
             const float* ks = qkv + ((size_t)b * N + kc) * 3 * E + E + head * VD;
-#pragma unroll
-            for (int d = 0; d < VD; ++d) Ks[tid][d] = ks[d];
+            Ks[i][tid] = ks[tid];
+            Vs[i][tid] = ks[E + tid];
         }
         __syncthreads();
         const int nk = (N - k0) < 64 ? (N - k0) : 64;
         for (int kk = 0; kk < nk; ++kk) {
-            float s = 0.f;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;   // four independent chains: the 64-long dependent FMA chain was the bound
 #pragma unroll
-            for (int d = 0; d < VD; ++d) s = fmaf(qr[d], Ks[kk][d], s);
+            for (int d = 0; d < VD; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(&Ks[kk][d]);
+                s0 = fmaf(qr[d], kv.x, s0); s1 = fmaf(qr[d + 1], kv.y, s1); s2 = fmaf(qr[d + 2], kv.z, s2); s3 = fmaf(qr[d + 3], kv.w, s3);
+            }
+            const float s = (s0 + s1) + (s2 + s3);
             const float mn = fmaxf(m, s);
-            l = l * __expf(m - mn) + __expf(s - mn);
+            const float al = __expf(m - mn), p = __expf(s - mn);
+            l = l * al + p;
+#pragma unroll
+            for (int d = 0; d < VD; d += 4) {
+                const float4 vv = *reinterpret_cast<const float4*>(&Vs[kk][d]);
+                o[d] = fmaf(p, vv.x, o[d] * al); o[d + 1] = fmaf(p, vv.y, o[d + 1] * al); o[d + 2] = fmaf(p, vv.z, o[d + 2] * al); o[d + 3] = fmaf(p, vv.w, o[d + 3] * al);
+            }
             m = mn;
         }
     }
     if (q < N) {
-        const float* dr = dO + ((size_t)b * N + q) * E + head * VD;
-        const float* orow = O + ((size_t)b * N + q) * E + head * VD;
-        float delta = 0.f;
+        const size_t row = (size_t)b * N + q;
+        float* po = part_o + ((size_t)seg * B * N + row) * E + head * VD;
 #pragma unroll
-        for (int d = 0; d < VD; ++d) delta = fmaf(dr[d], orow[d], delta);
-        float* rs = rowstat + (((size_t)b * heads + head) * N + q) * 3;
-        rs[0] = m; rs[1] = l; rs[2] = delta;
+        for (int d = 0; d < VD; ++d) po[d] = o[d];
+        float* pm = part_ml + (((size_t)seg * B * heads + (size_t)b * heads + head) * N + q) * 2;
+        pm[0] = m; pm[1] = l;
     }
 }
-// dq[q] = (1/8) sum_k dS[q][k] k[k],  dS = P (dO . v - delta)
-__global__ __launch_bounds__(64) void vit_attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ rowstat,
-                                                            float* __restrict__ dqkv, int N, int heads) {
-    __shared__ float Ks[64][VD + 1];
-    __shared__ float Vs[64][VD + 1];
+__global__ void vit_attn_fwd_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml, float* __restrict__ out, float* __restrict__ rowstat, int N,
+                                            int heads, int B) {
+    const int E = heads * VD;
+    const size_t n = (size_t)B * N * E;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int e = (int)(i % E), head = e / VD;
+        const size_t row = i / E;
+        const int q = (int)(row % N), b = (int)(row / N);
+        float ms[NSEG], ls[NSEG], M = -3.0e38f;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const float* pm = part_ml + (((size_t)s * B * heads + (size_t)b * heads + head) * N + q) * 2;
+            ms[s] = pm[0]; ls[s] = pm[1];
+            M = fmaxf(M, ms[s]);
+        }
+        float L = 0.f, acc = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSEG; ++s) {
+            const float w = ls[s] > 0.f ? __expf(ms[s] - M) : 0.f;
+            L += ls[s] * w;
+            acc += part_o[((size_t)s * B * N + row) * E + e] * w;
+        }
+        out[i] = acc / L;
+        if ((e & (VD - 1)) == 0) {
+            float* rs = rowstat + (((size_t)b * heads + head) * N + q) * 2;
+            rs[0] = M; rs[1] = L;
+        }
+    }
+}
+// partial dq[seg][q] = sum over the segment's keys of dS[q][k] k[k],  dS = P (dO . v - delta), delta = dO . O
+__global__ __launch_bounds__(64) void vit_attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ O,
+                                                            const float* __restrict__ rowstat, float* __restrict__ part, int N, int heads, int B) {
+    __shared__ __attribute__((aligned(16))) float Ks[64][VD];
+    __shared__ __attribute__((aligned(16))) float Vs[64][VD];
     const int nqb = (N + 63) / 64, E = heads * VD;
     int bid = blockIdx.x;
+    const int seg = bid % NSEG;
+    bid /= NSEG;
     const int qb = bid % nqb;
     bid /= nqb;
     const int head = bid % heads, b = bid / heads;
     const int tid = threadIdx.x, q = qb * 64 + tid, qc = q < N ? q : N - 1;
     float qr[VD], dOr[VD], dq[VD];
+    float delta = 0.f;
     {
         const float* src = qkv + ((size_t)b * N + qc) * 3 * E + head * VD;
         const float* dr = dO + ((size_t)b * N + qc) * E + head * VD;
+        const float* orow = O + ((size_t)b * N + qc) * E + head * VD;
 #pragma unroll
-        for (int d = 0; d < VD; ++d) { qr[d] = src[d] * 0.125f; dOr[d] = dr[d]; dq[d] = 0.f; }
+        for (int d = 0; d < VD; ++d) { qr[d] = src[d] * 0.125f; dOr[d] = dr[d]; dq[d] = 0.f; delta = fmaf(dOr[d], orow[d], delta); }
     }
-    const float* rs = rowstat + (((size_t)b * heads + head) * N + qc) * 3;
-    const float m = rs[0], il = 1.0f / rs[1], delta = rs[2];
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    const float* rs = rowstat + (((size_t)b * heads + head) * N + qc) * 2;
+    const float m = rs[0], il = 1.0f / rs[1];
+    for (int k0 = seg * 64; k0 < N; k0 += 64 * NSEG) {
         __syncthreads();
-        {
-            const int k = k0 + tid, kc = k < N ? k : N - 1;
+        for (int i = 0; i < 64; ++i) {   // row i of the tile, lane = channel: coalesced global reads, conflict-free LDS writes
+            const int k = k0 + i, kc = k < N ? k : N - 1;
             const float* ks = qkv + ((size_t)b * N + kc) * 3 * E + E + head * VD;
-#pragma unroll
-            for (int d = 0; d < VD; ++d) { Ks[tid][d] = ks[d]; Vs[tid][d] = ks[E + d]; }
+            Ks[i][tid] = ks[tid];
+            Vs[i][tid] = ks[E + tid];
         }
         __syncthreads();
         const int nk = (N - k0) < 64 ? (N - k0) : 64;
         for (int kk = 0; kk < nk; ++kk) {
-            float s = 0.f, dp = 0.f;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-            for (int d = 0; d < VD; ++d) { s = fmaf(qr[d], Ks[kk][d], s); dp = fmaf(dOr[d], Vs[kk][d], dp); }
+            for (int d = 0; d < VD; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(&Ks[kk][d]);
+                const float4 vv = *reinterpret_cast<const float4*>(&Vs[kk][d]);
+                s0 = fmaf(qr[d], kv.x, s0); s1 = fmaf(qr[d + 1], kv.y, s1); s2 = fmaf(qr[d + 2], kv.z, s2); s3 = fmaf(qr[d + 3], kv.w, s3);
+                p0 = fmaf(dOr[d], vv.x, p0); p1 = fmaf(dOr[d + 1], vv.y, p1); p2 = fmaf(dOr[d + 2], vv.z, p2); p3 = fmaf(dOr[d + 3], vv.w, p3);
+            }
+            const float s = (s0 + s1) + (s2 + s3), dp = (p0 + p1) + (p2 + p3);
             const float ds = __expf(s - m) * il * (dp - delta);
 #pragma unroll
-            for (int d = 0; d < VD; ++d) dq[d] = fmaf(ds, Ks[kk][d], dq[d]);
+            for (int d = 0; d < VD; d += 4) {
+                const float4 kv = *reinterpret_cast<const float4*>(&Ks[kk][d]);
+                dq[d] = fmaf(ds, kv.x, dq[d]); dq[d + 1] = fmaf(ds, kv.y, dq[d + 1]); dq[d + 2] = fmaf(ds, kv.z, dq[d + 2]); dq[d + 3] = fmaf(ds, kv.w, dq[d + 3]);
+            }
         }
     }
     if (q < N) {
-        float* dst = dqkv + ((size_t)b * N + q) * 3 * E + head * VD;
+        float* dst = part + ((size_t)seg * B * N + (size_t)b * N + q) * 3 * E + head * VD;
 #pragma unroll
         for (int d = 0; d < VD; ++d) dst[d] = dq[d] * 0.125f;
     }
 }
-// dk[k] = (1/8) sum_q dS[q][k] q[q],  dv[k] = sum_q P[q][k] dO[q]
-__global__ __launch_bounds__(64) void vit_attn_bwd_k_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ rowstat,
-                                                            float* __restrict__ dqkv, int N, int heads) {
-    __shared__ float Qs[64][VD + 1];
-    __shared__ float dOs[64][VD + 1];
+// partial dk[seg][k] = sum over the segment's queries of dS[q][k] q[q] / 8,  dv[seg][k] = sum P[q][k] dO[q]
+__global__ __launch_bounds__(64) void vit_attn_bwd_k_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ O,
+                                                            const float* __restrict__ rowstat, float* __restrict__ part, int N, int heads, int B) {
+    __shared__ __attribute__((aligned(16))) float Qs[64][VD];
+    __shared__ __attribute__((aligned(16))) float dOs[64][VD];
     __shared__ float st[64][3];
     const int nkb = (N + 63) / 64, E = heads * VD;
     int bid = blockIdx.x;
+    const int seg = bid % NSEG;
+    bid /= NSEG;
     const int kb = bid % nkb;
     bid /= nkb;
     const int head = bid % heads, b = bid / heads;
@@ -439,33 +498,58 @@ __global__ __launch_bounds__(64) void vit_attn_bwd_k_kernel(const float* __restr
 #pragma unroll
         for (int d = 0; d < VD; ++d) { kr[d] = ks[d]; vr[d] = ks[E + d]; dk[d] = 0.f; dv[d] = 0.f; }
     }
-    for (int q0 = 0; q0 < N; q0 += 64) {
+    for (int q0 = seg * 64; q0 < N; q0 += 64 * NSEG) {
         __syncthreads();
+        for (int i = 0; i < 64; ++i) {   // row i of the tile, lane = channel
+            const int q = q0 + i, qc = q < N ? q : N - 1;
+            Qs[i][tid] = qkv[((size_t)b * N + qc) * 3 * E + head * VD + tid] * 0.125f;
+            const float dv_ = dO[((size_t)b * N + qc) * E + head * VD + tid];
+            dOs[i][tid] = dv_;
+            float pr = dv_ * O[((size_t)b * N + qc) * E + head * VD + tid];   // delta_i = dO_i . O_i: a wave reduction
+            for (int o = 1; o < 64; o <<= 1) pr += __shfl_xor(pr, o);
+            if (tid == 0) st[i][2] = pr;
+        }
         {
             const int q = q0 + tid, qc = q < N ? q : N - 1;
-            const float* src = qkv + ((size_t)b * N + qc) * 3 * E + head * VD;
-            const float* dr = dO + ((size_t)b * N + qc) * E + head * VD;
-#pragma unroll
-            for (int d = 0; d < VD; ++d) { Qs[tid][d] = src[d] * 0.125f; dOs[tid][d] = dr[d]; }
-            const float* rs = rowstat + (((size_t)b * heads + head) * N + qc) * 3;
-            st[tid][0] = rs[0]; st[tid][1] = 1.0f / rs[1]; st[tid][2] = rs[2];
+            const float* rs = rowstat + (((size_t)b * heads + head) * N + qc) * 2;
+            st[tid][0] = rs[0]; st[tid][1] = 1.0f / rs[1];
         }
         __syncthreads();
         const int nq = (N - q0) < 64 ? (N - q0) : 64;
         for (int qq = 0; qq < nq; ++qq) {
-            float s = 0.f, dp = 0.f;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
 #pragma unroll
-            for (int d = 0; d < VD; ++d) { s = fmaf(Qs[qq][d], kr[d], s); dp = fmaf(dOs[qq][d], vr[d], dp); }
+            for (int d = 0; d < VD; d += 4) {
+                const float4 qv = *reinterpret_cast<const float4*>(&Qs[qq][d]);
+                const float4 gv = *reinterpret_cast<const float4*>(&dOs[qq][d]);
+                s0 = fmaf(qv.x, kr[d], s0); s1 = fmaf(qv.y, kr[d + 1], s1); s2 = fmaf(qv.z, kr[d + 2], s2); s3 = fmaf(qv.w, kr[d + 3], s3);
+                p0 = fmaf(gv.x, vr[d], p0); p1 = fmaf(gv.y, vr[d + 1], p1); p2 = fmaf(gv.z, vr[d + 2], p2); p3 = fmaf(gv.w, vr[d + 3], p3);
+            }
+            const float s = (s0 + s1) + (s2 + s3), dp = (p0 + p1) + (p2 + p3);
             const float p = __expf(s - st[qq][0]) * st[qq][1];
             const float ds = p * (dp - st[qq][2]);
 #pragma unroll
-            for (int d = 0; d < VD; ++d) { dk[d] = fmaf(ds, Qs[qq][d], dk[d]); dv[d] = fmaf(p, dOs[qq][d], dv[d]); }
+            for (int d = 0; d < VD; d += 4) {
+                const float4 qv = *reinterpret_cast<const float4*>(&Qs[qq][d]);
+                const float4 gv = *reinterpret_cast<const float4*>(&dOs[qq][d]);
+                dk[d] = fmaf(ds, qv.x, dk[d]); dk[d + 1] = fmaf(ds, qv.y, dk[d + 1]); dk[d + 2] = fmaf(ds, qv.z, dk[d + 2]); dk[d + 3] = fmaf(ds, qv.w, dk[d + 3]);
+                dv[d] = fmaf(p, gv.x, dv[d]); dv[d + 1] = fmaf(p, gv.y, dv[d + 1]); dv[d + 2] = fmaf(p, gv.z, dv[d + 2]); dv[d + 3] = fmaf(p, gv.w, dv[d + 3]);
+            }
         }
     }
     if (k < N) {
-        float* dst = dqkv + ((size_t)b * N + k) * 3 * E + E + head * VD;
+        float* dst = part + ((size_t)seg * B * N + (size_t)b * N + k) * 3 * E + E + head * VD;
 #pragma unroll
         for (int d = 0; d < VD; ++d) { dst[d] = dk[d]; dst[E + d] = dv[d]; }   // Qs already carries the 1/8
+    }
+}
+// dqkv = sum over the segments, in segment order
+__global__ void seg_sum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NSEG; ++k) s += part[(size_t)k * n + i];
+        out[i] = s;
     }
 }
 
@@ -530,12 +614,22 @@ int th_tokens_to_patches(const float* dtok, float* dpatch, int B, int NT, int E,
     hipLaunchKernelGGL(tokens_to_patches_kernel, dim3(gs_blocks((size_t)B * (NT - 1) * E)), dim3(256), 0, st, dtok, dpatch, B, NT, E);
     TK("tokens_to_patches");
 }
-// rowstat: B * heads * N * 3 floats
-int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err) {
-    const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64));
-    hipLaunchKernelGGL(vit_attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, N, heads);
-    hipLaunchKernelGGL(vit_attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, rowstat, dqkv, N, heads);
-    hipLaunchKernelGGL(vit_attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, rowstat, dqkv, N, heads);
+// part: NSEG * B * N * 3 * E floats of scratch; rowstat: B * heads * N * 2 floats, written by the forward and read by the backward
+size_t th_vit_attention_part_floats(int B, int N, int heads) { return (size_t)NSEG * B * N * 3 * heads * VD; }
+int th_vit_attention_fwd(const float* qkv, float* out, float* rowstat, float* part, int B, int N, int heads, hipStream_t st, std::string& err) {
+    const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64) * NSEG);
+    float* part_ml = part + (size_t)NSEG * B * N * heads * VD;
+    hipLaunchKernelGGL(vit_attn_fwd_seg_kernel, dim3(blocks), dim3(64), 0, st, qkv, part, part_ml, N, heads, B);
+    hipLaunchKernelGGL(vit_attn_fwd_combine_kernel, dim3(gs_blocks((size_t)B * N * heads * VD)), dim3(256), 0, st, part, part_ml, out, rowstat, N, heads, B);
+    TK("vit_attention_fwd");
+}
+int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, const float* rowstat, float* part, float* dqkv, int B, int N, int heads, hipStream_t st,
+                         std::string& err) {
+    const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64) * NSEG);
+    hipLaunchKernelGGL(vit_attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
+    hipLaunchKernelGGL(vit_attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
+    const size_t n = (size_t)B * N * 3 * heads * VD;
+    hipLaunchKernelGGL(seg_sum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dqkv, n);
     TK("vit_attention_bwd");
 }
 

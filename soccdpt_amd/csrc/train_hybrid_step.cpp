@@ -22,7 +22,10 @@ int th_maxpool_bwd(const float* dpool, const float* raw, const float* stats, con
 int th_readout_cat(const float* tok, float* cat, int B, int NT, int E, hipStream_t st, std::string& err);
 int th_readout_cat_bwd(const float* dcat, float* dtok, int B, int NT, int E, int accumulate, hipStream_t st, std::string& err);
 int th_tokens_to_patches(const float* dtok, float* dpatch, int B, int NT, int E, hipStream_t st, std::string& err);
-int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err);
+size_t th_vit_attention_part_floats(int B, int N, int heads);
+int th_vit_attention_fwd(const float* qkv, float* out, float* rowstat, float* part, int B, int N, int heads, hipStream_t st, std::string& err);
+int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, const float* rowstat, float* part, float* dqkv, int B, int N, int heads, hipStream_t st,
+                         std::string& err);
 
 namespace trn {
 namespace {
@@ -150,6 +153,7 @@ void hy_carve(const Handle& h, int B, TArena& ar, Tape& T, size_t& maxAct) {
         v.hpre = ar.f(Mt * 4 * E);
         v.hact = ar.f(Mt * 4 * E);
         v.xout = ar.f(Mt * E);
+        v.rowstat = ar.f((size_t)B * a.vit_heads * NT * 2);
     }
     for (int k = 0; k < 2; ++k) {
         Y.cat[k] = ar.f(Mp * 2 * E);
@@ -161,7 +165,7 @@ void hy_carve(const Handle& h, int B, TArena& ar, Tape& T, size_t& maxAct) {
     Y.GT = ar.f(Mt * E);
     Y.GR = ar.f((size_t)B * H2 * H2 * 256);
     Y.xg = ar.f((size_t)B * (H2 / 2) * (H2 / 2) * 256);
-    Y.rowstat = ar.f((size_t)B * a.vit_heads * NT * 3);
+    Y.attn_part = ar.f(th_vit_attention_part_floats(B, NT, a.vit_heads));
 }
 
 int hy_forward(Ctx& c, const float* x) {
@@ -260,7 +264,7 @@ int hy_forward(Ctx& c, const float* x) {
         IgemmDesc d;
         d.X = v.ln1; d.Wt = c.W(k + "attn.qkv.weight"); d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.qkv.bias"); d.out_f32 = v.qkv;
         TRY(gemm(c, d));
-        TRY(launch_vit_attention(v.qkv, v.attn, SOCCDPT_PREC_F32, B, NT, a.vit_heads, st, err));
+        TRY(th_vit_attention_fwd(v.qkv, v.attn, v.rowstat, Y.attn_part, B, NT, a.vit_heads, st, err));
         d = IgemmDesc();
         d.X = v.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.proj.bias"); d.res1 = v.xin; d.out_f32 = v.x1;
         TRY(gemm(c, d));
@@ -351,7 +355,7 @@ int hy_backward(Ctx& c) {
         TRY(tr_axpy(G[2], Y.GT, Mt * E, st, err));                                   // G2 = d x1
         // x1 = xin + proj(attn(qkv(LN1(xin))))
         TRY(linear_bwd(c, G[2], v.attn, c.W(k + "attn.proj.weight"), Mt, E, E, G[0], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
-        TRY(th_vit_attention_bwd(v.qkv, v.attn, G[0], Y.rowstat, G[4], B, NT, a.vit_heads, st, err));
+        TRY(th_vit_attention_bwd(v.qkv, v.attn, G[0], v.rowstat, Y.attn_part, G[4], B, NT, a.vit_heads, st, err));
         TRY(linear_bwd(c, G[4], v.ln1, c.W(k + "attn.qkv.weight"), Mt, 3 * E, E, G[1], nullptr, c.Gd(k + "attn.qkv.weight"), c.Gd(k + "attn.qkv.bias")));
         TRY(ln_bwd(c, v.xin, c.W(k + "norm1.weight"), G[1], G[0], G[3], Mt, E, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias"), kLnEps));
         TRY(copy_d2d(c, Y.GT, G[2], Mt * E * 4, "hy_backward"));

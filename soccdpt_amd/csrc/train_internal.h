@@ -47,7 +47,7 @@ struct RnBlkT {
 };
 struct VitBlkT {
     const float* xin;
-    float *ln1, *qkv, *attn, *x1, *ln2, *hpre, *hact, *xout;
+    float *ln1, *qkv, *attn, *x1, *ln2, *hpre, *hact, *xout, *rowstat;
 };
 struct HyTape {
     float *a0, *w_stem, *stem_raw, *stem_stats, *pool;
@@ -59,7 +59,7 @@ struct HyTape {
     float* gn_part;
     unsigned* gn_count;
     size_t gn_part_floats = 0;
-    float *GT, *GR, *xg, *rowstat;             // token-stream / residual-stream gradients, strided-shortcut operand, attention row statistics
+    float *GT, *GR, *xg, *attn_part;           // token-stream / residual-stream gradients, strided-shortcut operand, attention segment partials
 };
 
 struct Tape {

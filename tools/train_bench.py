@@ -1,6 +1,6 @@
 """Training-step timing (BASELINE configs[4]): train-mode forward + criterion + backward + fused Adam on synthetic data, exact f32.
 
-    python tools/train_bench.py [B] [steps] [encoder_percentage] [patchwise_percentage]
+    python tools/train_bench.py [B] [steps] [encoder_percentage] [patchwise_percentage] [model_type]
 Prints ms per optimisation step (one PatchWiseInplace patch = one forward + backward + Adam step, as scripts/train_SOccDPT.py runs them).
 """
 import os, sys, tempfile, time, json
@@ -18,14 +18,18 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 enc_pct = float(sys.argv[3]) if len(sys.argv) > 3 else 1.0
 patch_pct = float(sys.argv[4]) if len(sys.argv) > 4 else 1.0
+model_type = sys.argv[5] if len(sys.argv) > 5 else "dpt_swin2_tiny_256"
+from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
+backbone = MODEL_TYPE_TO_BACKBONE[model_type]
+S = backbone_image_size(backbone)
 dev = torch.device("cuda:0")
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
-net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
-net.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
+net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+net.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
 net = net.to(dev).train()
 freeze_pretrained_encoder(net)
 unfreeze_pretrained_encoder_by_percentage(net, enc_pct)
-ds = SyntheticDepthSegDataset(B, 256)
+ds = SyntheticDepthSegDataset(B, S)
 x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(ds, B, B)
 x = x.to(dev, torch.float32)
 y_disp, y_seg = y_disp.to(dev, torch.float32), y_seg.to(dev, torch.float32)
@@ -63,16 +67,16 @@ torch.cuda.synchronize()
 cpu = None
 if os.environ.get("TRAIN_BENCH_CPU", "1") != "0":
     from oracle import soccdpt_ref as R
-    sd = synth_state_dict(alias_pretrained=True)
+    sd = synth_state_dict(backbone, alias_pretrained=True)
     sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
     xc = x[:2].cpu()
     torch.set_num_threads(min(16, os.cpu_count() or 1))
     t0 = time.time()
-    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, xc, sigmoid=True, training=True, dropout_p=0.1)
+    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, xc, backbone=backbone, sigmoid=True, training=True, dropout_p=0.1)
     (o_inv.sum() + o_seg.sum()).backward()
     cpu = {"samples_per_s": round(2 / (time.time() - t0), 3), "cores": torch.get_num_threads(), "kind": "port",
            "sample": "oracle forward + torch autograd backward, 2 samples, no criterion / optimizer"}
-print(json.dumps({"cpu_baseline": cpu, "B": B, "encoder_percentage": enc_pct, "patchwise_percentage": patch_pct, "optimisation_steps": n,
+print(json.dumps({"cpu_baseline": cpu, "model_type": model_type, "B": B, "encoder_percentage": enc_pct, "patchwise_percentage": patch_pct, "optimisation_steps": n,
                   "ms_per_step": round(1e3 * dt / n, 2), "samples_per_s": round(B * n / dt, 1),
                   "train_forward_ms": round(ev[0].elapsed_time(ev[1]), 2), "criterion_ms": round(ev[1].elapsed_time(ev[2]), 2),
                   "backward_all_trainable_ms": round(ev[2].elapsed_time(ev[3]), 2), "loss": float(out["loss"]),
