@@ -302,7 +302,7 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
 
 /* ---- training step: replaces `masks_pred = net(images)` in train mode + `grad_scaler.scale(loss).backward()`
  * (scripts/train_SOccDPT.py:360-393) for the encoder + decoder + heads (model/SOccDPT.py:660-685, model/dpt.py:142-232).
- * SOCCDPT_PREC_F32 handles with a Swin-V2 backbone only; weights are read as bound (no soccdpt_prepare needed: they change every step).
+ * SOCCDPT_PREC_F32 handles only (Swin-V2 and ViT-hybrid backbones); weights are read as bound (no soccdpt_prepare needed: they change every step).
  * soccdpt_bind_grad: `dev_grad` (same shape as the weight, f32) receives d loss / d weight -- WRITTEN, not accumulated -- on every
  * soccdpt_train_backward; NULL unbinds (the weight is frozen and its weight-gradient GEMM is skipped: model/loss.py:110-152).
  * soccdpt_train_forward: train-mode forward (seg head BatchNorm on batch statistics, running buffers bound as "seg_head.1.running_mean/var"

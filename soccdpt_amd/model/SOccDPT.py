@@ -274,7 +274,7 @@ class SOccDPT_V3(SOccDPT):
         """Train-mode forward (model/SOccDPT.py:660-685 under nn.Module.train(): BatchNorm2d of the seg head on batch statistics with its
         running buffers updated, Dropout live) that keeps every activation the backward needs.  Returns (inv_depth [B,S,S],
         segmentation [B,C,S,S]) at network resolution -- what SOccDPT_V3.forward hands to the up-sampling / criterion.  Exact f32
-        (precision=PREC_F32) and Swin-V2 encoders only; follow it with backward(d_inv, d_seg)."""
+        (precision=PREC_F32); follow it with backward(d_inv, d_seg)."""
         from ..lib import PREC_F32
         if self.precision != PREC_F32:
             raise RuntimeError("the training step is built for precision=PREC_F32 (exact-f32 MFMA); construct the model with it")

@@ -5,11 +5,11 @@
 (:262-263), Adam (:311-318), ReduceLROnPlateau(min, patience 2) (:320-322), the `PatchWiseInplace` inner loop (:362-393), the criterion
 `loss_depth_w * SSI + loss_seg_w * BCE` (:323-338,380-386), one checkpoint per epoch (:437-449).
 
-What runs on MI355X: all of it.  The train-mode forward and the network backward (csrc/train_step.cpp, csrc/train.hip: exact f32, Swin-V2
-encoders) sit behind `net.train_forward(x)` / `net.backward(d_inv, d_seg)`; the criterion and its gradient w.r.t. the network outputs are
+What runs on MI355X: all of it.  The train-mode forward and the network backward (csrc/train_step.cpp, csrc/train_hybrid_step.cpp, csrc/train*.hip: exact f32, all
+three models) sit behind `net.train_forward(x)` / `net.backward(d_inv, d_seg)`; the criterion and its gradient w.r.t. the network outputs are
 csrc/loss.hip, the optimizer is the fused Adam (csrc/adam.hip).  A frozen parameter (freeze / unfreeze helpers, PatchWiseInplace) has no
 gradient bound and its weight-gradient GEMM is skipped.  `--forward_only` walks the schedule with the eval-mode forward + criterion only
-(any operand precision, also dpt_hybrid_384, which has no backward yet).  There is no autograd / eager-PyTorch fallback: the HIP library is
+(any operand precision).  There is no autograd / eager-PyTorch fallback: the HIP library is
 the product.
 
 Differences forced by the GPU box: wandb is absent -> the sweep is sampled locally (`method: random` with random.seed(0), `count` runs)
