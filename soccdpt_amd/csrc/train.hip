@@ -469,6 +469,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
                                                         int heads) {
     __shared__ float Kh[64][33];
     __shared__ float Vs[64][33];
+    __shared__ float dsT[64][65];
     const int N = ws * ws, nqb = (N + 63) / 64;
     const int C = heads * 32, nw = res / ws;
     int bid = blockIdx.x;
@@ -510,16 +511,6 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
     }
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     const int half = ws / 2;
-    auto logit = [&](int kk, int k0) -> float {   // S[q][k0 + kk] from the staged k^ tile
-        float s = 0.f;
-#pragma unroll
-        for (int d = 0; d < 32; ++d) s = fmaf(qn[d], Kh[kk][d], s);
-        s *= sc;
-        const int k = k0 + kk, rk = k / ws, ck = k % ws;
-        s += table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
-        if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) s += -100.0f;
-        return s;
-    };
     auto stage = [&](int k0) {
         __syncthreads();
         const int k = k0 + tid;
@@ -544,23 +535,34 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
 #pragma unroll
         for (int d = 0; d < 32; ++d) delta = fmaf(dOr[d], orow[d], delta);
     }
-    // pass 3: dS, dq^
+    // dS, dq^.  The dS tile of 64 queries x 64 keys goes through LDS so that the global rows are written 256 bytes at a time
+    // (a lane writing its own row was one 4-byte store per cache line).
     float dsc = 0.f;
-    float* dSrow = dS_out + (((size_t)widx * heads + head) * N + qc) * N;
+    float* dSbase = dS_out + ((size_t)widx * heads + head) * N * N;
     for (int k0 = 0; k0 < N; k0 += 64) {
         stage(k0);
         const int nk = (N - k0) < 64 ? (N - k0) : 64;
         for (int kk = 0; kk < nk; ++kk) {
-            const float p = __expf(logit(kk, k0) - m) / l;
-            float dp = 0.f;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f, p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;   // independent FMA chains
 #pragma unroll
-            for (int d = 0; d < 32; ++d) dp = fmaf(dOr[d], Vs[kk][d], dp);
-            const float ds = p * (dp - delta);
-            if (qv) dSrow[k0 + kk] = ds;
-            float dot = 0.f;
+            for (int d = 0; d < 32; d += 4) {
+                s0 = fmaf(qn[d], Kh[kk][d], s0); s1 = fmaf(qn[d + 1], Kh[kk][d + 1], s1); s2 = fmaf(qn[d + 2], Kh[kk][d + 2], s2); s3 = fmaf(qn[d + 3], Kh[kk][d + 3], s3);
+                p0 = fmaf(dOr[d], Vs[kk][d], p0); p1 = fmaf(dOr[d + 1], Vs[kk][d + 1], p1); p2 = fmaf(dOr[d + 2], Vs[kk][d + 2], p2); p3 = fmaf(dOr[d + 3], Vs[kk][d + 3], p3);
+            }
+            const float dot = (s0 + s1) + (s2 + s3), dp = (p0 + p1) + (p2 + p3);
+            const int k = k0 + kk, rk = k / ws, ck = k % ws;
+            float sl = dot * sc + table[(size_t)((rq - rk + ws - 1) * (2 * ws - 1) + (cq - ck + ws - 1)) * heads + head];
+            if ((lastrow && ((rk >= half) != (rq >= half))) || (lastcol && ((ck >= half) != (cq >= half)))) sl += -100.0f;
+            const float ds = __expf(sl - m) / l * (dp - delta);
+            dsT[tid][kk] = ds;
 #pragma unroll
-            for (int d = 0; d < 32; ++d) { dqh[d] = fmaf(ds, Kh[kk][d], dqh[d]); dot = fmaf(qn[d], Kh[kk][d], dot); }
+            for (int d = 0; d < 32; ++d) dqh[d] = fmaf(ds, Kh[kk][d], dqh[d]);
             dsc += ds * dot;      // d scale: S = scale * (qn . k^) + ...
+        }
+        __syncthreads();
+        for (int i = 0; i < 64; ++i) {
+            const int qq = qb * 64 + i;
+            if (qq < N && tid < nk) dSbase[(size_t)qq * N + k0 + tid] = dsT[i][tid];
         }
     }
     if (qv) {
