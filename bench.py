@@ -30,6 +30,104 @@ PEAK_F32_TFLOPS = 157.3     # f32-input MFMA (same table)
 PEAK_HBM_GBS = 8000.0       # HBM3E spec (same table)
 
 
+FWD_GFLOP_PER_FRAME = {"dpt_swin2_tiny_256": 78.82, "dpt_swin2_base_384": 259.6, "dpt_hybrid_384": 293.0}   # SURVEY.md 8d (algorithmic, forward)
+
+
+def train_step_bench(args):
+    """One JSON line for the training step (BASELINE configs[4]).  A step = one PatchWiseInplace patch: train-mode forward, SSI + BCE criterion
+    at 1080 x 1920 with its output gradients, network backward, fused Adam; inputs and targets resident in HBM.  value = samples/s.
+    roofline: the step is MFMA-bound in f32 (three GEMM passes: forward, dgrad, wgrad); achieved = 3 x the forward's algorithmic FLOPs per
+    sample x samples/s against the 157.3 TFLOP/s f32 MFMA peak -- only quoted when everything is trainable (frozen tensors skip their wgrad)."""
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    import torch
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.loss import freeze_pretrained_encoder, unfreeze_pretrained_encoder_by_percentage
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
+    from soccdpt_amd.scripts.train_SOccDPT import SyntheticDepthSegDataset, get_batch
+    from soccdpt_amd.utils.loss import training_loss
+    from soccdpt_amd.utils.optim import Adam, PatchWiseInplace
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
+    S = backbone_image_size(backbone)
+    B = args.batch
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=args.model_type)
+    sd = synth_state_dict(backbone, alias_pretrained=True)
+    net.load_state_dict(sd, strict=False)
+    net = net.to(dev).train()
+    freeze_pretrained_encoder(net)
+    unfreeze_pretrained_encoder_by_percentage(net, args.encoder_percentage)
+    x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(SyntheticDepthSegDataset(B, S), B, B)
+    x = x.to(dev, torch.float32)
+    y_disp, y_seg = y_disp.to(dev, torch.float32), y_seg.to(dev, torch.float32)
+    mask_disp, mask_seg = mask_disp.to(dev, torch.bool), mask_seg.to(dev, torch.bool)
+    opt = Adam(net.parameters(), lr=1e-5)
+
+    def one_batch():
+        n = 0
+        for net_patch in PatchWiseInplace(net, args.patchwise_percentage):
+            inv, seg = net_patch.train_forward(x, seed=n)
+            out = training_loss(inv, seg, y_disp, mask_disp, y_seg, mask_seg, 0.5, 0.5, compute_scale_and_shift=True)
+            opt.zero_grad(set_to_none=True)
+            net_patch.backward(out["d_inv"], out["d_seg"])
+            opt.step()
+            n += 1
+        return n
+
+    steps = max(1, min(args.steps, 50))
+    for _ in range(max(1, min(args.warmup, 5))):
+        one_batch()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 0
+    for _ in range(steps):
+        n += one_batch()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    sps = B * n / dt
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+    ev[0].record(); inv, seg = net.train_forward(x, seed=0); ev[1].record()
+    out = training_loss(inv, seg, y_disp, mask_disp, y_seg, mask_seg, 0.5, 0.5, compute_scale_and_shift=True); ev[2].record()
+    net.backward(out["d_inv"], out["d_seg"]); ev[3].record()
+    torch.cuda.synchronize()
+    all_trainable = args.encoder_percentage >= 1.0 and args.patchwise_percentage >= 1.0
+    roof = None
+    if all_trainable:
+        ach = 3.0 * FWD_GFLOP_PER_FRAME[args.model_type] * sps / 1e3
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F32_TFLOPS, 4), "traffic": None,
+                "kernel": "whole step (f32 igemm forward + dgrad + split-K wgrad; profiles/r02f_train_kernel_stats.csv splits it per kernel)",
+                "flops_per_sample_gflop": round(3.0 * FWD_GFLOP_PER_FRAME[args.model_type], 1)}
+    cpu = None
+    if not args.no_cpu_baseline and not args.headline_only:
+        from oracle import soccdpt_ref as R
+        sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+        torch.set_num_threads(min(16, os.cpu_count() or 1))
+        xc = x[:2].cpu()
+        t0 = time.perf_counter()
+        o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, xc, backbone=backbone, sigmoid=True, training=True, dropout_p=0.1)
+        (o_inv.sum() + o_seg.sum()).backward()
+        cpu = {"value": round(xc.shape[0] / (time.perf_counter() - t0), 3), "unit": "samples/s", "cores": torch.get_num_threads(), "kind": "port",
+               "sample": f"oracle forward + torch autograd backward on {xc.shape[0]} samples (no criterion / optimizer)"}
+    result = {"metric": f"samples/sec SOccDPT_V3 {args.model_type.replace('dpt_', '')} training step (train forward + criterion + backward + Adam)",
+              "value": round(sps, 2), "unit": "samples/s", "n_gpus": 1, "steps": n, "warmup": max(1, min(args.warmup, 5)), "ms_per_step": round(1e3 * dt / n, 3),
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+              "config": {"workload": f"SOccDPT_V3 {args.model_type} patch-wise training step, synthetic 1080x1920 targets", "batch_per_gpu": B, "image": S,
+                         "encoder_percentage": args.encoder_percentage, "patchwise_percentage": args.patchwise_percentage,
+                         "trainable_tensors": sum(1 for q in net.parameters() if q.requires_grad)},
+              "split_ms": {"train_forward": round(ev[0].elapsed_time(ev[1]), 2), "criterion": round(ev[1].elapsed_time(ev[2]), 2),
+                           "backward_all_unfrozen": round(ev[2].elapsed_time(ev[3]), 2)},
+              "roofline": roof, "cpu_baseline": cpu, "loss": round(float(out["loss"]), 6),
+              "train_workspace_gib": round(net._engine(dev).train_workspace(B).numel() / 2 ** 30, 2)}
+    os.dup2(real_stdout, 1)
+    print(json.dumps(result), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -52,7 +150,14 @@ def main():
     ap.add_argument("--with-two-streams", action="store_true",
                     help="also time the EXPERIMENTAL two-concurrent-sub-batches mode (soccdpt_set_streams(2); opt-in, DESIGN.md section 4)")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
+    ap.add_argument("--train-step", action="store_true",
+                    help="BASELINE configs[4] instead of the forward: one optimisation step (train-mode forward + criterion + backward + fused Adam, exact f32) "
+                         "per PatchWiseInplace patch; N = 1")
+    ap.add_argument("--encoder-percentage", type=float, default=1.0, help="--train-step: unfreeze_pretrained_encoder_by_percentage")
+    ap.add_argument("--patchwise-percentage", type=float, default=1.0, help="--train-step: PatchWiseInplace")
     args = ap.parse_args()
+    if args.train_step:
+        return train_step_bench(args)
     if args.headline_only:
         args.no_cpu_baseline = True
     if args.with_two_streams or args.streams > 1:
