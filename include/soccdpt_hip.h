@@ -310,6 +310,10 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
  * in the workspace.  soccdpt_train_backward: d_inv [B,S,S], d_seg [B,C,S,S] -> bound gradients; must follow a soccdpt_train_forward on the
  * same workspace and B. */
 int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad);
+/* Mixed precision for the backward (the reference's `amp` sweep parameter, scripts/train_SOccDPT.py:96-121,360-366): on != 0 runs the gradient
+ * GEMMs (dgrad / wgrad of every Linear and 3x3 convolution) with bf16 MFMA operands and f32 accumulation; the train-mode forward, every saved
+ * activation, weights and gradients stay f32, and bf16's f32-sized exponent needs no loss scaling.  Off by default. */
+int soccdpt_train_set_amp(void* handle, int on);
 size_t soccdpt_train_workspace_bytes(void* handle, int B);
 int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_inv, float* dev_seg, void* dev_workspace, size_t workspace_bytes,
                           float dropout_p, uint32_t seed, void* stream);

@@ -104,6 +104,12 @@ int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad) {
     h->weights[it->second].grad = dev_grad;
     return 0;
 }
+int soccdpt_train_set_amp(void* handle, int on) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    h->train_amp = on != 0;
+    return 0;
+}
 size_t soccdpt_train_workspace_bytes(void* handle, int B) { return handle && B > 0 ? train_workspace_bytes(*static_cast<Handle*>(handle), B) : 0; }
 int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems) {
     Handle* h = static_cast<Handle*>(handle);

@@ -135,6 +135,7 @@ struct Handle {
         int B = 0;
         float dropout_p = 0.f;
     } train_key;
+    bool train_amp = false;   // soccdpt_train_set_amp: bf16 MFMA operands for the gradient GEMMs (f32 accumulate, f32 weights / activations / gradients)
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;  // capture/replay stream (the caller's may be the legacy null stream, which cannot capture)

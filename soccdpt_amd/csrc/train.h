@@ -6,10 +6,14 @@
 namespace soccdpt {
 
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err);
+int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, hipStream_t st, std::string& err);
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
+int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err);
+int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, hipStream_t st, std::string& err);
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
 int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);

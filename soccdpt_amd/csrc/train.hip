@@ -6,6 +6,7 @@
 //   dX = dY W            -> igemm(X = dY, Wt = W^T)                      (transpose_kernel; conv: flipped tap-major weights + zero-haloed dY)
 //   dW = dY^T X          -> igemm(X = dY^T [N][M], Wt = X^T [K][M])      (transpose_kernel; conv: im2colT_kernel builds [9C][M])
 // Everything else here is an elementwise / row / column-reduction kernel, deterministic (no float atomics): fixed-order tree reductions.
+#include "half16.h"
 #include "kernels.h"
 
 namespace soccdpt {
@@ -13,9 +14,15 @@ namespace {
 
 constexpr float LN100 = 4.605170185988092f;
 
+// staging kernels write f32 or, in the mixed-precision mode (SOCCDPT train amp: bf16 MFMA operands for the gradient GEMMs), bf16
+template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+template <> __device__ __forceinline__ uint16_t cvt_out<uint16_t>(float v) { return f2h<false>(v); }
+
 // ---------------- layout ----------------
 // [R][C] -> [C][Rp] (Rp >= R: rows padded with zeros up to the k-tile multiple the igemm needs), 32 x 32 tiles through LDS
-__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int C, int Rp) {
+template <typename OT>
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, OT* __restrict__ out, int R, int C, int Rp) {
     __shared__ float t[32][33];
     const int bx = blockIdx.x * 32, by = blockIdx.y * 32;   // bx: column block of `in`, by: row block
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -26,12 +33,13 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = bx + i, r = by + tx;
-        if (c < C && r < Rp) out[(size_t)c * Rp + r] = t[tx][i];
+        if (c < C && r < Rp) out[(size_t)c * Rp + r] = cvt_out<OT>(t[tx][i]);
     }
 }
 
 // zero-haloed NHWC image [B][H+2][W+2][C] -> im2col^T [(tap*C + c)][m], m = (b, y, x): the Wt operand of the 3x3 wgrad GEMM
-__global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C, size_t Mp) {
+template <typename OT>
+__global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ halo, OT* __restrict__ out, int B, int H, int W, int C, size_t Mp) {
     __shared__ float t[32][33];
     const size_t M = (size_t)B * H * W;
     const int tap = blockIdx.z, ky = tap / 3, kx = tap % 3;
@@ -51,18 +59,19 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ 
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i;
         const size_t m = m0 + tx;
-        if (c < C && m < Mp) out[((size_t)tap * C + c) * Mp + m] = t[tx][i];
+        if (c < C && m < Mp) out[((size_t)tap * C + c) * Mp + m] = cvt_out<OT>(t[tx][i]);
     }
 }
 
 // W [N][C][3][3] -> Wd [C][2-ky][2-kx][N] (tap-major, flipped): Wt operand of the 3x3 dgrad (a convolution of dY with the rotated filter)
-__global__ void conv_w_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int N, int C) {
+template <typename OT>
+__global__ void conv_w_dgrad_kernel(const float* __restrict__ w, OT* __restrict__ out, int N, int C) {
     const size_t n = (size_t)N * C * 9;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int nn = (int)(i % N);
         size_t r = i / N;
         const int tap = (int)(r % 9), c = (int)(r / 9);
-        out[i] = w[((size_t)nn * C + c) * 9 + (8 - tap)];
+        out[i] = cvt_out<OT>(w[((size_t)nn * C + c) * 9 + (8 - tap)]);
     }
 }
 
@@ -78,7 +87,8 @@ __global__ void wgrad_permute_kernel(const float* __restrict__ in, float* __rest
 }
 
 // plain [B][H][W][C] <-> halo [B][H+2][W+2][C]
-__global__ void to_halo_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C) {
+template <typename OT>
+__global__ void to_halo_kernel(const float* __restrict__ in, OT* __restrict__ out, int B, int H, int W, int C) {
     const size_t n = (size_t)B * H * W * C;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
@@ -86,7 +96,7 @@ __global__ void to_halo_kernel(const float* __restrict__ in, float* __restrict__
         const int x = (int)(r % W);
         r /= W;
         const int y = (int)(r % H), b = (int)(r / H);
-        out[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = in[i];
+        out[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = cvt_out<OT>(in[i]);
     }
 }
 // out[i] (+)= halo interior
@@ -870,24 +880,40 @@ inline unsigned gs_blocks(size_t n) {
 #define TK(name) return check_launch(name, err)
 
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
+    hipLaunchKernelGGL(transpose_kernel<float>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose");
 }
+int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
+    TK("transpose16");
+}
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(im2colT_kernel, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
+    hipLaunchKernelGGL(im2colT_kernel<float>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT");
 }
+int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
+    TK("im2colT16");
+}
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(conv_w_dgrad_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+    hipLaunchKernelGGL(conv_w_dgrad_kernel<float>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad");
+}
+int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+    TK("conv_w_dgrad16");
 }
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(wgrad_permute_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
     TK("wgrad_permute");
 }
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(to_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+    hipLaunchKernelGGL(to_halo_kernel<float>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo");
+}
+int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+    TK("to_halo16");
 }
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);

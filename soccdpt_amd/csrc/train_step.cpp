@@ -113,8 +113,8 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.GP = ar.f(M1 * F);
     T.DOC = ar.f((size_t)B * a.fres(0) * a.fres(0) * F);
     for (int l = 0; l < 4; ++l) T.DF[l] = ar.f((size_t)B * a.fres(l) * a.fres(l) * a.fdim(l));
-    T.S_T1 = ar.f(maxAct + 32 * 4 * Cmax0);
-    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 32 * 9 * Cmax0);
+    T.S_T1 = ar.f(maxAct + 128 * 4 * Cmax0);
+    T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 128 * 9 * Cmax0);
     T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)));
     const size_t Cmax = a.hybrid ? 1024 : a.dim(3);
     const size_t wmax = std::max(std::max((size_t)9 * F * F, 4 * Cmax * Cmax), a.hybrid ? (size_t)9 * 768 * 768 : 0);
@@ -137,19 +137,28 @@ int gemm(Ctx& c, IgemmDesc d) {
 }
 
 // Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
-// in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.
+// in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.  amp: bf16 operands (K padded to 128 by the caller).
 int gemm_wgrad(Ctx& c, IgemmDesc d) {
-    d.f32 = 1;
+    const bool amp = c.h.train_amp;
+    d.f32 = amp ? 0 : 1;
+    d.f16 = 0;
     // 64 x 64 tiles: the 128 x 128 split-K form was measured slower (51.2 vs 45.2 ms per step at B = 8: fewer, longer workgroups)
-    const long tiles = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-    const long nk = (long)d.taps * d.Cin / 32;
+    const long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    const long nk = (long)d.taps * d.Cin / (amp ? 128 : 32);
     long S = (512 + tiles - 1) / tiles;
-    if (S > nk / 8) S = nk / 8;
+    if (S > nk / (amp ? 2 : 8)) S = nk / (amp ? 2 : 8);
     if (S > 64) S = 64;
     while (S > 1 && (size_t)S * d.M * d.N > kTrainSkPartFloats) --S;
     if (S > 1 && (size_t)tiles <= kTrainSkCountWords) {
         d.splitk = (int)S; d.sk_part = c.T.sk_part; d.sk_count = c.T.sk_count; d.sk_part_floats = kTrainSkPartFloats; d.sk_count_words = kTrainSkCountWords;
     }
+    return launch_igemm(d, c.st, c.err);
+}
+
+// amp: a backward GEMM with bf16 operands (f32 accumulate, f32 outputs)
+int gemm16(Ctx& c, IgemmDesc d) {
+    d.f32 = 0;
+    d.f16 = 0;
     return launch_igemm(d, c.st, c.err);
 }
 
@@ -162,18 +171,39 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
+    const bool amp = c.h.train_amp && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: bf16 operands for the two gradient GEMMs
     if (dX_out) {
-        TRY(tr_transpose(W, T.S_wt, N, K, N, c.st, c.err));   // [K][N]
         IgemmDesc d;
-        d.X = dY; d.Wt = T.S_wt; d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
-        TRY(gemm(c, d));
+        d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
+        if (amp) {
+            uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
+            uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
+            TRY(tr_transpose16(W, w16, N, K, N, c.st, c.err));
+            TRY(launch_cvt_bf16(dY, a16, M * N, 0, c.st, c.err));
+            d.X = a16; d.Wt = w16;
+            TRY(gemm16(c, d));
+        } else {
+            TRY(tr_transpose(W, T.S_wt, N, K, N, c.st, c.err));   // [K][N]
+            d.X = dY; d.Wt = T.S_wt;
+            TRY(gemm(c, d));
+        }
     }
     if (dW) {
-        const int Mp = (int)((M + 31) / 32 * 32);                    // k-tile multiple; the padding rows are zero
-        TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));   // [N][Mp]
-        TRY(tr_transpose(X, T.S_T2, (int)M, K, Mp, c.st, c.err));    // [K][Mp]
         IgemmDesc d;
-        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = K; d.Cin = Mp; d.ldx = Mp; d.out_f32 = dW;
+        d.M = N; d.N = K; d.out_f32 = dW;
+        if (amp) {
+            const int Mp = (int)((M + 127) / 128 * 128);
+            uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
+            uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
+            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
+            TRY(tr_transpose16(X, x16, (int)M, K, Mp, c.st, c.err));
+            d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
+        } else {
+            const int Mp = (int)((M + 31) / 32 * 32);                    // k-tile multiple; the padding rows are zero
+            TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));   // [N][Mp]
+            TRY(tr_transpose(X, T.S_T2, (int)M, K, Mp, c.st, c.err));    // [K][Mp]
+            d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
+        }
         TRY(gemm_wgrad(c, d));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
@@ -185,22 +215,43 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
     Tape& T = c.T;
     const int B = c.B;
     const size_t M = (size_t)B * r * r;
+    const bool amp = c.h.train_amp && N % 32 == 0 && C % 32 == 0;
     if (dX_out) {
-        const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * sizeof(float);
+        const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * (amp ? 2 : 4);
         hipError_t e = hipMemsetAsync(T.S_halo, 0, hb, c.st);
         if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
-        TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
-        TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err));   // [C][9][N], rotated
         IgemmDesc d;
-        d.X = T.S_halo; d.Wt = T.S_wt; d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
-        TRY(gemm(c, d));
+        d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
+        if (amp) {
+            uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
+            uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
+            TRY(tr_to_halo16(dY, h16, B, r, r, N, c.st, c.err));
+            TRY(tr_conv_w_dgrad16(W, w16, N, C, c.st, c.err));
+            d.X = h16; d.Wt = w16;
+            TRY(gemm16(c, d));
+        } else {
+            TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
+            TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err));   // [C][9][N], rotated
+            d.X = T.S_halo; d.Wt = T.S_wt;
+            TRY(gemm(c, d));
+        }
     }
     if (dW) {
-        const int Mp = (int)((M + 31) / 32 * 32);
-        TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));          // [N][Mp]
-        TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
         IgemmDesc d;
-        d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = Mp; d.ldx = Mp; d.out_f32 = T.S_dw;
+        d.M = N; d.N = 9 * C; d.out_f32 = T.S_dw;
+        if (amp) {
+            const int Mp = (int)((M + 127) / 128 * 128);
+            uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
+            uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
+            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
+            TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
+            d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
+        } else {
+            const int Mp = (int)((M + 31) / 32 * 32);
+            TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));          // [N][Mp]
+            TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
+            d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
+        }
         TRY(gemm_wgrad(c, d));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }

@@ -125,6 +125,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_network.restype = ci
     L.soccdpt_project.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     L.soccdpt_bind_grad.argtypes = [vp, ctypes.c_char_p, vp]
+    L.soccdpt_train_set_amp.argtypes = [vp, ci]
     L.soccdpt_train_workspace_bytes.argtypes = [vp, ci]
     L.soccdpt_train_workspace_bytes.restype = cs
     L.soccdpt_train_forward.argtypes = [vp, vp, ci, vp, vp, vp, cs, ctypes.c_float, ctypes.c_uint32, vp]
@@ -360,6 +361,9 @@ class Engine:
         self._check(self.L.soccdpt_bind_grad(self._h, key.encode(), _ptr(g)), "soccdpt_bind_grad")
         self._grads = getattr(self, "_grads", {})
         self._grads[key] = g  # keep alive
+
+    def train_set_amp(self, on: bool):
+        self._check(self.L.soccdpt_train_set_amp(self._h, int(bool(on))), "soccdpt_train_set_amp")
 
     def train_workspace(self, B: int) -> torch.Tensor:
         nbytes = self.L.soccdpt_train_workspace_bytes(self._h, B)

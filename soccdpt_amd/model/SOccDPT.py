@@ -282,6 +282,7 @@ class SOccDPT_V3(SOccDPT):
         assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
         eng = self._engine(x.device)
         live, keys, st = self._bind_for_training(eng)
+        eng.train_set_amp(bool(getattr(self, "train_amp", False)))   # the reference's `amp` sweep parameter: bf16 operands for the gradient GEMMs
         xin = x.detach().to(torch.float32).contiguous()
         B = xin.shape[0]
         inv = torch.empty((B, img, img), device=x.device)

@@ -129,7 +129,6 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     assert type(loss_weights) == list, "loss_weights must be a list"
     loss_depth_w, loss_seg_w = [float(w) for w in loss_weights]
     assert loss_depth_w >= 0.0 and loss_seg_w >= 0.0, "loss_weights must be >= 0.0"
-    assert not p["amp"], "amp=False is what every sweep file of the reference uses; the HIP path has its own operand precisions"
     device = torch.device(device)
     # REPRODUCIBILITY (train_SOccDPT.py:150-154)
     random.seed(0)
@@ -165,6 +164,7 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
         model_kwargs["precision"] = PREC_F32     # the training step (csrc/train_step.cpp) computes in exact f32, like the reference's amp=False runs
     net = load_model(arch=arch, model_kwargs=model_kwargs, device=torch.device("cpu"), model_path=p["load"] or None, model_type=model_type)
     net = net.to(device=device)
+    net.train_amp = bool(p["amp"])     # amp=True: bf16 MFMA operands for the gradient GEMMs (soccdpt_train_set_amp); no GradScaler needed
     freeze_pretrained_encoder(net)
     unfreeze_pretrained_encoder_by_percentage(net, p["encoder_percentage"])
     n_train_t = sum(1 for q in net.parameters() if q.requires_grad)

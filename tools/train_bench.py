@@ -27,6 +27,7 @@ calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
 net.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
 net = net.to(dev).train()
+net.train_amp = os.environ.get("TRAIN_AMP", "0") == "1"
 freeze_pretrained_encoder(net)
 unfreeze_pretrained_encoder_by_percentage(net, enc_pct)
 ds = SyntheticDepthSegDataset(B, S)
@@ -76,7 +77,7 @@ if os.environ.get("TRAIN_BENCH_CPU", "1") != "0":
     (o_inv.sum() + o_seg.sum()).backward()
     cpu = {"samples_per_s": round(2 / (time.time() - t0), 3), "cores": torch.get_num_threads(), "kind": "port",
            "sample": "oracle forward + torch autograd backward, 2 samples, no criterion / optimizer"}
-print(json.dumps({"cpu_baseline": cpu, "model_type": model_type, "B": B, "encoder_percentage": enc_pct, "patchwise_percentage": patch_pct, "optimisation_steps": n,
+print(json.dumps({"cpu_baseline": cpu, "model_type": model_type, "amp": net.train_amp, "B": B, "encoder_percentage": enc_pct, "patchwise_percentage": patch_pct, "optimisation_steps": n,
                   "ms_per_step": round(1e3 * dt / n, 2), "samples_per_s": round(B * n / dt, 1),
                   "train_forward_ms": round(ev[0].elapsed_time(ev[1]), 2), "criterion_ms": round(ev[1].elapsed_time(ev[2]), 2),
                   "backward_all_trainable_ms": round(ev[2].elapsed_time(ev[3]), 2), "loss": float(out["loss"]),

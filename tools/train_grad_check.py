@@ -27,6 +27,7 @@ sd = synth_state_dict(backbone, alias_pretrained=True)
 m.load_state_dict(sd, strict=False)
 m = m.to(dev).train()
 m.seg_head[3].p = 0.0
+m.train_amp = os.environ.get("TRAIN_AMP", "0") == "1"     # bf16 operands for the gradient GEMMs
 x = synth_input(B, size=S, seed0=3)
 g = torch.Generator().manual_seed(11)
 a = torch.randn((B, S, S), generator=g)
