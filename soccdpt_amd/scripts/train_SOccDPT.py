@@ -3,7 +3,9 @@
 :485-546), the same wandb-sweep JSON schema (`config/*.json`: `parameters.<name>.values`, :452-479), the same run set-up -- seeding
 (:150-154), dataset split (:199-224), `load_model` (:248-253), `freeze_pretrained_encoder` + `unfreeze_pretrained_encoder_by_percentage`
 (:262-263), Adam (:311-318), ReduceLROnPlateau(min, patience 2) (:320-322), the `PatchWiseInplace` inner loop (:362-393), the criterion
-`loss_depth_w * SSI + loss_seg_w * BCE` (:323-338,380-386), one checkpoint per epoch (:437-449).
+`loss_depth_w * SSI + loss_seg_w * BCE` (:323-338,380-386), the evaluation round every n_train // (3 * batch_size) steps (:406-430: the seven depth
+metrics and the IoU over the validation split, here on the GPU through csrc/metrics.hip; wandb histograms / images are not produced), one
+checkpoint per epoch (:437-449).
 
 What runs on MI355X: all of it.  The train-mode forward and the network backward (csrc/train_step.cpp, csrc/train_hybrid_step.cpp, csrc/train*.hip: exact f32, all
 three models) sit behind `net.train_forward(x)` / `net.backward(d_inv, d_seg)`; the criterion and its gradient w.r.t. the network outputs are
@@ -32,8 +34,9 @@ import torch
 
 from ..loss import freeze_pretrained_encoder, unfreeze_pretrained_encoder_by_percentage
 from ..model.loader import load_model, load_transforms
-from ..model.SOccDPT import SOccDPT_versions, model_types
+from ..model.SOccDPT import DepthNet, SegNet, SOccDPT_versions, model_types
 from ..utils.loss import training_loss
+from ..utils.metrics import evaluate_depth, evaluate_seg
 from ..utils.optim import Adam, PatchWiseInplace
 from ..utils.synth import synth_input, write_synth_calib
 
@@ -174,7 +177,7 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     optimizer = Adam(net.parameters(), lr=p["learning_rate"], betas=(0.9, 0.999), eps=1e-08, weight_decay=p["weight_decay"], amsgrad=False)
     scheduler = ReduceLROnPlateau(optimizer, patience=2)
     batch_size = p["batch_size"]
-    global_step, history = 0, []
+    global_step, history, evals = 0, [], []
     for epoch in range(1, p["epochs"] + 1):
         net.train()
         epoch_loss = 0.0
@@ -202,6 +205,15 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
             print(f"epoch {epoch} step {global_step}: train_loss {loss:.6f} (disp {float(out['loss_disp']):.6f}, seg {float(out['loss_seg']):.6f}) lr {optimizer.lr:g}")
             division_step = max(n_train // (3 * batch_size), 1)
             if global_step % division_step == 0:
+                # evaluation round (train_SOccDPT.py:406-430 -> utils/__init__.py:598-768): the 7 depth metrics and the IoU over the validation
+                # split, computed on the GPU (csrc/metrics.hip); the wandb histograms / images of the reference are not produced
+                val_batches = [val_set[i] for i in range(len(val_set))]      # items carry their batch dimension (datasets' layout)
+                abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = evaluate_depth(DepthNet(net), val_batches, device, amp=p["amp"])
+                print("abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3", abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)
+                iou = evaluate_seg(SegNet(net), val_batches, device, amp=p["amp"])
+                print("iou", iou)
+                evals.append(dict(step=global_step, abs_rel=abs_rel, rmse=rmse, a1=a1, iou=iou))
+                net.train()
                 scheduler.step(loss)
             global_step += 1
             if max_steps and global_step >= max_steps:
