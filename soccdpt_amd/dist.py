@@ -62,6 +62,49 @@ class OccExchange:
         return bits
 
 
+class GradExchange:
+    """Callable installed as `net.grad_exchange` by attach_training: averages the flat f32 gradient buffer of the training step over the ranks.
+    `runs` are the [lo, hi) element ranges that hold this step's trainable tensors (PatchWiseInplace patches and the unfrozen encoder prefix
+    are contiguous index ranges of the parameter list, so a step needs one to three collectives); each is one all-reduce over RCCL / xGMI.
+    Buckets are capped at `bucket_elems` so that a 166 MB all-trainable step is a few ring-friendly messages rather than one."""
+
+    def __init__(self, group=None, bucket_elems: int = 16 << 20):
+        self.group = group
+        self.bucket = int(bucket_elems)
+        self.calls = 0      # collectives issued (tests)
+
+    def _all_reduce_mean(self, t: torch.Tensor):
+        world = dist.get_world_size(self.group)
+        if t.is_cuda and dist.get_backend(self.group) == "gloo":   # rehearsal only: gloo moves host memory
+            host = t.detach().cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            t.copy_(host)
+        else:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group)
+        t.mul_(1.0 / world)
+        self.calls += 1
+
+    def __call__(self, flat: torch.Tensor, runs):
+        for lo, hi in runs:
+            for a in range(lo, hi, self.bucket):
+                self._all_reduce_mean(flat[a:min(a + self.bucket, hi)])
+
+    def average_buffers(self, tensors):
+        for t in tensors:
+            self._all_reduce_mean(t)
+
+
+def attach_training(net, group=None, bucket_elems: int = 16 << 20):
+    """Data-parallel training of `net` (SOccDPT_V3): every rank runs train_forward / backward on its own batch shard; backward() then averages
+    the gradients over the ranks (GradExchange), so identical optimizer steps keep the replicas identical.  The seg head's BatchNorm normalises
+    with the LOCAL batch statistics (torch DDP's default, no SyncBN); its running buffers are averaged every step."""
+    import os
+    force = os.environ.get("SOCCDPT_FORCE_DIST", "0") == "1"
+    if dist.is_initialized() and (dist.get_world_size(group) > 1 or force):
+        net.grad_exchange = GradExchange(group, bucket_elems)
+    return net
+
+
 def init_from_env(backend: str = "nccl"):
     """Initialise torch.distributed from torchrun's env (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_*)."""
     import os

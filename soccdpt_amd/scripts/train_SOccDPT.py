@@ -133,6 +133,14 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     loss_depth_w, loss_seg_w = [float(w) for w in loss_weights]
     assert loss_depth_w >= 0.0 and loss_seg_w >= 0.0, "loss_weights must be >= 0.0"
     device = torch.device(device)
+    # Data parallel (not in the reference, which trains on one device): under torch.distributed.run every rank takes a contiguous shard of each
+    # batch, gradients are averaged by one bucketed all-reduce per step (soccdpt_amd.dist.attach_training), rank 0 logs and writes checkpoints.
+    from .. import dist as sdist
+    rank, local_rank, world = 0, 0, 1
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        rank, local_rank, world = sdist.init_from_env("nccl")
+        device = torch.device("cuda", local_rank)
+        torch.cuda.set_device(device)
     # REPRODUCIBILITY (train_SOccDPT.py:150-154)
     random.seed(0)
     np.random.seed(0)
@@ -168,6 +176,9 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     net = load_model(arch=arch, model_kwargs=model_kwargs, device=torch.device("cpu"), model_path=p["load"] or None, model_type=model_type)
     net = net.to(device=device)
     net.train_amp = bool(p["amp"])     # amp=True: bf16 MFMA operands for the gradient GEMMs (soccdpt_train_set_amp); no GradScaler needed
+    if world > 1:
+        assert p["batch_size"] >= world, "data parallel: batch_size must be at least the number of ranks"
+        sdist.attach_training(net)
     freeze_pretrained_encoder(net)
     unfreeze_pretrained_encoder_by_percentage(net, p["encoder_percentage"])
     n_train_t = sum(1 for q in net.parameters() if q.requires_grad)
@@ -182,7 +193,11 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
         net.train()
         epoch_loss = 0.0
         for batch_index in range(batch_size, len(train_set) + 1, batch_size):
-            x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(train_set, batch_index, batch_size)
+            if world > 1:      # this rank's contiguous shard of the batch
+                lo, hi = sdist.shard_range(batch_size, rank, world)
+                x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(train_set, batch_index - batch_size + hi, hi - lo)
+            else:
+                x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(train_set, batch_index, batch_size)
             x = x.to(device=device, dtype=torch.float32)
             y_disp, y_seg = y_disp.to(device=device, dtype=torch.float32), y_seg.to(device=device, dtype=torch.float32)
             mask_disp, mask_seg = mask_disp.to(device=device, dtype=torch.bool), mask_seg.to(device=device, dtype=torch.bool)
@@ -202,7 +217,8 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
             loss = float(out["loss"].item())
             epoch_loss += loss
             history.append(loss)
-            print(f"epoch {epoch} step {global_step}: train_loss {loss:.6f} (disp {float(out['loss_disp']):.6f}, seg {float(out['loss_seg']):.6f}) lr {optimizer.lr:g}")
+            if rank == 0:
+                print(f"epoch {epoch} step {global_step}: train_loss {loss:.6f} (disp {float(out['loss_disp']):.6f}, seg {float(out['loss_seg']):.6f}) lr {optimizer.lr:g}")
             division_step = max(n_train // (3 * batch_size), 1)
             if global_step % division_step == 0:
                 # evaluation round (train_SOccDPT.py:406-430 -> utils/__init__.py:598-768): the 7 depth metrics and the IoU over the validation
@@ -218,7 +234,7 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
             global_step += 1
             if max_steps and global_step >= max_steps:
                 break
-        if p["save_checkpoint"]:
+        if p["save_checkpoint"] and rank == 0:
             d = os.path.join(checkpoint_dir, run_id)
             Path(d).mkdir(parents=True, exist_ok=True)
             torch.save(net.state_dict(), os.path.join(d, "checkpoint_epoch_{}.pth".format(epoch)))

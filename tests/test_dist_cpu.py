@@ -125,3 +125,41 @@ def test_init_from_env_refuses_multi_rank_without_port(monkeypatch):
     monkeypatch.delenv("MASTER_PORT", raising=False)
     with pytest.raises(RuntimeError):
         init_from_env("gloo")
+
+
+def _grad_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from soccdpt_amd.dist import GradExchange
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(5000, generator=g)
+    before = flat.clone()
+    ex = GradExchange(bucket_elems=1000)
+    runs = [[0, 1536], [2048, 4800]]            # two runs of trainable tensors; [1536, 2048) and the tail belong to frozen ones
+    ex(flat, runs)
+    assert ex.calls == 2 + 3                    # ceil(1536 / 1000) + ceil(2752 / 1000) collectives
+    buf = torch.full((4,), float(rank))
+    ex.average_buffers([buf])
+    np.save(os.path.join(outdir, f"grad_{rank}.npy"), np.stack([before.numpy(), flat.numpy()]))
+    np.save(os.path.join(outdir, f"buf_{rank}.npy"), buf.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_grad_exchange_averages_trainable_runs(tmp_path, world):
+    """Data-parallel training exchange (soccdpt_amd.dist.GradExchange): inside the runs of trainable tensors every rank ends with the mean of
+    the ranks' gradients, bucketed; outside them (frozen tensors) the buffer is untouched; BatchNorm buffers are averaged."""
+    port = _free_port()
+    mp.spawn(_grad_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    data = [np.load(tmp_path / f"grad_{r}.npy") for r in range(world)]
+    mean = np.mean([d[0] for d in data], axis=0, dtype=np.float64)
+    for r in range(world):
+        before, after = data[r]
+        for lo, hi in ([0, 1536], [2048, 4800]):
+            assert np.allclose(after[lo:hi], mean[lo:hi], rtol=1e-6, atol=1e-7)
+        assert np.array_equal(after[1536:2048], before[1536:2048]) and np.array_equal(after[4800:], before[4800:])
+        assert np.allclose(np.load(tmp_path / f"buf_{r}.npy"), (world - 1) / 2.0)
+    for r in range(1, world):
+        assert np.array_equal(data[r][1][:1536], data[0][1][:1536])        # replicas hold bit-identical averaged gradients

@@ -51,3 +51,19 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
     assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["config"]["dist_backend"] == "gloo"
     assert abs(d["value"] - 4 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3      # whole-job frames / max-over-ranks time
     assert "cpu_baseline" not in d                                                         # N = 1 only
+
+
+def test_data_parallel_training_rehearsal(gpu_device):
+    """Data-parallel training (soccdpt_amd.dist.attach_training) with TWO ranks on the one GPU of a test box (gloo rehearsal): the exchanged
+    gradient equals the mean of the ranks' local gradients, and after two Adam steps both replicas hold bit-identical weights and BatchNorm
+    buffers.  On an 8-GPU node the same code runs with backend nccl (RCCL all-reduce over xGMI), one rank per GPU."""
+    env = dict(os.environ, SOCCDPT_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    worker = os.path.join(os.path.dirname(__file__), "dist_train_worker_gpu.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", "29561", worker], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = sorted(l.split() for l in r.stdout.splitlines() if l.startswith("RESULT"))
+    assert len(lines) == 2
+    assert all(float(l[2]) < 1e-6 for l in lines), lines          # averaged gradient == mean of the local gradients
+    assert lines[0][3] == lines[1][3], lines                       # identical replicas after two optimizer steps
+    assert all(int(l[4]) >= 3 for l in lines)
