@@ -686,14 +686,15 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "conv8p_bf16_256x256x64", "conv8p_bf16_128x256x64", "conv8p_bf16_256x128x64", "conv8p_var33", "conv8p_var34", "conv8p_var35", "conv8p_var36",
                                         "conv8p_var37", "conv8p_var38", "conv8p_var39"};
 
-static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4"};
+static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static int pick_cfg_f32(const IgemmDesc& d) {
     if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
     if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
     if (d.N <= 32) return 2;
     const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
-    return b128 >= 384 ? 0 : 1;
+    // 8 waves (64 x 32 per wave) like the bf16 form: f32 forward 1093 -> 1126 frames/s, training step 45.0 -> 44.2 ms, alternated in one GPU call
+    return b128 >= 384 ? 3 : 1;
 }
 
 static int pick_cfg(const IgemmDesc& d) {
@@ -806,6 +807,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, true, true>(d, stream, err)
                          : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, false, false, true>(d, stream, err)
                                        : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float>(d, stream, err);
+            case 3: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, float>(d, stream, err);   // 8 waves, 64 x 32 per wave
             default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, float>(d, stream, err);
         }
     }
