@@ -319,6 +319,10 @@ int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_in
                           float dropout_p, uint32_t seed, void* stream);
 int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float* dev_d_inv, const float* dev_d_seg, void* dev_workspace,
                            size_t workspace_bytes, void* stream);
+/* Test entry: the encoder's backward alone.  dev_d_feat[l] (l = 0..3, finest first): gradient w.r.t. the l-th hooked feature map the encoder
+ * hands to scratch.layer<l+1>_rn, f32 [B * r_l^2][C_l] in NHWC order.  Must follow a soccdpt_train_forward on the same workspace.  The Swin-V2
+ * encoder has no ReLU, so its gradients can be compared with autograd without the mask-flip floor of the whole network (tests/test_train_step_gpu.py). */
+int soccdpt_train_backward_encoder(void* handle, int B, const float* const* dev_d_feat, void* dev_workspace, size_t workspace_bytes, void* stream);
 /* Location of a saved activation / gradient inside the training workspace (tests, debugging): f32 [pixels][channels], NHWC order.
  * "seg_conv" (seg_head.0 output), "seg_act" (after BatchNorm + ReLU + Dropout), "seg_logits", "depth_conv0", "depth_conv2", "lrn_raw<l>"
  * (layer<l+1>_rn output), "fused_raw<l>" (RCU2 input of refinenet<l+1>, l < 3), "rcu2_out<l>", "fusion_out<l>" (out_conv output, before

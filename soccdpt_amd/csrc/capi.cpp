@@ -111,6 +111,13 @@ int soccdpt_train_set_amp(void* handle, int on) {
     return 0;
 }
 size_t soccdpt_train_workspace_bytes(void* handle, int B) { return handle && B > 0 ? train_workspace_bytes(*static_cast<Handle*>(handle), B) : 0; }
+int soccdpt_train_backward_encoder(void* handle, int B, const float* const* dev_d_feat, void* dev_workspace, size_t workspace_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (h->train_key.ws != dev_workspace || h->train_key.B != B || !dev_workspace)
+        return fail(h, "soccdpt_train_backward_encoder: no soccdpt_train_forward ran on this workspace with this batch size");
+    return train_backward_encoder(*h, B, dev_d_feat, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+}
 int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !byte_offset || !elems) return 1;

@@ -42,6 +42,7 @@ int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStre
 
 // train_step.cpp: SOccDPT_V3 training step (model/SOccDPT.py:660-685 in train mode + autograd), SOCCDPT_PREC_F32 only
 size_t train_workspace_bytes(Handle& h, int B);
+int train_backward_encoder(Handle& h, int B, const float* const* d_feat, void* ws, size_t ws_bytes, hipStream_t st, std::string& err);
 int train_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems);
 int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void* ws, size_t ws_bytes, float dropout_p, unsigned seed, hipStream_t st, std::string& err);
 int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err);

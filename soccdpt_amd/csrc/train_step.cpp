@@ -486,6 +486,115 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
     return 0;
 }
 
+// Encoder part of the backward: consumes the gradients of the four hooked feature maps (T.DF[l], [pixels][channels]) left by the decoder pass.
+static int encoder_backward(Ctx& c) {
+    Handle& h = c.h;
+    const Arch& a = h.arch;
+    Tape& T = c.T;
+    const int B = c.B;
+    hipStream_t st = c.st;
+    std::string& err = c.err;
+    float** G = T.G;
+    if (a.hybrid) return hy_backward(c);
+    {
+        const float* xcur = T.x0;
+        for (int s = 0; s < 4; ++s) {
+            for (auto& b : T.blk[s]) { b.xin = xcur; xcur = b.xout; }
+            if (s < 3) xcur = T.mx[s];
+        }
+    }
+    // ---------------- encoder, last stage -> first ----------------
+    bool have = false;   // GX holds a gradient
+    // trainable parameters at or before (stage s, block j) in forward order?  The walk ends below the earliest one.
+    auto trains_upto = [&](int s, int j) {
+        if (any_grad(h, ENC + "patch_embed.")) return true;
+        for (int t = 0; t <= s; ++t) {
+            if (t < s && any_grad(h, ENC + "layers." + std::to_string(t) + ".")) return true;
+            if (t == s)
+                for (int i = 0; i <= j; ++i)
+                    if (any_grad(h, blk_key(s, i))) return true;
+        }
+        return false;
+    };
+    for (int s = 3; s >= 0; --s) {
+        const int C = a.dim(s), res = a.res(s), wsz = a.ws(s), H = a.heads[s];
+        const size_t M = (size_t)B * res * res;
+        for (int j = a.depths[s] - 1; j >= 0; --j) {
+            BlkT& b = T.blk[s][j];
+            const std::string k = blk_key(s, j);
+            if (j == a.hooks[s]) {
+                if (have) TRY(tr_axpy(T.GX, T.DF[s], M * C, st, err));
+                else TRY(copy_d2d(c, T.GX, T.DF[s], M * C * 4, "train_backward"));
+                have = true;
+            }
+            if (!have) continue;   // blocks after the last hooked one do not reach the outputs
+            if (!trains_upto(s, j)) return 0;
+            // xout = x1 + LN2(m_pre)
+            TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), T.GX, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
+            TRY(linear_bwd(c, G[0], b.hact, c.W(k + "mlp.fc2.weight"), M, C, 4 * C, G[2], nullptr, c.Gd(k + "mlp.fc2.weight"), c.Gd(k + "mlp.fc2.bias")));
+            TRY(tr_gelu_bwd(G[2], b.hpre, G[2], M * 4 * C, st, err));
+            TRY(linear_bwd(c, G[2], b.x1, c.W(k + "mlp.fc1.weight"), M, 4 * C, C, G[3], T.GX, c.Gd(k + "mlp.fc1.weight"), c.Gd(k + "mlp.fc1.bias")));   // G3 = d x1
+            // x1 = xin + LN1(a_pre)
+            TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), G[3], G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
+            TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
+            TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            {
+                float* dls = c.Gd(k + "attn.logit_scale");
+                float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
+                float* db0 = c.Gd(k + "attn.cpb_mlp.0.bias");
+                float* dw2 = c.Gd(k + "attn.cpb_mlp.2.weight");
+                if (dls || dw0 || db0 || dw2)
+                    TRY(tr_attn_param_grads(T.dS, T.dscale_part, b.table, c.W(k + "attn.logit_scale"), c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"),
+                                            c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, T.S_cpb, dls, dw0, db0, dw2, B * (res / wsz) * (res / wsz), wsz,
+                                            a.pretrained_window[s], H, st, err));
+            }
+            {
+                float* dq = c.Gd(k + "attn.q_bias");
+                float* dv = c.Gd(k + "attn.v_bias");
+                float* dbias = (dq || dv) ? T.S_vec : nullptr;
+                TRY(linear_bwd(c, G[4], b.xin, c.W(k + "attn.qkv.weight"), M, 3 * C, C, T.GX, G[3], c.Gd(k + "attn.qkv.weight"), dbias));
+                if (dbias) TRY(tr_qv_bias_grad(dbias, dq, dv, C, st, err));
+            }
+        }
+        if (!have) continue;
+        {   // anything trainable in patch_embed or stages < s (their blocks and PatchMerging)?
+            bool below = any_grad(h, ENC + "patch_embed.");
+            for (int t = 0; t < s; ++t) below = below || any_grad(h, ENC + "layers." + std::to_string(t) + ".");
+            if (!below) return 0;
+        }
+        if (s > 0) {
+            // x_s = LN(reduction(gather(x_{s-1})))   (timm PatchMerging of Swin-V2: reduction then norm)
+            const int Cp = a.dim(s - 1);
+            const std::string dk = ENC + "layers." + std::to_string(s - 1) + ".downsample.";
+            TRY(ln_bwd(c, T.mr_pre[s - 1], c.W(dk + "norm.weight"), T.GX, G[0], G[1], M, C, c.Gd(dk + "norm.weight"), c.Gd(dk + "norm.bias")));
+            TRY(linear_bwd(c, G[0], T.mg[s - 1], c.W(dk + "reduction.weight"), M, C, 4 * Cp, G[2], nullptr, c.Gd(dk + "reduction.weight"), nullptr));
+            TRY(tr_merge_scatter(G[2], T.GX, B, a.res(s - 1), Cp, st, err));
+        } else {
+            const int C0 = a.embed;
+            TRY(ln_bwd(c, T.pe_pre, c.W(ENC + "patch_embed.norm.weight"), T.GX, G[0], G[1], M, C0, c.Gd(ENC + "patch_embed.norm.weight"), c.Gd(ENC + "patch_embed.norm.bias")));
+            float* dw = c.Gd(ENC + "patch_embed.proj.weight");
+            TRY(linear_bwd(c, G[0], T.patches, T.pe_wpad, M, C0, 64, nullptr, nullptr, dw ? T.S_dw + 65536 : nullptr, c.Gd(ENC + "patch_embed.proj.bias")));
+            if (dw) TRY(tr_pad_cols(T.S_dw + 65536, dw, C0, 64, 48, st, err));
+        }
+    }
+    return 0;
+}
+
+// Test entry: the encoder backward alone, from caller-supplied gradients of the hooked feature maps (d_feat[l]: [B * fres(l)^2][fdim(l)] f32).
+int train_backward_encoder(Handle& h, int B, const float* const* d_feat, void* ws, size_t ws_bytes, hipStream_t st, std::string& err) {
+    if (check_train(h, B, ws, ws_bytes, err)) return 1;
+    TArena ar(ws);
+    Tape T;
+    carve(h, B, ar, T);
+    Ctx c{h, T, B, st, err};
+    for (int l = 0; l < 4; ++l) {
+        if (!d_feat || !d_feat[l]) { err = "soccdpt_train_backward_encoder: null feature gradient"; return 1; }
+        const size_t n = (size_t)B * h.arch.fres(l) * h.arch.fres(l) * h.arch.fdim(l);
+        TRY(copy_d2d(c, T.DF[l], d_feat[l], n * 4, "train_backward_encoder"));
+    }
+    return encoder_backward(c);
+}
+
 int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err) {
     if (check_train(h, B, ws, ws_bytes, err)) return 1;
     (void)x;
@@ -590,82 +699,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         TRY(conv3_bwd(c, d_lrn, T.feat[l], c.W(lk), r, F, a.fdim(l), enc_train ? T.DF[l] : nullptr, nullptr, c.Gd(lk), nullptr));
     }
     if (!enc_train) return 0;
-    if (a.hybrid) return hy_backward(c);
-    // ---------------- encoder, last stage -> first ----------------
-    bool have = false;   // GX holds a gradient
-    // trainable parameters at or before (stage s, block j) in forward order?  The walk ends below the earliest one.
-    auto trains_upto = [&](int s, int j) {
-        if (any_grad(h, ENC + "patch_embed.")) return true;
-        for (int t = 0; t <= s; ++t) {
-            if (t < s && any_grad(h, ENC + "layers." + std::to_string(t) + ".")) return true;
-            if (t == s)
-                for (int i = 0; i <= j; ++i)
-                    if (any_grad(h, blk_key(s, i))) return true;
-        }
-        return false;
-    };
-    for (int s = 3; s >= 0; --s) {
-        const int C = a.dim(s), res = a.res(s), wsz = a.ws(s), H = a.heads[s];
-        const size_t M = (size_t)B * res * res;
-        for (int j = a.depths[s] - 1; j >= 0; --j) {
-            BlkT& b = T.blk[s][j];
-            const std::string k = blk_key(s, j);
-            if (j == a.hooks[s]) {
-                if (have) TRY(tr_axpy(T.GX, T.DF[s], M * C, st, err));
-                else TRY(copy_d2d(c, T.GX, T.DF[s], M * C * 4, "train_backward"));
-                have = true;
-            }
-            if (!have) continue;   // blocks after the last hooked one do not reach the outputs
-            if (!trains_upto(s, j)) return 0;
-            // xout = x1 + LN2(m_pre)
-            TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), T.GX, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
-            TRY(linear_bwd(c, G[0], b.hact, c.W(k + "mlp.fc2.weight"), M, C, 4 * C, G[2], nullptr, c.Gd(k + "mlp.fc2.weight"), c.Gd(k + "mlp.fc2.bias")));
-            TRY(tr_gelu_bwd(G[2], b.hpre, G[2], M * 4 * C, st, err));
-            TRY(linear_bwd(c, G[2], b.x1, c.W(k + "mlp.fc1.weight"), M, 4 * C, C, G[3], T.GX, c.Gd(k + "mlp.fc1.weight"), c.Gd(k + "mlp.fc1.bias")));   // G3 = d x1
-            // x1 = xin + LN1(a_pre)
-            TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), G[3], G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
-            TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
-            TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
-            {
-                float* dls = c.Gd(k + "attn.logit_scale");
-                float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
-                float* db0 = c.Gd(k + "attn.cpb_mlp.0.bias");
-                float* dw2 = c.Gd(k + "attn.cpb_mlp.2.weight");
-                if (dls || dw0 || db0 || dw2)
-                    TRY(tr_attn_param_grads(T.dS, T.dscale_part, b.table, c.W(k + "attn.logit_scale"), c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"),
-                                            c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, T.S_cpb, dls, dw0, db0, dw2, B * (res / wsz) * (res / wsz), wsz,
-                                            a.pretrained_window[s], H, st, err));
-            }
-            {
-                float* dq = c.Gd(k + "attn.q_bias");
-                float* dv = c.Gd(k + "attn.v_bias");
-                float* dbias = (dq || dv) ? T.S_vec : nullptr;
-                TRY(linear_bwd(c, G[4], b.xin, c.W(k + "attn.qkv.weight"), M, 3 * C, C, T.GX, G[3], c.Gd(k + "attn.qkv.weight"), dbias));
-                if (dbias) TRY(tr_qv_bias_grad(dbias, dq, dv, C, st, err));
-            }
-        }
-        if (!have) continue;
-        {   // anything trainable in patch_embed or stages < s (their blocks and PatchMerging)?
-            bool below = any_grad(h, ENC + "patch_embed.");
-            for (int t = 0; t < s; ++t) below = below || any_grad(h, ENC + "layers." + std::to_string(t) + ".");
-            if (!below) return 0;
-        }
-        if (s > 0) {
-            // x_s = LN(reduction(gather(x_{s-1})))   (timm PatchMerging of Swin-V2: reduction then norm)
-            const int Cp = a.dim(s - 1);
-            const std::string dk = ENC + "layers." + std::to_string(s - 1) + ".downsample.";
-            TRY(ln_bwd(c, T.mr_pre[s - 1], c.W(dk + "norm.weight"), T.GX, G[0], G[1], M, C, c.Gd(dk + "norm.weight"), c.Gd(dk + "norm.bias")));
-            TRY(linear_bwd(c, G[0], T.mg[s - 1], c.W(dk + "reduction.weight"), M, C, 4 * Cp, G[2], nullptr, c.Gd(dk + "reduction.weight"), nullptr));
-            TRY(tr_merge_scatter(G[2], T.GX, B, a.res(s - 1), Cp, st, err));
-        } else {
-            const int C0 = a.embed;
-            TRY(ln_bwd(c, T.pe_pre, c.W(ENC + "patch_embed.norm.weight"), T.GX, G[0], G[1], M, C0, c.Gd(ENC + "patch_embed.norm.weight"), c.Gd(ENC + "patch_embed.norm.bias")));
-            float* dw = c.Gd(ENC + "patch_embed.proj.weight");
-            TRY(linear_bwd(c, G[0], T.patches, T.pe_wpad, M, C0, 64, nullptr, nullptr, dw ? T.S_dw + 65536 : nullptr, c.Gd(ENC + "patch_embed.proj.bias")));
-            if (dw) TRY(tr_pad_cols(T.S_dw + 65536, dw, C0, 64, 48, st, err));
-        }
-    }
-    return 0;
+    return encoder_backward(c);
 }
 
 }  // namespace soccdpt

@@ -130,6 +130,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_train_workspace_bytes.restype = cs
     L.soccdpt_train_forward.argtypes = [vp, vp, ci, vp, vp, vp, cs, ctypes.c_float, ctypes.c_uint32, vp]
     L.soccdpt_train_backward.argtypes = [vp, vp, ci, vp, vp, vp, cs, vp]
+    L.soccdpt_train_backward_encoder.argtypes = [vp, ci, ctypes.POINTER(vp), vp, cs, vp]
     L.soccdpt_train_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs)]
     L.soccdpt_project.restype = ci
     L.soccdpt_occ_or.argtypes = [vp, vp, vp, ci, vp]
@@ -371,6 +372,15 @@ class Engine:
         if cur is None or cur.numel() < nbytes:
             self._train_ws = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
         return self._train_ws
+
+    def train_backward_encoder(self, B: int, d_feats):
+        """Encoder backward alone from the gradients of the four hooked feature maps ([B * r^2, C] f32 each, finest first)."""
+        ws = self.train_workspace(B)
+        keep = [t.detach().to(torch.float32).contiguous() for t in d_feats]
+        arr = (ctypes.c_void_p * 4)(*[t.data_ptr() for t in keep])
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_train_backward_encoder(self._h, B, arr, ws.data_ptr(), ws.numel(), _stream_ptr(self.device)),
+                        "soccdpt_train_backward_encoder")
 
     def train_tensor(self, B: int, name: str, channels: int) -> torch.Tensor:
         """A saved activation / gradient of the training workspace as an f32 [pixels, channels] view (see soccdpt_train_workspace_tensor)."""

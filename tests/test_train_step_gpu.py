@@ -380,3 +380,88 @@ def test_amp_gradients_with_criterion(gpu_device):
     med = sorted(e for e, _ in errs)[len(errs) // 2]
     print(f"amp: {len(errs)} parameter gradients vs torch f32 autograd: median {med:.2e}, worst {max(errs)[0]:.2e} ({max(errs)[1]})")
     assert med < 1e-2 and max(errs)[0] < 5e-2, max(errs)
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+
+
+def test_swin_encoder_backward_exact(gpu_device):
+    """The Swin-V2 encoder has no ReLU (the log-CPB MLP's ReLU sees weight-only inputs), so its backward can be compared with autograd free of
+    the mask-flip floor: gradients w.r.t. the four hooked feature maps are injected directly (soccdpt_train_backward_encoder) and every
+    encoder parameter gradient -- window attention with cosine similarity, clamped logit scale, relative-position-bias MLP, shifted-window masks,
+    LayerNorm, GELU MLP, PatchMerging, patch embedding -- must agree with torch f32 autograd over the oracle encoder: median below 1e-4, every tensor below
+    1e-3 relative L2 (the worst ones, 1e-4 .. 4e-4, are the q_bias / logit_scale vectors: sums over all tokens of random-sign terms)."""
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _make(gpu_device)
+    m.train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    B = 2
+    x = synth_input(B, seed0=3)
+    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    feats = R.swin_encoder(sd_o, x, R.ARCHS["swin2t16_256"])
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.randn(f.shape, generator=g) for f in feats]
+    sum((f * w).sum() for f, w in zip(feats, ws)).backward()
+    m.train_forward(x.to(gpu_device))
+    for p in m.parameters():
+        p.grad = None
+    eng = m._engine(gpu_device)
+    eng.train_backward_encoder(B, [_nhwc(w).to(gpu_device) for w in ws])
+    torch.cuda.synchronize()
+    st = m._train_state[id(eng)]
+    errs = []
+    for k, gbuf in st["grads"].items():
+        if gbuf is None or "pretrained.model" not in k:
+            continue
+        ref = sd_o[k].grad
+        if ref is None:
+            continue
+        errs.append((_rel(gbuf.cpu(), ref), k))
+    assert len(errs) > 150
+    print(f"{len(errs)} encoder parameter gradients vs torch f32 autograd: median {sorted(e for e, _ in errs)[len(errs) // 2]:.2e}, worst {max(errs)[0]:.2e} ({max(errs)[1]})")
+    med = sorted(e for e, _ in errs)[len(errs) // 2]
+    bad = [(e, k) for e, k in errs if e > 1e-3]
+    assert not bad and med < 1e-4, (med, bad[:10])
+
+
+def test_hybrid_vit_backward_exact(gpu_device):
+    """dpt_hybrid_384: gradients injected at the two ViT-derived feature maps only (act_postprocess3 / 4 outputs).  The ViT blocks, the read-out
+    projections and the reassemble convolutions (incl. the stride-2 3x3) contain no ReLU, so their parameter gradients are free of mask flips and
+    must agree with torch f32 autograd over the oracle (median below 2e-4, every tensor below 5e-4; measured median 5.7e-5, worst 1.1e-4): global softmax attention backward, pre-norm LayerNorm, GELU MLP, ProjectReadout,
+    class token / position embedding, patch projection.  (The ResNetV2 parameters further upstream go through ReLUs and are covered by
+    test_hybrid_backward_matches_autograd.)"""
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type="dpt_hybrid_384")
+    sd = synth_state_dict("vitb_rn50_384", alias_pretrained=True)
+    m.load_state_dict(sd, strict=False)
+    m = m.to(gpu_device).train()
+    for p in m.parameters():
+        p.requires_grad_(True)
+    x = synth_input(1, size=384, seed0=3)
+    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    feats = R.hybrid_encoder(sd_o, x)
+    g = torch.Generator().manual_seed(5)
+    ws = [torch.zeros(feats[0].shape), torch.zeros(feats[1].shape), torch.randn(feats[2].shape, generator=g), torch.randn(feats[3].shape, generator=g)]
+    sum((f * w).sum() for f, w in zip(feats, ws)).backward()
+    m.train_forward(x.to(gpu_device))
+    eng = m._engine(gpu_device)
+    eng.train_backward_encoder(1, [_nhwc(w).to(gpu_device) for w in ws])
+    torch.cuda.synchronize()
+    st = m._train_state[id(eng)]
+    errs = []
+    for k, gbuf in st["grads"].items():
+        flip_free = ("model.blocks." in k or "act_postprocess" in k or k.endswith("cls_token") or k.endswith("pos_embed") or "patch_embed.proj" in k)
+        if gbuf is None or not flip_free or sd_o[k].grad is None:
+            continue
+        errs.append((_rel(gbuf.cpu(), sd_o[k].grad), k))
+    assert len(errs) >= 12 * 12 + 10
+    print(f"{len(errs)} ViT / read-out parameter gradients vs torch f32 autograd: median {sorted(e for e, _ in errs)[len(errs) // 2]:.2e}, "
+          f"worst {max(errs)[0]:.2e} ({max(errs)[1]})")
+    med = sorted(e for e, _ in errs)[len(errs) // 2]
+    bad = [(e, k) for e, k in errs if e > 5e-4]
+    assert not bad and med < 2e-4, (med, bad[:10])
