@@ -311,12 +311,19 @@ class SOccDPT_V3(SOccDPT):
         return inv, seg
 
     def backward(self, d_inv: torch.Tensor, d_seg: torch.Tensor):
-        """d loss / d (inv_depth, segmentation) of the last train_forward -> .grad of every trainable parameter (accumulated like
-        autograd does when .grad is already populated).  Replaces loss.backward() of scripts/train_SOccDPT.py:390."""
+        """d loss / d (inv_depth, segmentation) of the last train_forward -> .grad of every trainable parameter, accumulated like
+        autograd does when .grad is already populated (no zero_grad since the previous backward).  Replaces loss.backward() of scripts/train_SOccDPT.py:390."""
         if getattr(self, "_train_x", None) is None:
             raise RuntimeError("backward() needs a train_forward() first")
         eng, xin = self._train_x
         live, keys, st = self._bind_for_training(eng)
+        # the library WRITES its gradient buffers: a parameter whose .grad still is that buffer (no zero_grad since the last backward: gradient
+        # accumulation over micro-batches) keeps its old value aside so that the new gradient can be added like autograd does
+        carried = []
+        for k in keys:
+            g = st["grads"].get(k)
+            if g is not None and live[k].grad is g:
+                carried.append((g, g.clone()))
         eng.train_backward(xin, d_inv.detach().to(torch.float32).contiguous(), d_seg.detach().to(torch.float32).contiguous())
         if getattr(self, "grad_exchange", None) is not None:
             # data parallel: average the gradients over the ranks, one collective per contiguous run of trainable tensors
@@ -330,6 +337,8 @@ class SOccDPT_V3(SOccDPT):
                     else:
                         runs.append([lo, hi])
             self.grad_exchange(st["flat"], runs)
+        for g, prev in carried:
+            g.add_(prev)
         seen = set()
         for k in keys:
             g = st["grads"].get(k)

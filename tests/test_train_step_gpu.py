@@ -465,3 +465,33 @@ def test_hybrid_vit_backward_exact(gpu_device):
     med = sorted(e for e, _ in errs)[len(errs) // 2]
     bad = [(e, k) for e, k in errs if e > 5e-4]
     assert not bad and med < 2e-4, (med, bad[:10])
+
+
+def test_backward_accumulates_without_zero_grad(gpu_device):
+    """Gradient accumulation over micro-batches: a second backward without zero_grad adds to .grad like autograd does (the library itself
+    writes its buffers; the Python layer carries the previous values over), and the data-parallel exchange would then average the sum."""
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _make(gpu_device)
+    m.train()
+    m.seg_head[3].p = 0.0
+    for k, p in m.named_parameters():
+        p.requires_grad_("scratch.output_conv" in k or "seg_head" in k)
+    g = torch.Generator().manual_seed(3)
+    a = torch.randn((1, 256, 256), generator=g).to(gpu_device)
+    b = torch.randn((1, 3, 256, 256), generator=g).to(gpu_device)
+    xs = [synth_input(1, seed0=s).to(gpu_device) for s in (1, 2)]
+    singles = []
+    for x in xs:
+        for p in m.parameters():
+            p.grad = None
+        m.train_forward(x)
+        m.backward(a, b)
+        singles.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    for p in m.parameters():
+        p.grad = None
+    for x in xs:
+        m.train_forward(x)
+        m.backward(a, b)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, singles[0][k] + singles[1][k]), k
