@@ -1,4 +1,5 @@
-// Training step of SOccDPT_V3 (Swin-V2 encoders): train-mode forward that keeps every activation the backward needs (the "tape"),
+// Training step of SOccDPT_V3 (Swin-V2 encoders here, the ViT-hybrid encoder in train_hybrid_step.cpp; decoder and heads shared): train-mode
+// forward that keeps every activation the backward needs (the "tape"),
 // and the backward that autograd runs for the reference (scripts/train_SOccDPT.py:360-393 over model/SOccDPT.py:660-685, model/dpt.py:142-232,
 // model/blocks.py:391-497 and timm's SwinTransformerV2).  Exact f32 (SOCCDPT_PREC_F32): every GEMM-shaped gradient goes through the f32
 // MFMA igemm (igemm.hip), the rest through train.hip.  Train mode differs from eval in the seg head only (model/SOccDPT.py:660-671):
@@ -619,14 +620,6 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     bool need_level[5];             // the gradient has to reach level l's out_conv output
     need_level[4] = false;
     for (int l = 3; l >= 0; --l) need_level[l] = lvl_own[l] || lvl_side[l] || need_level[l + 1];
-    // the block buffers are re-derived from the same walk as the forward's: xin pointers
-    if (!a.hybrid) {
-        const float* xcur = T.x0;
-        for (int s = 0; s < 4; ++s) {
-            for (auto& b : T.blk[s]) { b.xin = xcur; xcur = b.xout; }
-            if (s < 3) xcur = T.mx[s];
-        }
-    }
     // ---------------- depth head ----------------
     {
         TRY(tr_depth_tail_bwd(d_inv, T.inv, T.e, c.W(SCR + "output_conv.4.weight"), G[0], G[1], M0p, 32, st, err));
