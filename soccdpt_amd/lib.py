@@ -73,12 +73,15 @@ _lib = None
 
 
 def csrc_sha() -> str:
-    """Short hash of the kernel sources the loaded library was (presumably) built from.  profiles/*_pmc_traffic.json carry it, so
-    that bench.py can tell whether committed PMC counters still describe the current kernels."""
+    """Short hash of the sources the FORWARD path's kernels are built from (everything in csrc/ except the training step's own translation
+    units train*.{hip,cpp,h}, which launch no kernel of the forward).  profiles/*_pmc_traffic.json carry it, so that bench.py can tell
+    whether committed PMC counters still describe the current kernels."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(_HERE, "csrc")
     for name in sorted(os.listdir(d)):
+        if name.startswith("train"):
+            continue
         if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
             h.update(name.encode())
             h.update(open(os.path.join(d, name), "rb").read())
