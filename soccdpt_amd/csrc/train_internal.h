@@ -107,7 +107,8 @@ int gemm_wgrad(Ctx& c, IgemmDesc d);
 int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what);
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db);
-int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db);
+int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db,
+              bool reuse_xt = false);   // reuse_xt: the im2col^T of Xhalo is still in S_T2 from the previous call
 int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps = 1e-5f);
 IgemmDesc conv_desc(const void* X, int Cin, const void* Wt, int N, int r, int B);
 bool any_grad(const Handle& h, const std::string& prefix);

@@ -212,7 +212,8 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
 }
 
 // y = conv3x3(Xhalo, W) + b backward.  dY plain [B*r*r][N], Xhalo [B][r+2][r+2][C], W [N][C][3][3].
-int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db) {
+int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db,
+              bool reuse_xt) {
     Tape& T = c.T;
     const int B = c.B;
     const size_t M = (size_t)B * r * r;
@@ -245,12 +246,12 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
             TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
-            TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
+            if (!reuse_xt) TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
             d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
         } else {
             const int Mp = (int)((M + 31) / 32 * 32);
             TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));          // [N][Mp]
-            TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
+            if (!reuse_xt) TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
         TRY(gemm_wgrad(c, d));
@@ -654,7 +655,9 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         if (float* p = c.Gd("seg_head.1.bias")) TRY(copy_d2d(c, p, dbeta, F * 4, "train_backward"));
         if (float* p = c.Gd("seg_head.1.weight")) TRY(copy_d2d(c, p, dgamma, F * 4, "train_backward"));
         TRY(tr_bn_bwd(G[0], T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), dbeta, dgamma, G[2], M1, F, st, err));
-        TRY(conv3_bwd(c, G[2], T.path1, c.W("seg_head.0.weight"), r1, F, F, need_level[0] ? T.GP : nullptr, T.GP, c.Gd("seg_head.0.weight"), nullptr));
+        // path_1's im2col^T is still in S_T2 from output_conv.0's weight gradient (same input image, nothing in between writes S_T2)
+        const bool xt_ready = c.Gd(SCR + "output_conv.0.weight") != nullptr;
+        TRY(conv3_bwd(c, G[2], T.path1, c.W("seg_head.0.weight"), r1, F, F, need_level[0] ? T.GP : nullptr, T.GP, c.Gd("seg_head.0.weight"), nullptr, xt_ready));
     }
     if (!need_level[0]) return 0;
     TRY(tr_bilinear_bwd(T.GP, T.DOC, B, a.fres(0), a.fres(0), r1, r1, F, 0, st, err));
