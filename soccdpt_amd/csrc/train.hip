@@ -475,14 +475,17 @@ __global__ void pad_cols_kernel(const float* __restrict__ in, float* __restrict_
 // The bias-table and logit-scale gradients are reduced from that scratch by their own kernels.
 __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
                                                         const float* __restrict__ scale, const float* __restrict__ rowstat, const float* __restrict__ attn_out,
-                                                        float* __restrict__ dS_out, float* __restrict__ dqkv, float* __restrict__ dscale_part, int res, int ws, int shift,
-                                                        int heads) {
+                                                        float* __restrict__ dS_out, float* __restrict__ dqkv_part, float* __restrict__ dscale_part, int res, int ws,
+                                                        int shift, int heads, int nseg, size_t part_stride) {
     __shared__ float Kh[64][33];
     __shared__ float Vs[64][33];
     __shared__ float dsT[64][65];
     const int N = ws * ws, nqb = (N + 63) / 64;
     const int C = heads * 32, nw = res / ws;
     int bid = blockIdx.x;
+    const int seg = bid % nseg;      // key tiles seg, seg + nseg, ...: more waves for the stages with few windows (deterministic partial sums)
+    bid /= nseg;
+    float* dqkv = dqkv_part + (size_t)seg * part_stride;
     const int qb = bid % nqb;
     bid /= nqb;
     const int head = bid % heads;
@@ -549,7 +552,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
     // (a lane writing its own row was one 4-byte store per cache line).
     float dsc = 0.f;
     float* dSbase = dS_out + ((size_t)widx * heads + head) * N * N;
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = seg * 64; k0 < N; k0 += 64 * nseg) {
         stage(k0);
         const int nk = (N - k0) < 64 ? (N - k0) : 64;
         for (int kk = 0; kk < nk; ++kk) {
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
     // per-(window, head, query block) partial of d scale (reduced in fixed order by attn_scale_reduce_kernel)
     dsc = qv ? dsc : 0.f;
     for (int o = 1; o < 64; o <<= 1) dsc += __shfl_xor(dsc, o);
-    if (tid == 0) dscale_part[((size_t)widx * heads + head) * nqb + qb] = dsc;
+    if (tid == 0) dscale_part[(((size_t)widx * heads + head) * nqb + qb) * nseg + seg] = dsc;
 }
 
 // Pass B, one thread = one key: dv_k = sum_q P[q][k] dO_q needs P, so recompute it from dS?  No: P is recomputed from the logits with the
@@ -595,13 +598,16 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
 // dk^_k = sum_q dS[q][k] q^_q ; dv_k = sum_q P[q][k] dO_q.
 __global__ __launch_bounds__(64) void attn_bwd_k_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
                                                         const float* __restrict__ scale, const float* __restrict__ dS_in, const float* __restrict__ rowstat,
-                                                        float* __restrict__ dqkv, int res, int ws, int shift, int heads) {
+                                                        float* __restrict__ dqkv_part, int res, int ws, int shift, int heads, int nseg, size_t part_stride) {
     __shared__ float Qh[64][33];
     __shared__ float dOs[64][33];
     __shared__ float st_m[64], st_l[64];
     const int N = ws * ws, nkb = (N + 63) / 64;
     const int C = heads * 32, nw = res / ws;
     int bid = blockIdx.x;
+    const int seg = bid % nseg;
+    bid /= nseg;
+    float* dqkv = dqkv_part + (size_t)seg * part_stride;
     const int kb = bid % nkb;
     bid /= nkb;
     const int head = bid % heads;
@@ -637,7 +643,7 @@ __global__ __launch_bounds__(64) void attn_bwd_k_kernel(const float* __restrict_
     }
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     const int half = ws / 2;
-    for (int q0 = 0; q0 < N; q0 += 64) {
+    for (int q0 = seg * 64; q0 < N; q0 += 64 * nseg) {
         __syncthreads();
         {
             const int q = q0 + tid;
@@ -689,11 +695,14 @@ __global__ __launch_bounds__(64) void attn_bwd_k_kernel(const float* __restrict_
 
 // row statistics {max, sum exp} of every query (pass A of the forward recomputation, shared by attn_bwd_k_kernel)
 __global__ __launch_bounds__(64) void attn_rowstat_kernel(const float* __restrict__ qkv, const float* __restrict__ table, const float* __restrict__ scale,
-                                                          float* __restrict__ rowstat, int res, int ws, int shift, int heads) {
+                                                          float* __restrict__ rowstat_part, int res, int ws, int shift, int heads, int nseg, size_t part_stride) {
     __shared__ float Kh[64][33];
     const int N = ws * ws, nqb = (N + 63) / 64;
     const int C = heads * 32, nw = res / ws;
     int bid = blockIdx.x;
+    const int seg = bid % nseg;
+    bid /= nseg;
+    float* rowstat = rowstat_part + (size_t)seg * part_stride;
     const int qb = bid % nqb;
     bid /= nqb;
     const int head = bid % heads;
@@ -728,7 +737,7 @@ __global__ __launch_bounds__(64) void attn_rowstat_kernel(const float* __restric
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     const int half = ws / 2;
     float m = -3.0e38f, l = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
+    for (int k0 = seg * 64; k0 < N; k0 += 64 * nseg) {
         __syncthreads();
         {
             const int k = k0 + tid;
@@ -761,6 +770,29 @@ __global__ __launch_bounds__(64) void attn_rowstat_kernel(const float* __restric
         float* rs = rowstat + (((size_t)widx * heads + head) * N + q) * 2;
         rs[0] = m;
         rs[1] = l;
+    }
+}
+
+// merge the per-segment {max, sum exp} pairs into the row statistics
+__global__ void attn_rowstat_combine_kernel(const float* __restrict__ part, float* __restrict__ rowstat, size_t rows, int nseg) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < rows; i += (size_t)gridDim.x * blockDim.x) {
+        float M = -3.0e38f;
+        for (int s = 0; s < nseg; ++s) M = fmaxf(M, part[((size_t)s * rows + i) * 2]);
+        float L = 0.f;
+        for (int s = 0; s < nseg; ++s) {
+            const float l = part[((size_t)s * rows + i) * 2 + 1];
+            if (l > 0.f) L += l * __expf(part[((size_t)s * rows + i) * 2] - M);
+        }
+        rowstat[i * 2] = M;
+        rowstat[i * 2 + 1] = L;
+    }
+}
+// sum of the per-segment gradient slabs, in segment order
+__global__ void attn_seg_sum_kernel(const float* __restrict__ part, float* __restrict__ out, size_t n, int nseg) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int k = 0; k < nseg; ++k) s += part[(size_t)k * n + i];
+        out[i] = s;
     }
 }
 
@@ -1022,21 +1054,31 @@ int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream
     hipLaunchKernelGGL(pad_cols_kernel, dim3(gs_blocks((size_t)N * cout)), dim3(256), 0, st, in, out, N, cin, cout);
     TK("pad_cols");
 }
-// dS scratch: nwin * heads * N * N floats; rowstat: nwin * heads * N * 2; dscale_part: nwin * heads * nqb
+// Segments of the walked axis per (window, head, tile): up to 4 (one per 64-row tile of a 16 x 16 window)
+static int attn_nseg(int ws) {
+    const int tiles = (ws * ws + 63) / 64;
+    return tiles < 4 ? tiles : 4;
+}
+// dS scratch: nwin * heads * N * N floats; rowstat: nwin * heads * N * 2; dscale_part: nwin * heads * nqb * 4;
+// part: 4 * (B * res * res * 3 * heads * 32 + nwin * heads * N * 2) floats of scratch
 int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part,
-                     float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err) {
-    const int nw = res / ws, N = ws * ws, nqb = (N + 63) / 64;
-    const unsigned blocks = (unsigned)(B * nw * nw * heads * nqb);
-    hipLaunchKernelGGL(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, rowstat, res, ws, shift, heads);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, rowstat, attn_out, dS, dqkv, dscale_part, res, ws, shift, heads);
-    hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, dqkv, res, ws, shift, heads);
+                     float* part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err) {
+    const int nw = res / ws, N = ws * ws, nqb = (N + 63) / 64, nseg = attn_nseg(ws);
+    const unsigned blocks = (unsigned)(B * nw * nw * heads * nqb * nseg);
+    const size_t rows = (size_t)B * nw * nw * heads * N, nq = (size_t)B * res * res * 3 * heads * 32;
+    float* part_stat = part + (size_t)nseg * nq;
+    hipLaunchKernelGGL(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, part_stat, res, ws, shift, heads, nseg, rows * 2);
+    hipLaunchKernelGGL(attn_rowstat_combine_kernel, dim3(gs_blocks(rows)), dim3(256), 0, st, part_stat, rowstat, rows, nseg);
+    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, rowstat, attn_out, dS, part, dscale_part, res, ws, shift, heads, nseg, nq);
+    hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, part, res, ws, shift, heads, nseg, nq);
+    hipLaunchKernelGGL(attn_seg_sum_kernel, dim3(gs_blocks(nq)), dim3(256), 0, st, part, dqkv, nq, nseg);
     TK("attention_bwd");
 }
 // dS is overwritten by its sum over the windows (first nwin = 1 slab); hid: 2 * (2ws-1)^2 * 512 floats of scratch
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
                         float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
     const int T2 = (2 * ws - 1) * (2 * ws - 1), N = ws * ws, nqb = (N + 63) / 64;
-    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb);
+    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb * attn_nseg(ws));
     if (dw0 || db0 || dw2) {
         const size_t n = (size_t)heads * N * N;
         // in place: column i of slab 0 is read before it is written, the other slabs are only read

@@ -81,7 +81,7 @@ struct Tape {
     // backward scratch
     float *G[5], *GX, *GP, *DOC, *DF[4];
     float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
-    float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb;
+    float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb, *attn_part;
     float* sk_part;
     unsigned* sk_count;
     size_t maxAct = 0;

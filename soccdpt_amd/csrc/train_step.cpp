@@ -126,7 +126,8 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
     T.dS = ar.f(maxDS);
     T.rowstat = ar.f(maxStat);
-    T.dscale_part = ar.f(maxPart);
+    T.dscale_part = ar.f(maxPart * 4);
+    T.attn_part = ar.f(a.hybrid ? 64 : 4 * (M0 * 3 * a.embed + maxStat));
     T.dtable = ar.f(maxTab);
     T.dt = ar.f(maxTab);
     T.S_cpb = ar.f(a.hybrid ? 64 : (size_t)2 * (2 * a.window - 1) * (2 * a.window - 1) * 512);
@@ -539,7 +540,7 @@ static int encoder_backward(Ctx& c) {
             // x1 = xin + LN1(a_pre)
             TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), G[3], G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
             TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
-            TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, T.attn_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
             {
                 float* dls = c.Gd(k + "attn.logit_scale");
                 float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
