@@ -135,6 +135,17 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
 
 int gemm(Ctx& c, IgemmDesc d) {
     d.f32 = 1;
+    // Small grids with a long K (coarse decoder levels, stage-3 Linear layers, their dgrads): split K like the weight-gradient GEMMs do
+    const long tiles = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    const long nk = (long)d.taps * d.Cin / 32;
+    if (tiles <= 96 && nk >= 48 && !d.ln_g && !d.gn_stats && !d.out_dot && d.stride == 1 && d.pad == 1 && d.in_halo == 1 && !d.Hi && !d.gather1 && !d.grp_rows &&
+        (size_t)tiles <= kTrainSkCountWords) {
+        long S = (256 + tiles - 1) / tiles;
+        if (S > nk / 8) S = nk / 8;
+        if (S > 16) S = 16;
+        while (S > 1 && (size_t)S * d.M * d.N > kTrainSkPartFloats) --S;
+        if (S > 1) { d.splitk = (int)S; d.sk_part = c.T.sk_part; d.sk_count = c.T.sk_count; d.sk_part_floats = kTrainSkPartFloats; d.sk_count_words = kTrainSkCountWords; }
+    }
     return launch_igemm(d, c.st, c.err);
 }
 
