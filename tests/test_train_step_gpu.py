@@ -543,3 +543,42 @@ def test_training_step_gradients_with_criterion_other_models(gpu_device, model_t
     med = sorted(e for e, _ in errs)[len(errs) // 2]
     print(f"{model_type}: {len(errs)} parameter gradients vs torch f32 autograd: median {med:.2e}, worst {max(errs)[0]:.2e} ({max(errs)[1]})")
     assert med < med_tol and max(errs)[0] < tol, max(errs)
+
+
+def test_random_trainable_subsets_match_full_backward(gpu_device):
+    """Fuzz of the frozen-prefix logic (weight-gradient skipping, early exits of the decoder / encoder walks): 16 random requires_grad patterns,
+    from one tensor to most of them, must each reproduce exactly the gradients of the all-trainable backward for the tensors they keep."""
+    import random
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _make(gpu_device)
+    m.train()
+    m.seg_head[3].p = 0.0
+    x = synth_input(1, seed0=21).to(gpu_device)
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn((1, 256, 256), generator=g).to(gpu_device)
+    b = torch.randn((1, 3, 256, 256), generator=g).to(gpu_device)
+    for p in m.parameters():
+        p.requires_grad_(True)
+    m.train_forward(x)
+    m.backward(a, b)
+    full = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    names = [k for k, _ in m.named_parameters() if k in full]
+    rng = random.Random(1234)
+    for trial in range(16):
+        n_keep = rng.choice([1, 1, 2, 3, 8, 30, len(names) // 2, len(names) - 3])
+        if trial % 4 == 3:     # a contiguous index range, like a PatchWiseInplace patch
+            lo = rng.randrange(0, len(names) - n_keep + 1)
+            keep = set(names[lo:lo + n_keep])
+        else:
+            keep = set(rng.sample(names, n_keep))
+        for k, p in m.named_parameters():
+            p.requires_grad_(k in keep)
+            p.grad = None
+        m.train_forward(x)
+        m.backward(a, b)
+        torch.cuda.synchronize()
+        for k, p in m.named_parameters():
+            if k in keep:
+                assert p.grad is not None and torch.equal(p.grad, full[k]), (trial, sorted(keep)[:4], k)
+            else:
+                assert p.grad is None, (trial, k)
