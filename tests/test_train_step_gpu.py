@@ -5,7 +5,7 @@ The reference differentiates SOccDPT_V3.forward in train mode with autograd (scr
 `loss.backward()` over it IS the reference's gradient.
 
 Tolerance.  The test's upstream gradients are random-sign, so every parameter gradient is a heavily cancelling sum, and the network is
-full of ReLUs: a pre-activation within f32 rounding of zero gets a different mask in two f32 forwards (tools/train_mask_flips.py counts
+full of ReLUs: a pre-activation within f32 rounding of zero gets a different mask in two f32 forwards (tests/tools/train_mask_flips.py counts
 them: B = 1, seg head, 4.2 M activations: 6 masks of torch's f32 forward and 10 of the HIP forward differ from the float64 oracle's; the
 depth head has none in either, and its gradients then agree to 1e-6).  Every flipped mask is an O(1) local difference, which puts torch's
 own f32 autograd ~1e-3 (relative L2 per tensor) away from the same oracle differentiated in float64.  The float64 run is therefore the

@@ -1,6 +1,6 @@
 """Times the GPU ground-truth occupancy generator at 1080 x 1920 (B = 8) and the C oracle / a numpy restatement per frame on the host."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import torch
 from oracle import cref

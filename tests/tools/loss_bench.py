@@ -1,7 +1,7 @@
 """Times the fused training criterion (B = 3 and 8, 256^2 -> 1080 x 1920) and, beside it, the same criterion as the reference
 forms it with torch ops + autograd on the GPU (oracle/loss_ref.py moved to the device: test infrastructure, timed as the baseline)."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import loss_ref as LR
 from soccdpt_amd.utils.loss import training_loss

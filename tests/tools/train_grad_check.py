@@ -1,12 +1,12 @@
 """Per-parameter gradient report of the HIP training step against torch autograd over the CPU oracle (the same comparison as
 tests/test_train_step_gpu.py, printed in network order so that the first wrong gradient walking backwards locates a bug).
 
-    python tools/train_grad_check.py [B] [sigmoid 0|1] [model_type] [random|criterion]
+    python tests/tools/train_grad_check.py [B] [sigmoid 0|1] [model_type] [random|criterion]
 "criterion": the upstream gradients come from the training criterion (HIP soccdpt_training_loss on the GPU side, oracle/loss_ref.py +
 autograd on the oracle side) on the synthetic camera-resolution targets, i.e. the whole optimisation step's gradient.
 """
 import os, sys, tempfile, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import soccdpt_ref as R
 from soccdpt_amd.lib import PREC_F32

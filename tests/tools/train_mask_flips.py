@@ -2,10 +2,10 @@
 forward.  A flipped mask (a pre-activation within rounding of zero) is an O(1) local difference in the gradient: it, not kernel
 arithmetic, sets the ~1e-3 floor of the gradient comparison in tests/test_train_step_gpu.py.
 
-    python tools/train_mask_flips.py [B]
+    python tests/tools/train_mask_flips.py [B]
 """
 import os, sys, tempfile
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import torch.nn.functional as F
 from oracle import soccdpt_ref as R

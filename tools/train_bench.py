@@ -64,19 +64,7 @@ ev[0].record(); inv, seg = net.train_forward(x, seed=0); ev[1].record()
 out = training_loss(inv, seg, y_disp, mask_disp, y_seg, mask_seg, 0.5, 0.5, compute_scale_and_shift=True); ev[2].record()
 net.backward(out["d_inv"], out["d_seg"]); ev[3].record()
 torch.cuda.synchronize()
-# CPU baseline beside it: the oracle's forward + torch autograd backward (what the reference's training loop runs, on the host cores), 2 samples
-cpu = None
-if os.environ.get("TRAIN_BENCH_CPU", "1") != "0":
-    from oracle import soccdpt_ref as R
-    sd = synth_state_dict(backbone, alias_pretrained=True)
-    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
-    xc = x[:2].cpu()
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    t0 = time.time()
-    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, xc, backbone=backbone, sigmoid=True, training=True, dropout_p=0.1)
-    (o_inv.sum() + o_seg.sum()).backward()
-    cpu = {"samples_per_s": round(2 / (time.time() - t0), 3), "cores": torch.get_num_threads(), "kind": "port",
-           "sample": "oracle forward + torch autograd backward, 2 samples, no criterion / optimizer"}
+cpu = None   # the CPU baseline of the step is bench.py --train-step's cpu_baseline leg (only tests/, smoke() and bench.py may use oracle/)
 print(json.dumps({"cpu_baseline": cpu, "model_type": model_type, "amp": net.train_amp, "B": B, "encoder_percentage": enc_pct, "patchwise_percentage": patch_pct, "optimisation_steps": n,
                   "ms_per_step": round(1e3 * dt / n, 2), "samples_per_s": round(B * n / dt, 1),
                   "train_forward_ms": round(ev[0].elapsed_time(ev[1]), 2), "criterion_ms": round(ev[1].elapsed_time(ev[2]), 2),
