@@ -155,7 +155,8 @@ int gemm_wgrad(Ctx& c, IgemmDesc d) {
     const bool amp = c.h.train_amp;
     d.f32 = amp ? 0 : 1;
     d.f16 = 0;
-    // 64 x 64 tiles: the 128 x 128 split-K form was measured slower (51.2 vs 45.2 ms per step at B = 8: fewer, longer workgroups)
+    // 64 x 64 tiles: the 128 x 128 split-K forms were measured slower (4 waves: 51.2 vs 45.2 ms per step at B = 8; 8 waves: 47.9 vs 42.2 --
+    // fewer, longer workgroups and a partial-tile exchange four times the size)
     const long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
     const long nk = (long)d.taps * d.Cin / (amp ? 128 : 32);
     long S = (512 + tiles - 1) / tiles;
