@@ -58,6 +58,11 @@ struct IgemmDesc {
     // Second A segment: columns k >= seg2_k come from the PER-GROUP row X + (m / grp_rows) * grp_stride + seg2_off + (k - seg2_k):
     // cat(token, class token) @ W^T of ProjectReadout (/root/reference/SOccDPT/model/backbones/utils.py:27-40) without the cat.
     int seg2_k = 0, seg2_off = 0;
+    // Weight row groups (generalised addressing; the 3x3 weight-gradient GEMM of the training step, train_step.cpp: conv3_bwd): row n of Wt
+    // lives at Wt + (n % wt_grp_rows) * K + shift(n / wt_grp_rows), shift(g) = wt_base + (g / 3 - 1) * wt_rp + (g % 3 - 1) + (g % 3 != 1 ? wt_odd : 0)
+    // -- nine shifted views (one per tap) of ONE transposed halo image instead of an im2col^T.  wt_grp_rows must be a multiple of 64 (a weight
+    // tile never straddles two groups); every shift must be >= 0 (the caller offsets Wt).
+    int wt_grp_rows = 0, wt_rp = 0, wt_base = 0, wt_odd = 0;
     // ---- epilogue: v = acc (+bias[n]) (+res1[m][n]) (+res2[m][n]); act; stores ----
     const float* bias = nullptr;
     const float* res1 = nullptr;  // f32 [M][N]

@@ -135,6 +135,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const int row = cid / C::CPR, c = cid % C::CPR;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
+        if (GEN && d.wt_grp_rows) {   // weight row groups: the tile's rows belong to ONE group (wt_grp_rows % BN == 0): a shifted view of the same matrix
+            const int g = n0 / d.wt_grp_rows, ky = g / 3, kx = g - ky * 3;
+            const uint32_t shift = (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + (kx - 1) + (kx != 1 ? d.wt_odd : 0));
+            w_off[i] = (uint32_t)(n - g * d.wt_grp_rows) * (uint32_t)Ktot + shift + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+        } else
         w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
     }
 
@@ -602,7 +607,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 
 // does the descriptor use what only the GEN instantiations implement?
 static bool need_gen(const IgemmDesc& d) {
-    return d.stride != 1 || d.pad != 1 || d.in_halo != 1 || d.Hi || d.Wi || d.gather1 || d.grp_rows || d.seg2_k || d.stamps;
+    return d.stride != 1 || d.pad != 1 || d.in_halo != 1 || d.Hi || d.Wi || d.gather1 || d.grp_rows || d.seg2_k || d.stamps || d.wt_grp_rows;
 }
 
 template <class C, typename T, bool LN = false, bool SK = false, bool ST = false, bool GEN = false>
@@ -802,6 +807,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     }
     if (d.seg2_k && (d.taps != 1 || d.gather1 || !d.grp_rows || d.seg2_k % 128 != 0 || d.seg2_k >= d.Cin)) { err = "igemm: bad second-segment descriptor"; return 1; }
     if (d.grp_rows && (d.taps != 1 || d.gather1)) { err = "igemm: row groups are a plain-mode feature"; return 1; }
+    if (d.wt_grp_rows && (d.taps != 1 || d.gather1 || d.wt_grp_rows % 64 != 0 || d.N > 9 * d.wt_grp_rows || d.N % d.wt_grp_rows != 0 ||
+                          d.wt_base - d.wt_rp - 1 + (d.wt_odd < 0 ? d.wt_odd : 0) < 0)) { err = "igemm: bad weight row-group descriptor"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
@@ -809,7 +816,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         // split-K in f32: the weight-gradient GEMMs of the training step (K = pixels, a handful of output tiles; train_step.cpp picks the split)
         if (d.splitk > 1) {
-            if (d.ln_g || d.gn_stats || need_gen(d) || d.out_dot) { err = "igemm: f32 split-K is a plain / 3x3 launch without LayerNorm, statistics or dot epilogues"; return 1; }
+            if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: f32 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
+            if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, true, false, true>(d, stream, err);   // weight row groups (training wgrad)
             return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, true>(d, stream, err);
         }
         switch (pick_cfg_f32(d)) {

@@ -63,6 +63,42 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ 
     }
 }
 
+// Weight gradient of a 3x3 convolution WITHOUT im2col: with both operands transposed in HALO pixel order (mh over B x (r+2) x (r+2), the
+// gradient zero on the border pixels), tap (ky, kx) is the plain GEMM  dW_t[n][c] = sum_mh dYh^T[n][mh] * Xh^T[c][mh + off_t],
+// off_t = (ky - 1)(r + 2) + (kx - 1): nine pointer offsets into ONE transposed halo image (train_step.cpp: conv3_bwd).  The igemm's 16-byte
+// LDS-DMA loads accept the 4-byte-aligned bases this produces (tests/tools/unaligned_operand_probe.py: same results, same speed).
+// dY [B*r*r][N] plain -> out [N][ld]: column margin + mh holds the pixel's gradient (zero on border pixels and in the margins)
+template <typename OT>
+__global__ __launch_bounds__(256) void dy_halo_T_kernel(const float* __restrict__ dy, OT* __restrict__ out, int B, int r, int N, int margin, int ld) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int rp = r + 2, Mh = B * rp * rp;
+    for (int i = ty; i < 32; i += 8) {
+        const int mh = k0 + i - margin, n = n0 + tx;
+        float v = 0.f;
+        if (mh >= 0 && mh < Mh && n < N) {
+            const int b = mh / (rp * rp), q = mh - b * rp * rp, yh = q / rp, xh = q - yh * rp;
+            if (yh >= 1 && yh <= r && xh >= 1 && xh <= r) v = dy[((size_t)(b * r + yh - 1) * r + xh - 1) * N + n];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int n = n0 + i, k = k0 + tx;
+        if (n < N && k < ld) out[(size_t)n * ld + k] = cvt_out<OT>(t[tx][i]);
+    }
+}
+// dW slabs [9][N][C] -> parameter layout [N][C][3][3]
+__global__ void wgrad_permute9_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C) {
+    const size_t n = (size_t)N * C * 9;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % 9);
+        const size_t r = i / 9;    // n * C + c
+        out[i] = in[(size_t)tap * N * C + r];
+    }
+}
+
 // W [N][C][3][3] -> Wd [C][2-ky][2-kx][N] (tap-major, flipped): Wt operand of the 3x3 dgrad (a convolution of dY with the rotated filter)
 template <typename OT>
 __global__ void conv_w_dgrad_kernel(const float* __restrict__ w, OT* __restrict__ out, int N, int C) {
@@ -926,6 +962,16 @@ int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t
 int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT16");
+}
+int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err) {
+    const dim3 grid((N + 31) / 32, (ld + 31) / 32);
+    if (out16) hipLaunchKernelGGL(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
+    else hipLaunchKernelGGL(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld);
+    TK("dy_halo_T");
+}
+int tr_wgrad_permute9(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(wgrad_permute9_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
+    TK("wgrad_permute9");
 }
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(conv_w_dgrad_kernel<float>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);

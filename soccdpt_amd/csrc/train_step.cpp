@@ -251,7 +251,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(gemm(c, d));
         }
     }
-    if (dW) {
+    if (dW && C % 64 != 0) {   // (layer1_rn of tiny_256, C = 96: a weight tile would straddle two taps) explicit im2col^T
         IgemmDesc d;
         d.M = N; d.N = 9 * C; d.out_f32 = T.S_dw;
         if (amp) {
@@ -259,15 +259,45 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
             TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
-            if (!reuse_xt) TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
+            TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
             d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
         } else {
             const int Mp = (int)((M + 31) / 32 * 32);
-            TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));          // [N][Mp]
-            if (!reuse_xt) TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
+            TRY(tr_transpose(dY, T.S_T1, (int)M, N, Mp, c.st, c.err));             // [N][Mp]
+            TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
         TRY(gemm_wgrad(c, d));
+        TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+    } else if (dW) {
+        // No im2col: both operands transposed in halo pixel order, tap (ky, kx) = the plain GEMM over a shifted view of the ONE transposed halo
+        // image (train.hip: dy_halo_T_kernel).  Margins of r + 3 zero columns on both sides of every row absorb the shifts.
+        const int rp = r + 2, Mh = B * rp * rp, margin = r + 3;
+        const int ld = (2 * margin + Mh + 127) / 128 * 128;
+        const size_t esz = amp ? 2 : 4;
+        char* yT = reinterpret_cast<char*>(T.S_T1);
+        char* xT = reinterpret_cast<char*>(T.S_T2);            // amp: two copies, shifted by 0 / 1 element, so that every tap's base stays 4-byte aligned
+        const size_t head = (size_t)(margin + 13) / 8 * 8;     // zeroed elements in FRONT of each copy: the most negative shift reads base - (r + 4)
+        const size_t copy_bytes = ((size_t)(C + 1) * ld + 64 + head) * esz;
+        xT += head * esz;
+        TRY(tr_dy_halo_T(dY, yT, amp ? 1 : 0, B, r, N, margin, ld, c.st, c.err));
+        if (!reuse_xt) {
+            for (int cp = 0; cp < (amp ? 2 : 1); ++cp) {
+                char* base = xT + cp * copy_bytes;
+                // headroom + the first row's left margin; every other gap is the zero tail of a row (tr_transpose pads rows up to ld)
+                hipError_t e = hipMemsetAsync(base - head * esz, 0, (head + margin) * esz, c.st);
+                if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+                if (amp) TRY(tr_transpose16(Xhalo, reinterpret_cast<uint16_t*>(base) + margin - cp, Mh, C, ld, c.st, c.err));
+                else TRY(tr_transpose(Xhalo, reinterpret_cast<float*>(base) + margin, Mh, C, ld, c.st, c.err));
+            }
+        }
+        {   // ONE GEMM: M = N out-channels, N = 9 groups of C rows of the weight operand (one shifted view per tap), K = ld halo-order pixels
+            IgemmDesc d;
+            d.X = yT; d.Wt = xT - head * esz; d.M = N; d.N = 9 * C; d.Cin = ld; d.ldx = ld; d.out_f32 = T.S_dw;
+            d.wt_grp_rows = C; d.wt_rp = rp; d.wt_base = (int)head;
+            d.wt_odd = amp ? (int)(copy_bytes / esz) - 1 : 0;   // amp: taps with kx != 1 read copy 1 (x[k + 1] at k) so that every base stays 4-byte aligned
+            TRY(gemm_wgrad(c, d));
+        }
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
