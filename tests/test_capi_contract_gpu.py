@@ -83,3 +83,61 @@ def test_errors_are_returned(model, gpu_device):
     cfg.backbone = 0
     cfg.abi_version = 12345
     assert eng.L.soccdpt_create(ctypes.byref(cfg), ctypes.byref(h)) != 0
+
+
+def test_training_entry_points_return_errors(gpu_device):
+    """soccdpt_train_* contract: wrong precision, unbound weights, short workspace, a backward without its forward, a mismatching batch size
+    and bad dropout probabilities are refused with a message (non-zero return), never executed; garbage in the workspace is harmless because
+    the library zero-fills what it needs."""
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    stream = torch.cuda.current_stream(gpu_device).cuda_stream
+    x = synth_input(1, seed0=2).to(gpu_device)
+    inv = torch.empty((1, 256, 256), device=gpu_device)
+    seg = torch.empty((1, 3, 256, 256), device=gpu_device)
+    err = lambda e: e.L.soccdpt_last_error(e._h).decode()
+
+    # bf16 handle: refused
+    m16 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False)
+    m16.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
+    m16 = m16.to(gpu_device)
+    e16 = m16._engine(gpu_device)
+    m16._sync_weights(e16)
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device=gpu_device)
+    assert e16.L.soccdpt_train_forward(e16._h, x.data_ptr(), 1, inv.data_ptr(), seg.data_ptr(), ws.data_ptr(), ws.numel(), 0.0, 0, stream) != 0
+    assert "SOCCDPT_PREC_F32" in err(e16)
+
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
+    m.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
+    m = m.to(gpu_device).train()
+    eng = m._engine(gpu_device)
+    need = eng.L.soccdpt_train_workspace_bytes(eng._h, 1)
+    big = torch.full((need,), 0xA5, dtype=torch.uint8, device=gpu_device)        # garbage: NaN patterns in every float
+    # weights not bound yet
+    assert eng.L.soccdpt_train_forward(eng._h, x.data_ptr(), 1, inv.data_ptr(), seg.data_ptr(), big.data_ptr(), big.numel(), 0.0, 0, stream) != 0
+    assert "not bound" in err(eng)
+    m._bind_for_training(eng)
+    # short workspace, bad dropout, null pointers
+    assert eng.L.soccdpt_train_forward(eng._h, x.data_ptr(), 1, inv.data_ptr(), seg.data_ptr(), big.data_ptr(), need // 2, 0.0, 0, stream) != 0
+    assert "workspace too small" in err(eng)
+    assert eng.L.soccdpt_train_forward(eng._h, x.data_ptr(), 1, inv.data_ptr(), seg.data_ptr(), big.data_ptr(), big.numel(), 1.0, 0, stream) != 0
+    assert eng.L.soccdpt_train_forward(eng._h, None, 1, inv.data_ptr(), seg.data_ptr(), big.data_ptr(), big.numel(), 0.0, 0, stream) != 0
+    # backward before any forward on this workspace
+    g1 = torch.zeros_like(inv)
+    g2 = torch.zeros_like(seg)
+    assert eng.L.soccdpt_train_backward(eng._h, x.data_ptr(), 1, g1.data_ptr(), g2.data_ptr(), big.data_ptr(), big.numel(), stream) != 0
+    assert "no soccdpt_train_forward ran" in err(eng)
+    # a proper forward on the garbage-filled workspace works and matches the Python path
+    assert eng.L.soccdpt_train_forward(eng._h, x.data_ptr(), 1, inv.data_ptr(), seg.data_ptr(), big.data_ptr(), big.numel(), 0.0, 0, stream) == 0
+    torch.cuda.synchronize()
+    assert torch.isfinite(inv).all() and torch.isfinite(seg).all()
+    # backward with another batch size than the forward's
+    assert eng.L.soccdpt_train_backward(eng._h, x.data_ptr(), 2, g1.data_ptr(), g2.data_ptr(), big.data_ptr(), big.numel(), stream) != 0
+    assert eng.L.soccdpt_train_backward(eng._h, x.data_ptr(), 1, g1.data_ptr(), g2.data_ptr(), big.data_ptr(), big.numel(), stream) == 0
+    torch.cuda.synchronize()
+    assert eng.L.soccdpt_bind_grad(eng._h, b"no.such.key", None) != 0 and "unknown key" in err(eng)
+    inv2, seg2 = m.train_forward(x, seed=0)
+    # the same step through the Python mirror (running buffers have moved on by one update: compare the depth output only)
+    assert torch.equal(inv2, inv)
