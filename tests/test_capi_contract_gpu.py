@@ -135,8 +135,14 @@ def test_training_entry_points_return_errors(gpu_device):
     assert torch.isfinite(inv).all() and torch.isfinite(seg).all()
     # backward with another batch size than the forward's
     assert eng.L.soccdpt_train_backward(eng._h, x.data_ptr(), 2, g1.data_ptr(), g2.data_ptr(), big.data_ptr(), big.numel(), stream) != 0
+    g1.normal_()
+    g2.normal_()
     assert eng.L.soccdpt_train_backward(eng._h, x.data_ptr(), 1, g1.data_ptr(), g2.data_ptr(), big.data_ptr(), big.numel(), stream) == 0
     torch.cuda.synchronize()
+    # every scratch region the backward reads was initialised by the library: no NaN of the garbage fill reaches a gradient
+    grads = m._train_state[id(eng)]["grads"]
+    assert sum(g is not None for g in grads.values()) > 250
+    assert all(torch.isfinite(g).all() for g in grads.values() if g is not None)
     assert eng.L.soccdpt_bind_grad(eng._h, b"no.such.key", None) != 0 and "unknown key" in err(eng)
     inv2, seg2 = m.train_forward(x, seed=0)
     # the same step through the Python mirror (running buffers have moved on by one update: compare the depth output only)

@@ -365,6 +365,7 @@ def test_amp_gradients_with_criterion(gpu_device):
     inv0, seg0 = m.train_forward(x.to(dev))
     inv0, seg0 = inv0.clone(), seg0.clone()
     m.train_amp = True
+    m._engine(dev).train_workspace(B).fill_(0xA5)     # garbage: the bf16 staging buffers (two shifted copies, margins) must be fully initialised
     inv, seg = m.train_forward(x.to(dev))
     assert torch.equal(inv, inv0) and torch.equal(seg, seg0)
     r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
@@ -448,8 +449,9 @@ def test_hybrid_vit_backward_exact(gpu_device):
     g = torch.Generator().manual_seed(5)
     ws = [torch.zeros(feats[0].shape), torch.zeros(feats[1].shape), torch.randn(feats[2].shape, generator=g), torch.randn(feats[3].shape, generator=g)]
     sum((f * w).sum() for f, w in zip(feats, ws)).backward()
-    m.train_forward(x.to(gpu_device))
     eng = m._engine(gpu_device)
+    eng.train_workspace(1).fill_(0xA5)     # garbage (NaN bit patterns): every region the step reads must be initialised by the library itself
+    m.train_forward(x.to(gpu_device))
     eng.train_backward_encoder(1, [_nhwc(w).to(gpu_device) for w in ws])
     torch.cuda.synchronize()
     st = m._train_state[id(eng)]
