@@ -832,25 +832,26 @@ __global__ void attn_seg_sum_kernel(const float* __restrict__ part, float* __res
     }
 }
 
-// d table[r][h] = sum over (q, k with rel(q, k) = r) of dSsum[h][q][k], dSsum = dS summed over the windows (rowsum_kernel)
-__global__ void attn_table_grad_kernel(const float* __restrict__ dSsum, float* __restrict__ dtable, int ws, int heads) {
+// d table[r][h] = sum over (q, k with rel(q, k) = r) of dSsum[h][q][k], dSsum = dS summed over the windows (rowsum_kernel).
+// One wave per (r, h): lane = one key row rk of the window (ws <= 64), the ck loop inside; fixed-order wave reduction.
+__global__ __launch_bounds__(64) void attn_table_grad_kernel(const float* __restrict__ dSsum, float* __restrict__ dtable, int ws, int heads) {
     const int T = 2 * ws - 1, N = ws * ws;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= T * T * heads) return;
+    const int i = blockIdx.x;                       // (r, h)
     const int h = i % heads, r = i / heads;
     const int dr = r / T - (ws - 1), dc = r % T - (ws - 1);   // rq - rk, cq - ck
     const float* base = dSsum + (size_t)h * N * N;
+    const int rk = threadIdx.x;
     float s = 0.f;
-    for (int rk = 0; rk < ws; ++rk) {
-        const int rq = rk + dr;
-        if (rq < 0 || rq >= ws) continue;
+    const int rq = rk + dr;
+    if (rk < ws && rq >= 0 && rq < ws) {
         for (int ck = 0; ck < ws; ++ck) {
             const int cq = ck + dc;
             if (cq < 0 || cq >= ws) continue;
             s += base[(size_t)(rq * ws + cq) * N + rk * ws + ck];
         }
     }
-    dtable[i] = s;
+    for (int o = 1; o < 64; o <<= 1) s += __shfl_xor(s, o);
+    if (threadIdx.x == 0) dtable[i] = s;
 }
 // logit_scale gradient: scale = exp(min(ls, ln 100)); d ls = scale * d scale when ls < ln 100
 __global__ void attn_scale_reduce_kernel(const float* __restrict__ part, const float* __restrict__ ls, float* __restrict__ dls, int nwin, int heads, int nqb) {
@@ -1129,7 +1130,7 @@ int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table,
         const size_t n = (size_t)heads * N * N;
         // in place: column i of slab 0 is read before it is written, the other slabs are only read
         hipLaunchKernelGGL(rowsum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dS, dS, nwin, n);
-        hipLaunchKernelGGL(attn_table_grad_kernel, dim3((T2 * heads + 63) / 64), dim3(64), 0, st, dS, dtable, ws, heads);
+        hipLaunchKernelGGL(attn_table_grad_kernel, dim3(T2 * heads), dim3(64), 0, st, dS, dtable, ws, heads);
         hipLaunchKernelGGL(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
         float* dhid = hid + (size_t)T2 * 512;
         hipLaunchKernelGGL(cpb_hidden_kernel, dim3((T2 * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, w2, hid, dhid, ws, pws, heads);
