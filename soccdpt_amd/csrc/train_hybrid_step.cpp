@@ -85,7 +85,7 @@ int conv_gen_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* Wtap,
         TRY(th_im2colT_gen(Xhalo, T.S_T2, B, Hi, Ho, C, stride, pad, (size_t)Mp, c.st, c.err));
         IgemmDesc d;
         d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = Mp; d.ldx = Mp; d.out_f32 = dWtap_out;
-        TRY(gemm_wgrad(c, d));
+        TRY(gemm_wgrad(c, d, false));   // f32 staging (the strided / weight-standardised convolutions do not take the amp path)
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, Mo, N, 0, c.st, c.err));
     return 0;

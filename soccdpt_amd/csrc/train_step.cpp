@@ -151,8 +151,8 @@ int gemm(Ctx& c, IgemmDesc d) {
 
 // Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
 // in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.  amp: bf16 operands (K padded to 128 by the caller).
-int gemm_wgrad(Ctx& c, IgemmDesc d) {
-    const bool amp = c.h.train_amp;
+int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands) {
+    const bool amp = bf16_operands;   // the CALLER says what its staging kernels wrote (amp applies per GEMM: shapes that do not fit stay f32)
     d.f32 = amp ? 0 : 1;
     d.f16 = 0;
     // 64 x 64 tiles: the 128 x 128 split-K forms were measured slower (4 waves: 51.2 vs 45.2 ms per step at B = 8; 8 waves: 47.9 vs 42.2 --
@@ -218,7 +218,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             TRY(tr_transpose(X, T.S_T2, (int)M, K, Mp, c.st, c.err));    // [K][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
-        TRY(gemm_wgrad(c, d));
+        TRY(gemm_wgrad(c, d, amp));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
     return 0;
@@ -267,7 +267,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
-        TRY(gemm_wgrad(c, d));
+        TRY(gemm_wgrad(c, d, amp));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     } else if (dW) {
         // No im2col: both operands transposed in halo pixel order, tap (ky, kx) = the plain GEMM over a shifted view of the ONE transposed halo
@@ -296,7 +296,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             d.X = yT; d.Wt = xT - head * esz; d.M = N; d.N = 9 * C; d.Cin = ld; d.ldx = ld; d.out_f32 = T.S_dw;
             d.wt_grp_rows = C; d.wt_rp = rp; d.wt_base = (int)head;
             d.wt_odd = amp ? (int)(copy_bytes / esz) - 1 : 0;   // amp: taps with kx != 1 read copy 1 (x[k + 1] at k) so that every base stays 4-byte aligned
-            TRY(gemm_wgrad(c, d));
+            TRY(gemm_wgrad(c, d, amp));
         }
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }

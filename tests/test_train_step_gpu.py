@@ -545,6 +545,24 @@ def test_training_step_gradients_with_criterion_other_models(gpu_device, model_t
     med = sorted(e for e, _ in errs)[len(errs) // 2]
     print(f"{model_type}: {len(errs)} parameter gradients vs torch f32 autograd: median {med:.2e}, worst {max(errs)[0]:.2e} ({max(errs)[1]})")
     assert med < med_tol and max(errs)[0] < tol, max(errs)
+    # the same step with amp (bf16 operands for the gradient GEMMs that take them; the hybrid's strided / weight-standardised convolutions stay f32)
+    m.train_amp = True
+    for p in m.parameters():
+        p.grad = None
+    inv, seg = m.train_forward(x.to(dev))
+    r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
+    m.backward(r["d_inv"], r["d_seg"])
+    torch.cuda.synchronize()
+    aerrs = []
+    for k, p in m.named_parameters():
+        ref = sd_o[k].grad
+        if ref is None or float(ref.norm()) < 1e-5:
+            continue
+        assert p.grad is not None and torch.isfinite(p.grad).all(), ("amp", k)
+        aerrs.append((_rel(p.grad.cpu(), ref), k))
+    amed = sorted(e for e, _ in aerrs)[len(aerrs) // 2]
+    print(f"{model_type} amp: median {amed:.2e}, worst {max(aerrs)[0]:.2e} ({max(aerrs)[1]})")
+    assert amed < max(1e-2, 3 * med_tol) and max(aerrs)[0] < max(6e-2, 3 * tol), max(aerrs)
 
 
 def test_random_trainable_subsets_match_full_backward(gpu_device):
