@@ -565,18 +565,23 @@ def test_training_step_gradients_with_criterion_other_models(gpu_device, model_t
     assert amed < max(1e-2, 3 * med_tol) and max(aerrs)[0] < max(6e-2, 3 * tol), max(aerrs)
 
 
-def test_random_trainable_subsets_match_full_backward(gpu_device):
-    """Fuzz of the frozen-prefix logic (weight-gradient skipping, early exits of the decoder / encoder walks): 16 random requires_grad patterns,
+@pytest.mark.parametrize("model_type,backbone,size,trials", [("dpt_swin2_tiny_256", "swin2t16_256", 256, 16), ("dpt_hybrid_384", "vitb_rn50_384", 384, 8)])
+def test_random_trainable_subsets_match_full_backward(gpu_device, model_type, backbone, size, trials):
+    """Fuzz of the frozen-prefix logic (weight-gradient skipping, early exits of the decoder / encoder walks): random requires_grad patterns,
     from one tensor to most of them, must each reproduce exactly the gradients of the all-trainable backward for the tensors they keep."""
     import random
-    from soccdpt_amd.utils.synth import synth_input
-    m, sd = _make(gpu_device)
-    m.train()
+    from soccdpt_amd.lib import PREC_F32
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+    m.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
+    m = m.to(gpu_device).train()
     m.seg_head[3].p = 0.0
-    x = synth_input(1, seed0=21).to(gpu_device)
+    x = synth_input(1, size=size, seed0=21).to(gpu_device)
     g = torch.Generator().manual_seed(9)
-    a = torch.randn((1, 256, 256), generator=g).to(gpu_device)
-    b = torch.randn((1, 3, 256, 256), generator=g).to(gpu_device)
+    a = torch.randn((1, size, size), generator=g).to(gpu_device)
+    b = torch.randn((1, 3, size, size), generator=g).to(gpu_device)
     for p in m.parameters():
         p.requires_grad_(True)
     m.train_forward(x)
@@ -584,7 +589,7 @@ def test_random_trainable_subsets_match_full_backward(gpu_device):
     full = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
     names = [k for k, _ in m.named_parameters() if k in full]
     rng = random.Random(1234)
-    for trial in range(16):
+    for trial in range(trials):
         n_keep = rng.choice([1, 1, 2, 3, 8, 30, len(names) // 2, len(names) - 3])
         if trial % 4 == 3:     # a contiguous index range, like a PatchWiseInplace patch
             lo = rng.randrange(0, len(names) - n_keep + 1)
