@@ -310,10 +310,15 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
  * in the workspace.  soccdpt_train_backward: d_inv [B,S,S], d_seg [B,C,S,S] -> bound gradients; must follow a soccdpt_train_forward on the
  * same workspace and B. */
 int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad);
-/* Mixed precision for the backward (the reference's `amp` sweep parameter, scripts/train_SOccDPT.py:96-121,360-366): on != 0 runs the gradient
- * GEMMs (dgrad / wgrad of every Linear and 3x3 convolution) with bf16 MFMA operands and f32 accumulation; the train-mode forward, every saved
- * activation, weights and gradients stay f32, and bf16's f32-sized exponent needs no loss scaling.  Off by default. */
-int soccdpt_train_set_amp(void* handle, int on);
+/* Mixed precision for the backward (the reference's `amp` sweep parameter, scripts/train_SOccDPT.py:96-121,360-366: fp16 autocast + GradScaler): the
+ * gradient GEMMs (dgrad / wgrad of every Linear and 3x3 convolution) run with 16-bit MFMA operands and f32 accumulation; the train-mode forward,
+ * every saved activation, weights and gradients stay f32.  mode 0: off (default); 1: bf16 operands (f32-sized exponent: no loss scaling needed);
+ * 2: fp16 operands (11-bit significand) -- the caller scales d_inv / d_seg like GradScaler scales the loss (the gradients come out scaled by the
+ * same factor; values beyond +-65504 saturate in the operand conversion instead of becoming inf). */
+int soccdpt_train_set_amp(void* handle, int mode);
+/* GradScaler.unscale_ of the fp16 mode over n gradients: dev_grads[i] *= inv_scale; *dev_found_inf |= 1 when a result is not finite (the caller
+ * zeroes the flag, skips its optimizer step when it is set and backs the scale off: scripts/train_SOccDPT.py:390-393). */
+int soccdpt_train_unscale(float* dev_grads, size_t n, float inv_scale, int* dev_found_inf, void* stream);
 size_t soccdpt_train_workspace_bytes(void* handle, int B);
 int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_inv, float* dev_seg, void* dev_workspace, size_t workspace_bytes,
                           float dropout_p, uint32_t seed, void* stream);

@@ -107,7 +107,15 @@ int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad) {
 int soccdpt_train_set_amp(void* handle, int on) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
-    h->train_amp = on != 0;
+    if (on < 0 || on > 2) return fail(h, "soccdpt_train_set_amp: mode must be 0 (off), 1 (bf16) or 2 (fp16)");
+    h->train_amp = on;
+    return 0;
+}
+int soccdpt_train_unscale(float* dev_grads, size_t n, float inv_scale, int* dev_found_inf, void* stream) {
+    if (!dev_grads || !dev_found_inf) return fail(nullptr, "soccdpt_train_unscale: null argument");
+    if (n == 0) return 0;
+    std::string err;
+    if (tr_unscale_check(dev_grads, n, inv_scale, dev_found_inf, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;
 }
 size_t soccdpt_train_workspace_bytes(void* handle, int B) { return handle && B > 0 ? train_workspace_bytes(*static_cast<Handle*>(handle), B) : 0; }

@@ -135,7 +135,7 @@ struct Handle {
         int B = 0;
         float dropout_p = 0.f;
     } train_key;
-    bool train_amp = false;   // soccdpt_train_set_amp: bf16 MFMA operands for the gradient GEMMs (f32 accumulate, f32 weights / activations / gradients)
+    int train_amp = 0;        // soccdpt_train_set_amp: 16-bit MFMA operands for the gradient GEMMs (f32 accumulate, f32 weights / activations / gradients): 1 bf16, 2 fp16
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t graph_stream = nullptr;  // capture/replay stream (the caller's may be the legacy null stream, which cannot capture)

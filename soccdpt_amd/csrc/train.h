@@ -6,16 +6,16 @@
 namespace soccdpt {
 
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err);
-int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, hipStream_t st, std::string& err);
+int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err);
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
-int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
+int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, int f16, hipStream_t st, std::string& err);
 int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err);
 int tr_wgrad_permute9(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err);
-int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, hipStream_t st, std::string& err);
+int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, int f16, hipStream_t st, std::string& err);
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
-int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, hipStream_t st, std::string& err);
+int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err);
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
 int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);
@@ -40,6 +40,7 @@ int tr_patch_im2col(const float* x, float* out, int B, int S, hipStream_t st, st
 int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream_t st, std::string& err);
 int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err);
+int tr_unscale_check(float* g, size_t n, float inv_scale, int* found, hipStream_t st, std::string& err);
 int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err);
 
 // train_step.cpp: SOccDPT_V3 training step (model/SOccDPT.py:660-685 in train mode + autograd), SOCCDPT_PREC_F32 only

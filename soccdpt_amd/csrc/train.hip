@@ -18,6 +18,8 @@ constexpr float LN100 = 4.605170185988092f;
 template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
 template <> __device__ __forceinline__ uint16_t cvt_out<uint16_t>(float v) { return f2h<false>(v); }
+struct f16raw { uint16_t v; };   // IEEE fp16 bits (the amp mode with loss scaling); uint16_t alone means bf16
+template <> __device__ __forceinline__ f16raw cvt_out<f16raw>(float v) { return f16raw{f2h<true>(v)}; }
 
 // ---------------- layout ----------------
 // [R][C] -> [C][Rp] (Rp >= R: rows padded with zeros up to the k-tile multiple the igemm needs), 32 x 32 tiles through LDS
@@ -939,6 +941,17 @@ __global__ void qv_bias_grad_kernel(const float* __restrict__ dqkv_bias, float* 
     if (dv) dv[i] = dqkv_bias[2 * C + i];
 }
 
+// GradScaler.unscale_ + inf check of the fp16 amp mode, over a run of the flat gradient buffer: g *= inv_scale; *found |= any non-finite
+__global__ void unscale_check_kernel(float* __restrict__ g, size_t n, float inv_scale, int* __restrict__ found) {
+    int bad = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float v = g[i] * inv_scale;
+        g[i] = v;
+        bad |= !(fabsf(v) <= 3.0e38f);
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(found, 1);
+}
+
 inline unsigned gs_blocks(size_t n) {
     size_t b = (n + 255) / 256;
     return (unsigned)(b > 4096 ? 4096 : (b ? b : 1));
@@ -952,21 +965,24 @@ int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t 
     hipLaunchKernelGGL(transpose_kernel<float>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose");
 }
-int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
+int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err) {
+    if (f16) hipLaunchKernelGGL(transpose_kernel<f16raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), R, C, Rp);
+    else hipLaunchKernelGGL(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose16");
 }
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(im2colT_kernel<float>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT");
 }
-int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
+int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, int f16, hipStream_t st, std::string& err) {
+    if (f16) hipLaunchKernelGGL(im2colT_kernel<f16raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<f16raw*>(out), B, H, W, C, Mp);
+    else hipLaunchKernelGGL(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT16");
 }
 int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err) {
     const dim3 grid((N + 31) / 32, (ld + 31) / 32);
-    if (out16) hipLaunchKernelGGL(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
+    if (out16 == 2) hipLaunchKernelGGL(dy_halo_T_kernel<f16raw>, grid, dim3(256), 0, st, dy, static_cast<f16raw*>(out), B, r, N, margin, ld);
+    else if (out16) hipLaunchKernelGGL(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
     else hipLaunchKernelGGL(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld);
     TK("dy_halo_T");
 }
@@ -978,8 +994,9 @@ int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, st
     hipLaunchKernelGGL(conv_w_dgrad_kernel<float>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad");
 }
-int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, int f16, hipStream_t st, std::string& err) {
+    if (f16) hipLaunchKernelGGL(conv_w_dgrad_kernel<f16raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<f16raw*>(out), N, C);
+    else hipLaunchKernelGGL(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad16");
 }
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
@@ -990,8 +1007,9 @@ int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStrea
     hipLaunchKernelGGL(to_halo_kernel<float>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo");
 }
-int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err) {
+    if (f16) hipLaunchKernelGGL(to_halo_kernel<f16raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), B, H, W, C);
+    else hipLaunchKernelGGL(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo16");
 }
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
@@ -1138,6 +1156,10 @@ int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table,
         if (dw0 || db0) hipLaunchKernelGGL(cpb_reduce_kernel, dim3(8, 3), dim3(1024), 0, st, dhid, dt, dw0, db0, ws, pws, heads, 1);
     }
     TK("attn_param_grads");
+}
+int tr_unscale_check(float* g, size_t n, float inv_scale, int* found, hipStream_t st, std::string& err) {
+    hipLaunchKernelGGL(unscale_check_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, g, n, inv_scale, found);
+    TK("unscale_check");
 }
 int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err) {
     hipLaunchKernelGGL(qv_bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dqkv_bias, dq, dv, C);

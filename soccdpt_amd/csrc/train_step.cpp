@@ -154,7 +154,7 @@ int gemm(Ctx& c, IgemmDesc d) {
 int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands) {
     const bool amp = bf16_operands;   // the CALLER says what its staging kernels wrote (amp applies per GEMM: shapes that do not fit stay f32)
     d.f32 = amp ? 0 : 1;
-    d.f16 = 0;
+    d.f16 = c.h.train_amp == 2 ? 1 : 0;   // 16-bit format of the amp mode: bf16 (1) or fp16 with the caller's loss scaling (2)
     // 64 x 64 tiles: the 128 x 128 split-K forms were measured slower (4 waves: 51.2 vs 45.2 ms per step at B = 8; 8 waves: 47.9 vs 42.2 --
     // fewer, longer workgroups and a partial-tile exchange four times the size)
     const long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
@@ -172,7 +172,7 @@ int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands) {
 // amp: a backward GEMM with bf16 operands (f32 accumulate, f32 outputs)
 int gemm16(Ctx& c, IgemmDesc d) {
     d.f32 = 0;
-    d.f16 = 0;
+    d.f16 = c.h.train_amp == 2 ? 1 : 0;
     return launch_igemm(d, c.st, c.err);
 }
 
@@ -185,15 +185,16 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
-    const bool amp = c.h.train_amp && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: bf16 operands for the two gradient GEMMs
+    const bool amp = c.h.train_amp && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: 16-bit operands for the two gradient GEMMs
+    const int F16 = c.h.train_amp == 2 ? 1 : 0;
     if (dX_out) {
         IgemmDesc d;
         d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
         if (amp) {
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
-            TRY(tr_transpose16(W, w16, N, K, N, c.st, c.err));
-            TRY(launch_cvt_bf16(dY, a16, M * N, 0, c.st, c.err));
+            TRY(tr_transpose16(W, w16, N, K, N, F16, c.st, c.err));
+            TRY(launch_cvt_bf16(dY, a16, M * N, F16, c.st, c.err));
             d.X = a16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
@@ -209,8 +210,8 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             const int Mp = (int)((M + 127) / 128 * 128);
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
-            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
-            TRY(tr_transpose16(X, x16, (int)M, K, Mp, c.st, c.err));
+            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, F16, c.st, c.err));
+            TRY(tr_transpose16(X, x16, (int)M, K, Mp, F16, c.st, c.err));
             d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
         } else {
             const int Mp = (int)((M + 31) / 32 * 32);                    // k-tile multiple; the padding rows are zero
@@ -231,6 +232,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
     const int B = c.B;
     const size_t M = (size_t)B * r * r;
     const bool amp = c.h.train_amp && N % 32 == 0 && C % 32 == 0;
+    const int F16 = c.h.train_amp == 2 ? 1 : 0;
     if (dX_out) {
         const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * (amp ? 2 : 4);
         hipError_t e = hipMemsetAsync(T.S_halo, 0, hb, c.st);
@@ -240,8 +242,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         if (amp) {
             uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
-            TRY(tr_to_halo16(dY, h16, B, r, r, N, c.st, c.err));
-            TRY(tr_conv_w_dgrad16(W, w16, N, C, c.st, c.err));
+            TRY(tr_to_halo16(dY, h16, B, r, r, N, F16, c.st, c.err));
+            TRY(tr_conv_w_dgrad16(W, w16, N, C, F16, c.st, c.err));
             d.X = h16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
@@ -258,8 +260,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             const int Mp = (int)((M + 127) / 128 * 128);
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
-            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, c.st, c.err));
-            TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, c.st, c.err));
+            TRY(tr_transpose16(dY, y16, (int)M, N, Mp, F16, c.st, c.err));
+            TRY(tr_im2colT16(Xhalo, x16, B, r, r, C, (size_t)Mp, F16, c.st, c.err));
             d.X = y16; d.Wt = x16; d.Cin = Mp; d.ldx = Mp;
         } else {
             const int Mp = (int)((M + 31) / 32 * 32);
@@ -280,14 +282,14 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         const size_t head = (size_t)(margin + 13) / 8 * 8;     // zeroed elements in FRONT of each copy: the most negative shift reads base - (r + 4)
         const size_t copy_bytes = ((size_t)(C + 1) * ld + 64 + head) * esz;
         xT += head * esz;
-        TRY(tr_dy_halo_T(dY, yT, amp ? 1 : 0, B, r, N, margin, ld, c.st, c.err));
+        TRY(tr_dy_halo_T(dY, yT, amp ? 1 + F16 : 0, B, r, N, margin, ld, c.st, c.err));
         if (!reuse_xt) {
             for (int cp = 0; cp < (amp ? 2 : 1); ++cp) {
                 char* base = xT + cp * copy_bytes;
                 // headroom + the first row's left margin; every other gap is the zero tail of a row (tr_transpose pads rows up to ld)
                 hipError_t e = hipMemsetAsync(base - head * esz, 0, (head + margin) * esz, c.st);
                 if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
-                if (amp) TRY(tr_transpose16(Xhalo, reinterpret_cast<uint16_t*>(base) + margin - cp, Mh, C, ld, c.st, c.err));
+                if (amp) TRY(tr_transpose16(Xhalo, reinterpret_cast<uint16_t*>(base) + margin - cp, Mh, C, ld, F16, c.st, c.err));
                 else TRY(tr_transpose(Xhalo, reinterpret_cast<float*>(base) + margin, Mh, C, ld, c.st, c.err));
             }
         }

@@ -129,6 +129,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_project.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     L.soccdpt_bind_grad.argtypes = [vp, ctypes.c_char_p, vp]
     L.soccdpt_train_set_amp.argtypes = [vp, ci]
+    L.soccdpt_train_unscale.argtypes = [vp, cs, ctypes.c_float, vp, vp]
     L.soccdpt_train_workspace_bytes.argtypes = [vp, ci]
     L.soccdpt_train_workspace_bytes.restype = cs
     L.soccdpt_train_forward.argtypes = [vp, vp, ci, vp, vp, vp, cs, ctypes.c_float, ctypes.c_uint32, vp]
@@ -366,8 +367,17 @@ class Engine:
         self._grads = getattr(self, "_grads", {})
         self._grads[key] = g  # keep alive
 
-    def train_set_amp(self, on: bool):
-        self._check(self.L.soccdpt_train_set_amp(self._h, int(bool(on))), "soccdpt_train_set_amp")
+    def train_set_amp(self, mode):
+        """0 / False: f32; 1 / True / "bf16": bf16 operands for the gradient GEMMs; 2 / "f16": fp16 operands (use a GradScaler)."""
+        code = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, "bf16": 1, "f16": 2, "fp16": 2, None: 0}[mode]
+        self._check(self.L.soccdpt_train_set_amp(self._h, code), "soccdpt_train_set_amp")
+
+    def train_unscale(self, grads: torch.Tensor, inv_scale: float, found_inf: torch.Tensor):
+        assert grads.is_contiguous() and grads.dtype == torch.float32 and found_inf.dtype == torch.int32
+        with torch.cuda.device(self.device):
+            rc = self.L.soccdpt_train_unscale(grads.data_ptr(), grads.numel(), float(inv_scale), found_inf.data_ptr(), _stream_ptr(self.device))
+        if rc != 0:
+            raise RuntimeError("soccdpt_train_unscale failed: " + self.L.soccdpt_last_error(None).decode())
 
     def train_workspace(self, B: int) -> torch.Tensor:
         nbytes = self.L.soccdpt_train_workspace_bytes(self._h, B)

@@ -293,7 +293,7 @@ class SOccDPT_V3(SOccDPT):
         assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
         eng = self._engine(x.device)
         live, keys, st = self._bind_for_training(eng)
-        eng.train_set_amp(bool(getattr(self, "train_amp", False)))   # the reference's `amp` sweep parameter: bf16 operands for the gradient GEMMs
+        eng.train_set_amp(getattr(self, "train_amp", False))   # the reference's `amp` sweep parameter: False | True / "bf16" | "f16" (with a GradScaler)
         xin = x.detach().to(torch.float32).contiguous()
         B = xin.shape[0]
         inv = torch.empty((B, img, img), device=x.device)
@@ -325,17 +325,19 @@ class SOccDPT_V3(SOccDPT):
             if g is not None and live[k].grad is g:
                 carried.append((g, g.clone()))
         eng.train_backward(xin, d_inv.detach().to(torch.float32).contiguous(), d_seg.detach().to(torch.float32).contiguous())
+        # contiguous runs of this step's trainable tensors in the flat gradient buffer (data-parallel exchange, GradScaler.unscale_)
+        runs = []
+        for k in keys:
+            if st["req"].get(k):
+                lo, hi = st["span"][k]
+                hi = (hi + 63) // 64 * 64
+                if runs and runs[-1][1] == lo:
+                    runs[-1][1] = hi
+                else:
+                    runs.append([lo, hi])
+        self._last_grad_runs = (eng, st["flat"], runs)
         if getattr(self, "grad_exchange", None) is not None:
-            # data parallel: average the gradients over the ranks, one collective per contiguous run of trainable tensors
-            runs = []
-            for k in keys:
-                if st["req"].get(k):
-                    lo, hi = st["span"][k]
-                    hi = (hi + 63) // 64 * 64
-                    if runs and runs[-1][1] == lo:
-                        runs[-1][1] = hi
-                    else:
-                        runs.append([lo, hi])
+            # data parallel: average the gradients over the ranks, one collective per run
             self.grad_exchange(st["flat"], runs)
         for g, prev in carried:
             g.add_(prev)

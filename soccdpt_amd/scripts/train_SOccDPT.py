@@ -37,7 +37,7 @@ from ..model.loader import load_model, load_transforms
 from ..model.SOccDPT import DepthNet, SegNet, SOccDPT_versions, model_types
 from ..utils.loss import training_loss
 from ..utils.metrics import evaluate_depth, evaluate_seg
-from ..utils.optim import Adam, PatchWiseInplace
+from ..utils.optim import Adam, GradScaler, PatchWiseInplace
 from ..utils.synth import synth_input, write_synth_calib
 
 # keys of the reference's sweep files (config/*.json) and the defaults train_net() gives them (train_SOccDPT.py:96-121)
@@ -175,7 +175,11 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
         model_kwargs["precision"] = PREC_F32     # the training step (csrc/train_step.cpp) computes in exact f32, like the reference's amp=False runs
     net = load_model(arch=arch, model_kwargs=model_kwargs, device=torch.device("cpu"), model_path=p["load"] or None, model_type=model_type)
     net = net.to(device=device)
-    net.train_amp = bool(p["amp"])     # amp=True: bf16 MFMA operands for the gradient GEMMs (soccdpt_train_set_amp); no GradScaler needed
+    # amp=True is the reference's fp16 autocast + GradScaler (:340,360-366,390-393): fp16 MFMA operands for the gradient GEMMs, the criterion's output
+    # gradients scaled, parameter gradients unscaled and inf-checked before the step.  SOCCDPT_AMP=bf16 selects bf16 operands instead (no scaling needed).
+    amp_mode = (os.environ.get("SOCCDPT_AMP", "f16") if p["amp"] else False)
+    net.train_amp = amp_mode
+    grad_scaler = GradScaler(enabled=(amp_mode == "f16"))
     if world > 1:
         assert p["batch_size"] >= world, "data parallel: batch_size must be at least the number of ranks"
         sdist.attach_training(net)
@@ -212,8 +216,9 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
                                     compute_scale_and_shift=p["compute_scale_and_shift"])
                 optimizer.zero_grad(set_to_none=True)
                 if not forward_only:
-                    net_patch.backward(out["d_inv"], out["d_seg"])
-                    optimizer.step()
+                    net_patch.backward(*grad_scaler.scale(out["d_inv"], out["d_seg"]))
+                    grad_scaler.step(optimizer, net_patch)
+                    grad_scaler.update()
             loss = float(out["loss"].item())
             epoch_loss += loss
             history.append(loss)

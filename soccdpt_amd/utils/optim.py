@@ -96,3 +96,54 @@ class PatchWiseInplace:
         finally:   # the reference restores the flags when the iteration is exhausted; also do so if the loop is left early
             for p, f in zip(self._all, self._flags):
                 p.requires_grad = f
+
+
+class GradScaler:
+    """torch.cuda.amp.GradScaler for the HIP training step's fp16 amp mode (the reference: scripts/train_SOccDPT.py:340,390-393).
+    `scale(d_inv, d_seg)` multiplies the criterion's output gradients (= scaling the loss), `step(optimizer, net)` unscales the parameter
+    gradients in the flat buffer (one launch per run, csrc/train.hip) and skips the optimizer step when one of them is not finite,
+    `update()` backs the scale off after a skipped step and grows it after `growth_interval` clean ones."""
+
+    def __init__(self, init_scale: float = 65536.0, growth_factor: float = 2.0, backoff_factor: float = 0.5, growth_interval: int = 2000, enabled: bool = True):
+        self._scale, self.growth_factor, self.backoff_factor, self.growth_interval, self.enabled = float(init_scale), growth_factor, backoff_factor, growth_interval, enabled
+        self._good_steps = 0
+        self._found_inf = False
+        self._flag = None
+        self.skipped_steps = 0
+
+    def get_scale(self) -> float:
+        return self._scale if self.enabled else 1.0
+
+    def scale(self, *tensors):
+        if not self.enabled:
+            return tensors if len(tensors) > 1 else tensors[0]
+        out = tuple(t * self._scale for t in tensors)
+        return out if len(out) > 1 else out[0]
+
+    def step(self, optimizer, net):
+        if not self.enabled:
+            optimizer.step()
+            return
+        eng, flat, runs = net._last_grad_runs
+        if self._flag is None or self._flag.device != flat.device:
+            self._flag = torch.zeros(1, dtype=torch.int32, device=flat.device)
+        self._flag.zero_()
+        for lo, hi in runs:
+            eng.train_unscale(flat[lo:hi], 1.0 / self._scale, self._flag)
+        self._found_inf = bool(self._flag.item())
+        if self._found_inf:
+            self.skipped_steps += 1
+        else:
+            optimizer.step()
+
+    def update(self):
+        if not self.enabled:
+            return
+        if self._found_inf:
+            self._scale *= self.backoff_factor
+            self._good_steps = 0
+        else:
+            self._good_steps += 1
+            if self._good_steps >= self.growth_interval:
+                self._scale *= self.growth_factor
+                self._good_steps = 0

@@ -381,6 +381,44 @@ def test_amp_gradients_with_criterion(gpu_device):
     med = sorted(e for e, _ in errs)[len(errs) // 2]
     print(f"amp: {len(errs)} parameter gradients vs torch f32 autograd: median {med:.2e}, worst {max(errs)[0]:.2e} ({max(errs)[1]})")
     assert med < 1e-2 and max(errs)[0] < 5e-2, max(errs)
+    # fp16 operands with loss scaling (the reference's autocast + GradScaler): 11-bit significands -> ~8x closer than bf16
+    from soccdpt_amd.utils.optim import GradScaler
+    m.train_amp = "f16"
+    scaler = GradScaler()
+    for p in m.parameters():
+        p.grad = None
+    inv, seg = m.train_forward(x.to(dev))
+    assert torch.equal(inv, inv0)
+    r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
+    m.backward(*scaler.scale(r["d_inv"], r["d_seg"]))
+
+    class _Opt:
+        stepped = 0
+
+        def step(self):
+            self.stepped += 1
+
+    opt = _Opt()
+    scaler.step(opt, m)
+    scaler.update()
+    torch.cuda.synchronize()
+    assert opt.stepped == 1 and scaler.skipped_steps == 0 and scaler.get_scale() == 65536.0
+    errs16 = []
+    for k, p in m.named_parameters():
+        ref = sd_o[k].grad
+        if ref is None or float(ref.norm()) < 1e-5:
+            continue
+        errs16.append((_rel(p.grad.cpu(), ref), k))
+    med16 = sorted(e for e, _ in errs16)[len(errs16) // 2]
+    print(f"amp f16 + GradScaler: median {med16:.2e}, worst {max(errs16)[0]:.2e} ({max(errs16)[1]})")
+    assert med16 < 2e-3 and max(errs16)[0] < 1e-2, max(errs16)
+    # an overflowing gradient makes the scaler skip the step and halve the scale
+    m.train_forward(x.to(dev))
+    big = torch.full_like(r["d_inv"], float("inf"))
+    m.backward(big, r["d_seg"])
+    scaler.step(opt, m)
+    scaler.update()
+    assert opt.stepped == 1 and scaler.skipped_steps == 1 and scaler.get_scale() == 32768.0
 
 
 def _nhwc(t):
