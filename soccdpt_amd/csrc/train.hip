@@ -1,10 +1,13 @@
-// Backward (and train-mode forward) kernels of the SOccDPT_V3 training step for gfx950, exact-f32 (SOCCDPT_PREC_F32).
+// Backward (and train-mode forward) kernels of the SOccDPT_V3 training step for gfx950: exact f32, or 16-bit operand copies for the gradient
+// GEMMs under amp (soccdpt_train_set_amp).
 //
 // What autograd does for the reference in scripts/train_SOccDPT.py:390-393 (`grad_scaler.scale(loss).backward()`) over
 // model/SOccDPT.py:660-685, model/dpt.py:142-232, model/blocks.py:391-497 and timm's SwinTransformerV2 blocks.  GEMM-shaped gradients
 // (dgrad of every Linear / convolution, wgrad of every weight) run on the f32 MFMA igemm (igemm.hip) over operands these kernels lay out:
 //   dX = dY W            -> igemm(X = dY, Wt = W^T)                      (transpose_kernel; conv: flipped tap-major weights + zero-haloed dY)
-//   dW = dY^T X          -> igemm(X = dY^T [N][M], Wt = X^T [K][M])      (transpose_kernel; conv: im2colT_kernel builds [9C][M])
+//   dW = dY^T X          -> igemm(X = dY^T [N][M], Wt = X^T [K][M])      (transpose_kernel; 3x3 conv: both operands in halo pixel order and nine
+//                                                                          shifted views of ONE transposed halo image, dy_halo_T_kernel; im2colT_kernel
+//                                                                          only where a 64-row weight tile would straddle two taps, C % 64 != 0)
 // Everything else here is an elementwise / row / column-reduction kernel, deterministic (no float atomics): fixed-order tree reductions.
 #include "half16.h"
 #include "kernels.h"
@@ -631,8 +634,7 @@ __global__ __launch_bounds__(64) void attn_bwd_q_kernel(const float* __restrict_
     if (tid == 0) dscale_part[(((size_t)widx * heads + head) * nqb + qb) * nseg + seg] = dsc;
 }
 
-// Pass B, one thread = one key: dv_k = sum_q P[q][k] dO_q needs P, so recompute it from dS?  No: P is recomputed from the logits with the
-// row statistics (stats[q] = {max, sum}) written by pass A2 below.  To keep this simple and exact, pass B re-derives P[q][k] itself per query tile:
+// Pass B, one thread = one key: P[q][k] is recomputed from the logits with the row statistics of attn_rowstat_kernel, dS is read back:
 // dk^_k = sum_q dS[q][k] q^_q ; dv_k = sum_q P[q][k] dO_q.
 __global__ __launch_bounds__(64) void attn_bwd_k_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ table,
                                                         const float* __restrict__ scale, const float* __restrict__ dS_in, const float* __restrict__ rowstat,
