@@ -645,3 +645,17 @@ def test_random_trainable_subsets_match_full_backward(gpu_device, model_type, ba
                 assert p.grad is not None and torch.equal(p.grad, full[k]), (trial, sorted(keep)[:4], k)
             else:
                 assert p.grad is None, (trial, k)
+
+
+def test_training_is_bit_reproducible_across_processes(gpu_device):
+    """Six optimisation steps in two fresh processes end in bit-identical weights and BatchNorm buffers: every reduction of the step (split-K
+    partials, column sums, attention segments, GroupNorm / BatchNorm statistics) has a fixed order, no float atomics anywhere."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(__file__), "tools", "train_determinism.py")
+    outs = []
+    for _ in range(2):
+        r = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=300, env=dict(os.environ))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("HASH")][-1])
+    assert outs[0] == outs[1], outs
