@@ -43,6 +43,10 @@ extern "C" {
 #define SOCCDPT_PREC_F16 2  /* IEEE fp16 MFMA operands (11-bit significand), f32 accumulate and f32 residual streams: the
                                same kernels and MFMA rate as BF16 with 8x smaller operand rounding; what the reference's
                                optimize=True path (model/loader.py:126-139, .half()) computes in */
+#define SOCCDPT_PREC_F16X3 3 /* split-operand fp16: every GEMM / convolution operand is an fp16 pair (hi, lo * 2^11) and every product three
+                               fp16 MFMAs (hi hi + hi lo + lo hi) with f32 accumulation: ~22 significand bits at 1/3 of the 16-bit MFMA
+                               rate (the f32 MFMA runs at 1/16); attention, normalisations and residual streams in f32.  The fast
+                               parity-grade mode for models whose reference arithmetic is fp32 (dpt_hybrid_384: model/loader.py:115-120) */
 
 /* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
 typedef struct soccdpt_config {

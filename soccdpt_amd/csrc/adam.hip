@@ -65,7 +65,7 @@ int launch_adam(int n_tensors, float* const* params, const float* const* grads, 
         unsigned gx = (unsigned)((nmax + 255) / 256);
         if (gx > 512) gx = 512;
         if (gx < 1) gx = 1;
-        hipLaunchKernelGGL(adam_kernel, dim3(gx, cnt), dim3(256), 0, st, t, s);
+        SOCCDPT_LAUNCH(adam_kernel, dim3(gx, cnt), dim3(256), 0, st, t, s);
         if (check_launch("adam", err)) return 1;
     }
     return 0;

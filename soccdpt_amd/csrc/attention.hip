@@ -659,7 +659,7 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
     const size_t total = attn_bias_elems(ws, heads);
     size_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(attn_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, table, bias_acc, ws, heads);
+    SOCCDPT_LAUNCH(attn_bias_kernel, dim3((unsigned)blocks), dim3(256), 0, st, table, bias_acc, ws, heads);
     return check_launch("attn_bias", err);
 }
 
@@ -669,7 +669,7 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
     const int nw = res / ws;
     if (ws != 16 && !(ws == 8 && shift == 0)) {  // any other window size: the generic exact kernel (parity mode of base_384)
         const int nqb = (ws * ws + 63) / 64;
-        hipLaunchKernelGGL(window_attention_f32_any_kernel, dim3((unsigned)(B * nw * nw * heads * nqb)), dim3(64), 0, st, qkv, table, scale, out, res, ws,
+        SOCCDPT_LAUNCH(window_attention_f32_any_kernel, dim3((unsigned)(B * nw * nw * heads * nqb)), dim3(64), 0, st, qkv, table, scale, out, res, ws,
                            shift, heads);
         return check_launch("window_attention_f32_any", err);
     }
@@ -681,10 +681,10 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
     }
     if (ws == 16) {
         using A = AttnCfgF32<16>;
-        hipLaunchKernelGGL((window_attention_f32_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        SOCCDPT_LAUNCH((window_attention_f32_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 8 && shift == 0) {
         using A = AttnCfgF32<8>;
-        hipLaunchKernelGGL((window_attention_f32_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        SOCCDPT_LAUNCH((window_attention_f32_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else {
         err = "window_attention_f32: window size not instantiated (16 and unshifted 8 are)";
         return 1;
@@ -707,13 +707,13 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
             attr16.done();
         }
-        if (hf) hipLaunchKernelGGL((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else hipLaunchKernelGGL((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) SOCCDPT_LAUNCH((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else SOCCDPT_LAUNCH((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 8) {
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
-        if (hf) hipLaunchKernelGGL((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else hipLaunchKernelGGL((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) SOCCDPT_LAUNCH((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        else SOCCDPT_LAUNCH((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
     } else if (ws == 24 || ws == 12) {
         static PerDeviceOnce attr_done;
         if (attr_done.need()) {
@@ -722,7 +722,7 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
 #undef FLASH_ATTR
             attr_done.done();
         }
-#define FLASH(W, H, Q) hipLaunchKernelGGL((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+#define FLASH(W, H, Q) SOCCDPT_LAUNCH((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
         if (ws == 24 && blocks < 256) { if (hf) FLASH(24, true, 2); else FLASH(24, false, 2); }   // too few (window, head) pairs: split the queries
         else if (ws == 24) { if (hf) FLASH(24, true, 1); else FLASH(24, false, 1); }
         else { if (hf) FLASH(12, true, 1); else FLASH(12, false, 1); }

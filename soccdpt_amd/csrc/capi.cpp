@@ -13,6 +13,13 @@ using namespace soccdpt;
 
 static std::string g_create_error;
 
+namespace soccdpt {
+LaunchTimer*& launch_timer() {
+    static thread_local LaunchTimer* t = nullptr;
+    return t;
+}
+}  // namespace soccdpt
+
 // algorithmic HBM bytes of the projection kernel: inputs once + every requested output once
 static double project_bytes(const soccdpt_config& c, int B, int h, int w, const void* inv_up, const void* seg_up, const void* points) {
     const double px = (double)c.cam_width * c.cam_height * B;
@@ -271,9 +278,14 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
     if (!h || !out || !n_entries) return 1;
     int n = 0;
     for (const ProfRec& r : h->prof.recs) {
-        if (hipEventSynchronize(r.e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: event sync failed");
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: elapsed failed");
+        for (size_t i = r.first_pair; i < r.first_pair + r.n_pairs; ++i) {   // each pair is bound to one dispatch: stop - start = the kernel's own duration
+            hipEvent_t e0 = h->prof.pool[2 * i], e1 = h->prof.pool[2 * i + 1];
+            if (hipEventSynchronize(e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: event sync failed");
+            float t = 0.f;
+            if (hipEventElapsedTime(&t, e0, e1) != hipSuccess) return fail(h, "soccdpt_profile_collect: elapsed failed");
+            ms += t;
+        }
         int k = 0;
         for (; k < n; ++k)
             if (!std::strcmp(out[k].name, r.name)) break;
@@ -283,7 +295,7 @@ int soccdpt_profile_collect(void* handle, soccdpt_kernel_stat* out, int max_entr
             std::strncpy(out[n].name, r.name, sizeof(out[n].name) - 1);
             ++n;
         }
-        out[k].launches += 1;
+        out[k].launches += (int)r.n_pairs;
         out[k].ms += ms;
         out[k].flops += r.flops;
         out[k].bytes += r.bytes;

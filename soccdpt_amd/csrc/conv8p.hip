@@ -315,7 +315,7 @@ int launch_c8_var(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&conv8p_kernel<C, false, VAR>), hipFuncAttributeMaxDynamicSharedMemorySize, C::LDS);
         attr_done.done();
     }
-    hipLaunchKernelGGL((conv8p_kernel<C, false, VAR>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
+    SOCCDPT_LAUNCH((conv8p_kernel<C, false, VAR>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("conv8p launch: ") + hipGetErrorString(e); return 1; }
     return 0;
@@ -332,8 +332,8 @@ int launch_c8(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         if (e != hipSuccess) { err = std::string("conv8p: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done.done();
     }
-    if (d.f16) hipLaunchKernelGGL((conv8p_kernel<C, true>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
-    else hipLaunchKernelGGL((conv8p_kernel<C, false>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
+    if (d.f16) SOCCDPT_LAUNCH((conv8p_kernel<C, true>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
+    else SOCCDPT_LAUNCH((conv8p_kernel<C, false>), dim3((unsigned)(mtiles * ntiles)), dim3(512), C::LDS, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("conv8p launch: ") + hipGetErrorString(e); return 1; }
     return 0;

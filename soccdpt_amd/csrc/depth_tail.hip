@@ -171,8 +171,8 @@ int launch_depth_tail(const bf16_t* d1, const bf16_t* wt, const float* bias, con
     }
     const int ntiles = B * (2 * h / TH) * (2 * w / TW);
     const int blocks = ntiles < 256 ? ntiles : 256;  // persistent: one workgroup per CU keeps the weights resident
-    if (hf) hipLaunchKernelGGL(depth_tail_kernel<true>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
-    else hipLaunchKernelGGL(depth_tail_kernel<false>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
+    if (hf) SOCCDPT_LAUNCH(depth_tail_kernel<true>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
+    else SOCCDPT_LAUNCH(depth_tail_kernel<false>, dim3(blocks), dim3(NTHR), LDS_BYTES, st, d1, wt, bias, w4, b4, out, B, h, w);
     return check_launch("depth_tail", err);
 }
 

@@ -39,8 +39,8 @@ __device__ __forceinline__ float row_sum(float v) {
 // launch K<false> (bf16) or K<true> (fp16) by the runtime format flag
 #define LAUNCH_HF(hf, K, ...)                                   \
     do {                                                        \
-        if (hf) hipLaunchKernelGGL((K<true>), __VA_ARGS__);     \
-        else hipLaunchKernelGGL((K<false>), __VA_ARGS__);       \
+        if (hf) SOCCDPT_LAUNCH((K<true>), __VA_ARGS__);     \
+        else SOCCDPT_LAUNCH((K<false>), __VA_ARGS__);       \
     } while (0)
 
 // ---------------------------------------------------------------------------------------------
@@ -256,8 +256,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     if (C % 256 == 0 && C <= 1024) {
 #define LN4_CASE(V)                                                                                                                       \
     do {                                                                                                                                  \
-        if (hf) hipLaunchKernelGGL((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
-        else hipLaunchKernelGGL((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
+        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
     } while (0)
         switch (C / 256) { case 1: LN4_CASE(1); break; case 2: LN4_CASE(2); break; case 3: LN4_CASE(3); break; default: LN4_CASE(4); break; }
 #undef LN4_CASE
@@ -265,8 +265,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     }
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
-        if (hf) hipLaunchKernelGGL((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
-        else hipLaunchKernelGGL((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
+        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
     } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);
@@ -304,7 +304,7 @@ int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem
     const size_t total = (size_t)B * (R / 2) * (R / 2) * 4 * cpt;
     size_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(in), static_cast<uint4*>(out), B, R, cpt);
+    SOCCDPT_LAUNCH(merge_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, st, static_cast<const uint4*>(in), static_cast<uint4*>(out), B, R, cpt);
     return check_launch("merge_gather", err);
 }
 
@@ -419,10 +419,10 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
 #define BL_ARGS(T) dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C
-    if (in_is_bf16 && hf) hipLaunchKernelGGL((bilinear_kernel<bf16_t, true>), BL_ARGS(bf16_t));
-    else if (in_is_bf16) hipLaunchKernelGGL((bilinear_kernel<bf16_t, false>), BL_ARGS(bf16_t));
-    else if (hf) hipLaunchKernelGGL((bilinear_kernel<float, true>), BL_ARGS(float));
-    else hipLaunchKernelGGL((bilinear_kernel<float, false>), BL_ARGS(float));
+    if (in_is_bf16 && hf) SOCCDPT_LAUNCH((bilinear_kernel<bf16_t, true>), BL_ARGS(bf16_t));
+    else if (in_is_bf16) SOCCDPT_LAUNCH((bilinear_kernel<bf16_t, false>), BL_ARGS(bf16_t));
+    else if (hf) SOCCDPT_LAUNCH((bilinear_kernel<float, true>), BL_ARGS(float));
+    else SOCCDPT_LAUNCH((bilinear_kernel<float, false>), BL_ARGS(float));
 #undef BL_ARGS
     return check_launch("bilinear", err);
 }
@@ -528,13 +528,13 @@ int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, c
     const int M = B * h * wd;
     const dim3 grid((unsigned)(((size_t)M * 16 + 255) / 256));
     unsigned gl = grid.x > 2048 ? 2048 : grid.x;   // grid-stride (16-bit path): weights are loaded once per thread
-    if (feat_is_f32) hipLaunchKernelGGL(conv1x1_c3_f32_kernel, grid, dim3(256), 0, st, static_cast<const float*>(feat), w, bias, tmp, M);
+    if (feat_is_f32) SOCCDPT_LAUNCH(conv1x1_c3_f32_kernel, grid, dim3(256), 0, st, static_cast<const float*>(feat), w, bias, tmp, M);
     else LAUNCH_HF(hf, conv1x1_c3_kernel, dim3(gl), dim3(256), 0, st, static_cast<const bf16_t*>(feat), w, bias, tmp, M);
     if (check_launch("conv1x1_c3", err)) return 1;
     const size_t total = (size_t)B * 4 * h * wd;
     size_t blocks = (total + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(seg_up_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tmp, seg, B, h, wd, sigmoid);
+    SOCCDPT_LAUNCH(seg_up_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tmp, seg, B, h, wd, sigmoid);
     return check_launch("seg_up_act", err);
 }
 
@@ -578,7 +578,7 @@ __global__ void patch_w_kernel(const float* __restrict__ w, float* __restrict__ 
     }
 }
 int launch_patch_w(const float* w, float* out, int C0, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(patch_w_kernel, dim3(24), dim3(256), 0, st, w, out, C0);
+    SOCCDPT_LAUNCH(patch_w_kernel, dim3(24), dim3(256), 0, st, w, out, C0);
     return check_launch("patch_w", err);
 }
 // BatchNorm2d eval fold (model/SOccDPT.py:668): scale = g / sqrt(var + eps), shift = b - mean * scale
@@ -628,27 +628,27 @@ int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, int hf, hipStream_t 
 int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int hf, int Cout, int Cin, hipStream_t st, std::string& err) {
     size_t n = (size_t)Cout * Cin * 9, blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    if (out_is_f32) hipLaunchKernelGGL(conv_w_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
+    if (out_is_f32) SOCCDPT_LAUNCH(conv_w_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
     else LAUNCH_HF(hf, conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<bf16_t*>(out), Cout, Cin);
     return check_launch("conv_w", err);
 }
 int launch_bn_fold(const float* g, const float* b, const float* mean, const float* var, float* scale, float* shift, int C, hipStream_t st,
                    std::string& err) {
-    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, b, mean, var, scale, shift, C);
+    SOCCDPT_LAUNCH(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, g, b, mean, var, scale, shift, C);
     return check_launch("bn_fold", err);
 }
 int launch_qkv_bias(const float* q, const float* v, float* out, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(qkv_bias_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, q, v, out, C);
+    SOCCDPT_LAUNCH(qkv_bias_kernel, dim3((3 * C + 255) / 256), dim3(256), 0, st, q, v, out, C);
     return check_launch("qkv_bias", err);
 }
 int launch_logit_scale(const float* ls, float* out, int H, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(logit_scale_kernel, dim3(1), dim3(64), 0, st, ls, out, H);
+    SOCCDPT_LAUNCH(logit_scale_kernel, dim3(1), dim3(64), 0, st, ls, out, H);
     return check_launch("logit_scale", err);
 }
 int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* table, int ws, int pws, int H, hipStream_t st,
                      std::string& err) {
     const int n = (2 * ws - 1) * (2 * ws - 1) * H;
-    hipLaunchKernelGGL(cpb_table_kernel, dim3((n + 127) / 128), dim3(128), 0, st, w0, b0, w2, table, ws, pws, H);
+    SOCCDPT_LAUNCH(cpb_table_kernel, dim3((n + 127) / 128), dim3(128), 0, st, w0, b0, w2, table, ws, pws, H);
     return check_launch("cpb_table", err);
 }
 

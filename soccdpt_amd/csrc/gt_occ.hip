@@ -115,10 +115,10 @@ int launch_gt_occupancy(int B, int H, int W, int C, const double* intr /*fx,fy,c
     const size_t total = (size_t)B * H * W;
     unsigned blocks = (unsigned)((total + 255) / 256);
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(gt_points_count_kernel, dim3(blocks), dim3(256), 0, st, P, disparity, seg_class, depth, points, counts);
+    SOCCDPT_LAUNCH(gt_points_count_kernel, dim3(blocks), dim3(256), 0, st, P, disparity, seg_class, depth, points, counts);
     unsigned tb = (unsigned)((ncell + 255) / 256);
     if (tb > 8192) tb = 8192;
-    hipLaunchKernelGGL(gt_threshold_kernel, dim3(tb), dim3(256), 0, st, counts, occ, ncell, threshold);
+    SOCCDPT_LAUNCH(gt_threshold_kernel, dim3(tb), dim3(256), 0, st, counts, occ, ncell, threshold);
     return check_launch("gt_occupancy", err);
 }
 

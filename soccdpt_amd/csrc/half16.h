@@ -57,4 +57,51 @@ __device__ __forceinline__ f32x16_t mfma_32x32x16(h16x8 a, h16x8 b, f32x16_t c) 
     else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b), c, 0, 0, 0);
 }
 
+// ---- "x3" split-fp16 operand format (SOCCDPT_PREC_F16X3) -------------------------------------------------------------------
+// A value a is carried as TWO fp16 numbers, hi = RN16(a) and lo = RN16((a - hi) * 2^11): together 22+ significand bits (the pair
+// represents a to 2^-24 relative, like f32 itself; the 2^11 keeps lo in fp16's normal range).  A product is then three fp16 MFMAs
+//     a b  ~=  hi_a hi_b  +  2^-11 (hi_a lo_b + lo_a hi_b)            (the dropped lo_a lo_b term is <= 2^-24 |a b|)
+// with the hi*hi sum and the cross sum in two f32 accumulators: near-f32 results at 1/3 of the fp16 MFMA rate instead of the f32
+// MFMA's 1/16.  Memory layout of an x3 tensor: 4 bytes per element like f32 (same buffer sizes and element offsets); every aligned
+// group of 8 elements ("unit" u = e >> 3) is 32 bytes = one 16-byte chunk of 8 hi values + one 16-byte chunk of 8 lo values, hi chunk
+// FIRST in even units and SECOND in odd units.  (The alternation makes the MFMA fragment reads of igemm's XOR-swizzled 128-byte LDS
+// rows conflict-free: lane quarter q reads unit q, and chunks {0, 3, 4, 7} / {1, 2, 5, 6} fall on distinct bank slots where
+// {0, 2, 4, 6} would collide pairwise.)  Rows of an x3 tensor must start at multiples of 16 elements.
+struct x3_t { uint32_t v; };   // element tag of the x3 instantiations: 4 bytes per element
+
+__device__ __forceinline__ void x3_split(float v, _Float16& hi, _Float16& lo) {
+    float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
+    c = (v != v) ? v : c;                      // a NaN stays a NaN (fmed3 would swallow it)
+    hi = (_Float16)c;
+    const float r = (v - (float)hi) * 2048.f;  // exact in f32
+    lo = (_Float16)__builtin_amdgcn_fmed3f(r, -65504.f, 65504.f);
+}
+// byte offsets of element e's hi / lo halves from the tensor base
+__device__ __forceinline__ size_t x3_hi_off(size_t e) { return (e >> 3) * 32 + (((e >> 3) & 1) ? 16 : 0) + (e & 7) * 2; }
+__device__ __forceinline__ size_t x3_lo_off(size_t e) { return (e >> 3) * 32 + (((e >> 3) & 1) ? 0 : 16) + (e & 7) * 2; }
+// store 4 consecutive elements e .. e+3 (e % 4 == 0): two 8-byte stores
+__device__ __forceinline__ void x3_store4(void* base, size_t e, float a, float b, float c, float d) {
+    _Float16 h[4], l[4];
+    x3_split(a, h[0], l[0]); x3_split(b, h[1], l[1]); x3_split(c, h[2], l[2]); x3_split(d, h[3], l[3]);
+    uint2 ph, pl;
+    ph.x = (uint32_t)__builtin_bit_cast(uint16_t, h[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[1]) << 16);
+    ph.y = (uint32_t)__builtin_bit_cast(uint16_t, h[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, h[3]) << 16);
+    pl.x = (uint32_t)__builtin_bit_cast(uint16_t, l[0]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[1]) << 16);
+    pl.y = (uint32_t)__builtin_bit_cast(uint16_t, l[2]) | ((uint32_t)__builtin_bit_cast(uint16_t, l[3]) << 16);
+    char* p = static_cast<char*>(base);
+    *reinterpret_cast<uint2*>(p + x3_hi_off(e)) = ph;
+    *reinterpret_cast<uint2*>(p + x3_lo_off(e)) = pl;
+}
+__device__ __forceinline__ void x3_store1(void* base, size_t e, float a) {
+    _Float16 h, l;
+    x3_split(a, h, l);
+    char* p = static_cast<char*>(base);
+    *reinterpret_cast<_Float16*>(p + x3_hi_off(e)) = h;
+    *reinterpret_cast<_Float16*>(p + x3_lo_off(e)) = l;
+}
+__device__ __forceinline__ float x3_load1(const void* base, size_t e) {
+    const char* p = static_cast<const char*>(base);
+    return (float)*reinterpret_cast<const _Float16*>(p + x3_hi_off(e)) + (float)*reinterpret_cast<const _Float16*>(p + x3_lo_off(e)) * (1.0f / 2048.f);
+}
+
 }  // namespace soccdpt

@@ -279,7 +279,7 @@ __global__ void pos_embed_resize_kernel(const float* __restrict__ pos, float* __
 
 int launch_ws_conv_w(const float* w, void* out, int out_mode, int Cout, int Cin, int k, int Kpad, float eps, hipStream_t st, std::string& err) {
     if (Kpad < Cin * k * k) { err = "ws_conv_w: Kpad too small"; return 1; }
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL(ws_conv_w_kernel<OUT>, dim3((unsigned)Cout), dim3(256), 0, st, w, out, Cin, k * k, Kpad, eps));
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(ws_conv_w_kernel<OUT>, dim3((unsigned)Cout), dim3(256), 0, st, w, out, Cin, k * k, Kpad, eps));
     return check_launch("ws_conv_w", err);
 }
 
@@ -289,7 +289,7 @@ int launch_stem_im2col(const float* x, void* A, int out_mode, int B, int S, hipS
     const int total_pad = (Ho - 1) * 2 + 7 - S;   // TF 'SAME'
     const int pad_lo = (total_pad > 0 ? total_pad : 0) / 2;
     const size_t total = (size_t)B * Ho * Ho * 20;
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL(stem_im2col_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, A, B, S, Ho, pad_lo));
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(stem_im2col_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, x, A, B, S, Ho, pad_lo));
     return check_launch("stem_im2col", err);
 }
 
@@ -297,7 +297,7 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     if (a.C % 4 || a.cpg < 2 || (a.cpg != 2 && a.cpg % 4) || a.C % a.cpg || a.HW <= 0 || a.M % (size_t)a.HW) { err = "gn_apply: bad geometry"; return 1; }
     if (a.raw2 && a.res) { err = "gn_apply: one shortcut kind at a time"; return 1; }
     const size_t total = a.M * (size_t)(a.C / 4);
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL(gn_apply_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.raw, a.stats, a.gamma, a.beta, a.raw2,
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(gn_apply_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.raw, a.stats, a.gamma, a.beta, a.raw2,
                                                a.stats2, a.gamma2, a.beta2, a.res, a.out_f32, a.out_op, a.out_halo, a.relu, a.M, a.HW, a.W, a.C, a.cpg));
     return check_launch("gn_apply", err);
 }
@@ -306,7 +306,7 @@ int launch_gn_relu_maxpool(const float* raw, const float* stats, const float* ga
                            hipStream_t st, std::string& err) {
     const int Ho = (Hi + 1) / 2;
     const size_t total = (size_t)B * Ho * Ho * (C / 4);
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL(gn_relu_maxpool_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, raw, stats, gamma, beta, out, B, Hi,
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(gn_relu_maxpool_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, raw, stats, gamma, beta, out, B, Hi,
                                                Ho, C, cpg));
     return check_launch("gn_relu_maxpool", err);
 }
@@ -315,20 +315,20 @@ int launch_vit_tokens_ln(const float* y, const float* cls, const float* pos, flo
                          int C, float eps, hipStream_t st, std::string& err) {
     if (C != 768) { err = "vit_tokens_ln: C must be 768"; return 1; }
     const int rows = B * ntok;
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL((ln768_kernel<OUT, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, y, cls, pos, xf, g, be, xb, rows, ntok, eps));
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH((ln768_kernel<OUT, 1>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, y, cls, pos, xf, g, be, xb, rows, ntok, eps));
     return check_launch("vit_tokens_ln", err);
 }
 
 int launch_ln_rows(float* xf, const float* g, const float* be, void* xb, int out_mode, int rows, int C, float eps, hipStream_t st, std::string& err) {
     if (C != 768) { err = "ln_rows: C must be 768"; return 1; }
-    DISPATCH_OUT(out_mode, hipLaunchKernelGGL((ln768_kernel<OUT, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, nullptr, nullptr, nullptr, xf, g, be, xb, rows,
+    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH((ln768_kernel<OUT, 0>), dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, nullptr, nullptr, nullptr, xf, g, be, xb, rows,
                                                0, eps));
     return check_launch("ln_rows", err);
 }
 
 int launch_pos_embed_resize(const float* pos, float* out, int g0, int g, int C, hipStream_t st, std::string& err) {
     const size_t total = (size_t)(1 + g * g) * C;
-    hipLaunchKernelGGL(pos_embed_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pos, out, g0, g, C);
+    SOCCDPT_LAUNCH(pos_embed_resize_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, pos, out, g0, g, C);
     return check_launch("pos_embed_resize", err);
 }
 

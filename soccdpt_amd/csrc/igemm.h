@@ -8,6 +8,8 @@
 #include <atomic>
 #include <string>
 
+#include "launch.h"
+
 namespace soccdpt {
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) is a per-DEVICE property of a kernel: one flag per device and call site (a

@@ -637,7 +637,7 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     const int splits = SK ? d.splitk : 1;
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
                (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
-    hipLaunchKernelGGL((igemm_kernel<C, T, LN, SK, ST, GEN>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    SOCCDPT_LAUNCH((igemm_kernel<C, T, LN, SK, ST, GEN>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;

@@ -90,7 +90,7 @@ int launch_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd,
     const size_t total = (size_t)B * Hd * Wd;
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(input_transform_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, out, B, Hs, Ws, Hd, Wd, scale_x, scale_y, mean[0],
+    SOCCDPT_LAUNCH(input_transform_u8_kernel, dim3((unsigned)blocks), dim3(256), 0, st, img, out, B, Hs, Ws, Hd, Wd, scale_x, scale_y, mean[0],
                        mean[1], mean[2], stdv[0], stdv[1], stdv[2]);
     return check_launch("input_transform_u8", err);
 }

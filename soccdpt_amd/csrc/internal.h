@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../../include/soccdpt_hip.h"
+#include "launch.h"
 
 namespace soccdpt {
 
@@ -50,17 +51,18 @@ struct WeightSlot {
 
 struct Prepared;  // model.cpp
 
-// hipEvent pairs around launches (soccdpt_profile_enable); aggregated per kernel family on collect.
+// Per-kernel device times (soccdpt_profile_enable): while a ProfScope is open, every kernel launched on this thread carries a start / stop
+// event pair bound to its own dispatch (launch.h); a scope's time is the sum of its kernels' begin -> end times.  Aggregated per family on collect.
 struct ProfRec {
     const char* name;
     double flops, bytes;
-    hipEvent_t e0, e1;
+    size_t first_pair, n_pairs;
 };
-struct Profiler {
+struct Profiler : LaunchTimer {
     bool on = false;
     std::vector<ProfRec> recs;
-    std::vector<hipEvent_t> pool;
-    size_t used = 0;
+    std::vector<hipEvent_t> pool;   // pairs: pool[2 i], pool[2 i + 1]
+    size_t used = 0;                // events handed out
     hipEvent_t get() {
         if (used == pool.size()) {
             hipEvent_t e;
@@ -69,23 +71,26 @@ struct Profiler {
         }
         return pool[used++];
     }
-    ~Profiler() {
+    void next_pair(hipEvent_t* e0, hipEvent_t* e1) override { *e0 = get(); *e1 = get(); }
+    ~Profiler() override {
         for (auto e : pool) (void)hipEventDestroy(e);
     }
 };
 struct ProfScope {
     Profiler* p;
-    hipStream_t st;
-    hipEvent_t e1 = nullptr;
-    ProfScope(Profiler& prof, const char* name, double flops, double bytes, hipStream_t s) : p(prof.on ? &prof : nullptr), st(s) {
+    LaunchTimer* prev = nullptr;
+    size_t rec = 0;
+    ProfScope(Profiler& prof, const char* name, double flops, double bytes, hipStream_t) : p(prof.on ? &prof : nullptr) {
         if (!p) return;
-        hipEvent_t e0 = p->get();
-        e1 = p->get();
-        (void)hipEventRecord(e0, st);
-        p->recs.push_back(ProfRec{name, flops, bytes, e0, e1});
+        rec = p->recs.size();
+        p->recs.push_back(ProfRec{name, flops, bytes, p->used / 2, 0});
+        prev = launch_timer();
+        launch_timer() = p;
     }
     ~ProfScope() {
-        if (p) (void)hipEventRecord(e1, st);
+        if (!p) return;
+        p->recs[rec].n_pairs = p->used / 2 - p->recs[rec].first_pair;
+        launch_timer() = prev;
     }
 };
 

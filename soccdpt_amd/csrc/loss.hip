@@ -391,16 +391,16 @@ int launch_training_loss(int B, int H, int W, int h, int w, int C, int compute_s
     // (2048 x B workgroups: 590 us; 256 x B: see tools/loss_bench.py)
     unsigned gx = (unsigned)((npix + 255) / 256);
     if (gx > 256) gx = 256;
-    hipLaunchKernelGGL(loss_up_stats_kernel, dim3(gx, B), dim3(256), 0, st, P, inv, y_disp, mask_disp, raw_up, sc);
-    hipLaunchKernelGGL(loss_terms_kernel, dim3(gx, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc);
-    hipLaunchKernelGGL(loss_bwd_vert_kernel, dim3((W + 255) / 256, h, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc, T);
-    hipLaunchKernelGGL(loss_bwd_horz_kernel, dim3((unsigned)(((size_t)B * h * w + 255) / 256)), dim3(256), 0, st, P, T, d_inv);
+    SOCCDPT_LAUNCH(loss_up_stats_kernel, dim3(gx, B), dim3(256), 0, st, P, inv, y_disp, mask_disp, raw_up, sc);
+    SOCCDPT_LAUNCH(loss_terms_kernel, dim3(gx, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc);
+    SOCCDPT_LAUNCH(loss_bwd_vert_kernel, dim3((W + 255) / 256, h, B), dim3(256), 0, st, P, raw_up, y_disp, mask_disp, g, sc, T);
+    SOCCDPT_LAUNCH(loss_bwd_horz_kernel, dim3((unsigned)(((size_t)B * h * w + 255) / 256)), dim3(256), 0, st, P, T, d_inv);
     const size_t nseg = (size_t)B * C * h * w;
     unsigned gs = (unsigned)((nseg + 255) / 256);
     if (gs > 1024) gs = 1024;
-    hipLaunchKernelGGL(loss_bce_kernel, dim3(gs), dim3(256), 0, st, P, seg, y_seg, mask_seg, d_seg, sc);
-    hipLaunchKernelGGL(loss_scale_dseg_kernel, dim3(gs), dim3(256), 0, st, P, sc, d_seg);
-    hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, P, sc, out);
+    SOCCDPT_LAUNCH(loss_bce_kernel, dim3(gs), dim3(256), 0, st, P, seg, y_seg, mask_seg, d_seg, sc);
+    SOCCDPT_LAUNCH(loss_scale_dseg_kernel, dim3(gs), dim3(256), 0, st, P, sc, d_seg);
+    SOCCDPT_LAUNCH(loss_finish_kernel, dim3(1), dim3(64), 0, st, P, sc, out);
     return check_launch("training_loss", err);
 }
 

@@ -163,9 +163,9 @@ int launch_depth_metrics(const float* pred, const float* gt, const uint8_t* mask
     unsigned bx = (unsigned)((npix + 256 * 8 - 1) / (256 * 8));
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(lsq_sums_kernel, dim3(bx, B), dim3(256), 0, st, pred, gt, mask, sums, npix);
-    hipLaunchKernelGGL(masked_err_kernel, dim3(bx, B), dim3(256), 0, st, pred, gt, mask, sums, acc, npix);
-    hipLaunchKernelGGL(depth_finalize_kernel, dim3(1), dim3(256), 0, st, sums, acc, out, B);
+    SOCCDPT_LAUNCH(lsq_sums_kernel, dim3(bx, B), dim3(256), 0, st, pred, gt, mask, sums, npix);
+    SOCCDPT_LAUNCH(masked_err_kernel, dim3(bx, B), dim3(256), 0, st, pred, gt, mask, sums, acc, npix);
+    SOCCDPT_LAUNCH(depth_finalize_kernel, dim3(1), dim3(256), 0, st, sums, acc, out, B);
     return check_launch("depth_metrics", err);
 }
 
@@ -176,8 +176,8 @@ int launch_iou_metrics(const float* pred, const float* gt, int B, int C, size_t 
     unsigned bx = (unsigned)((npix + 256 * 8 - 1) / (256 * 8));
     if (bx > 512) bx = 512;
     if (bx < 1) bx = 1;
-    hipLaunchKernelGGL(iou_counts_kernel, dim3(bx, B * C), dim3(256), 0, st, pred, gt, counts, npix);
-    hipLaunchKernelGGL(iou_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, st, counts, out, B, C);
+    SOCCDPT_LAUNCH(iou_counts_kernel, dim3(bx, B * C), dim3(256), 0, st, pred, gt, counts, npix);
+    SOCCDPT_LAUNCH(iou_finalize_kernel, dim3((B + 63) / 64), dim3(64), 0, st, counts, out, B, C);
     return check_launch("iou_metrics", err);
 }
 

@@ -232,7 +232,7 @@ int launch_one(const uint16_t* xop, float* xf, const uint16_t* w1, const float* 
         if (e != hipSuccess) { err = std::string("mlp_ln: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done.done();
     }
-    hipLaunchKernelGGL((mlp_ln_kernel<K, F16>), dim3((unsigned)((M + K::BM - 1) / K::BM)), dim3(K::THREADS), K::LDS, st, xop, xf, w1, b1, w2, b2, g, be,
+    SOCCDPT_LAUNCH((mlp_ln_kernel<K, F16>), dim3((unsigned)((M + K::BM - 1) / K::BM)), dim3(K::THREADS), K::LDS, st, xop, xf, w1, b1, w2, b2, g, be,
                        xop_out, halo, M, H, W, merge);
     return check_launch("mlp_ln", err);
 }

@@ -388,7 +388,7 @@ int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg
     const float sx_h = (float)P.w / (float)P.Wc;
     if (vec4 && (int)(1024.0f * sx_h) + 8 <= SW) {
         const int nseg = (P.Wc + 1023) / 1024;
-        hipLaunchKernelGGL((project_rows_kernel<3, SW>), dim3((unsigned)(B * P.Hc * nseg)), dim3(256), 0, stream, P, nseg);
+        SOCCDPT_LAUNCH((project_rows_kernel<3, SW>), dim3((unsigned)(B * P.Hc * nseg)), dim3(256), 0, stream, P, nseg);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { err = hipGetErrorString(e2); return 1; }
         return 0;
@@ -397,9 +397,9 @@ int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg
     long long blocks = (total + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;  // grid-stride beyond 16 blocks per CU
     if (vec4)
-        hipLaunchKernelGGL((project_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
+        SOCCDPT_LAUNCH((project_kernel<3, 4>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
     else
-        hipLaunchKernelGGL((project_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
+        SOCCDPT_LAUNCH((project_kernel<3, 1>), dim3((unsigned)blocks), dim3(256), 0, stream, P);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
     return 0;
@@ -410,7 +410,7 @@ int launch_occ_expand(const soccdpt_config& cfg, const uint32_t* bits, int B, fl
     if (ncell % 32 != 0) { err = "occupancy cell count must be a multiple of 32"; return 1; }
     size_t blocks = (ncell / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
-    hipLaunchKernelGGL(occ_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, occ, ncell, B);
+    SOCCDPT_LAUNCH(occ_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, occ, ncell, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
     return 0;
@@ -420,7 +420,7 @@ int launch_occ_or(const soccdpt_config& cfg, uint32_t* dst, const uint32_t* src,
     const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
     const size_t nwords = (ncell + 31) / 32;
     size_t blocks = (nwords + 255) / 256;
-    hipLaunchKernelGGL(occ_or_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, nwords, nsets);
+    SOCCDPT_LAUNCH(occ_or_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, dst, src, nwords, nsets);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
     return 0;

@@ -964,58 +964,58 @@ inline unsigned gs_blocks(size_t n) {
 #define TK(name) return check_launch(name, err)
 
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(transpose_kernel<float>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
+    SOCCDPT_LAUNCH(transpose_kernel<float>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose");
 }
 int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err) {
-    if (f16) hipLaunchKernelGGL(transpose_kernel<f16raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), R, C, Rp);
-    else hipLaunchKernelGGL(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
+    if (f16) SOCCDPT_LAUNCH(transpose_kernel<f16raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), R, C, Rp);
+    else SOCCDPT_LAUNCH(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose16");
 }
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(im2colT_kernel<float>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
+    SOCCDPT_LAUNCH(im2colT_kernel<float>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT");
 }
 int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, int f16, hipStream_t st, std::string& err) {
-    if (f16) hipLaunchKernelGGL(im2colT_kernel<f16raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<f16raw*>(out), B, H, W, C, Mp);
-    else hipLaunchKernelGGL(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
+    if (f16) SOCCDPT_LAUNCH(im2colT_kernel<f16raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<f16raw*>(out), B, H, W, C, Mp);
+    else SOCCDPT_LAUNCH(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT16");
 }
 int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err) {
     const dim3 grid((N + 31) / 32, (ld + 31) / 32);
-    if (out16 == 2) hipLaunchKernelGGL(dy_halo_T_kernel<f16raw>, grid, dim3(256), 0, st, dy, static_cast<f16raw*>(out), B, r, N, margin, ld);
-    else if (out16) hipLaunchKernelGGL(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
-    else hipLaunchKernelGGL(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld);
+    if (out16 == 2) SOCCDPT_LAUNCH(dy_halo_T_kernel<f16raw>, grid, dim3(256), 0, st, dy, static_cast<f16raw*>(out), B, r, N, margin, ld);
+    else if (out16) SOCCDPT_LAUNCH(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
+    else SOCCDPT_LAUNCH(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld);
     TK("dy_halo_T");
 }
 int tr_wgrad_permute9(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(wgrad_permute9_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
+    SOCCDPT_LAUNCH(wgrad_permute9_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
     TK("wgrad_permute9");
 }
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(conv_w_dgrad_kernel<float>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+    SOCCDPT_LAUNCH(conv_w_dgrad_kernel<float>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad");
 }
 int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, int f16, hipStream_t st, std::string& err) {
-    if (f16) hipLaunchKernelGGL(conv_w_dgrad_kernel<f16raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<f16raw*>(out), N, C);
-    else hipLaunchKernelGGL(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
+    if (f16) SOCCDPT_LAUNCH(conv_w_dgrad_kernel<f16raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<f16raw*>(out), N, C);
+    else SOCCDPT_LAUNCH(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad16");
 }
 int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(wgrad_permute_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
+    SOCCDPT_LAUNCH(wgrad_permute_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
     TK("wgrad_permute");
 }
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(to_halo_kernel<float>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+    SOCCDPT_LAUNCH(to_halo_kernel<float>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo");
 }
 int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err) {
-    if (f16) hipLaunchKernelGGL(to_halo_kernel<f16raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), B, H, W, C);
-    else hipLaunchKernelGGL(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
+    if (f16) SOCCDPT_LAUNCH(to_halo_kernel<f16raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), B, H, W, C);
+    else SOCCDPT_LAUNCH(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo16");
 }
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);
+    SOCCDPT_LAUNCH(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);
     TK("from_halo");
 }
 // scratch: up to 65536 + N floats
@@ -1024,32 +1024,32 @@ int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t
     int chunks = 512 / cb;
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
+    SOCCDPT_LAUNCH(colsum_part_kernel, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
     TK("colsum");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);
+    SOCCDPT_LAUNCH(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);
     TK("axpy");
 }
 int tr_relu_bwd(const float* dy, const float* ref, const float* add, float* dx, size_t n, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(relu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, ref, add, dx, n);
+    SOCCDPT_LAUNCH(relu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, ref, add, dx, n);
     TK("relu_bwd");
 }
 int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, float* dx, int B, int H, int W, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(relu_bwd_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, dy, ref_halo, add, dx, B, H, W, C);
+    SOCCDPT_LAUNCH(relu_bwd_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, dy, ref_halo, add, dx, B, H, W, C);
     TK("relu_bwd_halo");
 }
 int tr_gelu_bwd(const float* dy, const float* pre, float* dx, size_t n, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(gelu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, pre, dx, n);
+    SOCCDPT_LAUNCH(gelu_bwd_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dy, pre, dx, n);
     TK("gelu_bwd");
 }
 int tr_ln_bwd(const float* y, const float* g, const float* dout, float* dy, float* xhat, int M, int C, float eps, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, g, dout, dy, xhat, M, C, eps);
+    SOCCDPT_LAUNCH(ln_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, y, g, dout, dy, xhat, M, C, eps);
     TK("ln_bwd");
 }
 int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
+    SOCCDPT_LAUNCH(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
     TK("bilinear_bwd");
 }
 // scratch: (128 * C + C) doubles
@@ -1058,67 +1058,67 @@ int tr_bn_stats(const float* x, float* stats, float* rmean, float* rvar, void* s
     double* part = static_cast<double*>(scratch);
     double* mean = part + (size_t)chunks * C;
     for (int pass = 0; pass < 2; ++pass) {
-        hipLaunchKernelGGL(bn_moment_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, mean, part, M, C, chunks, pass);
-        hipLaunchKernelGGL(bn_moment_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, mean, stats, rmean, rvar, C, M, chunks, eps, momentum, pass);
+        SOCCDPT_LAUNCH(bn_moment_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, x, mean, part, M, C, chunks, pass);
+        SOCCDPT_LAUNCH(bn_moment_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, mean, stats, rmean, rvar, C, M, chunks, eps, momentum, pass);
     }
     TK("bn_stats");
 }
 int tr_bn_relu_dropout_fwd(const float* x, const float* stats, const float* gamma, const float* beta, float* out, uint8_t* keep, size_t M, int C, float p, uint32_t seed,
                            hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(bn_relu_dropout_fwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, gamma, beta, out, keep, M, C, p, seed);
+    SOCCDPT_LAUNCH(bn_relu_dropout_fwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, gamma, beta, out, keep, M, C, p, seed);
     TK("bn_relu_dropout_fwd");
 }
 int tr_bn_relu_dropout_bwd_pre(const float* dout, const float* out, const uint8_t* keep, float* dz, size_t n, float p, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(bn_relu_dropout_bwd_pre_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dout, out, keep, dz, n, p);
+    SOCCDPT_LAUNCH(bn_relu_dropout_bwd_pre_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dout, out, keep, dz, n, p);
     TK("bn_relu_dropout_bwd_pre");
 }
 int tr_bn_bwd(const float* dz, const float* x, const float* stats, const float* gamma, const float* dbeta, const float* dgamma, float* dx, size_t M, int C, hipStream_t st,
               std::string& err) {
-    hipLaunchKernelGGL(bn_bwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dz, x, stats, gamma, dbeta, dgamma, dx, M, C);
+    SOCCDPT_LAUNCH(bn_bwd_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dz, x, stats, gamma, dbeta, dgamma, dx, M, C);
     TK("bn_bwd");
 }
 int tr_bn_xhat(const float* x, const float* stats, float* xh, size_t M, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(bn_xhat_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, xh, M, C);
+    SOCCDPT_LAUNCH(bn_xhat_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, x, stats, xh, M, C);
     TK("bn_xhat");
 }
 int tr_smallk_fwd(const float* x, const float* w, const float* bias, float* out, size_t M, int C, int K, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(smallk_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, w, bias, out, M, C, K);
+    SOCCDPT_LAUNCH(smallk_fwd_kernel, dim3((unsigned)((M + 3) / 4)), dim3(256), 0, st, x, w, bias, out, M, C, K);
     TK("smallk_fwd");
 }
 int tr_smallk_dgrad(const float* dl, const float* w, float* dx, size_t M, int C, int K, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(smallk_dgrad_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dl, w, dx, M, C, K);
+    SOCCDPT_LAUNCH(smallk_dgrad_kernel, dim3(gs_blocks(M * C)), dim3(256), 0, st, dl, w, dx, M, C, K);
     TK("smallk_dgrad");
 }
 // scratch: 256 * K * C floats (K <= 4)
 int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, size_t M, int C, int K, hipStream_t st, std::string& err) {
     if (K > 4) { err = "smallk_wgrad: K > 4"; return 1; }
     const int chunks = 256;
-    hipLaunchKernelGGL(smallk_wgrad_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
+    SOCCDPT_LAUNCH(smallk_wgrad_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
     TK("smallk_wgrad");
 }
 int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(seg_act_bwd_kernel, dim3(gs_blocks((size_t)B * S * S * K)), dim3(256), 0, st, dseg, seg, dup, B, K, S, sigmoid);
+    SOCCDPT_LAUNCH(seg_act_bwd_kernel, dim3(gs_blocks((size_t)B * S * S * K)), dim3(256), 0, st, dseg, seg, dup, B, K, S, sigmoid);
     TK("seg_act_bwd");
 }
 int tr_depth_tail_fwd(const float* e, const float* w4, const float* b4, float* inv, size_t M, int K, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(depth_tail_fwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, e, w4, b4, inv, M, K);
+    SOCCDPT_LAUNCH(depth_tail_fwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, e, w4, b4, inv, M, K);
     TK("depth_tail_fwd");
 }
 int tr_depth_tail_bwd(const float* dinv, const float* inv, const float* e, const float* w4, float* de, float* rowterm, size_t M, int K, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(depth_tail_bwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M, K);
+    SOCCDPT_LAUNCH(depth_tail_bwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M, K);
     TK("depth_tail_bwd");
 }
 int tr_merge_scatter(const float* dg, float* dx, int B, int R, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(merge_scatter_kernel, dim3(gs_blocks((size_t)B * R * R * C)), dim3(256), 0, st, dg, dx, B, R, C);
+    SOCCDPT_LAUNCH(merge_scatter_kernel, dim3(gs_blocks((size_t)B * R * R * C)), dim3(256), 0, st, dg, dx, B, R, C);
     TK("merge_scatter");
 }
 int tr_patch_im2col(const float* x, float* out, int B, int S, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(patch_im2col_kernel, dim3(gs_blocks((size_t)B * (S / 4) * (S / 4) * 64)), dim3(256), 0, st, x, out, B, S);
+    SOCCDPT_LAUNCH(patch_im2col_kernel, dim3(gs_blocks((size_t)B * (S / 4) * (S / 4) * 64)), dim3(256), 0, st, x, out, B, S);
     TK("patch_im2col");
 }
 int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(pad_cols_kernel, dim3(gs_blocks((size_t)N * cout)), dim3(256), 0, st, in, out, N, cin, cout);
+    SOCCDPT_LAUNCH(pad_cols_kernel, dim3(gs_blocks((size_t)N * cout)), dim3(256), 0, st, in, out, N, cin, cout);
     TK("pad_cols");
 }
 // Segments of the walked axis per (window, head, tile): up to 4 (one per 64-row tile of a 16 x 16 window)
@@ -1134,37 +1134,37 @@ int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, c
     const unsigned blocks = (unsigned)(B * nw * nw * heads * nqb * nseg);
     const size_t rows = (size_t)B * nw * nw * heads * N, nq = (size_t)B * res * res * 3 * heads * 32;
     float* part_stat = part + (size_t)nseg * nq;
-    hipLaunchKernelGGL(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, part_stat, res, ws, shift, heads, nseg, rows * 2);
-    hipLaunchKernelGGL(attn_rowstat_combine_kernel, dim3(gs_blocks(rows)), dim3(256), 0, st, part_stat, rowstat, rows, nseg);
-    hipLaunchKernelGGL(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, rowstat, attn_out, dS, part, dscale_part, res, ws, shift, heads, nseg, nq);
-    hipLaunchKernelGGL(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, part, res, ws, shift, heads, nseg, nq);
-    hipLaunchKernelGGL(attn_seg_sum_kernel, dim3(gs_blocks(nq)), dim3(256), 0, st, part, dqkv, nq, nseg);
+    SOCCDPT_LAUNCH(attn_rowstat_kernel, dim3(blocks), dim3(64), 0, st, qkv, table, scale, part_stat, res, ws, shift, heads, nseg, rows * 2);
+    SOCCDPT_LAUNCH(attn_rowstat_combine_kernel, dim3(gs_blocks(rows)), dim3(256), 0, st, part_stat, rowstat, rows, nseg);
+    SOCCDPT_LAUNCH(attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, rowstat, attn_out, dS, part, dscale_part, res, ws, shift, heads, nseg, nq);
+    SOCCDPT_LAUNCH(attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, table, scale, dS, rowstat, part, res, ws, shift, heads, nseg, nq);
+    SOCCDPT_LAUNCH(attn_seg_sum_kernel, dim3(gs_blocks(nq)), dim3(256), 0, st, part, dqkv, nq, nseg);
     TK("attention_bwd");
 }
 // dS is overwritten by its sum over the windows (first nwin = 1 slab); hid: 2 * (2ws-1)^2 * 512 floats of scratch
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
                         float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
     const int T2 = (2 * ws - 1) * (2 * ws - 1), N = ws * ws, nqb = (N + 63) / 64;
-    if (dls) hipLaunchKernelGGL(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb * attn_nseg(ws));
+    if (dls) SOCCDPT_LAUNCH(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb * attn_nseg(ws));
     if (dw0 || db0 || dw2) {
         const size_t n = (size_t)heads * N * N;
         // in place: column i of slab 0 is read before it is written, the other slabs are only read
-        hipLaunchKernelGGL(rowsum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dS, dS, nwin, n);
-        hipLaunchKernelGGL(attn_table_grad_kernel, dim3(T2 * heads), dim3(64), 0, st, dS, dtable, ws, heads);
-        hipLaunchKernelGGL(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
+        SOCCDPT_LAUNCH(rowsum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, dS, dS, nwin, n);
+        SOCCDPT_LAUNCH(attn_table_grad_kernel, dim3(T2 * heads), dim3(64), 0, st, dS, dtable, ws, heads);
+        SOCCDPT_LAUNCH(cpb_dt_kernel, dim3((T2 * heads + 255) / 256), dim3(256), 0, st, dtable, table, dt, T2 * heads);
         float* dhid = hid + (size_t)T2 * 512;
-        hipLaunchKernelGGL(cpb_hidden_kernel, dim3((T2 * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, w2, hid, dhid, ws, pws, heads);
-        if (dw2) hipLaunchKernelGGL(cpb_reduce_kernel, dim3(8, heads), dim3(1024), 0, st, hid, dt, dw2, (float*)nullptr, ws, pws, heads, 0);
-        if (dw0 || db0) hipLaunchKernelGGL(cpb_reduce_kernel, dim3(8, 3), dim3(1024), 0, st, dhid, dt, dw0, db0, ws, pws, heads, 1);
+        SOCCDPT_LAUNCH(cpb_hidden_kernel, dim3((T2 * 512 + 255) / 256), dim3(256), 0, st, dt, w0, b0, w2, hid, dhid, ws, pws, heads);
+        if (dw2) SOCCDPT_LAUNCH(cpb_reduce_kernel, dim3(8, heads), dim3(1024), 0, st, hid, dt, dw2, (float*)nullptr, ws, pws, heads, 0);
+        if (dw0 || db0) SOCCDPT_LAUNCH(cpb_reduce_kernel, dim3(8, 3), dim3(1024), 0, st, dhid, dt, dw0, db0, ws, pws, heads, 1);
     }
     TK("attn_param_grads");
 }
 int tr_unscale_check(float* g, size_t n, float inv_scale, int* found, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(unscale_check_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, g, n, inv_scale, found);
+    SOCCDPT_LAUNCH(unscale_check_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, g, n, inv_scale, found);
     TK("unscale_check");
 }
 int tr_qv_bias_grad(const float* dqkv_bias, float* dq, float* dv, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(qv_bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dqkv_bias, dq, dv, C);
+    SOCCDPT_LAUNCH(qv_bias_grad_kernel, dim3((C + 255) / 256), dim3(256), 0, st, dqkv_bias, dq, dv, C);
     TK("qv_bias_grad");
 }
 

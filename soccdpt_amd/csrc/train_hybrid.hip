@@ -566,52 +566,52 @@ int th_gn_bwd(const float* dout, const float* x, const float* stats, const float
     if (chunks < 1) chunks = 1;
     float* part = scratch;
     float* gm = scratch + (size_t)B * chunks * 2 * C;
-    hipLaunchKernelGGL(gn_bwd_part_kernel, dim3((C + 63) / 64, chunks, B), dim3(256), 0, st, dout, x, stats, gamma, beta, part, HW, C, cpg, chunks, relu);
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, part, gamma, gm, dgamma, dbeta, B, HW, C, cpg, chunks);
-    if (dx) hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(gs_blocks((size_t)B * HW * C)), dim3(256), 0, st, dout, x, stats, gamma, beta, gm, dx, (size_t)B * HW, HW, C, cpg, relu);
+    SOCCDPT_LAUNCH(gn_bwd_part_kernel, dim3((C + 63) / 64, chunks, B), dim3(256), 0, st, dout, x, stats, gamma, beta, part, HW, C, cpg, chunks, relu);
+    SOCCDPT_LAUNCH(gn_bwd_reduce_kernel, dim3(1), dim3(256), 0, st, part, gamma, gm, dgamma, dbeta, B, HW, C, cpg, chunks);
+    if (dx) SOCCDPT_LAUNCH(gn_bwd_apply_kernel, dim3(gs_blocks((size_t)B * HW * C)), dim3(256), 0, st, dout, x, stats, gamma, beta, gm, dx, (size_t)B * HW, HW, C, cpg, relu);
     TK("gn_bwd");
 }
 int th_ws_bwd(const float* dwh, const float* wh, const float* w, float* dw, int Cout, int Cin, int k, int Kpad, float eps, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(ws_bwd_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dwh, wh, w, dw, Cin, k * k, Kpad, eps);
+    SOCCDPT_LAUNCH(ws_bwd_kernel, dim3((unsigned)Cout), dim3(256), 0, st, dwh, wh, w, dw, Cin, k * k, Kpad, eps);
     TK("ws_bwd");
 }
 int th_conv_w_dgrad_tap(const float* wt, float* out, int N, int C, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(conv_w_dgrad_tap_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, wt, out, N, C);
+    SOCCDPT_LAUNCH(conv_w_dgrad_tap_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, wt, out, N, C);
     TK("conv_w_dgrad_tap");
 }
 int th_im2colT_gen(const float* halo, float* out, int B, int Hi, int Ho, int C, int stride, int pad, size_t Mp, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(im2colT_gen_kernel, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, Hi, Ho, C, stride, 1 - pad, Mp);
+    SOCCDPT_LAUNCH(im2colT_gen_kernel, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, Hi, Ho, C, stride, 1 - pad, Mp);
     TK("im2colT_gen");
 }
 int th_col2im(const float* dcol, float* dx, int B, int Hi, int Ho, int C, int stride, int pad, int accumulate, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(col2im_kernel, dim3(gs_blocks((size_t)B * Hi * Hi * C)), dim3(256), 0, st, dcol, dx, B, Hi, Ho, C, stride, pad, accumulate);
+    SOCCDPT_LAUNCH(col2im_kernel, dim3(gs_blocks((size_t)B * Hi * Hi * C)), dim3(256), 0, st, dcol, dx, B, Hi, Ho, C, stride, pad, accumulate);
     TK("col2im");
 }
 int th_stride_gather(const float* in, float* out, int B, int Hi, int Ho, int C, int stride, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(stride_gather_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, in, out, B, Hi, Ho, C, stride);
+    SOCCDPT_LAUNCH(stride_gather_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, in, out, B, Hi, Ho, C, stride);
     TK("stride_gather");
 }
 int th_stride_scatter_add(const float* dg, float* dx, int B, int Hi, int Ho, int C, int stride, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(stride_scatter_add_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, dg, dx, B, Hi, Ho, C, stride);
+    SOCCDPT_LAUNCH(stride_scatter_add_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, dg, dx, B, Hi, Ho, C, stride);
     TK("stride_scatter_add");
 }
 int th_maxpool_bwd(const float* dpool, const float* raw, const float* stats, const float* gamma, const float* beta, uint8_t* idx, float* dA, int B, int Hi, int C, int cpg,
                    hipStream_t st, std::string& err) {
     const int Ho = (Hi + 1) / 2;
-    hipLaunchKernelGGL(maxpool_argmax_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, raw, stats, gamma, beta, idx, B, Hi, Ho, C, cpg);
-    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(gs_blocks((size_t)B * Hi * Hi * C)), dim3(256), 0, st, dpool, idx, dA, B, Hi, Ho, C);
+    SOCCDPT_LAUNCH(maxpool_argmax_kernel, dim3(gs_blocks((size_t)B * Ho * Ho * C)), dim3(256), 0, st, raw, stats, gamma, beta, idx, B, Hi, Ho, C, cpg);
+    SOCCDPT_LAUNCH(maxpool_bwd_kernel, dim3(gs_blocks((size_t)B * Hi * Hi * C)), dim3(256), 0, st, dpool, idx, dA, B, Hi, Ho, C);
     TK("maxpool_bwd");
 }
 int th_readout_cat(const float* tok, float* cat, int B, int NT, int E, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(readout_cat_kernel, dim3(gs_blocks((size_t)B * (NT - 1) * 2 * E)), dim3(256), 0, st, tok, cat, B, NT, E);
+    SOCCDPT_LAUNCH(readout_cat_kernel, dim3(gs_blocks((size_t)B * (NT - 1) * 2 * E)), dim3(256), 0, st, tok, cat, B, NT, E);
     TK("readout_cat");
 }
 int th_readout_cat_bwd(const float* dcat, float* dtok, int B, int NT, int E, int accumulate, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(readout_cat_bwd_kernel, dim3(gs_blocks((size_t)B * NT * E)), dim3(256), 0, st, dcat, dtok, B, NT, E, accumulate);
+    SOCCDPT_LAUNCH(readout_cat_bwd_kernel, dim3(gs_blocks((size_t)B * NT * E)), dim3(256), 0, st, dcat, dtok, B, NT, E, accumulate);
     TK("readout_cat_bwd");
 }
 int th_tokens_to_patches(const float* dtok, float* dpatch, int B, int NT, int E, hipStream_t st, std::string& err) {
-    hipLaunchKernelGGL(tokens_to_patches_kernel, dim3(gs_blocks((size_t)B * (NT - 1) * E)), dim3(256), 0, st, dtok, dpatch, B, NT, E);
+    SOCCDPT_LAUNCH(tokens_to_patches_kernel, dim3(gs_blocks((size_t)B * (NT - 1) * E)), dim3(256), 0, st, dtok, dpatch, B, NT, E);
     TK("tokens_to_patches");
 }
 // part: NSEG * B * N * 3 * E floats of scratch; rowstat: B * heads * N * 2 floats, written by the forward and read by the backward
@@ -619,17 +619,17 @@ size_t th_vit_attention_part_floats(int B, int N, int heads) { return (size_t)NS
 int th_vit_attention_fwd(const float* qkv, float* out, float* rowstat, float* part, int B, int N, int heads, hipStream_t st, std::string& err) {
     const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64) * NSEG);
     float* part_ml = part + (size_t)NSEG * B * N * heads * VD;
-    hipLaunchKernelGGL(vit_attn_fwd_seg_kernel, dim3(blocks), dim3(64), 0, st, qkv, part, part_ml, N, heads, B);
-    hipLaunchKernelGGL(vit_attn_fwd_combine_kernel, dim3(gs_blocks((size_t)B * N * heads * VD)), dim3(256), 0, st, part, part_ml, out, rowstat, N, heads, B);
+    SOCCDPT_LAUNCH(vit_attn_fwd_seg_kernel, dim3(blocks), dim3(64), 0, st, qkv, part, part_ml, N, heads, B);
+    SOCCDPT_LAUNCH(vit_attn_fwd_combine_kernel, dim3(gs_blocks((size_t)B * N * heads * VD)), dim3(256), 0, st, part, part_ml, out, rowstat, N, heads, B);
     TK("vit_attention_fwd");
 }
 int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, const float* rowstat, float* part, float* dqkv, int B, int N, int heads, hipStream_t st,
                          std::string& err) {
     const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64) * NSEG);
-    hipLaunchKernelGGL(vit_attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
-    hipLaunchKernelGGL(vit_attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
+    SOCCDPT_LAUNCH(vit_attn_bwd_q_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
+    SOCCDPT_LAUNCH(vit_attn_bwd_k_kernel, dim3(blocks), dim3(64), 0, st, qkv, dO, O, rowstat, part, N, heads, B);
     const size_t n = (size_t)B * N * 3 * heads * VD;
-    hipLaunchKernelGGL(seg_sum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dqkv, n);
+    SOCCDPT_LAUNCH(seg_sum_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, part, dqkv, n);
     TK("vit_attention_bwd");
 }
 

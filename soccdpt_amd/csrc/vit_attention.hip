@@ -161,59 +161,155 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
     }
 }
 
-// Exact-f32 variant (SOCCDPT_PREC_F32, the parity mode; not a throughput kernel): one thread owns one query (q and the output row in
-// registers), keys are staged 64 at a time in LDS and read by broadcast, online softmax in f32.
-__global__ __launch_bounds__(64) void vit_attention_f32_kernel(const float* __restrict__ qkv, float* __restrict__ out, int N, int heads) {
-    __shared__ float Ks[64][D + 1];
-    __shared__ float Vs[64][D + 1];
-    const int C = heads * D, nqb = (N + 63) / 64;
+// Exact-f32 variant (SOCCDPT_PREC_F32, and the attention of SOCCDPT_PREC_F16X3): the same swapped-product decomposition on
+// v_mfma_f32_32x32x2_f32 (bitwise an f32 fma chain at the f32 VALU peak rate, all of it on the matrix pipe).
+//  * one workgroup = 4 waves = 4 blocks of 32 queries of one (sample, head); key / value tiles of 32 tokens stream through a
+//    double-buffered LDS ring (row-major, K rows padded to 68 floats: conflict-free ds_read_b128 of a lane's 32 consecutive d),
+//    the next tile's global loads are issued before the current tile's MFMAs and written to LDS after them: one barrier per tile;
+//  * S^T = K Q^T: the MFMA's two k-slots (lane halves h = 0 / 1) take d = st and d = 32 + st at step st -- any pairing of the 64
+//    head dimensions is a valid summation order as long as both operands use it -- so a lane's Q and K fragments are 32 consecutive
+//    floats (Q: eight 16-byte loads straight from HBM, scaled by 2^-3 exactly);
+//  * the exponentiated S^T accumulator is directly the B operand of O^T = V^T P^T: accumulator register r of the two lane halves holds
+//    keys 32t + (r&3) + 8(r>>2) + 4h, exactly one K = 2 MFMA step, whose A operand V[key][d = lane&31 (+32)] is a conflict-free
+//    ds_read_b32 of the row-major tile (all 32 lanes of a half read one row).
+// 64 MFMAs x 64 cycles per (32 query x 32 key) tile per wave; 19 x 19 tiles per (sample, head) at N = 577.
+// OUT: 2 = plain f32 output, 3 = x3 split-fp16 output (half16.h) for the proj GEMM of the F16X3 mode.
+constexpr int KS_STRIDE = 68;   // floats per K row in LDS (272 B = 17 x 16: the 16-byte slot of column c in row r is (r + c) mod 16)
+
+template <int OUT>
+__global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __restrict__ qkv, void* __restrict__ out, int N, int heads, int NQB) {
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * KS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * D];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * D;
     int bid = blockIdx.x;
-    const int qb = bid % nqb;
-    bid /= nqb;
+    {   // the NQB query parts of one (sample, head) share K / V: consecutive logical ids -> one XCD (blocks b, b + 8 share an L2)
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    const int part = bid % NQB;
+    bid /= NQB;
     const int head = bid % heads;
     const int b = bid / heads;
-    const int tid = threadIdx.x;
     const float* base = qkv + (size_t)b * N * (3 * C) + head * D;
-    const int q = qb * 64 + tid;
-    const int qc = q < N ? q : N - 1;
-    float qh[D], o[D];
+    const int NT = (N + 31) / 32;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int qb = part * 4 + wave;
+    const int qrow = qb * 32 + r32;
+    const bool active = qb * 32 < N;           // wave-uniform: this wave owns at least one real query
+    const int qcl = qrow < N ? qrow : N - 1;
+
+    // staging map: thread -> (token of the tile = idx >> 4, 16-byte chunk c = idx & 15), idx = tid and tid + 256
+    float4 kr[2], vr[2];
+    auto gload = [&](int t) {
 #pragma unroll
-    for (int d = 0; d < D; ++d) { qh[d] = base[(size_t)qc * (3 * C) + d] * 0.125f; o[d] = 0.f; }
-    float m = -3.0e38f, l = 0.f;
-    for (int k0 = 0; k0 < N; k0 += 64) {
-        __syncthreads();
-        {   // stage 64 keys: 16 threads x float4 per row
-            for (int idx = tid; idx < 64 * 16; idx += 64) {
-                const int kr = idx >> 4, c4 = (idx & 15) * 4;
-                const int k = k0 + kr;
-                float4 kv = make_float4(0.f, 0.f, 0.f, 0.f), vv = kv;
-                if (k < N) {
-                    kv = *reinterpret_cast<const float4*>(base + (size_t)k * (3 * C) + C + c4);
-                    vv = *reinterpret_cast<const float4*>(base + (size_t)k * (3 * C) + 2 * C + c4);
-                }
-                Ks[kr][c4] = kv.x; Ks[kr][c4 + 1] = kv.y; Ks[kr][c4 + 2] = kv.z; Ks[kr][c4 + 3] = kv.w;
-                Vs[kr][c4] = vv.x; Vs[kr][c4 + 1] = vv.y; Vs[kr][c4 + 2] = vv.z; Vs[kr][c4 + 3] = vv.w;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int p = t * 32 + (idx >> 4), c = idx & 15;
+            kr[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            vr[i] = kr[i];
+            if (p < N) {
+                const float* src = base + (size_t)p * (3 * C) + c * 4;
+                kr[i] = *reinterpret_cast<const float4*>(src + C);
+                vr[i] = *reinterpret_cast<const float4*>(src + 2 * C);
             }
         }
-        __syncthreads();
-        const int nk = (N - k0) < 64 ? (N - k0) : 64;
-        for (int kk = 0; kk < nk; ++kk) {
-            float s = 0.f;
+    };
+    auto lstore = [&](int buf) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) s = fmaf(qh[d], Ks[kk][d], s);
-            const float mn = fmaxf(m, s);
-            const float alpha = __expf(m - mn), p = __expf(s - mn);
-            l = l * alpha + p;
-#pragma unroll
-            for (int d = 0; d < D; ++d) o[d] = fmaf(p, Vs[kk][d], o[d] * alpha);
-            m = mn;
+        for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 256 * i;
+            const int kt = idx >> 4, c = idx & 15;
+            *reinterpret_cast<float4*>(&Ks[buf][kt * KS_STRIDE + c * 4]) = kr[i];
+            *reinterpret_cast<float4*>(&Vs[buf][kt * D + c * 4]) = vr[i];
         }
-    }
-    if (q < N) {
-        const float inv = 1.0f / l;
-        float* orow = out + ((size_t)b * N + q) * C + head * D;
+    };
+
+    // Q fragment (B operand): lane (query r32, half h), step st <-> d = 32 h + st
+    float qf[32];
 #pragma unroll
-        for (int d = 0; d < D; d += 4) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+    for (int j = 0; j < 8; ++j) {
+        const float4 q4 = *reinterpret_cast<const float4*>(base + (size_t)qcl * (3 * C) + 32 * h + 4 * j);
+        qf[4 * j] = q4.x * 0.125f; qf[4 * j + 1] = q4.y * 0.125f; qf[4 * j + 2] = q4.z * 0.125f; qf[4 * j + 3] = q4.w * 0.125f;
+    }
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    constexpr float LOG2E = 1.4426950408889634f;
+    float m = -3.0e38f, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) { o0[rg] = 0.f; o1[rg] = 0.f; }
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) gload(t + 1);
+        if (active) {
+            f32x16 acc;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+            const float* krow = &Ks[buf][r32 * KS_STRIDE + 32 * h];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[4 * j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[4 * j + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[4 * j + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[4 * j + 3], acc, 0, 0, 0);
+            }
+            if (t == NT - 1) {   // keys beyond the sequence: excluded from max, sum and P V
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int key = t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                    if (key >= N) acc[rg] = -3.0e38f;
+                }
+            }
+            float mt = acc[0];
+#pragma unroll
+            for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, acc[rg]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float mnl = mn * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mnl));
+            float psum = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], LOG2E, -mnl));
+                psum += acc[rg];
+                o0[rg] *= alpha;
+                o1[rg] *= alpha;
+            }
+            l = l * alpha + psum;
+            m = mn;
+            const float* vcol = &Vs[buf][(4 * h) * D + r32];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                const int kk = (rg & 3) + 8 * (rg >> 2);
+                o0 = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kk * D], acc[rg], o0, 0, 0, 0);
+                o1 = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[kk * D + 32], acc[rg], o1, 0, 0, 0);
+            }
+        }
+        if (t + 1 < NT) lstore(buf ^ 1);   // slot buf^1 was last read in iteration t-1: everybody has passed that iteration's barrier
+        __syncthreads();
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32);
+    if (qrow < N) {   // lane owns query column r32; accumulator register rg is d = (rg&3) + 8(rg>>2) + 4h (+32 for o1)
+        const float inv = 1.0f / l;
+        const size_t e0 = ((size_t)b * N + qrow) * C + head * D;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int d0 = 8 * g + 4 * h;
+            if constexpr (OUT == 3) {
+                x3_store4(out, e0 + d0, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                x3_store4(out, e0 + 32 + d0, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            } else {
+                float* orow = static_cast<float*>(out) + e0;
+                *reinterpret_cast<float4*>(orow + d0) = make_float4(o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                *reinterpret_cast<float4*>(orow + 32 + d0) = make_float4(o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+            }
+        }
     }
 }
 
@@ -221,9 +317,11 @@ __global__ __launch_bounds__(64) void vit_attention_f32_kernel(const float* __re
 
 int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err) {
     if (B <= 0 || N <= 0 || heads <= 0) { err = "vit_attention: bad geometry"; return 1; }
-    if (prec == SOCCDPT_PREC_F32) {
-        const unsigned blocks = (unsigned)(B * heads * ((N + 63) / 64));
-        hipLaunchKernelGGL(vit_attention_f32_kernel, dim3(blocks), dim3(64), 0, st, static_cast<const float*>(qkv), static_cast<float*>(out), N, heads);
+    if (prec == SOCCDPT_PREC_F32 || prec == SOCCDPT_PREC_F16X3) {   // qkv plain f32 in both; the F16X3 mode wants its output in the x3 operand format
+        const int NQB = (N + 127) / 128;
+        const unsigned blocks = (unsigned)(B * heads * NQB);
+        if (prec == SOCCDPT_PREC_F16X3) SOCCDPT_LAUNCH(vit_attention_f32_kernel<3>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(qkv), out, N, heads, NQB);
+        else SOCCDPT_LAUNCH(vit_attention_f32_kernel<2>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(qkv), out, N, heads, NQB);
         return check_launch("vit_attention_f32", err);
     }
     const int NPAD = (N + 31) / 32 * 32, NT = NPAD / 32;
@@ -243,9 +341,9 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
     }
     const unsigned blocks = (unsigned)(B * heads * QS);
     if (prec == SOCCDPT_PREC_F16)
-        hipLaunchKernelGGL(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+        SOCCDPT_LAUNCH(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
     else
-        hipLaunchKernelGGL(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+        SOCCDPT_LAUNCH(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
     return check_launch("vit_attention", err);
 }
 

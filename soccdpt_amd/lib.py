@@ -20,6 +20,7 @@ BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2
+PREC_F16X3 = 3
 
 
 class SoccdptConfig(ctypes.Structure):
@@ -72,19 +73,22 @@ class IgemmArgs(ctypes.Structure):
 _lib = None
 
 
+# Translation units (and the headers they share) that DEFINE OR SEQUENCE the forward path's kernels.  capi.cpp / internal.h (entry points,
+# handle bookkeeping), the training step (train*), the criterion, optimiser, metrics, GT-occupancy and input-transform kernels launch
+# nothing inside soccdpt_forward, so editing them does not invalidate PMC counters collected for the forward's kernels.
+FORWARD_SOURCES = ("Makefile", "attention.hip", "conv8p.hip", "depth_tail.hip", "elementwise.hip", "gelu.h", "half16.h", "hybrid.hip", "igemm.h",
+                   "igemm.hip", "kernels.h", "launch.h", "mlp_fused.hip", "model.cpp", "projection.hip", "resample.h", "vit_attention.hip")
+
+
 def csrc_sha() -> str:
-    """Short hash of the sources the FORWARD path's kernels are built from (everything in csrc/ except the training step's own translation
-    units train*.{hip,cpp,h}, which launch no kernel of the forward).  profiles/*_pmc_traffic.json carry it, so that bench.py can tell
-    whether committed PMC counters still describe the current kernels."""
+    """Short hash of the sources the FORWARD path's kernels are built from (FORWARD_SOURCES).  profiles/*_pmc_traffic.json carry it, so that
+    bench.py -- and tests/test_profiles_current.py -- can tell whether the committed PMC counters still describe the current kernels."""
     import hashlib
     h = hashlib.sha1()
     d = os.path.join(_HERE, "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.startswith("train"):
-            continue
-        if name.endswith((".hip", ".cpp", ".h")) or name == "Makefile":
-            h.update(name.encode())
-            h.update(open(os.path.join(d, name), "rb").read())
+    for name in FORWARD_SOURCES:
+        h.update(name.encode())
+        h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 
 

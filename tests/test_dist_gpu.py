@@ -40,8 +40,10 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
     import json
     env = dict(os.environ, SOCCDPT_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
-    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29553", bench, "--gpus", "2", "--steps", "5", "--warmup", "2", "--prewarm", "3", "--batch", "2"],
+    # bench.py is called the way the driver may call it: plainly, with --gpus 2 and no launcher around it.  The parent starts the two ranks itself
+    # (python -m torch.distributed.run as a child process, before anything touches the GPU), relays rank 0's line and checks rccl_ranks == 2.
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r = subprocess.run([sys.executable, bench, "--gpus", "2", "--steps", "5", "--warmup", "2", "--prewarm", "3", "--batch", "2"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -50,6 +52,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
     assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and len(d["per_rank_ms_per_step"]) == 2
     assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["config"]["dist_backend"] == "gloo"
     assert abs(d["value"] - 4 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3      # whole-job frames / max-over-ranks time
+    assert d["repeats"]["count"] * d["repeats"]["steps_each"] >= 25 and len(d["repeats"]["ms_per_step"]) == d["repeats"]["count"]
     assert "cpu_baseline" not in d                                                         # N = 1 only
 
 
