@@ -236,7 +236,7 @@ struct AttnCfgF32 {
 template <int WS>
 __global__ __launch_bounds__(AttnCfgF32<WS>::THREADS) void window_attention_f32_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                                        const float* __restrict__ scale, float* __restrict__ out,
-                                                                                       int res, int shift, int heads) {
+                                                                                       int res, int shift, int heads, int x3) {
     using A = AttnCfgF32<WS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Qs = reinterpret_cast<float*>(smem);
@@ -348,10 +348,12 @@ __global__ __launch_bounds__(AttnCfgF32<WS>::THREADS) void window_attention_f32_
             for (int rg = 0; rg < 16; ++rg)
                 o = __builtin_amdgcn_mfma_f32_32x32x2f32(vrow[t * 32 + (rg & 3) + 8 * (rg >> 2)], s[t][rg], o, 0, 0, 0);
         const float inv = 1.0f / sum;
-        float* orow = out + token_row(qrow) * (size_t)C + head * 32;
+        const size_t e0 = token_row(qrow) * (size_t)C + head * 32;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<float4*>(orow + 8 * g + 4 * h) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        for (int g = 0; g < 4; ++g) {
+            if (x3) x3_store4(out, e0 + 8 * g + 4 * h, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);   // x3 operand of the proj GEMM (half16.h)
+            else *reinterpret_cast<float4*>(out + e0 + 8 * g + 4 * h) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        }
     }
 }
 
@@ -547,7 +549,7 @@ __global__ __launch_bounds__(AttnGenCfg<WS>::THREADS) void window_attention_flas
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void window_attention_f32_any_kernel(const float* __restrict__ qkv, const float* __restrict__ table,
                                                                       const float* __restrict__ scale, float* __restrict__ out, int res, int ws,
-                                                                      int shift, int heads) {
+                                                                      int shift, int heads, int x3) {
     __shared__ float Ks[64][33];
     __shared__ float Vs[64][33];
     const int N = ws * ws, nqb = (N + 63) / 64;
@@ -620,9 +622,12 @@ __global__ __launch_bounds__(64) void window_attention_f32_any_kernel(const floa
     }
     if (qv) {
         const float inv = 1.0f / l;
-        float* orow = out + token_row(q) * (size_t)C + head * 32;
+        const size_t e0 = token_row(q) * (size_t)C + head * 32;
 #pragma unroll
-        for (int d = 0; d < 32; d += 4) *reinterpret_cast<float4*>(orow + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+        for (int d = 0; d < 32; d += 4) {
+            if (x3) x3_store4(out, e0 + d, o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+            else *reinterpret_cast<float4*>(out + e0 + d) = make_float4(o[d] * inv, o[d + 1] * inv, o[d + 2] * inv, o[d + 3] * inv);
+        }
     }
 }
 
@@ -664,13 +669,13 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
 }
 
 int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
-                                int ws, int shift, int heads, hipStream_t st, std::string& err) {
+                                int ws, int shift, int heads, hipStream_t st, std::string& err, int x3) {
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
     const int nw = res / ws;
     if (ws != 16 && !(ws == 8 && shift == 0)) {  // any other window size: the generic exact kernel (parity mode of base_384)
         const int nqb = (ws * ws + 63) / 64;
         SOCCDPT_LAUNCH(window_attention_f32_any_kernel, dim3((unsigned)(B * nw * nw * heads * nqb)), dim3(64), 0, st, qkv, table, scale, out, res, ws,
-                           shift, heads);
+                           shift, heads, x3);
         return check_launch("window_attention_f32_any", err);
     }
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
@@ -681,10 +686,10 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
     }
     if (ws == 16) {
         using A = AttnCfgF32<16>;
-        SOCCDPT_LAUNCH((window_attention_f32_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        SOCCDPT_LAUNCH((window_attention_f32_kernel<16>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
     } else if (ws == 8 && shift == 0) {
         using A = AttnCfgF32<8>;
-        SOCCDPT_LAUNCH((window_attention_f32_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        SOCCDPT_LAUNCH((window_attention_f32_kernel<8>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
     } else {
         err = "window_attention_f32: window size not instantiated (16 and unshifted 8 are)";
         return 1;

@@ -42,7 +42,8 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
     if (cfg->num_classes != 3) return fail(nullptr, "soccdpt_create: num_classes must be 3 (model/SOccDPT.py:347-349)");
     if (cfg->features != 256) return fail(nullptr, "soccdpt_create: features must be 256");
     if (cfg->cam_width <= 0 || cfg->cam_height <= 0) return fail(nullptr, "soccdpt_create: bad camera size");
-    if (cfg->precision != SOCCDPT_PREC_BF16 && cfg->precision != SOCCDPT_PREC_F32 && cfg->precision != SOCCDPT_PREC_F16) return fail(nullptr, "soccdpt_create: unknown precision");
+    if (cfg->precision != SOCCDPT_PREC_BF16 && cfg->precision != SOCCDPT_PREC_F32 && cfg->precision != SOCCDPT_PREC_F16 && cfg->precision != SOCCDPT_PREC_F16X3)
+        return fail(nullptr, "soccdpt_create: unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
@@ -397,7 +398,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.X = a->x; d.Wt = a->wt;
     d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
-    d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
+    d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.x3 = a->precision == SOCCDPT_PREC_F16X3; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     d.splitk = a->splitk > 1 ? a->splitk : 1; d.sk_part = a->sk_part; d.sk_count = a->sk_count;
     d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words;
     if (a->conv_general) { d.stride = a->stride; d.pad = a->pad; d.in_halo = a->in_halo; d.Hi = a->Hi; d.Wi = a->Wi; d.gather1 = a->gather1; }
@@ -413,7 +414,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
 int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, int B, int N, int heads, void* stream) {
     std::string err;
     if (!dev_qkv || !dev_out) return fail(nullptr, "soccdpt_op_vit_attention: null argument");
-    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F32 && precision != SOCCDPT_PREC_F16)
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F32 && precision != SOCCDPT_PREC_F16 && precision != SOCCDPT_PREC_F16X3)
         return fail(nullptr, "soccdpt_op_vit_attention: unknown precision");
     if (launch_vit_attention(dev_qkv, dev_out, precision, B, N, heads, (hipStream_t)stream, err)) return fail(nullptr, err);
     return 0;
@@ -422,12 +423,12 @@ int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, 
 int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
                                 float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, void* stream) {
     std::string err;
-    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F32 && precision != SOCCDPT_PREC_F16)
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F32 && precision != SOCCDPT_PREC_F16 && precision != SOCCDPT_PREC_F16X3)
         return fail(nullptr, "soccdpt_op_window_attention: unknown precision");
     if (launch_attn_bias(dev_cpb_table, dev_bias_scratch, ws, heads, (hipStream_t)stream, err)) return fail(nullptr, err);
-    if (precision == SOCCDPT_PREC_F32) {
+    if (precision == SOCCDPT_PREC_F32 || precision == SOCCDPT_PREC_F16X3) {   // F16X3: f32 qkv in, x3 operand out
         if (launch_window_attention_f32(static_cast<const float*>(dev_qkv), dev_bias_scratch, dev_cpb_table, dev_scale, static_cast<float*>(dev_out), B,
-                                        res, ws, shift, heads, (hipStream_t)stream, err))
+                                        res, ws, shift, heads, (hipStream_t)stream, err, precision == SOCCDPT_PREC_F16X3 ? 1 : 0))
             return fail(nullptr, err);
         return 0;
     }

@@ -52,7 +52,7 @@ template <bool F16>
 __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
-                                                           bf16_t* __restrict__ xb, int B, int S, int C0) {
+                                                           bf16_t* __restrict__ xb, int B, int S, int C0, int x3) {
     // lane owns output channels `lane` and `lane + 64`; their 2 x 48 weights live in registers for the whole kernel,
     // the 48 patch values are broadcast lane -> SGPR with v_readlane (no LDS, no shuffles)
     const int G = S / 4, lane = threadIdx.x & 63;
@@ -107,12 +107,12 @@ __global__ __launch_bounds__(256) void patch_embed_kernel(const float* __restric
             if (a0) {
                 const float y = d0 * rstd * g0 + e0;
                 xf[(size_t)tok * C0 + lane] = y;
-                if (xb) xb[(size_t)tok * C0 + lane] = f2h<F16>(y);
+                if (xb) { if (x3) x3_store1(xb, (size_t)tok * C0 + lane, y); else xb[(size_t)tok * C0 + lane] = f2h<F16>(y); }
             }
             if (a1) {
                 const float y = d1 * rstd * g1 + e1;
                 xf[(size_t)tok * C0 + lane + 64] = y;
-                if (xb) xb[(size_t)tok * C0 + lane + 64] = f2h<F16>(y);
+                if (xb) { if (x3) x3_store1(xb, (size_t)tok * C0 + lane + 64, y); else xb[(size_t)tok * C0 + lane + 64] = f2h<F16>(y); }
             }
         }
     }
@@ -126,7 +126,7 @@ int launch_patch_embed(const float* x, const float* w, const float* bias, const 
     int blocks = (nstrips + 3) / 4;  // one 8-token strip per wave and pass; the FMA chain is latency-bound, so favour waves per SIMD
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
-    LAUNCH_HF(hf, patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0);
+    LAUNCH_HF(hf == 1, patch_embed_kernel, dim3(blocks), dim3(256), 0, st, x, w, bias, g, beta, xf, xb, B, S, C0, hf == 3 ? 1 : 0);   // hf: 0 bf16, 1 fp16, 3 x3 (half16.h)
     return check_launch("patch_embed", err);
 }
 
@@ -141,7 +141,7 @@ template <int VPL, bool F16>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge) {
+                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge, int x3) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -184,9 +184,14 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
             float o = v[t] * rstd * gg[t] + bb[t];
             if (residual) o += xr[t];
             xf[(size_t)row * C + c] = o;
-            const bf16_t ob = f2h<F16>(o);
-            if (xb) xb[boff + c] = ob;
-            if (halo) halo[hoff + c] = ob;
+            if (x3) {   // xb / halo are x3 tensors (half16.h)
+                if (xb) x3_store1(xb, boff + c, o);
+                if (halo) x3_store1(halo, hoff + c, o);
+            } else {
+                const bf16_t ob = f2h<F16>(o);
+                if (xb) xb[boff + c] = ob;
+                if (halo) halo[hoff + c] = ob;
+            }
             if (halo_f32) halo_f32[hoff + c] = o;
         }
     }
@@ -198,7 +203,7 @@ template <int V4, bool F16>  // float4 groups per lane = C / 256
 __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
                                                               bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                              int C, int residual, int res, int merge) {
+                                                              int C, int residual, int res, int merge, int x3) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -239,11 +244,16 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
         o.z = v[t].z * rstd * gg[t].z + bb[t].z + xr[t].z;
         o.w = v[t].w * rstd * gg[t].w + bb[t].w + xr[t].w;
         *reinterpret_cast<float4*>(xf + (size_t)row * C + c) = o;
-        uint2 ob;
-        ob.x = pack_h2<F16>(o.x, o.y);
-        ob.y = pack_h2<F16>(o.z, o.w);
-        if (xb) *reinterpret_cast<uint2*>(xb + boff + c) = ob;
-        if (halo) *reinterpret_cast<uint2*>(halo + hoff + c) = ob;
+        if (x3) {
+            if (xb) x3_store4(xb, boff + c, o.x, o.y, o.z, o.w);
+            if (halo) x3_store4(halo, hoff + c, o.x, o.y, o.z, o.w);
+        } else {
+            uint2 ob;
+            ob.x = pack_h2<F16>(o.x, o.y);
+            ob.y = pack_h2<F16>(o.z, o.w);
+            if (xb) *reinterpret_cast<uint2*>(xb + boff + c) = ob;
+            if (halo) *reinterpret_cast<uint2*>(halo + hoff + c) = ob;
+        }
         if (halo_f32) *reinterpret_cast<float4*>(halo_f32 + hoff + c) = o;
     }
 }
@@ -251,13 +261,16 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
                        int C, int residual, int res, int merge, hipStream_t st, std::string& err) {
     if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
+    const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 (half16.h)
+    if (x3 && (C % 16 || merge)) { err = "ln_residual: x3 rows are multiples of 16 elements, written unmerged"; return 1; }
+    hf = hf == 1;
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
     if (C % 256 == 0 && C <= 1024) {
 #define LN4_CASE(V)                                                                                                                       \
     do {                                                                                                                                  \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
-        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);  \
+        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);    \
     } while (0)
         switch (C / 256) { case 1: LN4_CASE(1); break; case 2: LN4_CASE(2); break; case 3: LN4_CASE(3); break; default: LN4_CASE(4); break; }
 #undef LN4_CASE
@@ -265,8 +278,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     }
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);  \
-        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);  \
+        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);    \
     } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);
@@ -324,7 +337,7 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
 
 template <typename TIn, bool F16>
 __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ in, float* __restrict__ out_f32, bf16_t* __restrict__ out_bf16,
-                                                        float* __restrict__ out_f32_halo, int out_halo, int B, int h, int w, int H, int W, int C) {
+                                                        float* __restrict__ out_f32_halo, int out_halo, int B, int h, int w, int H, int W, int C, int x3) {
     const int c4 = C / 4;
     const size_t total = (size_t)B * H * W * c4;
     const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
@@ -356,10 +369,14 @@ __global__ __launch_bounds__(256) void bilinear_kernel(const TIn* __restrict__ i
         if (out_f32_halo) *reinterpret_cast<float4*>(out_f32_halo + ((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) = o;
         if (out_bf16) {
             const size_t off = out_halo ? (((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc) : (pix * C + cc);
-            uint2 p;
-            p.x = pack_h2<F16>(o.x, o.y);
-            p.y = pack_h2<F16>(o.z, o.w);
-            *reinterpret_cast<uint2*>(out_bf16 + off) = p;
+            if (x3) {
+                x3_store4(out_bf16, off, o.x, o.y, o.z, o.w);
+            } else {
+                uint2 p;
+                p.x = pack_h2<F16>(o.x, o.y);
+                p.y = pack_h2<F16>(o.z, o.w);
+                *reinterpret_cast<uint2*>(out_bf16 + off) = p;
+            }
         }
     }
 }
@@ -408,7 +425,10 @@ __global__ __launch_bounds__(256) void bilinear_f32_to_halo8_kernel(const float*
 int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
                     int w, int H, int W, int C, hipStream_t st, std::string& err) {
     if (C % 4) { err = "bilinear: C % 4 != 0"; return 1; }
-    if (!in_is_bf16 && out_bf16 && out_halo && !out_f32 && !out_f32_halo && C % 8 == 0) {
+    const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 output in out_bf16 (half16.h)
+    if (x3 && (C % 16 || in_is_bf16)) { err = "bilinear: x3 output needs f32 input and C % 16 == 0"; return 1; }
+    hf = hf == 1;
+    if (!x3 && !in_is_bf16 && out_bf16 && out_halo && !out_f32 && !out_f32_halo && C % 8 == 0) {
         const size_t total8 = (size_t)B * H * W * (C / 8);
         size_t blocks8 = (total8 + 255) / 256;
         if (blocks8 > 8192) blocks8 = 8192;
@@ -418,7 +438,7 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
     const size_t total = (size_t)B * H * W * (C / 4);
     size_t blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-#define BL_ARGS(T) dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C
+#define BL_ARGS(T) dim3((unsigned)blocks), dim3(256), 0, st, (const T*)in, out_f32, out_bf16, out_f32_halo, out_halo, B, h, w, H, W, C, x3
     if (in_is_bf16 && hf) SOCCDPT_LAUNCH((bilinear_kernel<bf16_t, true>), BL_ARGS(bf16_t));
     else if (in_is_bf16) SOCCDPT_LAUNCH((bilinear_kernel<bf16_t, false>), BL_ARGS(bf16_t));
     else if (hf) SOCCDPT_LAUNCH((bilinear_kernel<float, true>), BL_ARGS(float));
@@ -545,6 +565,15 @@ template <bool F16>
 __global__ void cvt_bf16_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2h<F16>(in[i]);
 }
+__global__ void cvt_f16_ieee_kernel(const float* __restrict__ in, bf16_t* __restrict__ out, size_t n) {   // no clamp: overflow -> inf (training amp, half16.h)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f2h_ieee(in[i]);
+}
+__global__ void cvt_x3_kernel(const float* __restrict__ in, void* __restrict__ out, size_t n) {   // n % 4 == 0
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const float4 v = *reinterpret_cast<const float4*>(in + i);
+        x3_store4(out, i, v.x, v.y, v.z, v.w);
+    }
+}
 // [Cout][Cin][3][3] f32 -> [Cout][3][3][Cin] bf16, optionally scaled per Cout (BatchNorm fold)
 template <bool F16>
 __global__ void conv_w_kernel(const float* __restrict__ in, const float* __restrict__ scale, bf16_t* __restrict__ out, int Cout, int Cin) {
@@ -558,6 +587,7 @@ __global__ void conv_w_kernel(const float* __restrict__ in, const float* __restr
         out[i] = f2h<F16>(v);
     }
 }
+template <bool X3>
 __global__ void conv_w_f32_kernel(const float* __restrict__ in, const float* __restrict__ scale, float* __restrict__ out, int Cout, int Cin) {
     const size_t n = (size_t)Cout * Cin * 9;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -566,7 +596,7 @@ __global__ void conv_w_f32_kernel(const float* __restrict__ in, const float* __r
         const int tap = (int)(r % 9), co = (int)(r / 9);
         float v = in[((size_t)co * Cin + ci) * 9 + tap];
         if (scale) v *= scale[co];
-        out[i] = v;
+        if constexpr (X3) x3_store1(out, i, v); else out[i] = v;
     }
 }
 // patch-embed weight [C0][48] -> [48][128] zero-padded (coalesced per-lane loads in patch_embed_kernel)
@@ -622,13 +652,23 @@ __global__ void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, cons
 int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, int hf, hipStream_t st, std::string& err) {
     size_t blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
+    if (hf == 3) {   // x3 (half16.h): `out` holds 4 bytes per element
+        if (n % 16) { err = "cvt: x3 tensors are multiples of 16 elements"; return 1; }
+        SOCCDPT_LAUNCH(cvt_x3_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, static_cast<void*>(out), n);
+        return check_launch("cvt_x3", err);
+    }
+    if (hf == 5) {   // IEEE fp16 without saturation: the scaled operands of the training step's fp16 amp mode
+        SOCCDPT_LAUNCH(cvt_f16_ieee_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
+        return check_launch("cvt_f16_ieee", err);
+    }
     LAUNCH_HF(hf, cvt_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, n);
     return check_launch("cvt_bf16", err);
 }
 int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int hf, int Cout, int Cin, hipStream_t st, std::string& err) {
     size_t n = (size_t)Cout * Cin * 9, blocks = (n + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    if (out_is_f32) SOCCDPT_LAUNCH(conv_w_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
+    if (hf == 3) SOCCDPT_LAUNCH(conv_w_f32_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);   // x3, 4 bytes per element
+    else if (out_is_f32) SOCCDPT_LAUNCH(conv_w_f32_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<float*>(out), Cout, Cin);
     else LAUNCH_HF(hf, conv_w_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, scale, static_cast<bf16_t*>(out), Cout, Cin);
     return check_launch("conv_w", err);
 }

@@ -25,6 +25,10 @@ __device__ __forceinline__ uint16_t f2h(float f) {
         return __builtin_bit_cast(uint16_t, x);
     }
 }
+// f32 -> IEEE fp16 WITHOUT the clamp: overflow gives +-inf and a NaN stays a NaN.  The fp16 amp mode of the training step stages its scaled
+// operands through this, so that an overflow reaches the gradients as a non-finite value and GradScaler skips the step and backs the scale off
+// -- torch.cuda.amp semantics (/root/reference/SOccDPT/scripts/train_SOccDPT.py:340,390-393).  A saturating conversion would clip silently.
+__device__ __forceinline__ uint16_t f2h_ieee(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
 template <bool F16>
 __device__ __forceinline__ float h2f(uint16_t b) {
     if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);

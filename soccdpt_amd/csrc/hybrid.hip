@@ -8,7 +8,7 @@
 //     epilogue (igemm.hip, ST instantiation), and the stem's GroupNorm + ReLU + MaxPool2dSame(3, 2) fused,
 //   * class token + position embedding + the first pre-norm LayerNorm, and the pre-norm LayerNorm (eps 1e-6) of every ViT block.
 // All of them are HBM-bound elementwise / row kernels: 16-byte accesses, NHWC, no LDS staging needed except the row reductions.
-// OUT selects the operand format written for the next GEMM: 0 = bf16, 1 = fp16, 2 = f32 (SOCCDPT_PREC_*).
+// OUT selects the operand format written for the next GEMM: 0 = bf16, 1 = fp16, 2 = f32, 3 = x3 split fp16 (half16.h; SOCCDPT_PREC_F16X3).
 #include "half16.h"
 #include "kernels.h"
 
@@ -19,12 +19,16 @@ template <int OUT>
 struct OutT { typedef uint16_t type; };
 template <>
 struct OutT<2> { typedef float type; };
+template <>
+struct OutT<3> { typedef float type; };   // x3: 4 bytes per element
 
 // store 4 consecutive values as the operand type
 template <int OUT>
 __device__ __forceinline__ void store4(void* base, size_t idx, float a, float b, float c, float d) {
     if constexpr (OUT == 2) {
         *reinterpret_cast<float4*>(static_cast<float*>(base) + idx) = make_float4(a, b, c, d);
+    } else if constexpr (OUT == 3) {
+        x3_store4(base, idx, a, b, c, d);
     } else {
         uint2 p;
         p.x = pack_h2<OUT == 1>(a, b);
@@ -61,7 +65,9 @@ __global__ __launch_bounds__(256) void ws_conv_w_kernel(const float* __restrict_
             const int tap = i / Cin, ci = i - tap * Cin;
             v = (src[(size_t)ci * kk + tap] - fm) * fr;
         }
-        if constexpr (OUT == 2) dst[i] = v; else dst[i] = f2h<OUT == 1>(v);
+        if constexpr (OUT == 2) dst[i] = v;
+        else if constexpr (OUT == 3) x3_store1(out, (size_t)co * Kpad + i, v);
+        else dst[i] = f2h<OUT == 1>(v);
     }
 }
 
@@ -272,7 +278,8 @@ __global__ void pos_embed_resize_kernel(const float* __restrict__ pos, float* __
 
 #define DISPATCH_OUT(mode, ...)                                              \
     do {                                                                     \
-        if ((mode) == 2) { constexpr int OUT = 2; __VA_ARGS__; }             \
+        if ((mode) == 3) { constexpr int OUT = 3; __VA_ARGS__; }             \
+        else if ((mode) == 2) { constexpr int OUT = 2; __VA_ARGS__; }        \
         else if ((mode) == 1) { constexpr int OUT = 1; __VA_ARGS__; }        \
         else { constexpr int OUT = 0; __VA_ARGS__; }                         \
     } while (0)

@@ -39,6 +39,7 @@ struct IgemmDesc {
     const void* Wt = nullptr;  // weights [N][taps*Cin], K contiguous, same element type
     int f32 = 0;               // exact-f32 operands and f32 MFMA (SOCCDPT_PREC_F32)
     int f16 = 0;               // 16-bit operands are IEEE fp16 instead of bf16 (SOCCDPT_PREC_F16); ignored when f32 != 0
+    int x3 = 0;                // split-fp16 operands in the x3 layout (half16.h), three fp16 MFMAs per product (SOCCDPT_PREC_F16X3); wins over f32 / f16
     int M = 0, N = 0;
     int Cin = 0;      // channels per tap (K of a plain GEMM)
     int taps = 1;     // 1 (GEMM / 1x1) or 9 (3x3, pad 1)

@@ -55,7 +55,10 @@ __device__ __forceinline__ int swz_of_row(int row) {
     else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
 }
 
-// T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16) or float (v_mfma_f32_16x16x4_f32, exact f32).
+// T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16), float (v_mfma_f32_16x16x4_f32, exact f32) or x3_t: split-fp16 operands
+// (half16.h: every element an fp16 pair hi, lo * 2^11 in the 4-byte-per-element x3 layout; three v_mfma_f32_16x16x32_f16 per product --
+// hi hi into `acc`, hi lo + lo hi into a second accumulator set folded in with 2^-11 after the k-loop: SOCCDPT_PREC_F16X3).  The x3 tiles share
+// the f32 tiles' byte geometry (128-byte LDS rows = 32 elements = one MFMA k-step), staging code and epilogues.
 // LN: the fused post-norm LayerNorm + residual epilogue (d.ln_g) instead of the generic one; a separate instantiation so that
 // its registers (row statistics) do not inflate the generic kernels (measured: 110 -> 158 VGPRs, one block per CU less).
 // SK: split-K.  gridDim.x = tiles x d.splitk; every workgroup accumulates its slice of the k-tiles, stores the f32 partial
@@ -73,6 +76,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
     constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
     constexpr bool F16 = std::is_same<T, f16_t>::value;
+    constexpr bool X3 = std::is_same<T, x3_t>::value;
+    static_assert(!X3 || C::ROWB >= 128, "an x3 k-step (32 elements) is 128 bytes of a tile row");
     const T* const Xp = static_cast<const T*>(d.X);
     const T* const Wtp = static_cast<const T*>(d.Wt);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -179,6 +184,13 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     for (int i = 0; i < C::TN; ++i)
 #pragma unroll
         for (int j = 0; j < C::TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accx[X3 ? C::TN : 1][X3 ? C::TM : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
     // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
@@ -214,6 +226,19 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         xr_off[ks] = (wm * C::TM * 16 + frow) * C::ROWB + q;
         wr_off[ks] = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB + q;
     }
+    // x3: k-step s of a row covers units 4s .. 4s+3 (8 elements each); lane quarter fq takes unit u = 4s + fq, whose hi chunk is 2u + (u & 1)
+    // and lo chunk 2u + 1 - (u & 1) (half16.h) -- with the row's XOR swizzle the 16-lane groups of ds_read_b128 hit 16 distinct bank slots
+    constexpr int KSX = X3 ? C::ROWB / 128 : 1;
+    int x3h_off[KSX], x3l_off[KSX];   // byte offsets of the hi / lo chunk inside a tile row (before the row base)
+    if constexpr (X3) {
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+            const int u = ks * 4 + fq;
+            x3h_off[ks] = ((2 * u + (u & 1)) ^ fswz) * 16;
+            x3l_off[ks] = ((2 * u + 1 - (u & 1)) ^ fswz) * 16;
+        }
+    }
+    const int x_row0 = (wm * C::TM * 16 + frow) * C::ROWB, w_row0 = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB;
 
     // ---- NS-stage LDS ring: up to NS-1 k-tiles of LDS-DMA in flight, ONE raw barrier per k-tile.
     // Tile kt is waited for with a COUNTED vmcnt (the NS-2 younger tiles stay in flight), then the barrier
@@ -238,6 +263,30 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         if (GEN && kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
         const char* sb = smem + (kt % C::NS) * C::STAGE;
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                h16x8 wh[C::TN], wl[C::TN], xh[C::TM], xl[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) {
+                    wh[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + x3h_off[ks] + i * 16 * C::ROWB);
+                    wl[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + x3l_off[ks] + i * 16 * C::ROWB);
+                }
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) {
+                    xh[j] = *reinterpret_cast<const h16x8*>(sb + x_row0 + x3h_off[ks] + j * 16 * C::ROWB);
+                    xl[j] = *reinterpret_cast<const h16x8*>(sb + x_row0 + x3l_off[ks] + j * 16 * C::ROWB);
+                }
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TM; ++j) {
+                        acc[i][j] = mfma_16x16x32<true>(wh[i], xh[j], acc[i][j]);
+                        accx[i][j] = mfma_16x16x32<true>(wh[i], xl[j], accx[i][j]);
+                        accx[i][j] = mfma_16x16x32<true>(wl[i], xh[j], accx[i][j]);
+                    }
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
             if constexpr (sizeof(T) == 2) {
@@ -268,7 +317,16 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
             }
         }
+        }
     }
+    }
+    if constexpr (X3) {   // fold the cross terms in: a b = hi hi + 2^-11 (hi lo + lo hi)
+#pragma unroll
+        for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+            for (int j = 0; j < C::TM; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(accx[i][j][r], 1.0f / 2048.f, acc[i][j][r]);
     }
 
     const int N = d.N;
@@ -414,6 +472,9 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                     p.y = pack_h2<F16>(o[2], o[3]);
                     if (d.out_op) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
                     if (d.ln_halo) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                } else if constexpr (X3) {
+                    if (d.out_op) x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
+                    if (d.ln_halo) x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
                 } else {
                     if (d.ln_halo) *reinterpret_cast<float4*>(static_cast<float*>(d.ln_halo) + hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
                 }
@@ -514,6 +575,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                     p.x = pack_h2<F16>(a[0], a[1]);
                     p.y = pack_h2<F16>(a[2], a[3]);
                     *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                } else if constexpr (X3) {
+                    x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
                 } else {
                     *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
                 }
@@ -692,7 +755,15 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "conv8p_var37", "conv8p_var38", "conv8p_var39"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
+static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
+                                          "igemm_x3_64x64x32_s4_w8", "igemm_x3_128x128x32_s3_w8", "igemm_x3_128x128x32_s4_w8", "igemm_x3_128x64x32_s3",
+                                          "igemm_x3_128x128x64_s2_w8", "igemm_x3_64x64x64_s3", "igemm_x3_32x64x64_s3_w8", "igemm_x3_64x128x32_s3"};
+constexpr int kNumCfgX3 = 12;
 static int pick_cfg_f32(const IgemmDesc& d) {
+    if (d.x3 && d.tune >= 0 && d.tune < kNumCfgX3 && !d.gn_stats && !need_gen(d) && !d.ln_g && d.N > 32 && d.splitk <= 1) {   // in-network tuning (x3 tiles)
+        if (d.tune >= 8 && d.tune <= 10 && d.Cin % 64) return 1;   // 64-deep k-tiles
+        return d.tune;
+    }
     if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
     if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
@@ -757,7 +828,7 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     // and loads: the 8 XCD L2s are not coherent with each other inside a kernel), about one kernel floor.  It only pays for the
     // longest K on the smallest grid: layer4_rn (M=512, N=256, K=6912) 30.9 -> 18.3 us at 4 splits; K=2304..3456 on 64..256
     // tiles and the stage-3 Linear layers (K <= 3072) are break-even or slower and stay unsplit.
-    if (d.f32) {   // exact-f32 mode (64 x 64 tiles, 32-deep k-tiles): the same small-grid long-K launches, measured in the f32 forward and the training step
+    if (d.f32 || d.x3) {   // exact-f32 / x3 modes (64 x 64 tiles, 32-deep k-tiles): the same small-grid long-K launches, measured in the f32 forward and the training step
         // alternated with the unsplit build inside one GPU call: tiny_256 f32 forward 1129 -> 1154 frames/s, hybrid_384 f32 136.0 -> 137.0
         if (d.ln_g || d.out_dot || d.gn_stats || need_gen(d) || d.N <= 32 || d.tune >= 0) return 1;
         auto cdiv32 = [](long a, long b) { return (a + b - 1) / b; };
@@ -779,9 +850,10 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     return (int)S;
 }
 
-int igemm_config_id(const IgemmDesc& d) { return d.f32 ? -1 : pick_cfg(d); }
+int igemm_config_id(const IgemmDesc& d) { return d.x3 ? pick_cfg_f32(d) : (d.f32 ? -1 : pick_cfg(d)); }
 
 const char* igemm_family(const IgemmDesc& d) {
+    if (d.x3) return d.splitk > 1 ? "igemm_x3_64x64x32_s4_splitk" : kCfgNamesX3[pick_cfg_f32(d)];
     if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
     if (d.splitk > 1) {
@@ -812,7 +884,34 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
-    if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
+    if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32 && !d.x3) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
+    if (d.x3) {   // split-fp16 operands (SOCCDPT_PREC_F16X3): the f32 tile set with T = x3_t
+        if (d.wt_grp_rows) { err = "igemm: x3 operands have no shifted weight-row views (8-element units)"; return 1; }
+        if (d.ldx % 16 || d.Cin % 32 || (d.out_op && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
+        if (d.splitk > 1) {
+            if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: x3 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
+            if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true, false, true>(d, stream, err);
+            return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true>(d, stream, err);
+        }
+        switch (pick_cfg_f32(d)) {
+            case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, false, false, true, true>(d, stream, err)
+                         : d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, true>(d, stream, err)
+                                  : launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t>(d, stream, err);
+            case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, true, true>(d, stream, err)
+                         : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, false, true>(d, stream, err)
+                                       : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t>(d, stream, err);
+            case 3: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t>(d, stream, err);
+            case 4: return launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t>(d, stream, err);      // 8 waves, 32 x 16 per wave
+            case 5: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 3>, x3_t>(d, stream, err);    // 3-stage ring (96 KB)
+            case 6: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 4>, x3_t>(d, stream, err);    // 4-stage ring (128 KB)
+            case 7: return launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t>(d, stream, err);     // 4 waves, 64 x 32 per wave, two workgroups per CU
+            case 8: return launch_cfg_t<Cfg<128, 128, 128, 2, 4, 2>, x3_t>(d, stream, err);   // 64-deep k-tiles (256-byte rows): half the barriers
+            case 9: return launch_cfg_t<Cfg<64, 64, 128, 2, 2, 3>, x3_t>(d, stream, err);
+            case 10: return launch_cfg_t<Cfg<32, 64, 128, 2, 4, 3>, x3_t>(d, stream, err);    // small grids, long K
+            case 11: return launch_cfg_t<Cfg<64, 128, 64, 2, 2, 3>, x3_t>(d, stream, err);
+            default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, x3_t>(d, stream, err);
+        }
+    }
     if (d.f32) {  // exact-f32 operands (SOCCDPT_PREC_F32): 128-byte rows hold 32 elements, Cin % 32 == 0 suffices
         // split-K in f32: the weight-gradient GEMMs of the training step (K = pixels, a handful of output tiles; train_step.cpp picks the split)
         if (d.splitk > 1) {

@@ -1,5 +1,5 @@
 // Launchers of the non-GEMM kernels (elementwise.hip, attention.hip).
-// `hf` selects the 16-bit operand format of bf16_t buffers: 0 = bf16, 1 = IEEE fp16 (half16.h).
+// `hf` selects the operand format of bf16_t buffers: 0 = bf16, 1 = IEEE fp16, 3 = x3 split fp16 (4 bytes per element; half16.h) where a launcher says so.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -109,7 +109,8 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
                             int shift, int heads, hipStream_t st, std::string& err);
 
+// x3 != 0: `out` is written in the x3 split-fp16 operand format (half16.h) for the proj GEMM of SOCCDPT_PREC_F16X3
 int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
-                                int ws, int shift, int heads, hipStream_t st, std::string& err);
+                                int ws, int shift, int heads, hipStream_t st, std::string& err, int x3 = 0);
 
 }  // namespace soccdpt

@@ -113,25 +113,26 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     const bool run = ar.base != nullptr;
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const int HF = h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0;  // 16-bit operand format: 0 bf16, 1 fp16
+    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;   // split-fp16 operands: 4 bytes per element in the x3 layout (half16.h)
+    const int HF = X3 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0);  // operand format: 0 bf16, 1 fp16, 3 x3
     static const char kNoCopy = 0;  // non-null placeholder while measuring
     auto cvt = [&](const std::string& key, size_t n) -> const void* {
         if (F32) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
-        bf16_t* p = ar.take<bf16_t>(n);
+        bf16_t* p = X3 ? reinterpret_cast<bf16_t*>(ar.take<float>(n)) : ar.take<bf16_t>(n);
         if (run && launch_cvt_bf16(W(key), p, n, HF, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const void* {
         const size_t n = (size_t)Cout * Cin * 9;
-        void* p = F32 ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        void* p = (F32 || X3) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
         if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, HF, Cout, Cin, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    const int OM = F32 ? 2 : HF;   // operand format code of hybrid.hip
+    const int OM = F32 ? 2 : HF;   // operand format code of hybrid.hip: 0 bf16, 1 fp16, 2 f32, 3 x3
     // weight-standardised convolution weight (timm StdConv2dSame, eps 1e-8), tap-major [Cout][Kpad]
     auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad) -> const void* {
         const size_t n = (size_t)Cout * Kpad;
-        void* p = F32 ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        void* p = (F32 || X3) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
         if (run && launch_ws_conv_w(W(key), p, OM, Cout, Cin, k, Kpad, 1e-8f, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
@@ -324,7 +325,7 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
     const size_t M0 = (size_t)B * G * G;
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const size_t es = F32 ? 4 : 2;
+    const size_t es = (F32 || h.cfg.precision == SOCCDPT_PREC_F16X3) ? 4 : 2;   // f32 and x3 operands: 4 bytes per element
     auto op = [&](size_t elems) -> void* { return ar.take<char>(elems * es); };
     if (a.hybrid) {
         const int S = a.img, H1 = S / 2, H2 = S / 4, E = a.vit_dim, NT = G * G + 1;
@@ -573,12 +574,13 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
         return 0;
     };
-    const int hk = h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 5 : 2);  // zero-halo NHWC: 2 bf16, 3 f32, 5 fp16
+    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;
+    const int hk = X3 ? 7 : (h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 5 : 2));  // zero-halo NHWC: 2 bf16, 3 f32, 5 fp16, 7 x3
     for (int s = 0; s < 4; ++s)
         if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.fres(s), a.fres(s), a.fdim(s)}.elems(B), hk, a.fres(s), a.fres(s), a.fdim(s));
     const int r1 = 2 * a.fres(0);
     if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
-    if (n == "seg_feat") return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, hk == 3 ? 0 : hk - 1, r1, r1, h.cfg.features);  // seg head conv3x3 + BN + ReLU output
+    if (n == "seg_feat") return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, (hk == 3 || X3) ? 0 : hk - 1, r1, r1, h.cfg.features);  // seg head conv3x3 + BN + ReLU output
     if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
     if (n == "xf" && !a.hybrid) return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     if (n == "vit_tokens" && a.hybrid) return set(w.vt_xf, (size_t)B * (a.grid() * a.grid() + 1) * a.vit_dim, 0, 1, a.grid() * a.grid() + 1, a.vit_dim);  // residual stream after the last block
@@ -610,12 +612,17 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const Prepared& P = *h.prep;
     const int F = h.cfg.features;
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const int es = F32 ? 4 : 2;
-    const int HF = h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0;  // 16-bit operand format: 0 bf16, 1 fp16
+    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;   // GEMM / conv operands in the x3 split-fp16 format; everything else as in the f32 mode
+    const bool W4 = F32 || X3;                               // 4-byte operand elements: the launch sequence of the f32 mode
+    const int es = W4 ? 4 : 2;
+    const int HF = X3 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0);  // operand format: 0 bf16, 1 fp16, 3 x3
+    // a GEMM output that a NON-GEMM kernel consumes (attention, bilinear, the seg tail) is plain f32 in both 4-byte modes: f32 operands ARE
+    // plain f32, in the x3 mode it goes to out_f32 instead of out_op
+    auto to_plain = [&](IgemmDesc& d, void* buf) { if (X3) { d.out_f32 = static_cast<float*>(buf); d.act_on_f32 = 1; } else d.out_op = buf; };
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d) {
-        if (!d.f32) { d.f32 = F32 ? 1 : 0; d.f16 = HF; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
+        if (!d.f32) { d.f32 = F32 ? 1 : 0; d.f16 = HF == 1; d.x3 = X3 ? 1 : 0; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
         const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps);
         if (!h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py)
             auto it = h.tune_by_shape.find(key);
@@ -645,7 +652,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         // forward_flex (/root/reference/SOccDPT/model/backbones/vit.py:44-85) + forward_adapted_unflatten (backbones/utils.py:84-133);
         // launch for launch what oracle/soccdpt_ref.py hybrid_encoder() states.
         const HybridW& Y = P.hy;
-        const int OM = F32 ? 2 : HF;
+        const int OM = F32 ? 2 : HF;   // 0 bf16, 1 fp16, 2 f32, 3 x3
         const int S = a.img, H1 = S / 2, H2 = S / 4;
         // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
         auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
@@ -734,7 +741,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         for (int i = 0; i < a.vit_depth; ++i) {
             const VitBlockW& vb = Y.blocks[i];
             IgemmDesc d;
-            d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b; d.out_op = w.vt_qkv;
+            d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b; to_plain(d, w.vt_qkv);
             RUN(gemm(d));
             { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * es);
               RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, h.cfg.precision, B, NT, a.vit_heads, st, err)); }
@@ -783,13 +790,13 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         bool merged = false;   // the stage's last block wrote its operand copy straight into the PatchMerging layout (w.hbuf)
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
-            const bool to_merge = !F32 && s < 3 && j == a.depths[s] - 1;
+            const bool to_merge = !W4 && s < 3 && j == a.depths[s] - 1;
             IgemmDesc d;
-            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; d.out_op = w.qkv;
+            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; to_plain(d, w.qkv);
             RUN(gemm(d));
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
-              if (F32) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
-                                                       a.shift(s, j), H, st, err));
+              if (W4) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
+                                                       a.shift(s, j), H, st, err, X3 ? 1 : 0));
               else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), HF, B, res, wsz,
                                                a.shift(s, j), H, st, err)); }
             const bool fuse_ln = C <= 128;  // whole rows fit one igemm tile; measured: a win for C = 96, a wash at 192, a loss beyond
@@ -804,7 +811,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
                   RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, 0, st, err)); }
             }
-            if (!F32 && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
+            if (!W4 && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
                 const bool hook = (j == a.hooks[s]);
                 PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
                 RUN(launch_mlp_ln(static_cast<const bf16_t*>(w.xb), w.xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
@@ -896,25 +903,25 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     {
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
-        d.bias = P.d0_b; d.out_op = w.d1;
+        d.bias = P.d0_b; to_plain(d, w.d1);
         RUN(gemm(d));
-        if (!F32 && F == 256) {
+        if (!W4 && F == 256) {
             // fused: up-sample + conv3x3(128->32) + ReLU + 1x1 + ReLU straight from the half-resolution map
             PROF("depth_tail_fused", 2.0 * B * r0 * r0 * 32.0 * 9.0 * (F / 2), 0.0);
             RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, HF, B, r1, r1, st, err));
         } else {
             { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
-              RUN(launch_bilinear(w.d1, F32 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, HF, B, r1,
+              RUN(launch_bilinear(w.d1, W4 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, HF, B, r1,
                                   r1, r0, r0, F / 2, st, err)); }
             d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
             d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
             RUN(gemm(d));
         }
         d = conv(w.path1, F, P.s0_w, F, r1);
-        d.bias = P.bn_shift; d.act = ACT_RELU; d.out_op = w.s1;
+        d.bias = P.bn_shift; d.act = ACT_RELU; to_plain(d, w.s1);
         RUN(gemm(d));
         { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
-          RUN(launch_seg_tail(w.s1, F32 ? 1 : 0, HF, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
+          RUN(launch_seg_tail(w.s1, W4 ? 1 : 0, HF == 1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
         ++launches;
     }
 #undef RUN

@@ -22,7 +22,7 @@ template <typename OT> __device__ __forceinline__ OT cvt_out(float v);
 template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
 template <> __device__ __forceinline__ uint16_t cvt_out<uint16_t>(float v) { return f2h<false>(v); }
 struct f16raw { uint16_t v; };   // IEEE fp16 bits (the amp mode with loss scaling); uint16_t alone means bf16
-template <> __device__ __forceinline__ f16raw cvt_out<f16raw>(float v) { return f16raw{f2h<true>(v)}; }
+template <> __device__ __forceinline__ f16raw cvt_out<f16raw>(float v) { return f16raw{f2h_ieee(v)}; }   // overflow -> inf: GradScaler must see it (half16.h)
 
 // ---------------- layout ----------------
 // [R][C] -> [C][Rp] (Rp >= R: rows padded with zeros up to the k-tile multiple the igemm needs), 32 x 32 tiles through LDS

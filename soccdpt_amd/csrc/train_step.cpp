@@ -194,7 +194,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
             TRY(tr_transpose16(W, w16, N, K, N, F16, c.st, c.err));
-            TRY(launch_cvt_bf16(dY, a16, M * N, F16, c.st, c.err));
+            TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));   // fp16: IEEE conversion, an overflow of the scaled gradient becomes inf
             d.X = a16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {

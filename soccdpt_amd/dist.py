@@ -45,6 +45,17 @@ def gather_occ_bits(bits: torch.Tensor, group=None, out: Optional[torch.Tensor] 
     return flat.reshape(world, bits.numel())
 
 
+def all_reduce_mean_scalar(value: float, group=None) -> float:
+    """Mean of a host scalar over the ranks (the training loop's loss for ReduceLROnPlateau / logging): identical on every rank."""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return float(value)
+    t = torch.tensor([float(value)], dtype=torch.float64)
+    if dist.get_backend(group) == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return float(t.item()) / dist.get_world_size(group)
+
+
 class OccExchange:
     """Callable installed as `net.occ_exchange`: local packed grid -> union over all ranks."""
 

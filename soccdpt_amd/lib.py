@@ -247,6 +247,28 @@ def make_config(backbone: str, num_classes: int, features: int, sigmoid: bool, c
     return cfg
 
 
+def x3_encode(t: torch.Tensor) -> torch.Tensor:
+    """float tensor -> the x3 split-fp16 operand bytes (csrc/half16.h; SOCCDPT_PREC_F16X3) as a flat fp16 tensor of 2 * numel on the same
+    device: every aligned group of 8 elements is 8 hi values (RN fp16 of a) + 8 lo values (RN fp16 of (a - hi) * 2048), hi first in even
+    groups, lo first in odd ones.  numel (and every row length) must be a multiple of 16."""
+    f = t.detach().to(torch.float32).contiguous().reshape(-1, 8)
+    assert f.shape[0] % 2 == 0, "x3 tensors are multiples of 16 elements"
+    hi = f.clamp(-65504.0, 65504.0).to(torch.float16)
+    lo = ((f - hi.float()) * 2048.0).clamp(-65504.0, 65504.0).to(torch.float16)
+    odd = (torch.arange(f.shape[0], device=f.device) & 1).bool()[:, None]
+    return torch.stack([torch.where(odd, lo, hi), torch.where(odd, hi, lo)], dim=1).reshape(-1)
+
+
+def x3_decode(raw: torch.Tensor, shape) -> torch.Tensor:
+    """Inverse of x3_encode: flat fp16 (or raw bytes) of an x3 tensor -> float64 tensor of `shape` (hi + lo / 2048, exact)."""
+    r = raw.view(torch.float16) if raw.dtype != torch.float16 else raw
+    r = r.reshape(-1, 2, 8).double()
+    odd = (torch.arange(r.shape[0], device=r.device) & 1).bool()[:, None]
+    hi = torch.where(odd, r[:, 1], r[:, 0])
+    lo = torch.where(odd, r[:, 0], r[:, 1])
+    return (hi + lo / 2048.0).reshape(shape)
+
+
 class Engine:
     """One handle of libsoccdpt_hip.so bound to one GPU (one per rank)."""
 
@@ -465,13 +487,16 @@ class Engine:
             raise KeyError(name)
         raw = self._workspace[off.value:]
         if "@" in name:  # one concurrent sub-batch of a multi-stream layout: its frame count follows from the element count
-            halo = kind.value in (2, 3, 5)
+            halo = kind.value in (2, 3, 5, 7)
             B = n.value // ((H.value + 2 * halo) * (W.value + 2 * halo) * C.value)
         if kind.value == 0:
             return raw[: n.value * 4].view(torch.float32).reshape(B, H.value, W.value, C.value).clone()
         if kind.value == 3:
             t = raw[: n.value * 4].view(torch.float32).reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]
             return t.clone()
+        if kind.value == 7:   # zero-halo NHWC in the x3 split-fp16 format (SOCCDPT_PREC_F16X3)
+            t = x3_decode(raw[: n.value * 4], (B, H.value + 2, W.value + 2, C.value))[:, 1:-1, 1:-1]
+            return t.float()
         t = raw[: n.value * 2].view(torch.float16 if kind.value in (4, 5) else torch.bfloat16)
         if kind.value in (2, 5):
             t = t.reshape(B, H.value + 2, W.value + 2, C.value)[:, 1:-1, 1:-1]

@@ -181,7 +181,9 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     net.train_amp = amp_mode
     grad_scaler = GradScaler(enabled=(amp_mode == "f16"))
     if world > 1:
-        assert p["batch_size"] >= world, "data parallel: batch_size must be at least the number of ranks"
+        # equal shards: the gradient exchange averages with a flat 1 / world, which is the global-batch gradient only when every rank holds
+        # batch_size / world frames
+        assert p["batch_size"] % world == 0, f"data parallel: batch_size ({p['batch_size']}) must be a multiple of the number of ranks ({world})"
         sdist.attach_training(net)
     freeze_pretrained_encoder(net)
     unfreeze_pretrained_encoder_by_percentage(net, p["encoder_percentage"])
@@ -196,7 +198,7 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     for epoch in range(1, p["epochs"] + 1):
         net.train()
         epoch_loss = 0.0
-        for batch_index in range(batch_size, len(train_set) + 1, batch_size):
+        for batch_index in range(batch_size, len(train_set), batch_size):   # the reference's range (scripts/train_SOccDPT.py:350): a trailing full batch is NOT run
             if world > 1:      # this rank's contiguous shard of the batch
                 lo, hi = sdist.shard_range(batch_size, rank, world)
                 x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(train_set, batch_index - batch_size + hi, hi - lo)
@@ -220,6 +222,9 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
                     grad_scaler.step(optimizer, net_patch)
                     grad_scaler.update()
             loss = float(out["loss"].item())
+            if world > 1:   # the GLOBAL-batch loss on every rank: ReduceLROnPlateau must see the same number everywhere, or the ranks cut the
+                            # learning rate at different steps and the replicas diverge silently
+                loss = sdist.all_reduce_mean_scalar(loss)
             epoch_loss += loss
             history.append(loss)
             if rank == 0:
@@ -229,13 +234,14 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
                 # evaluation round (train_SOccDPT.py:406-430 -> utils/__init__.py:598-768): the 7 depth metrics and the IoU over the validation
                 # split, computed on the GPU (csrc/metrics.hip); the wandb histograms / images of the reference are not produced
                 val_batches = [val_set[i] for i in range(len(val_set))]      # items carry their batch dimension (datasets' layout)
-                abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = evaluate_depth(DepthNet(net), val_batches, device, amp=p["amp"])
-                print("abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3", abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)
-                iou = evaluate_seg(SegNet(net), val_batches, device, amp=p["amp"])
-                print("iou", iou)
-                evals.append(dict(step=global_step, abs_rel=abs_rel, rmse=rmse, a1=a1, iou=iou))
-                net.train()
-                scheduler.step(loss)
+                if rank == 0:      # the replicas are identical: one rank evaluates and prints
+                    abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = evaluate_depth(DepthNet(net), val_batches, device, amp=p["amp"])
+                    print("abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3", abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)
+                    iou = evaluate_seg(SegNet(net), val_batches, device, amp=p["amp"])
+                    print("iou", iou)
+                    evals.append(dict(step=global_step, abs_rel=abs_rel, rmse=rmse, a1=a1, iou=iou))
+                    net.train()
+                scheduler.step(loss)   # `loss` is the all-reduced global-batch loss: every rank takes the same decision
             global_step += 1
             if max_steps and global_step >= max_steps:
                 break

@@ -163,3 +163,33 @@ def test_grad_exchange_averages_trainable_runs(tmp_path, world):
         assert np.allclose(np.load(tmp_path / f"buf_{r}.npy"), (world - 1) / 2.0)
     for r in range(1, world):
         assert np.array_equal(data[r][1][:1536], data[0][1][:1536])        # replicas hold bit-identical averaged gradients
+
+
+def _loss_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from soccdpt_amd.dist import all_reduce_mean_scalar
+    from soccdpt_amd.scripts.train_SOccDPT import ReduceLROnPlateau
+    from soccdpt_amd.utils.optim import Adam
+    opt = Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3)
+    sched = ReduceLROnPlateau(opt, patience=2)
+    lrs = []
+    for step in range(12):
+        local = 1.0 + (0.5 if rank == 0 else -0.5) * ((-1) ** step) + (0.0 if step < 2 else 0.1)   # rank-local losses disagree about "plateau"
+        g = all_reduce_mean_scalar(local)
+        sched.step(g)
+        lrs.append((g, opt.lr))
+    np.save(os.path.join(outdir, f"lrs_{rank}.npy"), np.array(lrs))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_training_loss_is_all_reduced_before_the_scheduler(tmp_path):
+    """Data-parallel training: ReduceLROnPlateau steps on the mean loss over the ranks, so every rank cuts the learning rate at
+    the same step although the rank-local shard losses differ."""
+    world, port = 2, _free_port()
+    mp.spawn(_loss_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    a, b = np.load(tmp_path / "lrs_0.npy"), np.load(tmp_path / "lrs_1.npy")
+    assert np.array_equal(a, b)
+    assert a[-1, 1] < a[0, 1]           # the plateau was detected (identically)

@@ -419,6 +419,14 @@ def test_amp_gradients_with_criterion(gpu_device):
     scaler.step(opt, m)
     scaler.update()
     assert opt.stepped == 1 and scaler.skipped_steps == 1 and scaler.get_scale() == 32768.0
+    # a FINITE output gradient whose scaled fp16 operands overflow (a scale far too large, what unbounded growth would end in): the staging
+    # conversions emit inf instead of saturating at 65504, so the step is skipped and the scale backs off (silent clipping before)
+    scaler._scale = 2.0 ** 40
+    m.train_forward(x.to(dev))
+    m.backward(*scaler.scale(r["d_inv"], r["d_seg"]))
+    scaler.step(opt, m)
+    scaler.update()
+    assert opt.stepped == 1 and scaler.skipped_steps == 2 and scaler.get_scale() == 2.0 ** 39
 
 
 def _nhwc(t):

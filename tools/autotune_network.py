@@ -14,7 +14,8 @@ from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_c
 
 model_type = sys.argv[1] if len(sys.argv) > 1 else "dpt_swin2_tiny_256"
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
-prec = {"bf16": 0, "f16": 2}[sys.argv[3] if len(sys.argv) > 3 else "bf16"]
+pname = sys.argv[3] if len(sys.argv) > 3 else "bf16"
+prec = {"bf16": 0, "f16": 2, "f16x3": 3}[pname]
 dev = torch.device("cuda:0")
 backbone = MODEL_TYPE_TO_BACKBONE[model_type]
 img = backbone_image_size(backbone)
@@ -50,6 +51,8 @@ results = []
 for s in sites:
     Cin = s["K"] // s["taps"]
     cands = [c for c in (K64 if Cin % 64 == 0 else []) + K32 if not (c in (20, 22) and Cin % 128)]
+    if pname == "f16x3":   # the x3 tile set (igemm.hip kCfgNamesX3)
+        cands = [c for c in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11) if not (c in (8, 9, 10) and Cin % 64)]
     if s["N"] <= 32 or s["M"] < int(os.environ.get('AUTOTUNE_MIN_M', '0')):
         continue
     row = {"auto": (s["cfg"], base[s["site"]])}
@@ -70,4 +73,4 @@ for s in sites:
     print(f"{s['site']} M={s['M']:6d} N={s['N']:5d} K={s['K']:5d} taps={s['taps']} x{s['launches'] // (REPS * (len(cands) + 1)) or 1}: auto cfg {s['cfg']:2d} {row['auto'][1]:7.1f} us | best {best[0]} {best[1]:7.1f} | {alts}", flush=True)
 gain = sum(r["gain_us"] for r in results if r["gain_us"] > 0)
 print(f"sum of per-shape gains over the heuristic: {gain:.0f} us per forward")
-json.dump(results, open(f"gpurun_out/autotune_{model_type}_B{B}.json", "w"), indent=1)
+json.dump(results, open(f"gpurun_out/autotune_{model_type}_B{B}_{pname}.json", "w"), indent=1)
