@@ -141,6 +141,15 @@ int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, in
                     float* dev_inv_up, float* dev_seg_up, float* dev_points, uint32_t* dev_occ_bits, int clear_bits,
                     void* stream);
 
+/* Backward of soccdpt_project's differentiable outputs: what torch autograd runs through get_semantic_occupancy (model/SOccDPT.py:264-353) when a
+ * criterion written in torch ops is applied to the tuple SOccDPT_V3.forward returns in train mode (scripts/train_SOccDPT.py:365-391).
+ * dev_inv_up [B,Hc,Wc] is the forward's clamped output (the clamp mask and the points' depth are read from it); dev_d_inv_up [B,Hc,Wc],
+ * dev_d_seg_up [B,C,Hc,Wc], dev_d_points [B,Hc,Wc,3] are the upstream gradients (each may be NULL = zero).  Writes dev_d_inv [B,in_h,in_w] and
+ * dev_d_seg [B,C,in_h,in_w] -- the arguments of soccdpt_train_backward.  Scratch: soccdpt_project_backward_scratch_bytes.  Deterministic gathers. */
+size_t soccdpt_project_backward_scratch_bytes(void* handle, int B, int in_h);
+int soccdpt_project_backward(void* handle, const float* dev_inv_up, const float* dev_d_inv_up, const float* dev_d_seg_up, const float* dev_d_points,
+                             int B, int in_h, int in_w, float* dev_d_inv, float* dev_d_seg, void* dev_scratch, size_t scratch_bytes, void* stream);
+
 /* dst |= src[0] | ... | src[n_sets-1]  (each set = soccdpt_occ_words() words). */
 int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src_bits, int n_sets, void* stream);
 /* packed bits -> dense f32 rows, identical in every batch row (model/SOccDPT.py:449-455). */
@@ -163,11 +172,12 @@ int soccdpt_metrics_depth(const float* dev_pred, const float* dev_gt, const uint
 int soccdpt_metrics_iou(const float* dev_pred, const float* dev_gt, int B, int C, size_t npix, float* dev_out, void* dev_scratch,
                         void* stream);
 
-/* ---- per-kernel timing with HIP events on the caller's stream (bench.py roofline) ----
- * While enabled, every kernel launch of soccdpt_network / soccdpt_project / soccdpt_occ_expand /
- * soccdpt_forward is bracketed by a hipEvent pair on `stream`.  soccdpt_profile_collect synchronises the
- * recorded events, aggregates per kernel family (sum of elapsed ms, launches, algorithmic FLOPs and
- * algorithmic HBM bytes as defined in DESIGN.md) and resets the recording. */
+/* ---- per-kernel device time (bench.py roofline) ----
+ * While enabled, every kernel launched by soccdpt_network / soccdpt_project / soccdpt_occ_expand / soccdpt_forward carries a
+ * HIP start / stop event pair bound to its own dispatch (hipExtLaunchKernelGGL): the pair's elapsed time is the kernel's begin -> end on
+ * the device, the figure rocprofv3 --kernel-trace reports, and nothing is recorded between kernels.  soccdpt_profile_collect synchronises
+ * the events, aggregates per kernel family (sum of kernel ms, launches, algorithmic FLOPs and algorithmic HBM bytes as defined in
+ * DESIGN.md) and resets the recording. */
 typedef struct soccdpt_kernel_stat {
     char name[48];
     int32_t launches;

@@ -176,6 +176,22 @@ size_t soccdpt_occ_words(void* handle) {
     return (ncell + 31) / 32;
 }
 
+size_t soccdpt_project_backward_scratch_bytes(void* handle, int B, int in_h) {
+    Handle* h = static_cast<Handle*>(handle);
+    return (h && B > 0 && in_h > 0) ? upsample_bwd_scratch_bytes(h->cfg, B, in_h) : 0;
+}
+
+int soccdpt_project_backward(void* handle, const float* dev_inv_up, const float* dev_d_inv_up, const float* dev_d_seg_up, const float* dev_d_points,
+                             int B, int in_h, int in_w, float* dev_d_inv, float* dev_d_seg, void* dev_scratch, size_t scratch_bytes, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (B <= 0 || in_h <= 0 || scratch_bytes < upsample_bwd_scratch_bytes(h->cfg, B, in_h)) return fail(h, "soccdpt_project_backward: scratch too small");
+    if (launch_upsample_bwd(h->cfg, dev_inv_up, dev_d_inv_up, dev_d_seg_up, dev_d_points, B, in_h, in_w, dev_d_inv, dev_d_seg, dev_scratch,
+                            (hipStream_t)stream, h->err))
+        return 1;
+    return 0;
+}
+
 int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src_bits, int n_sets, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;

@@ -31,9 +31,11 @@ struct f16_t { uint16_t v; };  // element tag of the fp16 instantiations (SOCCDP
 
 // BK_ is the k-tile depth in bf16 elements; a tile row is ROWB = 2*BK_ bytes (128 or 64).  With f32 operands
 // (SOCCDPT_PREC_F32) the same byte geometry holds BK_/2 elements per row.
-template <int BM_, int BN_, int BK_, int WM_, int WN_, int NS_>
+// MF_: MFMA shape of the 16-bit instantiations: 16 = v_mfma_f32_16x16x32 (a wave tile is TM x TN tiles of 16 x 16), 32 = v_mfma_f32_32x32x16 (a wave tile
+// is (BM/WM/32) x (BN/WN/32) tiles of 32 x 32; half the MFMA issue slots per FLOP).  Same LDS bytes per FLOP for the same wave tile.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NS_, int MF_ = 16>
 struct Cfg {
-    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NS = NS_;  // NS: LDS stages (tiles in flight + 1)
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NS = NS_, MF = MF_;  // NS: LDS stages (tiles in flight + 1)
     static constexpr int THREADS = WM * WN * 64;
     static constexpr int ROWB = BK * 2;    // bytes per LDS tile row
     static constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
@@ -48,8 +50,11 @@ struct Cfg {
     static_assert(NS >= 2 && (NS - 2) * LOADS <= 63, "vmcnt immediate is 6 bits");
 };
 
-template <int BK>
+template <int BK, int MF = 16>
 __device__ __forceinline__ int swz_of_row(int row) {
+    // 32 x 32 MFMA fragments: the 32 lanes of a half-wave read 32 ROWS at ONE chunk; ds_read_b128 serves lane groups {0-3, 12-15, 20-27} /
+    // {4-11, 16-19, 28-31}: rows of equal parity share a 128-byte bank half, (row >> 1) & 7 gives each of a group's 8 such rows its own slot
+    if constexpr (MF == 32 && BK == 64) return (row >> 1) & 7;
     if constexpr (BK == 128) return row & 15;        // 256-byte rows (one full bank sweep each): 16 chunks
     else if constexpr (BK == 64) return row & 7;     // 128-byte rows: 8 chunks
     else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
@@ -78,6 +83,12 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     constexpr bool F16 = std::is_same<T, f16_t>::value;
     constexpr bool X3 = std::is_same<T, x3_t>::value;
     static_assert(!X3 || C::ROWB >= 128, "an x3 k-step (32 elements) is 128 bytes of a tile row");
+    constexpr int MF = C::MF;
+    static_assert(MF == 16 || (MF == 32 && sizeof(T) == 2 && C::BK == 64 && !LN && !SK && !ST), "32x32x16 tiles: 16-bit operands, 64-deep k-tiles, plain epilogue");
+    // epilogue view of a wave's accumulators, common to both MFMA shapes: TME m-tiles x TNE groups of 4 consecutive channels per lane;
+    // m_of(j) / n_of(i) = the pixel / first channel a lane owns in group (i, j)
+    constexpr int TME = MF == 32 ? BM / C::WM / 32 : C::TM;
+    constexpr int TNE = MF == 32 ? (BN / C::WN / 32) * 4 : C::TN;
     const T* const Xp = static_cast<const T*>(d.X);
     const T* const Wtp = static_cast<const T*>(d.Wt);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -101,6 +112,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
     const int tile_id = bid;
     const int nt = bid % ntiles, mt = bid / ntiles;
     const int m0 = mt * BM, n0 = nt * BN;
+    auto m_of = [&](int j) { return m0 + wm * (BM / C::WM) + (MF == 32 ? j * 32 + (lane & 31) : j * 16 + (lane & 15)); };
+    auto n_of = [&](int i) { return n0 + wn * (BN / C::WN) + (MF == 32 ? (i >> 2) * 32 + (i & 3) * 8 + (lane >> 5) * 4 : i * 16 + (lane >> 4) * 4); };
     const int Ktot = d.taps * d.Cin;
     const int Wp = d.W + 2;                 // OUTPUT halo geometry (out_halo / ln_halo stores)
     const bool conv_addr = d.taps == 9 || (GEN && d.gather1);
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         } else {
             base = (uint32_t)m * (uint32_t)d.ldx;
         }
-        const uint32_t sw = (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+        const uint32_t sw = (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
         x_off[i] = base + sw;
         x_off2[i] = base2 - base;   // delta to the second-segment row (mod 2^32), added when the k-tile lies in the second segment
     }
@@ -143,9 +156,9 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         if (GEN && d.wt_grp_rows) {   // weight row groups: the tile's rows belong to ONE group (wt_grp_rows % BN == 0): a shifted view of the same matrix
             const int g = n0 / d.wt_grp_rows, ky = g / 3, kx = g - ky * 3;
             const uint32_t shift = (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + (kx - 1) + (kx != 1 ? d.wt_odd : 0));
-            w_off[i] = (uint32_t)(n - g * d.wt_grp_rows) * (uint32_t)Ktot + shift + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+            w_off[i] = (uint32_t)(n - g * d.wt_grp_rows) * (uint32_t)Ktot + shift + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
         } else
-        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK>(row)) * EPC);
+        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
     }
 
     auto stage = [&](int kt, int buf) {
@@ -179,36 +192,47 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         }
     };
 
-    f32x4 acc[C::TN][C::TM];
+    f32x4 acc[TNE][TME];
 #pragma unroll
-    for (int i = 0; i < C::TN; ++i)
+    for (int i = 0; i < TNE; ++i)
 #pragma unroll
-        for (int j = 0; j < C::TM; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accx[X3 ? C::TN : 1][X3 ? C::TM : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
+        for (int j = 0; j < TME; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accx[X3 ? TNE : 1][X3 ? TME : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
     if constexpr (X3) {
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i)
+        for (int i = 0; i < TNE; ++i)
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < TME; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    constexpr int TN32 = MF == 32 ? BN / C::WN / 32 : 1, TM32 = MF == 32 ? BM / C::WM / 32 : 1;
+    f32x16_t acc32[TN32][TM32];   // MF == 32: the 32 x 32 accumulators of the main loop (re-viewed as `acc` groups for the epilogue)
+    if constexpr (MF == 32) {
+#pragma unroll
+        for (int i = 0; i < TN32; ++i)
+#pragma unroll
+            for (int j = 0; j < TM32; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
     }
 
     // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
     // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
     // its own.  Big tiles prefetch only the bias (their residual rows would cost 64 registers).
-    constexpr bool PRE = !SK && (C::TN * C::TM <= 8);
+    constexpr bool PRE = !SK && (TNE * TME <= 8);
     constexpr bool PREB = !SK;   // the bias alone is cheap enough (TN x 4 registers) for every tile size: 128x128 convs 338 -> 323 us
-    float4 bias_pre[PREB ? C::TN : 1];
-    float4 res1_pre[PRE ? C::TN : 1][PRE ? C::TM : 1];
+    float4 bias_pre[PREB ? TNE : 1];
+    float4 res1_pre[PRE ? TNE : 1][PRE ? TME : 1];
     if constexpr (PREB) {
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i) {
-            int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < TNE; ++i) {
+            int n = n_of(i);
             n = n < d.N ? n : 0;
             bias_pre[i] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (PRE)
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) {
-                int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+            for (int j = 0; j < TME; ++j) {
+                int m = m_of(j);
                 m = m < d.M ? m : d.M - 1;
                 res1_pre[i][j] = d.res1 ? *reinterpret_cast<const float4*>(d.res1 + (size_t)m * d.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
@@ -218,7 +242,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
 
     // fragment read offsets (bytes within a stage), constant per lane
     const int frow = lane & 15, fq = lane >> 4;
-    const int fswz = swz_of_row<C::BK>(frow);
+    const int fswz = swz_of_row<C::BK, C::MF>(frow);
     int xr_off[C::KS], wr_off[C::KS];
 #pragma unroll
     for (int ks = 0; ks < C::KS; ++ks) {
@@ -239,6 +263,18 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         }
     }
     const int x_row0 = (wm * C::TM * 16 + frow) * C::ROWB, w_row0 = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB;
+    // 32 x 32 x 16 fragments: lane (row r32, half h2) reads chunk 2 ks + h2 of k-step ks (16 elements per step)
+    constexpr int KS32 = MF == 32 ? C::BK / 16 : 1;
+    int x32_off[KS32], w32_off[KS32];
+    if constexpr (MF == 32) {
+        const int r32 = lane & 31, h2 = lane >> 5, sw32 = swz_of_row<C::BK, C::MF>(r32);
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            const int q = ((ks * 2 + h2) ^ sw32) * 16;
+            x32_off[ks] = (wm * (BM / C::WM) + r32) * C::ROWB + q;
+            w32_off[ks] = C::X_BYTES + (wn * (BN / C::WN) + r32) * C::ROWB + q;
+        }
+    }
 
     // ---- NS-stage LDS ring: up to NS-1 k-tiles of LDS-DMA in flight, ONE raw barrier per k-tile.
     // Tile kt is waited for with a COUNTED vmcnt (the NS-2 younger tiles stay in flight), then the barrier
@@ -286,6 +322,19 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                         accx[i][j] = mfma_16x16x32<true>(wl[i], xh[j], accx[i][j]);
                     }
             }
+        } else if constexpr (MF == 32) {
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+                h16x8 wf[TN32], xf[TM32];
+#pragma unroll
+                for (int i = 0; i < TN32; ++i) wf[i] = *reinterpret_cast<const h16x8*>(sb + w32_off[ks] + i * 32 * C::ROWB);
+#pragma unroll
+                for (int j = 0; j < TM32; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + x32_off[ks] + j * 32 * C::ROWB);
+#pragma unroll
+                for (int i = 0; i < TN32; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM32; ++j) acc32[i][j] = mfma_32x32x16<F16>(wf[i], xf[j], acc32[i][j]);
+            }
         } else {
 #pragma unroll
         for (int ks = 0; ks < C::KS; ++ks) {
@@ -320,11 +369,21 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         }
     }
     }
+    if constexpr (MF == 32) {   // accumulator register 4 g + r of tile (i, j) = channel 8 g + 4 h2 + r of pixel (lane & 31): epilogue group (4 i + g, j)
+#pragma unroll
+        for (int i = 0; i < TN32; ++i)
+#pragma unroll
+            for (int j = 0; j < TM32; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i * 4 + g][j][r] = acc32[i][j][4 * g + r];
+    }
     if constexpr (X3) {   // fold the cross terms in: a b = hi hi + 2^-11 (hi lo + lo hi)
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i)
+        for (int i = 0; i < TNE; ++i)
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j)
+            for (int j = 0; j < TME; ++j)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(accx[i][j][r], 1.0f / 2048.f, acc[i][j][r]);
     }
@@ -338,11 +397,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const size_t MN = (size_t)d.M * N;
         float* mine = d.sk_part + (size_t)split * MN;
 #pragma unroll
-        for (int j = 0; j < C::TM; ++j) {
-            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i) {
-                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
                 if (m < d.M && n < N) {
                     float* q = mine + (size_t)m * N + n;
 #pragma unroll
@@ -358,11 +417,11 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         if (*arrival != (unsigned)d.splitk - 1) return;   // not the last split of this tile: done (nobody waits)
         if (tid == 0) __hip_atomic_store(d.sk_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
 #pragma unroll
-        for (int j = 0; j < C::TM; ++j) {
-            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i) {
-                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
                 f32x4 sum = {0.f, 0.f, 0.f, 0.f};
                 if (m < d.M && n < N) {
                     for (int sp = 0; sp < d.splitk; ++sp) {   // fixed order: bitwise reproducible
@@ -382,40 +441,40 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         float* red = reinterpret_cast<float*>(smem);  // [BM][WN]
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i) {
-            const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < TNE; ++i) {
+            const int n = n_of(i);
             float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
             if constexpr (PREB) { if (n < N) b4 = bias_pre[i]; }
             else if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) {
+            for (int j = 0; j < TME; ++j) {
                 acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
             }
         }
         // the residual rows are requested before the two reduction passes (their latency hides behind the barriers)
-        float4 xres[C::TN][C::TM];
+        float4 xres[TNE][TME];
         if (d.ln_residual) {
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) {
-                int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+            for (int j = 0; j < TME; ++j) {
+                int m = m_of(j);
                 m = m < d.M ? m : d.M - 1;
 #pragma unroll
-                for (int i = 0; i < C::TN; ++i) {
-                    int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                for (int i = 0; i < TNE; ++i) {
+                    int n = n_of(i);
                     n = n < N ? n : 0;
                     xres[i][j] = *reinterpret_cast<const float4*>(d.ln_xf + (size_t)m * N + n);
                 }
             }
         }
-        float mean[C::TM], rstd[C::TM];
+        float mean[TME], rstd[TME];
 #pragma unroll
         for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) {
+            for (int j = 0; j < TME; ++j) {
                 float sum = 0.f;
 #pragma unroll
-                for (int i = 0; i < C::TN; ++i) {
-                    const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+                for (int i = 0; i < TNE; ++i) {
+                    const int n = n_of(i);
                     if (n < N) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -426,22 +485,22 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 }
                 sum += __shfl_xor(sum, 16);
                 sum += __shfl_xor(sum, 32);
-                if ((lane >> 4) == 0) red[(wm * C::TM * 16 + j * 16 + (lane & 15)) * C::WN + wn] = sum;
+                if ((lane >> 4) == 0) red[(wm * TME * 16 + j * 16 + (lane & 15)) * C::WN + wn] = sum;
             }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < C::TM; ++j) {
+            for (int j = 0; j < TME; ++j) {
                 float tot = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < C::WN; ++wv) tot += red[(wm * C::TM * 16 + j * 16 + (lane & 15)) * C::WN + wv];
+                for (int wv = 0; wv < C::WN; ++wv) tot += red[(wm * TME * 16 + j * 16 + (lane & 15)) * C::WN + wv];
                 if (pass == 0) mean[j] = tot / (float)N;
                 else rstd[j] = rsqrtf(tot / (float)N + 1e-5f);
             }
             __syncthreads();
         }
 #pragma unroll
-        for (int j = 0; j < C::TM; ++j) {
-            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
             if (m >= d.M) continue;
             const size_t orow = (size_t)m * N;
             size_t hrow = 0;
@@ -452,8 +511,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                 hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
             }
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i) {
-                const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
                 if (n >= N) continue;
                 const float4 g4 = *reinterpret_cast<const float4*>(d.ln_g + n), e4 = *reinterpret_cast<const float4*>(d.ln_b + n);
                 float o[4];
@@ -483,19 +542,19 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         return;
     } else {
     // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
-    float dot_part[C::TM];
+    float dot_part[TME];
 #pragma unroll
-    for (int j = 0; j < C::TM; ++j) dot_part[j] = 0.f;
-    float gsum[ST ? C::TN : 1][4], gsq[ST ? C::TN : 1][4];   // ST: per-lane sums over this wave's pixel rows of its 4 channels per n-tile
+    for (int j = 0; j < TME; ++j) dot_part[j] = 0.f;
+    float gsum[ST ? TNE : 1][4], gsq[ST ? TNE : 1][4];   // ST: per-lane sums over this wave's pixel rows of its 4 channels per n-tile
     if constexpr (ST) {
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i)
+        for (int i = 0; i < TNE; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) { gsum[i][r] = 0.f; gsq[i][r] = 0.f; }
     }
 #pragma unroll
-    for (int j = 0; j < C::TM; ++j) {
-        const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+    for (int j = 0; j < TME; ++j) {
+        const int m = m_of(j);
         const bool mv = m < d.M;
         size_t orow = (size_t)m * N;
         size_t hrow = 0;
@@ -523,8 +582,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             }
         }
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i) {
-            const int n = n0 + wn * C::TN * 16 + i * 16 + (lane >> 4) * 4;
+        for (int i = 0; i < TNE; ++i) {
+            const int n = n_of(i);
             if (!mv || n >= N) continue;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if constexpr (PRE) {
@@ -594,7 +653,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         // sample to arrive adds the tile partials in tile order in f64 and writes {mean, rstd}.  Fixed orders everywhere: bitwise
         // reproducible; no workgroup waits for another one.
 #pragma unroll
-        for (int i = 0; i < C::TN; ++i)
+        for (int i = 0; i < TNE; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 float a = gsum[i][r], q = gsq[i][r];
@@ -606,10 +665,10 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         __syncthreads();
         if ((lane & 15) == 0) {
 #pragma unroll
-            for (int i = 0; i < C::TN; ++i)
+            for (int i = 0; i < TNE; ++i)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const int ch = wn * C::TN * 16 + i * 16 + (lane >> 4) * 4 + r;
+                    const int ch = wn * TNE * 16 + i * 16 + (lane >> 4) * 4 + r;
                     red[(wm * BN + ch) * 2] = gsum[i][r];
                     red[(wm * BN + ch) * 2 + 1] = gsq[i][r];
                 }
@@ -634,19 +693,46 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         __syncthreads();
         if (*arrival == (unsigned)(tps * ntiles) - 1u) {
             if (tid == 0) __hip_atomic_store(d.gn_count + sample, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (int g = tid; g < G; g += C::THREADS) {
+            // All threads share the walk over the sample's tps tile partials: thread (chunk = tid / G, group = tid % G) adds tiles chunk,
+            // chunk + nch, ... (four loads in flight at a time), then the chunks are added in chunk order: a fixed order for a given shape,
+            // so the statistics stay bitwise reproducible.  (One thread per group walking all tps partials with dependent L2-bypassing
+            // loads kept this workgroup alive for ~50 us at 72 tiles per sample -- most of the launch: r03 autotune, ResNetV2 stage 0.)
+            double* red64 = reinterpret_cast<double*>(smem + ((2 * C::WM * BN + 2) * 4 + 7) / 8 * 8);
+            const int nch = C::THREADS / G > 0 ? C::THREADS / G : 1;
+            const int g = tid % G, ch = tid / G;
+            if (ch < nch && G <= C::THREADS) {
                 double a = 0.0, q = 0.0;
-                for (int t = 0; t < tps; ++t) {
-                    const float* pp = d.gn_part + ((size_t)(sample * tps + t) * G + g) * 2;
+                const float* base = d.gn_part + ((size_t)sample * tps * G + g) * 2;
+                int t = ch;
+                for (; t + 3 * nch < tps; t += 4 * nch) {
+                    float va[4], vq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* pp = base + (size_t)(t + u * nch) * G * 2;
+                        va[u] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vq[u] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a += (double)va[u]; q += (double)vq[u]; }
+                }
+                for (; t < tps; t += nch) {
+                    const float* pp = base + (size_t)t * G * 2;
                     a += (double)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     q += (double)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
+                red64[(ch * G + g) * 2] = a;
+                red64[(ch * G + g) * 2 + 1] = q;
+            }
+            __syncthreads();
+            if (tid < G) {
+                double a = 0.0, q = 0.0;
+                for (int c2 = 0; c2 < nch; ++c2) { a += red64[(c2 * G + tid) * 2]; q += red64[(c2 * G + tid) * 2 + 1]; }
                 const double cnt = (double)d.gn_hw * cpg;
                 const double mean = a / cnt;
                 double var = q / cnt - mean * mean;
                 var = var > 0.0 ? var : 0.0;
-                d.gn_stats[((size_t)sample * G + g) * 2] = (float)mean;
-                d.gn_stats[((size_t)sample * G + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+                d.gn_stats[((size_t)sample * G + tid) * 2] = (float)mean;
+                d.gn_stats[((size_t)sample * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
             }
         }
     }
@@ -655,13 +741,13 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         __syncthreads();
         if (tid == 0) d.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
+    if (MF == 16 && d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
 #pragma unroll
-        for (int j = 0; j < C::TM; ++j) {
+        for (int j = 0; j < TME; ++j) {
             float s = dot_part[j];
             s += __shfl_xor(s, 16);
             s += __shfl_xor(s, 32);
-            const int m = m0 + wm * C::TM * 16 + j * 16 + (lane & 15);
+            const int m = m_of(j);
             if ((lane >> 4) == 0 && m < d.M) d.out_dot[m] = fmaxf(s + d.dot_b, 0.f);
         }
     }
@@ -686,7 +772,8 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     if constexpr (ST) {
         const int G = d.gn_cpg > 0 ? d.N / d.gn_cpg : 0;
         if (!d.gn_part || !d.gn_count || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
-            (size_t)mtiles * G * 2 > d.gn_part_floats || (size_t)(d.M / d.gn_hw) > d.gn_count_words || (size_t)(2 * C::WM * C::BN + 1) * 4 > lds) {
+            (size_t)mtiles * G * 2 > d.gn_part_floats || (size_t)(d.M / d.gn_hw) > d.gn_count_words || G > C::THREADS ||
+            (size_t)(2 * C::WM * C::BN + 4) * 4 + (size_t)C::THREADS * 16 > lds) {
             err = "igemm: bad GroupNorm-statistics descriptor (pixels per sample must be a multiple of the M tile)";
             return 1;
         }
@@ -752,7 +839,9 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_32x64x128_s3", "igemm_bf16_128x128x64_s2_w8", "igemm_bf16_32x64x128_s3_w8", "igemm_bf16_64x64x64_s4_w8", "igemm_bf16_128x128x32_s3_w8",
                                         "igemm_bf16_cfg25", "igemm_bf16_cfg26", "igemm_bf16_cfg27", "igemm_bf16_cfg28", "igemm_bf16_cfg29",
                                         "conv8p_bf16_256x256x64", "conv8p_bf16_128x256x64", "conv8p_bf16_256x128x64", "conv8p_var33", "conv8p_var34", "conv8p_var35", "conv8p_var36",
-                                        "conv8p_var37", "conv8p_var38", "conv8p_var39"};
+                                        "conv8p_var37", "conv8p_var38", "conv8p_var39",
+                                        "igemm_bf16_128x128x64_s2_m32", "igemm_bf16_128x128x64_s2_w8_m32", "igemm_bf16_256x128x64_s2_m32", "igemm_bf16_128x256x64_s2_m32",
+                                        "igemm_bf16_256x256x64_s2_m32", "igemm_bf16_128x128x64_s3_m32"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
@@ -760,7 +849,8 @@ static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64
                                           "igemm_x3_128x128x64_s2_w8", "igemm_x3_64x64x64_s3", "igemm_x3_32x64x64_s3_w8", "igemm_x3_64x128x32_s3"};
 constexpr int kNumCfgX3 = 12;
 static int pick_cfg_f32(const IgemmDesc& d) {
-    if (d.x3 && d.tune >= 0 && d.tune < kNumCfgX3 && !d.gn_stats && !need_gen(d) && !d.ln_g && d.N > 32 && d.splitk <= 1) {   // in-network tuning (x3 tiles)
+    const bool tunable = !d.gn_stats && !need_gen(d) && !d.ln_g && d.N > 32 && d.splitk <= 1;
+    if (d.x3 && d.tune >= 0 && d.tune < kNumCfgX3 && tunable) {   // in-network tuning (x3 tiles)
         if (d.tune >= 8 && d.tune <= 10 && d.Cin % 64) return 1;   // 64-deep k-tiles
         return d.tune;
     }
@@ -768,7 +858,23 @@ static int pick_cfg_f32(const IgemmDesc& d) {
     if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
     if (d.N <= 32) return 2;
-    const long b128 = (long)((d.M + 127) / 128) * ((d.N + 127) / 128);
+    auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+    const long b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
+    if (d.x3 && d.splitk <= 1) {
+        // Rules read off IN-NETWORK timings of every x3 tile at every launch site of the three models (tools/autotune_network.py ... f16x3,
+        // profiles/r03_autotune_x3_*.txt).  The x3 tiles carry 3 MFMAs per 2x the staged bytes of an fp16 tile, so what matters is (1) enough
+        // workgroups for the 256 CUs, (2) waves per SIMD to overlap LDS-DMA issue with the other wave's MFMAs: the 8-wave 64 x 64 tile replaces
+        // the 4-wave one everywhere except the mid-size 3x3 convolutions, 32 x 64 tiles with 64-deep k-steps take the small grids, and the
+        // large convolutions want two resident workgroups (128 x 64, 3 stages) or the 64-deep 128 x 128 tile.
+        const bool k64 = d.Cin % 64 == 0;
+        const long K = (long)d.taps * d.Cin, b64 = cdiv(d.M, 64) * cdiv(d.N, 64), t128x64 = cdiv(d.M, 128) * cdiv(d.N, 64);
+        if (d.taps == 9 && b128 >= 2048 && k64) return 8;
+        if (d.taps == 9 && b128 >= 384) return 7;
+        if (d.taps == 1 && K >= 768 && b128 >= 256 && k64) return 8;
+        if (d.taps == 1 && K >= 1536 && t128x64 >= 256) return 7;
+        if (b64 <= 256 && k64) return 10;
+        return d.taps == 9 ? 1 : 4;
+    }
     // 8 waves (64 x 32 per wave) like the bf16 form: f32 forward 1093 -> 1126 frames/s, training step 45.0 -> 44.2 ms, alternated in one GPU call
     return b128 >= 384 ? 3 : 1;
 }
@@ -933,7 +1039,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if (id >= 30 && id <= 39) return launch_conv8p(d, id - 30, stream, err);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 45)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
@@ -961,6 +1067,13 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 22: return launch_cfg<Cfg<32, 64, 128, 2, 4, 3>>(d, stream, err);   // 8 waves, 16x16 per wave: the small-grid long-K launches are latency chains,
         case 23: return launch_cfg_st<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
         case 24: return launch_cfg<Cfg<128, 128, 32, 2, 4, 3>>(d, stream, err);  // 8 waves, 64x32 per wave, 32-deep k-tiles (C = 96: layer1_rn 43 -> 34 us)
+        // v_mfma_f32_32x32x16 forms: same tiles, 32 x 32 MFMA fragments
+        case 40: return launch_cfg<Cfg<128, 128, 64, 2, 2, 2, 32>>(d, stream, err);   // 4 waves, 64 x 64 per wave (2 x 2 MFMAs)
+        case 41: return launch_cfg<Cfg<128, 128, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 64 x 32 per wave
+        case 42: return launch_cfg<Cfg<256, 128, 64, 4, 2, 2, 32>>(d, stream, err);   // 8 waves, 64 x 64 per wave
+        case 43: return launch_cfg<Cfg<128, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 64 x 64 per wave
+        case 44: return launch_cfg<Cfg<256, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 128 x 64 per wave
+        case 45: return launch_cfg<Cfg<128, 128, 64, 2, 2, 3, 32>>(d, stream, err);   // 4 waves, 3-stage ring
         case 20:
             if (d.gn_stats || (need_gen(d) && d.splitk <= 1)) return launch_cfg_gen<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, f16_t, false, true, false, true>(d, stream, err)

@@ -6,6 +6,7 @@
 
 #include <string>
 
+#include "../../include/soccdpt_hip.h"
 #include "igemm.h"
 
 namespace soccdpt {
@@ -59,6 +60,11 @@ int launch_training_loss(int B, int H, int W, int h, int w, int C, int compute_s
 int launch_gt_occupancy(int B, int H, int W, int C, const double* intr, const double* pc_scale, const double* pc_shift, const double* rot27,
                         const float* occ_shape, const int* grid, float threshold, const float* disparity, const int32_t* seg_class, float* depth,
                         double* points, uint32_t* counts, uint8_t* occ, hipStream_t st, std::string& err);
+
+// upsample_bwd.hip: backward of the projection stage's differentiable outputs (bicubic + clamp, nearest, back-projected points)
+size_t upsample_bwd_scratch_bytes(const soccdpt_config& cfg, int B, int h);
+int launch_upsample_bwd(const soccdpt_config& cfg, const float* inv_up, const float* d_inv_up, const float* d_seg_up, const float* d_points, int B, int h, int w,
+                        float* d_inv, float* d_seg, void* scratch, hipStream_t st, std::string& err);
 
 // input_transform.hip: uint8 HWC frame -> bicubic (OpenCV 8-bit fixed point) resize -> (x - mean) / std -> float32 CHW
 int launch_input_transform_u8(const uint8_t* img, int B, int Hs, int Ws, int Hd, int Wd, const double* mean, const double* stdv, float* out,

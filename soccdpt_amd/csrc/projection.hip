@@ -17,6 +17,7 @@
 // + one occupancy row gx*gy*gz*C*4.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "internal.h"
 #include "resample.h"
@@ -331,6 +332,236 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
     }
 }
 
+
+// Multi-row form of project_rows_kernel (round 3): one workgroup = R consecutive camera rows x 1024 pixels.  The round-2 kernel was bound by
+// VALU issue as much as by HBM (~250 instructions per pixel: the x-direction bicubic taps and weights, six IEEE divisions, three K = 3
+// rotations), so this form removes arithmetic that does not depend on the row:
+//   * a thread keeps its 4 columns' x taps / weights / nearest column / (v - cx) over the R rows (cubic_taps is ~45 instructions);
+//   * the R rows share their bicubic source rows (4 + ceil((R-1) h/Hc) + 1 <= NR rows) and nearest class rows (<= 2), staged once;
+//   * rotations Rb, Rc are skipped when they are exactly the identity (the constructor's correction_angle = (7, 0, 0)): for finite points
+//     fma(z, 0, fma(y, 0, x * 1)) == x bit for bit, and a non-finite coordinate leaves the voxel out either way (the isfinite test);
+//   * one barrier for staging and one for the cross-wave voxel de-duplication per workgroup instead of per row; the points leave through a
+//     wave-private LDS transpose (no barrier); the voxel check loads of all R rows are issued together, then the ORs.
+// Per-pixel arithmetic, its order and therefore every output bit are those of project_rows_kernel / oracle/projection_ref.c.
+template <int C, int SW, int R, int NR>
+__global__ __launch_bounds__(256) void project_rowsR_kernel(ProjParams P, int nseg, int rot_bc_identity) {
+    __shared__ float s_inv[NR][SW];
+    __shared__ float s_seg[C][2][SW];
+    __shared__ float4 s_pts[4][3 * 64];   // per wave: 64 threads x 3 float4
+    __shared__ int s_lk[R][4];
+    __shared__ uint32_t s_lc[R][4];
+    int bid = blockIdx.x;
+    const int seg = bid % nseg;
+    bid /= nseg;
+    const int ngrp = (P.Hc + R - 1) / R;
+    const int u0 = (bid % ngrp) * R;
+    const int b = bid / ngrp;
+    const float sy = (float)P.h / (float)P.Hc;
+    const float sx = (float)P.w / (float)P.Wc;
+    const size_t npix = (size_t)P.Hc * P.Wc;
+    const int vlo = seg * 1024;
+    const int vhi = (vlo + 1024 < P.Wc) ? vlo + 1024 : P.Wc;
+    const int ulast = (u0 + R - 1 < P.Hc) ? u0 + R - 1 : P.Hc - 1;
+    // source rows of the group: idx[0] of the first row .. idx[3] of the last (taps are clamped into [0, h-1], monotone in u)
+    const int r_lo = cubic_taps(u0, P.h, sy).idx[0];
+    const int su0 = nearest_src(u0, P.h, sy);
+    int c_lo = (int)floorf(fmaf(sx, (float)vlo + 0.5f, -0.5f)) - 1;
+    c_lo = c_lo < 0 ? 0 : c_lo;
+    {
+        const float* src = P.inv + (size_t)b * P.h * P.w;
+        int col = c_lo + (int)threadIdx.x;
+        col = col > P.w - 1 ? P.w - 1 : col;
+        if (threadIdx.x < SW) {
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                int rr = r_lo + i;
+                rr = rr > P.h - 1 ? P.h - 1 : rr;
+                s_inv[i][threadIdx.x] = src[(size_t)rr * P.w + col];
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) {
+                    int rr = su0 + k;
+                    rr = rr > P.h - 1 ? P.h - 1 : rr;
+                    s_seg[c][k][threadIdx.x] = P.seg[(((size_t)b * C + c) * P.h + rr) * P.w + col];
+                }
+        }
+    }
+    __syncthreads();
+    const int v0 = vlo + (int)threadIdx.x * 4;
+    const bool valid = v0 < vhi;   // (no early return: every thread reaches the barrier below)
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // ---- per-column state, shared by the R rows ----
+    int ci[4][4], csv[4];
+    float cw[4][4], xt[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int v = v0 + e;
+        const Taps tx = cubic_taps(v, P.w, sx);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { ci[e][k] = tx.idx[k] - c_lo; cw[e][k] = tx.w[k]; }
+        csv[e] = nearest_src(v, P.w, sx) - c_lo;
+        xt[e] = (float)v - P.cx;
+        if (!valid) {   // keep LDS indices in range for the (unused) lanes past the row end
+#pragma unroll
+            for (int k = 0; k < 4; ++k) ci[e][k] = 0;
+            csv[e] = 0;
+        }
+    }
+    int vkey[R][4];       // first cell index of the pixel's voxel (its C class bits are adjacent), -1 = not in the grid
+    uint32_t vcm[R][4];   // classes with non-zero probability
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int u = u0 + r;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { vkey[r][e] = -1; vcm[r][e] = 0; }
+        if (u > ulast) continue;    // wave-uniform
+        const Taps ty = cubic_taps(u, P.h, sy);
+        const int sr = nearest_src(u, P.h, sy) - su0;
+        const float* q0 = s_inv[ty.idx[0] - r_lo];
+        const float* q1 = s_inv[ty.idx[1] - r_lo];
+        const float* q2 = s_inv[ty.idx[2] - r_lo];
+        const float* q3 = s_inv[ty.idx[3] - r_lo];
+        const float yterm = (float)u - P.cy;
+        float iv[4], sem[C][4], pt[4][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int v = v0 + e;
+            const int i0 = ci[e][0], i1 = ci[e][1], i2 = ci[e][2], i3 = ci[e][3];
+            float t0 = dot4(q0[i0], q0[i1], q0[i2], q0[i3], cw[e]);
+            float t1 = dot4(q1[i0], q1[i1], q1[i2], q1[i3], cw[e]);
+            float t2 = dot4(q2[i0], q2[i1], q2[i2], q2[i3], cw[e]);
+            float t3 = dot4(q3[i0], q3[i1], q3[i2], q3[i3], cw[e]);
+            float val = dot4(t0, t1, t2, t3, ty.w);
+            if (val < 1e-8f) val = 1e-8f;  // NaN compares false and stays NaN
+            float d = 1.0f / val;
+            if (isinf(d) || isnan(d)) d = __builtin_inff();
+            iv[e] = val;
+#pragma unroll
+            for (int c = 0; c < C; ++c) sem[c][e] = s_seg[c][sr][csv[e]];
+            float p[3];
+            p[0] = (xt[e] * d) / P.fx;
+            p[1] = (yterm * d) / P.fy;
+            p[2] = d;
+            const size_t n = (size_t)u * P.Wc + v;
+            if (n < 3) {  // the reference scales/shifts flat pixels 0,1,2 of each image
+#pragma unroll
+                for (int k = 0; k < 3; ++k) p[k] = p[k] * P.pc_scale[n] + P.pc_shift[n];
+            }
+            pt[e][0] = p[0];
+            pt[e][1] = p[1];
+            pt[e][2] = p[2];
+            if (P.occ_bits && valid) {
+                float a[3], cq[3];
+                rot3(p, P.rot, a);
+                if (rot_bc_identity) {
+                    cq[0] = a[0]; cq[1] = a[1]; cq[2] = a[2];
+                } else {
+                    float bq[3];
+                    rot3(a, P.rot + 9, bq);
+                    rot3(bq, P.rot + 18, cq);
+                }
+                const bool fin = isfinite(cq[0]) && isfinite(cq[1]) && isfinite(cq[2]);
+                const float fi = (cq[0] / P.occ_shape[0]) * (float)P.grid[0];
+                const float fj = (cq[1] / P.occ_shape[1]) * (float)P.grid[1];
+                const float fk = (cq[2] / P.occ_shape[2]) * (float)P.grid[2];
+                const bool inr = fin && fi > -1.0f && fi < 65536.0f && fj > -1.0f && fj < 65536.0f && fk > -1.0f && fk < 65536.0f;
+                if (inr) {
+                    const int i = (int)fi, j = (int)fj, k = (int)fk;
+                    if (0 < i && i < P.grid[0] && 0 < j && j < P.grid[1] && 0 < k && k < P.grid[2]) {
+                        uint32_t cm = 0;
+#pragma unroll
+                        for (int c = 0; c < C; ++c) cm |= (sem[c][e] != 0.0f) ? (1u << c) : 0u;
+                        if (cm) {
+                            vkey[r][e] = ((i * P.grid[1] + j) * P.grid[2] + k) * C;
+                            vcm[r][e] = cm;
+                        }
+                    }
+                }
+            }
+        }
+        // ---- this row's stores ----
+        const size_t n0 = (size_t)u * P.Wc + v0;
+        typedef __attribute__((ext_vector_type(4))) float v4f;
+        if (valid) {
+            if (P.inv_up) __builtin_nontemporal_store(v4f{iv[0], iv[1], iv[2], iv[3]}, reinterpret_cast<v4f*>(P.inv_up + (size_t)b * npix + n0));
+            if (P.seg_up) {
+#pragma unroll
+                for (int c = 0; c < C; ++c)
+                    __builtin_nontemporal_store(v4f{sem[c][0], sem[c][1], sem[c][2], sem[c][3]}, reinterpret_cast<v4f*>(P.seg_up + ((size_t)b * C + c) * npix + n0));
+            }
+        }
+        if (P.points) {
+            // a thread's 4 points are 48 contiguous bytes; a wave's 64 threads own 3 KB of contiguous output: through the wave's private LDS
+            // slab they leave as three fully contiguous 1 KB stores (no workgroup barrier: only this wave touches the slab)
+            float4* sp = s_pts[wave];
+            sp[3 * lane + 0] = make_float4(pt[0][0], pt[0][1], pt[0][2], pt[1][0]);
+            sp[3 * lane + 1] = make_float4(pt[1][1], pt[1][2], pt[2][0], pt[2][1]);
+            sp[3 * lane + 2] = make_float4(pt[2][2], pt[3][0], pt[3][1], pt[3][2]);
+            __builtin_amdgcn_wave_barrier();
+            const int wv0 = vlo + wave * 256;                  // first pixel of this wave
+            const int nf4 = wv0 < vhi ? ((vhi - wv0 < 256 ? vhi - wv0 : 256) / 4) * 3 : 0;   // float4 slots the wave owns in this row
+            float4* o = reinterpret_cast<float4*>(P.points + ((size_t)b * npix + (size_t)u * P.Wc + wv0) * 3);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int idx = k * 64 + lane;
+                if (idx < nf4) {
+                    const float4 qv = sp[idx];
+                    __builtin_nontemporal_store(v4f{qv.x, qv.y, qv.z, qv.w}, reinterpret_cast<v4f*>(o + idx));
+                }
+            }
+            __builtin_amdgcn_wave_barrier();   // the slab is rewritten for the next row
+        }
+    }
+    // ---- voxel marking with run-length de-duplication along each camera row (see project_rows_kernel) ----
+    if (P.occ_bits) {
+        if (lane == 63) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { s_lk[r][wave] = vkey[r][3]; s_lc[r][wave] = vcm[r][3]; }
+        }
+        __syncthreads();
+        uint32_t cur_lo[R][4], cur_hi[R][4];
+        bool act[R][4];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            int pk = __shfl_up(vkey[r][3], 1);
+            uint32_t pc = __shfl_up(vcm[r][3], 1);
+            if (lane == 0) {
+                if (wave == 0) { pk = -2; pc = 0; }
+                else { pk = s_lk[r][wave - 1]; pc = s_lc[r][wave - 1]; }
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                act[r][e] = vkey[r][e] >= 0 && (vkey[r][e] != pk || (vcm[r][e] & ~pc));
+                cur_lo[r][e] = ~0u; cur_hi[r][e] = ~0u;
+                if (act[r][e]) {   // all R x 4 check loads go out before the first result is needed
+                    const uint32_t bit = (uint32_t)vkey[r][e];
+                    const uint32_t* wp = P.occ_bits + (bit >> 5);
+                    cur_lo[r][e] = __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if ((bit & 31) + C > 32) cur_hi[r][e] = __hip_atomic_load(wp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                pk = vkey[r][e];
+                pc = vcm[r][e];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (act[r][e]) {
+                    const uint32_t bit = (uint32_t)vkey[r][e];
+                    const unsigned long long m = (unsigned long long)vcm[r][e] << (bit & 31);
+                    const uint32_t mlo = (uint32_t)m, mhi = (uint32_t)(m >> 32);
+                    uint32_t* wp = P.occ_bits + (bit >> 5);
+                    // idempotent OR: a stale read only costs a redundant atomic
+                    if ((cur_lo[r][e] & mlo) != mlo) atomicOr(wp, mlo);
+                    if (mhi && (cur_hi[r][e] & mhi) != mhi) atomicOr(wp + 1, mhi);
+                }
+            }
+    }
+}
+
 // bits -> f32, every batch row gets the same union grid.  One thread = 4 consecutive cells.
 __global__ __launch_bounds__(256) void occ_expand_kernel(const uint32_t* __restrict__ bits, float* __restrict__ occ, size_t ncell, int B) {
     const size_t nq = ncell / 4;
@@ -388,6 +619,19 @@ int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg
     const float sx_h = (float)P.w / (float)P.Wc;
     if (vec4 && (int)(1024.0f * sx_h) + 8 <= SW) {
         const int nseg = (P.Wc + 1023) / 1024;
+        constexpr int R = 4, NR = 7;
+        // the R rows of a group need source rows idx0(u0) .. idx3(u0 + R - 1): at most 4 + ceil((R - 1) h / Hc) + 1
+        const float sy_h = (float)P.h / (float)P.Hc;
+        static const int force_rows1 = getenv("SOCCDPT_PROJECT_ROWS1") ? atoi(getenv("SOCCDPT_PROJECT_ROWS1")) : 0;   // A/B against the one-row kernel
+        if (!force_rows1 && 5 + (int)ceilf((R - 1) * sy_h) <= NR && 1.0f + (R - 1) * sy_h < 2.0f) {
+            bool ident = true;   // Rb and Rc exactly the identity? (rotate_points with b = c = 0)
+            for (int i = 0; i < 9; ++i) ident = ident && P.rot[9 + i] == ((i % 4 == 0) ? 1.0f : 0.0f) && P.rot[18 + i] == ((i % 4 == 0) ? 1.0f : 0.0f);
+            const int ngrp = (P.Hc + R - 1) / R;
+            SOCCDPT_LAUNCH((project_rowsR_kernel<3, SW, R, NR>), dim3((unsigned)(B * ngrp * nseg)), dim3(256), 0, stream, P, nseg, ident ? 1 : 0);
+            hipError_t e3 = hipGetLastError();
+            if (e3 != hipSuccess) { err = hipGetErrorString(e3); return 1; }
+            return 0;
+        }
         SOCCDPT_LAUNCH((project_rows_kernel<3, SW>), dim3((unsigned)(B * P.Hc * nseg)), dim3(256), 0, stream, P, nseg);
         hipError_t e2 = hipGetLastError();
         if (e2 != hipSuccess) { err = hipGetErrorString(e2); return 1; }

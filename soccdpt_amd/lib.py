@@ -141,6 +141,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_train_backward_encoder.argtypes = [vp, ci, ctypes.POINTER(vp), vp, cs, vp]
     L.soccdpt_train_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs)]
     L.soccdpt_project.restype = ci
+    L.soccdpt_project_backward_scratch_bytes.argtypes = [vp, ci, ci]
+    L.soccdpt_project_backward_scratch_bytes.restype = cs
+    L.soccdpt_project_backward.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, vp, vp, vp, cs, vp]
+    L.soccdpt_project_backward.restype = ci
     L.soccdpt_occ_or.argtypes = [vp, vp, vp, ci, vp]
     L.soccdpt_occ_or.restype = ci
     L.soccdpt_occ_expand.argtypes = [vp, vp, ci, vp, vp]
@@ -348,6 +352,22 @@ class Engine:
             self._check(self.L.soccdpt_project(self._h, _ptr(inv), _ptr(seg), B, h, w, _ptr(inv_up), _ptr(seg_up),
                                                _ptr(points), _ptr(occ_bits), 1 if clear_bits else 0,
                                                _stream_ptr(self.device)), "soccdpt_project")
+
+    def project_backward(self, inv_up: torch.Tensor, d_inv_up, d_seg_up, d_points, in_h: int, in_w: int):
+        """Gradients of the projection stage's differentiable outputs w.r.t. the network outputs (soccdpt_project_backward):
+        -> (d_inv [B,in_h,in_w], d_seg [B,C,in_h,in_w])."""
+        B = inv_up.shape[0]
+        C = self.cfg.num_classes
+        d_inv = torch.empty((B, in_h, in_w), device=self.device)
+        d_seg = torch.empty((B, C, in_h, in_w), device=self.device)
+        nbytes = self.L.soccdpt_project_backward_scratch_bytes(self._h, B, in_h)
+        scratch = torch.empty(max(nbytes, 16), dtype=torch.uint8, device=self.device)
+        prep = lambda t: None if t is None else t.detach().to(torch.float32).contiguous()
+        a, b, c = prep(d_inv_up), prep(d_seg_up), prep(d_points)
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_project_backward(self._h, _ptr(inv_up.contiguous()), _ptr(a), _ptr(b), _ptr(c), B, in_h, in_w, _ptr(d_inv), _ptr(d_seg),
+                                                        scratch.data_ptr(), scratch.numel(), _stream_ptr(self.device)), "soccdpt_project_backward")
+        return d_inv, d_seg
 
     # ---- in-network tile tuning (tools/autotune_network.py) ----
     def profile_sites(self, on: bool):

@@ -219,8 +219,9 @@ class SOccDPT_V3(SOccDPT):
         """x [B,3,S,S] f32 on cuda -> (inv_depth, segmentation, points, occupancy | None); see SOccDPT_V3.forward
         (/root/reference/SOccDPT/model/SOccDPT.py:681-685)."""
         if self.training:
-            raise RuntimeError("the MI355X path implements the eval-mode forward; call net.eval() "
-                               "(patch-wise training is the next scope row, SURVEY.md §8f)")
+            # train mode: the same 4-tuple with autograd attached, so the reference's loop body runs unchanged
+            # (scripts/train_SOccDPT.py:365-393: net_patch(x), any criterion in torch ops, grad_scaler.scale(loss).backward())
+            return self._forward_train(x)
         img = backbone_image_size(self._engine_backbone())
         assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, \
             f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
@@ -245,6 +246,26 @@ class SOccDPT_V3(SOccDPT):
             occ = self._finish_occupancy(eng, bits, B)
         self.last_occ_bits = bits
         return self._shape_outputs(inv_up, seg_up, points, occ)
+
+    def _forward_train(self, x: torch.Tensor):
+        """SOccDPT_V3.forward under net.train(): train-mode network forward (batch-statistics BatchNorm, Dropout) -> bicubic + clamp / nearest
+        up-sampling -> points (-> occupancy) exactly like the eval path, returned as autograd-tracked tensors.  loss.backward() on any torch
+        expression of inv_depth / segmentation / points runs soccdpt_project_backward + soccdpt_train_backward and leaves the gradients in .grad of
+        the parameters that have requires_grad (freeze / unfreeze-by-percentage / PatchWiseInplace work as with an nn.Module built from torch ops).
+        The library keeps ONE tape per handle: backward belongs to the most recent train-mode forward."""
+        anchor = self.__dict__.get("_autograd_anchor")
+        if anchor is None or anchor.device != x.device:
+            anchor = torch.zeros((), device=x.device, requires_grad=True)   # makes autograd record the node: the parameters are not inputs of it
+            self.__dict__["_autograd_anchor"] = anchor
+        if not torch.is_grad_enabled():
+            inv, seg = self.train_forward(x)
+            return self.get_semantic_occupancy(inv, seg)
+        out = _TrainForward.apply(self, x, anchor)
+        inv_up, seg_up, points = out[0], out[1], out[2]
+        occ = out[3] if len(out) > 3 else None
+        if seg_up.shape[0] == 1:          # the reference's .squeeze() quirk (model/SOccDPT.py:276-285), as a differentiable view
+            seg_up = seg_up[0]
+        return inv_up, seg_up, points, occ
 
     def _bind_for_training(self, eng: Engine):
         """Bind the LIVE parameters / buffers (the training step reads weights as bound: no prepare) and one gradient buffer per
@@ -363,6 +384,44 @@ class SOccDPT_V3(SOccDPT):
         seg = torch.empty((B, self.num_classes, S, S), device=x.device)
         eng.network(x.detach().to(torch.float32).contiguous(), inv, seg)
         return inv, seg
+
+
+class _TrainForward(torch.autograd.Function):
+    """Autograd node of the train-mode SOccDPT_V3.forward: forward = soccdpt_train_forward + soccdpt_project, backward =
+    soccdpt_project_backward + soccdpt_train_backward (parameter gradients land in .grad as a side effect, like any leaf accumulation)."""
+
+    @staticmethod
+    def forward(ctx, net, x, anchor):
+        ctx.set_materialize_grads(False)
+        inv, seg = net.train_forward(x)
+        net._train_generation = getattr(net, "_train_generation", 0) + 1
+        eng = net._engine(x.device)
+        dev = x.device
+        B, C, Hc, Wc = inv.shape[0], net.num_classes, net.height, net.width
+        inv_up = torch.empty((B, Hc, Wc), device=dev)
+        seg_up = torch.empty((B, C, Hc, Wc), device=dev)
+        points = torch.empty((B, Hc, Wc, 3), device=dev)
+        bits = torch.empty((eng.occ_words(),), dtype=torch.int32, device=dev) if net.compute_occ else None
+        eng.project(inv, seg, inv_up, seg_up, points, bits, clear_bits=True)
+        ctx.net, ctx.generation, ctx.hw = net, net._train_generation, (inv.shape[1], inv.shape[2])
+        ctx.save_for_backward(inv_up)
+        if net.compute_occ:
+            occ = net._finish_occupancy(eng, bits, B)
+            ctx.mark_non_differentiable(occ)
+            return inv_up, seg_up, points, occ
+        return inv_up, seg_up, points
+
+    @staticmethod
+    def backward(ctx, g_inv, g_seg, g_pts, *g_rest):
+        net = ctx.net
+        if ctx.generation != getattr(net, "_train_generation", 0):
+            raise RuntimeError("SOccDPT_V3: backward through a train-mode forward that is not the most recent one (the library keeps one tape per handle: "
+                               "call loss.backward() before the next net(x))")
+        (inv_up,) = ctx.saved_tensors
+        eng = net._engine(inv_up.device)
+        d_inv, d_seg = eng.project_backward(inv_up, g_inv, g_seg, g_pts, ctx.hw[0], ctx.hw[1])
+        net.backward(d_inv, d_seg)
+        return None, None, None
 
 
 def _not_in_scope(version):

@@ -82,7 +82,7 @@ def test_igemm_conv3x3(gpu_device, B, H, Cin, Cout):
         torch.testing.assert_close(o, ref, rtol=1e-4, atol=2e-4, msg=f"tune={tune}")
 
 
-@pytest.mark.parametrize("tune", [6, 7, 8, 10, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 24])
+@pytest.mark.parametrize("tune", [6, 7, 8, 10, 13, 14, 15, 16, 17, 18, 20, 21, 22, 23, 24, 40, 41, 42, 43, 44, 45])   # 40-45: the v_mfma_f32_32x32x16 forms
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 def test_igemm_big_tiles_ragged(gpu_device, tune, prec):
     """The 8-wave tiles (incl. the skewed wave-row schedule of the 2 x 4 layouts) and the other heuristic-only configurations on a
@@ -90,7 +90,7 @@ def test_igemm_big_tiles_ragged(gpu_device, tune, prec):
     from soccdpt_amd.lib import PREC_BF16, PREC_F16, op_igemm
     dt = torch.bfloat16 if prec == "bf16" else torch.float16
     B, H, Cout = 1, 40, 256
-    Cin = 128 if tune in (6, 7, 8, 10, 13, 14, 20, 21, 22, 23) else 96  # the x32 configurations also take Cin % 64 != 0
+    Cin = 128 if tune in (6, 7, 8, 10, 13, 14, 20, 21, 22, 23, 40, 41, 42, 43, 44, 45) else 96  # the x32 configurations also take Cin % 64 != 0
     g = torch.Generator().manual_seed(tune)
     x = torch.randn(B, Cin, H, H, generator=g).to(dt).to(gpu_device)
     w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).to(dt).to(gpu_device)

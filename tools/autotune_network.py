@@ -45,7 +45,7 @@ sites = eng.sites()
 total_base = sum(base.values())
 print(f"{model_type} B={B}: {len(sites)} distinct igemm shapes, {sum(s['launches'] for s in sites) // (REPS + 0)} launches profiled, "
       f"{total_base:.0f} us of igemm per forward with the heuristic")
-K64 = [2, 1, 13, 10, 14, 8, 6, 20, 21, 22, 23]
+K64 = [2, 1, 13, 10, 14, 8, 6, 20, 21, 22, 23] + ([40, 41, 42, 43, 45] if os.environ.get('AUTOTUNE_M32') == '1' else [])
 K32 = [4, 9, 19, 15, 16, 24] + [int(c) for c in os.environ.get('AUTOTUNE_EXTRA', '').split(',') if c]
 results = []
 for s in sites:

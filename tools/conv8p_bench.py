@@ -23,6 +23,8 @@ for name, B, H, Cin, Cout in shapes:
     outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=dev)
     M = B * H * H
     cands = [21, 1, 16, 30, 31, 32] if Cout % 256 == 0 else [21, 1, 32]
+    if os.environ.get("CONV_BENCH_M32") == "1":   # the v_mfma_f32_32x32x16 forms (40-45) against the 16x16x32 tiles of the same shape
+        cands = [21, 41, 1, 40, 45, 42] + ([43, 44, 30] if Cout % 256 == 0 else [])
     if ABL:
         cands = [21, 30, 33, 34, 35, 36, 37, 38, 39]
     res = {c: [] for c in cands}
