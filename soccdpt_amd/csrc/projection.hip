@@ -341,7 +341,13 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
 //   * rotations Rb, Rc are skipped when they are exactly the identity (the constructor's correction_angle = (7, 0, 0)): for finite points
 //     fma(z, 0, fma(y, 0, x * 1)) == x bit for bit, and a non-finite coordinate leaves the voxel out either way (the isfinite test);
 //   * one barrier for staging and one for the cross-wave voxel de-duplication per workgroup instead of per row; the points leave through a
-//     wave-private LDS transpose (no barrier); the voxel check loads of all R rows are issued together, then the ORs.
+//     wave-private LDS transpose (no barrier); the voxel check loads of all R rows are issued together, then the ORs;
+//   * the run-length de-duplication of the voxel marks is two-dimensional inside the group: a pixel covered by its left neighbour OR by the
+//     pixel above it does not touch the grid (a 0.5 m voxel spans several rows as well as tens of columns).
+// Measured in the network (B = 8, profiles/r03_*): 142 -> 111 us (3.33 -> 4.25 TB/s of algorithmic bytes).  Tried on top and dropped: R = 2 / 3 (slower),
+// software-pipelined marking without the barrier (133 us: a check load is only consumable after the row's older stores have drained, vmcnt is
+// in-order), forcing 5 waves per SIMD (spills: 184 us), and multiply-and-correct division by the five run-time constants (verified bit-equal to
+// IEEE division for all 2^23 significands per constant, but no faster: 111 us -- the kernel is not VALU-bound any more).
 // Per-pixel arithmetic, its order and therefore every output bit are those of project_rows_kernel / oracle/projection_ref.c.
 template <int C, int SW, int R, int NR>
 __global__ __launch_bounds__(256) void project_rowsR_kernel(ProjParams P, int nseg, int rot_bc_identity) {
@@ -534,6 +540,10 @@ __global__ __launch_bounds__(256) void project_rowsR_kernel(ProjParams P, int ns
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 act[r][e] = vkey[r][e] >= 0 && (vkey[r][e] != pk || (vcm[r][e] & ~pc));
+                // ... and not covered by the pixel ABOVE it in this group (same thread, previous row): a 0.5 m voxel spans several camera rows too.
+                // By induction along left / up chains every skipped pixel's bits are set by an acting pixel (row 0 chains left to the first
+                // pixel of the row, which always acts).
+                if (r > 0 && vkey[r][e] == vkey[r - 1][e] && !(vcm[r][e] & ~vcm[r - 1][e])) act[r][e] = false;
                 cur_lo[r][e] = ~0u; cur_hi[r][e] = ~0u;
                 if (act[r][e]) {   // all R x 4 check loads go out before the first result is needed
                     const uint32_t bit = (uint32_t)vkey[r][e];
