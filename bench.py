@@ -60,7 +60,7 @@ def train_step_bench(args):
     sd = synth_state_dict(backbone, alias_pretrained=True)
     net.load_state_dict(sd, strict=False)
     net = net.to(dev).train()
-    net.train_amp = bool(args.amp)
+    net.train_amp = args.amp or False
     freeze_pretrained_encoder(net)
     unfreeze_pretrained_encoder_by_percentage(net, args.encoder_percentage)
     x, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(SyntheticDepthSegDataset(B, S), B, B)
@@ -116,7 +116,7 @@ def train_step_bench(args):
                "sample": f"oracle forward + torch autograd backward on {xc.shape[0]} samples (no criterion / optimizer)"}
     result = {"metric": f"samples/sec SOccDPT_V3 {args.model_type.replace('dpt_', '')} training step (train forward + criterion + backward + Adam)",
               "value": round(sps, 2), "unit": "samples/s", "n_gpus": 1, "steps": n, "warmup": max(1, min(args.warmup, 5)), "ms_per_step": round(1e3 * dt / n, 3),
-              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32 forward, bf16-operand gradient GEMMs" if args.amp else "f32", "data": "synthetic",
+              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": (f"f32 forward, {args.amp}-operand gradient GEMMs" if args.amp else "f32"), "data": "synthetic",
               "config": {"workload": f"SOccDPT_V3 {args.model_type} patch-wise training step, synthetic 1080x1920 targets", "batch_per_gpu": B, "image": S,
                          "encoder_percentage": args.encoder_percentage, "patchwise_percentage": args.patchwise_percentage,
                          "trainable_tensors": sum(1 for q in net.parameters() if q.requires_grad)},
@@ -190,7 +190,9 @@ def main():
     ap.add_argument("--train-step", action="store_true",
                     help="BASELINE configs[4] instead of the forward: one optimisation step (train-mode forward + criterion + backward + fused Adam, exact f32) "
                          "per PatchWiseInplace patch; N = 1")
-    ap.add_argument("--amp", action="store_true", help="--train-step: bf16 MFMA operands for the gradient GEMMs (the reference's amp sweep parameter)")
+    ap.add_argument("--amp", nargs="?", const="bf16", default=None, choices=["bf16", "f16", "x3"],
+                    help="--train-step: operand format of the gradient GEMMs (the reference's amp sweep parameter): bf16 (default when given), f16, or "
+                         "x3 = split-operand fp16 (three fp16 MFMAs per product: f32-grade gradients, no loss scaling)")
     ap.add_argument("--encoder-percentage", type=float, default=1.0, help="--train-step: unfreeze_pretrained_encoder_by_percentage")
     ap.add_argument("--patchwise-percentage", type=float, default=1.0, help="--train-step: PatchWiseInplace")
     args = ap.parse_args()

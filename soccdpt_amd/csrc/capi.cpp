@@ -115,7 +115,7 @@ int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad) {
 int soccdpt_train_set_amp(void* handle, int on) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
-    if (on < 0 || on > 2) return fail(h, "soccdpt_train_set_amp: mode must be 0 (off), 1 (bf16) or 2 (fp16)");
+    if (on < 0 || on > 3) return fail(h, "soccdpt_train_set_amp: mode must be 0 (off), 1 (bf16), 2 (fp16) or 3 (x3 split fp16)");
     h->train_amp = on;
     return 0;
 }

@@ -66,6 +66,9 @@ struct IgemmDesc {
     // -- nine shifted views (one per tap) of ONE transposed halo image instead of an im2col^T.  wt_grp_rows must be a multiple of 64 (a weight
     // tile never straddles two groups); every shift must be >= 0 (the caller offsets Wt).
     int wt_grp_rows = 0, wt_rp = 0, wt_base = 0, wt_odd = 0;
+    // wt_kx != 0 (x3 operands): shift(g) = wt_base + (g / 3 - 1) * wt_rp + (g % 3) * wt_kx -- the horizontal tap selects one of three pre-shifted COPIES of the
+    // transposed image (copy stride wt_kx) instead of an element offset, so every view starts at a multiple of 16 elements (wt_base, wt_rp, wt_kx % 16 == 0)
+    int wt_kx = 0;
     // ---- epilogue: v = acc (+bias[n]) (+res1[m][n]) (+res2[m][n]); act; stores ----
     const float* bias = nullptr;
     const float* res1 = nullptr;  // f32 [M][N]

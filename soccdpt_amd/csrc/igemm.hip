@@ -155,7 +155,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         n = n < d.N ? n : d.N - 1;
         if (GEN && d.wt_grp_rows) {   // weight row groups: the tile's rows belong to ONE group (wt_grp_rows % BN == 0): a shifted view of the same matrix
             const int g = n0 / d.wt_grp_rows, ky = g / 3, kx = g - ky * 3;
-            const uint32_t shift = (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + (kx - 1) + (kx != 1 ? d.wt_odd : 0));
+            const uint32_t shift = d.wt_kx ? (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + kx * d.wt_kx)
+                                           : (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + (kx - 1) + (kx != 1 ? d.wt_odd : 0));
             w_off[i] = (uint32_t)(n - g * d.wt_grp_rows) * (uint32_t)Ktot + shift + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
         } else
         w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
@@ -986,17 +987,24 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.seg2_k && (d.taps != 1 || d.gather1 || !d.grp_rows || d.seg2_k % 128 != 0 || d.seg2_k >= d.Cin)) { err = "igemm: bad second-segment descriptor"; return 1; }
     if (d.grp_rows && (d.taps != 1 || d.gather1)) { err = "igemm: row groups are a plain-mode feature"; return 1; }
     if (d.wt_grp_rows && (d.taps != 1 || d.gather1 || d.wt_grp_rows % 64 != 0 || d.N > 9 * d.wt_grp_rows || d.N % d.wt_grp_rows != 0 ||
-                          d.wt_base - d.wt_rp - 1 + (d.wt_odd < 0 ? d.wt_odd : 0) < 0)) { err = "igemm: bad weight row-group descriptor"; return 1; }
+                          (!d.wt_kx && d.wt_base - d.wt_rp - 1 + (d.wt_odd < 0 ? d.wt_odd : 0) < 0))) { err = "igemm: bad weight row-group descriptor"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
     if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32 && !d.x3) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.x3) {   // split-fp16 operands (SOCCDPT_PREC_F16X3): the f32 tile set with T = x3_t
-        if (d.wt_grp_rows) { err = "igemm: x3 operands have no shifted weight-row views (8-element units)"; return 1; }
+        if (d.wt_grp_rows && (!d.wt_kx || d.wt_kx % 16 || d.wt_base % 16 || d.wt_rp % 16 || d.wt_base - d.wt_rp < 0)) {
+            err = "igemm: x3 weight-row views must start at multiples of 16 elements (wt_kx copies)";
+            return 1;
+        }
         if (d.ldx % 16 || d.Cin % 32 || (d.out_op && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
         if (d.splitk > 1) {
             if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: x3 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
             if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true, false, true>(d, stream, err);
+            // tune 3 / 8: the 8-wave 128 x 128 tiles (32- / 64-deep k-tiles) for the long-K weight-gradient GEMMs of the training step: four times
+            // the MFMA work per staged byte of the 64 x 64 tile, which the per-CU L2 -> LDS fill rate bounds (train_step.cpp: gemm_wgrad)
+            if (d.tune == 8 && d.Cin % 64 == 0) return launch_cfg_t<Cfg<128, 128, 128, 2, 4, 2>, x3_t, false, true>(d, stream, err);
+            if (d.tune == 3) return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, true>(d, stream, err);
             return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true>(d, stream, err);
         }
         switch (pick_cfg_f32(d)) {

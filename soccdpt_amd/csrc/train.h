@@ -9,7 +9,8 @@ int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t 
 int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err);
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
 int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, int f16, hipStream_t st, std::string& err);
-int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err);
+int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err, int rpp = 0);
+int tr_x_halo_T_x3(const float* halo, void* out, int B, int r, int C, int col0, int ld, int rpp, hipStream_t st, std::string& err);
 int tr_wgrad_permute9(const float* in, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, std::string& err);
 int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, int f16, hipStream_t st, std::string& err);

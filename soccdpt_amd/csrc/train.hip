@@ -23,6 +23,9 @@ template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v;
 template <> __device__ __forceinline__ uint16_t cvt_out<uint16_t>(float v) { return f2h<false>(v); }
 struct f16raw { uint16_t v; };   // IEEE fp16 bits (the amp mode with loss scaling); uint16_t alone means bf16
 template <> __device__ __forceinline__ f16raw cvt_out<f16raw>(float v) { return f16raw{f2h_ieee(v)}; }   // overflow -> inf: GradScaler must see it (half16.h)
+struct x3raw { uint32_t v; };    // element of an x3 split-fp16 operand tensor (half16.h): 4 bytes, written as an fp16 hi / lo pair
+template <typename OT> __device__ __forceinline__ void store_out(OT* out, size_t idx, float v) { out[idx] = cvt_out<OT>(v); }
+template <> __device__ __forceinline__ void store_out<x3raw>(x3raw* out, size_t idx, float v) { x3_store1(out, idx, v); }
 
 // ---------------- layout ----------------
 // [R][C] -> [C][Rp] (Rp >= R: rows padded with zeros up to the k-tile multiple the igemm needs), 32 x 32 tiles through LDS
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int c = bx + i, r = by + tx;
-        if (c < C && r < Rp) out[(size_t)c * Rp + r] = cvt_out<OT>(t[tx][i]);
+        if (c < C && r < Rp) store_out<OT>(out, (size_t)c * Rp + r, t[tx][i]);
     }
 }
 
@@ -64,7 +67,7 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ 
     for (int i = ty; i < 32; i += 8) {
         const int c = c0 + i;
         const size_t m = m0 + tx;
-        if (c < C && m < Mp) out[((size_t)tap * C + c) * Mp + m] = cvt_out<OT>(t[tx][i]);
+        if (c < C && m < Mp) store_out<OT>(out, ((size_t)tap * C + c) * Mp + m, t[tx][i]);
     }
 }
 
@@ -73,17 +76,19 @@ __global__ __launch_bounds__(256) void im2colT_kernel(const float* __restrict__ 
 // off_t = (ky - 1)(r + 2) + (kx - 1): nine pointer offsets into ONE transposed halo image (train_step.cpp: conv3_bwd).  The igemm's 16-byte
 // LDS-DMA loads accept the 4-byte-aligned bases this produces (tests/tools/unaligned_operand_probe.py: same results, same speed).
 // dY [B*r*r][N] plain -> out [N][ld]: column margin + mh holds the pixel's gradient (zero on border pixels and in the margins)
+// rpp: row pitch of the pixel order in the transposed image (>= r + 2).  The f32 / 16-bit paths use rpp = r + 2; the x3 path pads every halo row
+// to a multiple of 16 pixels so that the vertical tap shifts (+- rpp elements) keep the 8-element units of an x3 tensor intact.
 template <typename OT>
-__global__ __launch_bounds__(256) void dy_halo_T_kernel(const float* __restrict__ dy, OT* __restrict__ out, int B, int r, int N, int margin, int ld) {
+__global__ __launch_bounds__(256) void dy_halo_T_kernel(const float* __restrict__ dy, OT* __restrict__ out, int B, int r, int N, int margin, int ld, int rpp) {
     __shared__ float t[32][33];
     const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int rp = r + 2, Mh = B * rp * rp;
+    const int rp = r + 2, Mh = B * rp * rpp;
     for (int i = ty; i < 32; i += 8) {
         const int mh = k0 + i - margin, n = n0 + tx;
         float v = 0.f;
         if (mh >= 0 && mh < Mh && n < N) {
-            const int b = mh / (rp * rp), q = mh - b * rp * rp, yh = q / rp, xh = q - yh * rp;
+            const int b = mh / (rp * rpp), q = mh - b * rp * rpp, yh = q / rpp, xh = q - yh * rpp;
             if (yh >= 1 && yh <= r && xh >= 1 && xh <= r) v = dy[((size_t)(b * r + yh - 1) * r + xh - 1) * N + n];
         }
         t[i][tx] = v;
@@ -91,7 +96,31 @@ __global__ __launch_bounds__(256) void dy_halo_T_kernel(const float* __restrict_
     __syncthreads();
     for (int i = ty; i < 32; i += 8) {
         const int n = n0 + i, k = k0 + tx;
-        if (n < N && k < ld) out[(size_t)n * ld + k] = cvt_out<OT>(t[tx][i]);
+        if (n < N && k < ld) store_out<OT>(out, (size_t)n * ld + k, t[tx][i]);
+    }
+}
+// The other operand in the same pitched pixel order: halo image [B][r+2][r+2][C] -> out [C][ld], column col0 + (b (r+2) + yh) rpp + xh holds
+// halo[b][yh][xh][c]; pad columns (xh >= r + 2), the margins and everything beyond the last pixel are zero.  col0 = margin - (kx - 1) makes the
+// copy read at an ALIGNED column deliver the horizontal tap kx (three copies; the vertical taps are +- rpp, a multiple of 16).
+template <typename OT>
+__global__ __launch_bounds__(256) void x_halo_T_kernel(const float* __restrict__ halo, OT* __restrict__ out, int B, int r, int C, int col0, int ld, int rpp) {
+    __shared__ float t[32][33];
+    const int k0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int rp = r + 2, Mh = B * rp * rpp;
+    for (int i = ty; i < 32; i += 8) {
+        const int mh = k0 + i - col0, c = c0 + tx;
+        float v = 0.f;
+        if (mh >= 0 && mh < Mh && c < C) {
+            const int row = mh / rpp, xh = mh - row * rpp;     // row = b (r + 2) + yh
+            if (xh < rp) v = halo[((size_t)row * rp + xh) * C + c];
+        }
+        t[i][tx] = v;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, k = k0 + tx;
+        if (c < C && k < ld) store_out<OT>(out, (size_t)c * ld + k, t[tx][i]);
     }
 }
 // dW slabs [9][N][C] -> parameter layout [N][C][3][3]
@@ -112,7 +141,7 @@ __global__ void conv_w_dgrad_kernel(const float* __restrict__ w, OT* __restrict_
         const int nn = (int)(i % N);
         size_t r = i / N;
         const int tap = (int)(r % 9), c = (int)(r / 9);
-        out[i] = cvt_out<OT>(w[((size_t)nn * C + c) * 9 + (8 - tap)]);
+        store_out<OT>(out, i, w[((size_t)nn * C + c) * 9 + (8 - tap)]);
     }
 }
 
@@ -137,7 +166,7 @@ __global__ void to_halo_kernel(const float* __restrict__ in, OT* __restrict__ ou
         const int x = (int)(r % W);
         r /= W;
         const int y = (int)(r % H), b = (int)(r / H);
-        out[(((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c] = cvt_out<OT>(in[i]);
+        store_out<OT>(out, (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c, in[i]);
     }
 }
 // out[i] (+)= halo interior
@@ -968,7 +997,8 @@ int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t 
     TK("transpose");
 }
 int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err) {
-    if (f16) SOCCDPT_LAUNCH(transpose_kernel<f16raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), R, C, Rp);
+    if (f16 == 3) SOCCDPT_LAUNCH(transpose_kernel<x3raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<x3raw*>(out), R, C, Rp);   // x3: 4 bytes per element
+    else if (f16) SOCCDPT_LAUNCH(transpose_kernel<f16raw>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), R, C, Rp);
     else SOCCDPT_LAUNCH(transpose_kernel<uint16_t>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose16");
 }
@@ -977,16 +1007,25 @@ int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t
     TK("im2colT");
 }
 int tr_im2colT16(const float* halo, uint16_t* out, int B, int H, int W, int C, size_t Mp, int f16, hipStream_t st, std::string& err) {
-    if (f16) SOCCDPT_LAUNCH(im2colT_kernel<f16raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<f16raw*>(out), B, H, W, C, Mp);
+    if (f16 == 3) SOCCDPT_LAUNCH(im2colT_kernel<x3raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<x3raw*>(out), B, H, W, C, Mp);
+    else if (f16) SOCCDPT_LAUNCH(im2colT_kernel<f16raw>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, reinterpret_cast<f16raw*>(out), B, H, W, C, Mp);
     else SOCCDPT_LAUNCH(im2colT_kernel<uint16_t>, dim3((C + 31) / 32, (unsigned)((Mp + 31) / 32), 9), dim3(256), 0, st, halo, out, B, H, W, C, Mp);
     TK("im2colT16");
 }
-int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err) {
+int tr_dy_halo_T(const float* dy, void* out, int out16, int B, int r, int N, int margin, int ld, hipStream_t st, std::string& err, int rpp) {
     const dim3 grid((N + 31) / 32, (ld + 31) / 32);
-    if (out16 == 2) SOCCDPT_LAUNCH(dy_halo_T_kernel<f16raw>, grid, dim3(256), 0, st, dy, static_cast<f16raw*>(out), B, r, N, margin, ld);
-    else if (out16) SOCCDPT_LAUNCH(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld);
-    else SOCCDPT_LAUNCH(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld);
+    if (rpp <= 0) rpp = r + 2;
+    if (out16 == 3) SOCCDPT_LAUNCH(dy_halo_T_kernel<x3raw>, grid, dim3(256), 0, st, dy, static_cast<x3raw*>(out), B, r, N, margin, ld, rpp);
+    else if (out16 == 2) SOCCDPT_LAUNCH(dy_halo_T_kernel<f16raw>, grid, dim3(256), 0, st, dy, static_cast<f16raw*>(out), B, r, N, margin, ld, rpp);
+    else if (out16) SOCCDPT_LAUNCH(dy_halo_T_kernel<uint16_t>, grid, dim3(256), 0, st, dy, static_cast<uint16_t*>(out), B, r, N, margin, ld, rpp);
+    else SOCCDPT_LAUNCH(dy_halo_T_kernel<float>, grid, dim3(256), 0, st, dy, static_cast<float*>(out), B, r, N, margin, ld, rpp);
     TK("dy_halo_T");
+}
+// x3 only: the pitched transposed halo image of the activation (x_halo_T_kernel)
+int tr_x_halo_T_x3(const float* halo, void* out, int B, int r, int C, int col0, int ld, int rpp, hipStream_t st, std::string& err) {
+    const dim3 grid((C + 31) / 32, (ld + 31) / 32);
+    SOCCDPT_LAUNCH(x_halo_T_kernel<x3raw>, grid, dim3(256), 0, st, halo, static_cast<x3raw*>(out), B, r, C, col0, ld, rpp);
+    TK("x_halo_T_x3");
 }
 int tr_wgrad_permute9(const float* in, float* out, int N, int C, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(wgrad_permute9_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
@@ -997,7 +1036,8 @@ int tr_conv_w_dgrad(const float* w, float* out, int N, int C, hipStream_t st, st
     TK("conv_w_dgrad");
 }
 int tr_conv_w_dgrad16(const float* w, uint16_t* out, int N, int C, int f16, hipStream_t st, std::string& err) {
-    if (f16) SOCCDPT_LAUNCH(conv_w_dgrad_kernel<f16raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<f16raw*>(out), N, C);
+    if (f16 == 3) SOCCDPT_LAUNCH(conv_w_dgrad_kernel<x3raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<x3raw*>(out), N, C);
+    else if (f16) SOCCDPT_LAUNCH(conv_w_dgrad_kernel<f16raw>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, reinterpret_cast<f16raw*>(out), N, C);
     else SOCCDPT_LAUNCH(conv_w_dgrad_kernel<uint16_t>, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, w, out, N, C);
     TK("conv_w_dgrad16");
 }
@@ -1010,7 +1050,8 @@ int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStrea
     TK("to_halo");
 }
 int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err) {
-    if (f16) SOCCDPT_LAUNCH(to_halo_kernel<f16raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), B, H, W, C);
+    if (f16 == 3) SOCCDPT_LAUNCH(to_halo_kernel<x3raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<x3raw*>(out), B, H, W, C);
+    else if (f16) SOCCDPT_LAUNCH(to_halo_kernel<f16raw>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, reinterpret_cast<f16raw*>(out), B, H, W, C);
     else SOCCDPT_LAUNCH(to_halo_kernel<uint16_t>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo16");
 }

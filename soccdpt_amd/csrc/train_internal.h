@@ -102,8 +102,8 @@ struct Ctx {
 
 #define TRY(call) do { if (call) return 1; } while (0)
 
-int gemm(Ctx& c, IgemmDesc d);
-int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands);   // operands as written by the caller's staging kernels
+int gemm(Ctx& c, IgemmDesc d, bool x3 = false);
+int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3 = false);   // operands as written by the caller's staging kernels
 int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what);
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db);

@@ -7,6 +7,8 @@
 //
 // Gradients are WRITTEN (not accumulated) to the buffers bound with soccdpt_bind_grad; a weight without a bound gradient is frozen and its
 // weight-gradient GEMM is skipped (the reference freezes / partially unfreezes the encoder: model/loss.py:110-152).
+#include <cstdlib>
+
 #include "train_internal.h"
 
 #include <cstring>
@@ -133,8 +135,11 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.S_cpb = ar.f(a.hybrid ? 64 : (size_t)2 * (2 * a.window - 1) * (2 * a.window - 1) * 512);
 }
 
-int gemm(Ctx& c, IgemmDesc d) {
-    d.f32 = 1;
+// x3: the operands are x3 split-fp16 tensors (train amp mode 3: three fp16 MFMAs per product, f32-grade results; same tile set and
+// split-K decisions as the exact-f32 GEMMs)
+int gemm(Ctx& c, IgemmDesc d, bool x3) {
+    d.f32 = x3 ? 0 : 1;
+    d.x3 = x3 ? 1 : 0;
     // Small grids with a long K (coarse decoder levels, stage-3 Linear layers, their dgrads): split K like the weight-gradient GEMMs do
     const long tiles = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
     const long nk = (long)d.taps * d.Cin / 32;
@@ -151,15 +156,23 @@ int gemm(Ctx& c, IgemmDesc d) {
 
 // Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
 // in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.  amp: bf16 operands (K padded to 128 by the caller).
-int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands) {
+int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3) {
     const bool amp = bf16_operands;   // the CALLER says what its staging kernels wrote (amp applies per GEMM: shapes that do not fit stay f32)
-    d.f32 = amp ? 0 : 1;
+    d.f32 = (amp || x3) ? 0 : 1;
+    d.x3 = x3 ? 1 : 0;
     d.f16 = c.h.train_amp == 2 ? 1 : 0;   // 16-bit format of the amp mode: bf16 (1) or fp16 with the caller's loss scaling (2)
     // 64 x 64 tiles: the 128 x 128 split-K forms were measured slower (4 waves: 51.2 vs 45.2 ms per step at B = 8; 8 waves: 47.9 vs 42.2 --
     // fewer, longer workgroups and a partial-tile exchange four times the size)
-    const long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
-    const long nk = (long)d.taps * d.Cin / (amp ? 128 : 32);
+    long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+    long nk = (long)d.taps * d.Cin / (amp ? 128 : 32);
+    static const int x3_sk_tile = getenv("SOCCDPT_X3_SK_TILE") ? atoi(getenv("SOCCDPT_X3_SK_TILE")) : 0;   // 0: 64 x 64 (default: the 128 x 128 forms measured slower, 37.5 / 40.3 vs 36.6 ms per step); 3 / 8: 128 x 128 (32- / 64-deep)
+    if (x3 && x3_sk_tile && d.M % 128 == 0 && d.N % 128 == 0 && d.Cin % 64 == 0 && (long)(d.M / 128) * (d.N / 128) >= 8) {
+        d.tune = x3_sk_tile;
+        tiles = (long)(d.M / 128) * (d.N / 128);
+        if (x3_sk_tile == 8) nk = (long)d.Cin / 64;
+    }
     long S = (512 + tiles - 1) / tiles;
+    if (x3) S = 512 / tiles > 0 ? 512 / tiles : 1;   // x3 tiles are fill-bound at two workgroups per CU: at most ONE round of them (576 workgroups = 1.125 rounds cost 1 ms per step)
     if (S > nk / (amp ? 2 : 8)) S = nk / (amp ? 2 : 8);
     if (S > 64) S = 64;
     while (S > 1 && (size_t)S * d.M * d.N > kTrainSkPartFloats) --S;
@@ -185,12 +198,20 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
-    const bool amp = c.h.train_amp && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: 16-bit operands for the two gradient GEMMs
+    const bool x3 = c.h.train_amp == 3 && N % 32 == 0 && K % 32 == 0 && K > 32;              // x3 split-fp16 operands (f32-grade, 4 bytes per element)
+    const bool amp = (c.h.train_amp == 1 || c.h.train_amp == 2) && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: 16-bit operands for the two gradient GEMMs
     const int F16 = c.h.train_amp == 2 ? 1 : 0;
     if (dX_out) {
         IgemmDesc d;
         d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
-        if (amp) {
+        if (x3) {
+            uint16_t* w3 = reinterpret_cast<uint16_t*>(T.S_wt);
+            uint16_t* a3 = reinterpret_cast<uint16_t*>(T.S_T1);
+            TRY(tr_transpose16(W, w3, N, K, N, 3, c.st, c.err));
+            TRY(launch_cvt_bf16(dY, a3, M * N, 3, c.st, c.err));
+            d.X = a3; d.Wt = w3;
+            TRY(gemm(c, d, true));
+        } else if (amp) {
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
             TRY(tr_transpose16(W, w16, N, K, N, F16, c.st, c.err));
@@ -206,7 +227,14 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
     if (dW) {
         IgemmDesc d;
         d.M = N; d.N = K; d.out_f32 = dW;
-        if (amp) {
+        if (x3) {
+            const int Mp = (int)((M + 31) / 32 * 32);
+            uint16_t* y3 = reinterpret_cast<uint16_t*>(T.S_T1);
+            uint16_t* x3p = reinterpret_cast<uint16_t*>(T.S_T2);
+            TRY(tr_transpose16(dY, y3, (int)M, N, Mp, 3, c.st, c.err));
+            TRY(tr_transpose16(X, x3p, (int)M, K, Mp, 3, c.st, c.err));
+            d.X = y3; d.Wt = x3p; d.Cin = Mp; d.ldx = Mp;
+        } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
@@ -219,7 +247,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             TRY(tr_transpose(X, T.S_T2, (int)M, K, Mp, c.st, c.err));    // [K][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
-        TRY(gemm_wgrad(c, d, amp));
+        TRY(gemm_wgrad(c, d, amp, x3));
     }
     if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
     return 0;
@@ -231,7 +259,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
     Tape& T = c.T;
     const int B = c.B;
     const size_t M = (size_t)B * r * r;
-    const bool amp = c.h.train_amp && N % 32 == 0 && C % 32 == 0;
+    const bool x3 = c.h.train_amp == 3 && N % 32 == 0 && C % 32 == 0;
+    const bool amp = (c.h.train_amp == 1 || c.h.train_amp == 2) && N % 32 == 0 && C % 32 == 0;
     const int F16 = c.h.train_amp == 2 ? 1 : 0;
     if (dX_out) {
         const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * (amp ? 2 : 4);
@@ -239,7 +268,14 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
         IgemmDesc d;
         d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
-        if (amp) {
+        if (x3) {
+            uint16_t* h3 = reinterpret_cast<uint16_t*>(T.S_halo);
+            uint16_t* w3 = reinterpret_cast<uint16_t*>(T.S_wt);
+            TRY(tr_to_halo16(dY, h3, B, r, r, N, 3, c.st, c.err));
+            TRY(tr_conv_w_dgrad16(W, w3, N, C, 3, c.st, c.err));
+            d.X = h3; d.Wt = w3;
+            TRY(gemm(c, d, true));
+        } else if (amp) {
             uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
             TRY(tr_to_halo16(dY, h16, B, r, r, N, F16, c.st, c.err));
@@ -253,10 +289,42 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(gemm(c, d));
         }
     }
-    if (dW && C % 64 != 0) {   // (layer1_rn of tiny_256, C = 96: a weight tile would straddle two taps) explicit im2col^T
+    if (dW && x3 && C % 64 == 0) {
+        // x3, no im2col: like the f32 form below, but an x3 tensor is cut in 8-element units, so the views must start at multiples of 16 elements:
+        // the pixel order pads every halo row to rpp = roundup(r + 2, 16) pixels (vertical taps = +- rpp) and the horizontal taps read three copies
+        // of the transposed image pre-shifted by -1 / 0 / +1 pixel (x_halo_T_kernel).  9 views of 3 copies instead of a 9-fold im2col^T.
+        const int rp = r + 2, rpp = (rp + 15) / 16 * 16, Mh = B * rp * rpp, margin = rpp + 16;
+        const int ld = (2 * margin + Mh + 31) / 32 * 32;
+        const size_t head = (size_t)rpp + 16;                        // zeroed elements in front of and behind each copy (the +- rpp views)
+        const size_t copy_elems = (size_t)C * ld + 2 * head;
+        char* yT = reinterpret_cast<char*>(T.S_T1);
+        char* xT = reinterpret_cast<char*>(T.S_T2);
+        TRY(tr_dy_halo_T(dY, yT, 3, B, r, N, margin, ld, c.st, c.err, rpp));
+        if (!reuse_xt) {
+            for (int kx = 0; kx < 3; ++kx) {
+                char* base = xT + (size_t)kx * copy_elems * 4;
+                hipError_t e = hipMemsetAsync(base, 0, head * 4, c.st);
+                if (e == hipSuccess) e = hipMemsetAsync(base + (head + (size_t)C * ld) * 4, 0, head * 4, c.st);
+                if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+                TRY(tr_x_halo_T_x3(Xhalo, base + head * 4, B, r, C, margin - (kx - 1), ld, rpp, c.st, c.err));
+            }
+        }
+        IgemmDesc d;
+        d.X = yT; d.Wt = xT; d.M = N; d.N = 9 * C; d.Cin = ld; d.ldx = ld; d.out_f32 = T.S_dw;
+        d.wt_grp_rows = C; d.wt_rp = rpp; d.wt_base = (int)head; d.wt_kx = (int)copy_elems;
+        TRY(gemm_wgrad(c, d, false, true));
+        TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+    } else if (dW && (C % 64 != 0 || x3)) {   // (layer1_rn of tiny_256, C = 96: a weight tile would straddle two taps) explicit im2col^T
         IgemmDesc d;
         d.M = N; d.N = 9 * C; d.out_f32 = T.S_dw;
-        if (amp) {
+        if (x3) {
+            const int Mp = (int)((M + 31) / 32 * 32);
+            uint16_t* y3 = reinterpret_cast<uint16_t*>(T.S_T1);
+            uint16_t* x3p = reinterpret_cast<uint16_t*>(T.S_T2);
+            TRY(tr_transpose16(dY, y3, (int)M, N, Mp, 3, c.st, c.err));
+            TRY(tr_im2colT16(Xhalo, x3p, B, r, r, C, (size_t)Mp, 3, c.st, c.err));
+            d.X = y3; d.Wt = x3p; d.Cin = Mp; d.ldx = Mp;
+        } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
@@ -269,7 +337,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(tr_im2colT(Xhalo, T.S_T2, B, r, r, C, (size_t)Mp, c.st, c.err));   // [9C][Mp]
             d.X = T.S_T1; d.Wt = T.S_T2; d.Cin = Mp; d.ldx = Mp;
         }
-        TRY(gemm_wgrad(c, d, amp));
+        TRY(gemm_wgrad(c, d, amp, x3));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     } else if (dW) {
         // No im2col: both operands transposed in halo pixel order, tap (ky, kx) = the plain GEMM over a shifted view of the ONE transposed halo

@@ -414,8 +414,9 @@ class Engine:
         self._grads[key] = g  # keep alive
 
     def train_set_amp(self, mode):
-        """0 / False: f32; 1 / True / "bf16": bf16 operands for the gradient GEMMs; 2 / "f16": fp16 operands (use a GradScaler)."""
-        code = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, "bf16": 1, "f16": 2, "fp16": 2, None: 0}[mode]
+        """0 / False: f32; 1 / True / "bf16": bf16 operands for the gradient GEMMs; 2 / "f16": fp16 operands (use a GradScaler);
+        3 / "x3" / "f16x3": split-fp16 operands (three fp16 MFMAs per product): f32-grade gradients, no loss scaling needed."""
+        code = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, 3: 3, "bf16": 1, "f16": 2, "fp16": 2, "x3": 3, "f16x3": 3, None: 0}[mode]
         self._check(self.L.soccdpt_train_set_amp(self._h, code), "soccdpt_train_set_amp")
 
     def train_unscale(self, grads: torch.Tensor, inv_scale: float, found_inf: torch.Tensor):

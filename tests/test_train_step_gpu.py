@@ -412,6 +412,25 @@ def test_amp_gradients_with_criterion(gpu_device):
     med16 = sorted(e for e, _ in errs16)[len(errs16) // 2]
     print(f"amp f16 + GradScaler: median {med16:.2e}, worst {max(errs16)[0]:.2e} ({max(errs16)[1]})")
     assert med16 < 2e-3 and max(errs16)[0] < 1e-2, max(errs16)
+    # x3 split-fp16 operands (three fp16 MFMAs per product, no loss scaling): f32-grade -- the bound of the exact-f32 step (1e-3 per tensor)
+    m.train_amp = "x3"
+    for p in m.parameters():
+        p.grad = None
+    inv, seg = m.train_forward(x.to(dev))
+    assert torch.equal(inv, inv0)
+    r3 = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
+    m.backward(r3["d_inv"], r3["d_seg"])
+    torch.cuda.synchronize()
+    errs3 = []
+    for k, p in m.named_parameters():
+        ref = sd_o[k].grad
+        if ref is None or float(ref.norm()) < 1e-5:
+            continue
+        errs3.append((_rel(p.grad.cpu(), ref), k))
+    med3 = sorted(e for e, _ in errs3)[len(errs3) // 2]
+    print(f"amp x3 (split fp16): median {med3:.2e}, worst {max(errs3)[0]:.2e} ({max(errs3)[1]})")
+    assert med3 < 4e-4 and max(errs3)[0] < 1e-3, max(errs3)
+    m.train_amp = "f16"
     # an overflowing gradient makes the scaler skip the step and halve the scale
     m.train_forward(x.to(dev))
     big = torch.full_like(r["d_inv"], float("inf"))

@@ -27,7 +27,8 @@ calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
 net.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
 net = net.to(dev).train()
-net.train_amp = os.environ.get("TRAIN_AMP", "0") == "1"
+_amp = os.environ.get("TRAIN_AMP", "0")
+net.train_amp = {"0": False, "1": True}.get(_amp, _amp)   # "bf16" | "f16" | "x3"
 freeze_pretrained_encoder(net)
 unfreeze_pretrained_encoder_by_percentage(net, enc_pct)
 ds = SyntheticDepthSegDataset(B, S)
