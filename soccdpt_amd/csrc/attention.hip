@@ -15,6 +15,8 @@
 //    exponentiated accumulators are directly the B operand of O^T = V^T P^T (no LDS round trip);
 //  * the CPB bias is precomputed per weight load in MFMA accumulator order and loaded as the
 //    initial accumulator (4 x 16-byte loads per tile, coalesced); the shift mask is arithmetic.
+#include <stdlib.h>
+
 #include "half16.h"
 #include "kernels.h"
 
@@ -541,6 +543,170 @@ __global__ __launch_bounds__(AttnGenCfg<WS>::THREADS) void window_attention_flas
 }
 
 // ---------------------------------------------------------------------------------------------
+// Exact-f32 windowed cosine attention for the large windows (24 x 24 = 576 and 12 x 12 = 144 tokens of dpt_swin2_base_384) on
+// v_mfma_f32_32x32x2_f32: the streaming form of vit_attention_f32_kernel (vit_attention.hip) with head dimension 32, the window / cyclic-shift
+// token gather, q-hat / k-hat normalisation at staging time, the CPB bias tile as the initial accumulator (bias_acc is already in MFMA
+// accumulator order; padded keys carry -1e30 there) and the shift mask from the token coordinates.  One workgroup = 4 waves = 4 blocks of 32
+// queries of one (sample, window, head); key / value tiles of 32 tokens stream through a double-buffered LDS ring, one barrier per tile.
+// Replaces the one-thread-per-query VALU kernel below for these window sizes in the F32 and F16X3 modes (round 3: 10.5 -> see DESIGN ms per
+// base_384 forward at B = 8).  x3 != 0: the output is written as the x3 operand of the proj GEMM.
+// ---------------------------------------------------------------------------------------------
+constexpr int WKS = 36;   // floats per K row in LDS (144 B = 9 x 16: conflict-free ds_read_b128 over a half-wave's 32 rows)
+
+template <int WS>
+__global__ __launch_bounds__(256) void window_attention_f32_flash_kernel(const float* __restrict__ qkv, const float* __restrict__ bias_acc,
+                                                                         const float* __restrict__ scale, float* __restrict__ out, int res, int shift,
+                                                                         int heads, int x3) {
+    constexpr int N = WS * WS, NT = (N + 31) / 32, NQB = (NT + 3) / 4, HALF = WS / 2;
+    __shared__ __attribute__((aligned(16))) float Ks[2][32 * WKS];
+    __shared__ __attribute__((aligned(16))) float Vs[2][32 * 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int C = heads * 32;
+    const int nw = res / WS;
+    int bid = blockIdx.x;
+    const int part = bid % NQB;
+    bid /= NQB;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const float hscale = scale[head];
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / WS, c = p % WS;
+        int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    const int r32 = lane & 31, h = lane >> 5;
+    const int qb = part * 4 + wave;
+    const bool active = qb < NT;             // wave-uniform
+    const int qrow = qb * 32 + r32;
+    const int qcl = qrow < N ? qrow : N - 1;
+    const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
+    const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
+
+    // staging: thread -> (token of the tile = tid >> 3, 16-byte chunk c = tid & 7); k-hat = k / max(|k|, 1e-12): the 8 threads of a token share the norm
+    float4 kr, vr;
+    auto gload = [&](int t) {
+        const int p = t * 32 + (tid >> 3), c = tid & 7;
+        kr = make_float4(0.f, 0.f, 0.f, 0.f);
+        vr = kr;
+        if (p < N) {
+            const float* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 4;
+            kr = *reinterpret_cast<const float4*>(src + C);
+            vr = *reinterpret_cast<const float4*>(src + 2 * C);
+        }
+        float ks = kr.x * kr.x + kr.y * kr.y + kr.z * kr.z + kr.w * kr.w;
+        ks += __shfl_xor(ks, 1);
+        ks += __shfl_xor(ks, 2);
+        ks += __shfl_xor(ks, 4);
+        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
+        kr.x *= ki; kr.y *= ki; kr.z *= ki; kr.w *= ki;
+    };
+    auto lstore = [&](int buf) {
+        const int kt = tid >> 3, c = tid & 7;
+        *reinterpret_cast<float4*>(&Ks[buf][kt * WKS + c * 4]) = kr;
+        *reinterpret_cast<float4*>(&Vs[buf][kt * 32 + c * 4]) = vr;
+    };
+    // Q-hat fragment (B operand): lane (query r32, half h), step st <-> d = 16 h + st
+    float qf[16];
+    {
+        const float* src = qkv + token_row(qcl) * (size_t)(3 * C) + head * 32 + 16 * h;
+        float qs = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float4 q4 = *reinterpret_cast<const float4*>(src + 4 * j);
+            qf[4 * j] = q4.x; qf[4 * j + 1] = q4.y; qf[4 * j + 2] = q4.z; qf[4 * j + 3] = q4.w;
+            qs += q4.x * q4.x + q4.y * q4.y + q4.z * q4.z + q4.w * q4.w;
+        }
+        qs += __shfl_xor(qs, 32);
+        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) qf[j] *= qi;
+    }
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    constexpr float LOG2E = 1.4426950408889634f;
+    float m = -3.0e38f, l = 0.f;
+    f32x16 o;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) o[rg] = 0.f;
+    const float* bp = bias_acc + ((size_t)(head * NT + (active ? qb : 0)) * NT) * 1024 + lane * 16;
+    float4 nb0, nb1, nb2, nb3;
+    {
+        const float4* b4 = reinterpret_cast<const float4*>(bp);
+        nb0 = b4[0]; nb1 = b4[1]; nb2 = b4[2]; nb3 = b4[3];
+    }
+#pragma unroll 1
+    for (int t = 0; t < NT; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < NT) gload(t + 1);
+        if (active) {
+            const float4 b0 = nb0, b1 = nb1, b2 = nb2, b3 = nb3;
+            if (t + 1 < NT) {
+                const float4* b4 = reinterpret_cast<const float4*>(bp + (size_t)(t + 1) * 1024);
+                nb0 = b4[0]; nb1 = b4[1]; nb2 = b4[2]; nb3 = b4[3];
+            }
+            f32x16 acc = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w, b2.x, b2.y, b2.z, b2.w, b3.x, b3.y, b3.z, b3.w};
+            if (lastrow || lastcol) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    int key = t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                    key = key < N ? key : N - 1;
+                    const bool kr_hi = (key / WS) >= HALF, kc_hi = (key % WS) >= HALF;
+                    if ((lastrow && (kr_hi != qr_hi)) || (lastcol && (kc_hi != qc_hi))) acc[rg] += -100.0f;
+                }
+            }
+            const float* krow = &Ks[buf][r32 * WKS + 16 * h];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 k4 = *reinterpret_cast<const float4*>(krow + 4 * j);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, qf[4 * j], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, qf[4 * j + 1], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, qf[4 * j + 2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, qf[4 * j + 3], acc, 0, 0, 0);
+            }
+            float mt = acc[0];
+#pragma unroll
+            for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, acc[rg]);
+            mt = fmaxf(mt, __shfl_xor(mt, 32));
+            const float mn = fmaxf(m, mt);
+            const float mnl = mn * LOG2E;
+            const float alpha = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mnl));
+            float psum = 0.f;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], LOG2E, -mnl));
+                psum += acc[rg];
+                o[rg] *= alpha;
+            }
+            l = l * alpha + psum;
+            m = mn;
+            const float* vcol = &Vs[buf][(4 * h) * 32 + r32];
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vcol[((rg & 3) + 8 * (rg >> 2)) * 32], acc[rg], o, 0, 0, 0);
+        }
+        if (t + 1 < NT) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active) return;
+    l += __shfl_xor(l, 32);
+    if (qrow < N) {
+        const float inv = 1.0f / l;
+        const size_t e0 = token_row(qrow) * (size_t)C + head * 32;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            if (x3) x3_store4(out, e0 + 8 * g + 4 * h, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+            else *reinterpret_cast<float4*>(out + e0 + 8 * g + 4 * h) = make_float4(o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Exact-f32 attention for ANY window size (parity mode of dpt_swin2_base_384: 24x24 / 12x12 windows).
 // Not a throughput kernel: one thread owns one query (q-hat and the output row in registers), keys are staged
 // 64 at a time in LDS (normalised K and V rows, read by broadcast), online softmax in f32, CPB bias read from the
@@ -672,6 +838,14 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
                                 int ws, int shift, int heads, hipStream_t st, std::string& err, int x3) {
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
     const int nw = res / ws;
+    static const bool force_any = getenv("SOCCDPT_ATTN_F32_ANY") != nullptr;   // A/B switch: the one-thread-per-query kernel
+    if ((ws == 24 || ws == 12) && !force_any) {   // dpt_swin2_base_384: the streaming MFMA-f32 kernel
+        const int NT = (ws * ws + 31) / 32, NQB = (NT + 3) / 4;
+        const unsigned blocksf = (unsigned)(B * nw * nw * heads * NQB);
+        if (ws == 24) SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<24>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
+        else SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<12>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
+        return check_launch("window_attention_f32_flash", err);
+    }
     if (ws != 16 && !(ws == 8 && shift == 0)) {  // any other window size: the generic exact kernel (parity mode of base_384)
         const int nqb = (ws * ws + 63) / 64;
         SOCCDPT_LAUNCH(window_attention_f32_any_kernel, dim3((unsigned)(B * nw * nw * heads * nqb)), dim3(64), 0, st, qkv, table, scale, out, res, ws,

@@ -270,6 +270,32 @@ def test_window_attention_f16(gpu_device, B, res, ws, shift, heads):
     assert float(err.max()) < 8e-3 and float(err.mean()) < 8e-4, (float(err.max()), float(err.mean()))
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 8, 3), (2, 8, 8, 0, 24), (1, 96, 24, 12, 4), (2, 48, 24, 12, 8), (2, 24, 24, 0, 16), (3, 12, 12, 0, 32),
+                                                   (1, 32, 8, 4, 3)])
+def test_window_attention_f32(gpu_device, B, res, ws, shift, heads, precision):
+    """Exact-f32 cosine window attention (MFMA f32): the 16 x 16 / 8 x 8 kernel, the streaming kernel of the 24 x 24 / 12 x 12 windows (ragged last
+    key tile at 144 tokens, shifted and unshifted) and the generic fallback (shifted 8 x 8), f32 output and the x3 operand output of F16X3."""
+    from soccdpt_amd.lib import PREC_F16X3, PREC_F32, op_window_attention, x3_decode
+    g = torch.Generator().manual_seed(res * 100 + shift + heads)
+    C = heads * 32
+    qkv = torch.randn(B * res * res, 3 * C, generator=g).to(gpu_device)
+    table = (16 * torch.sigmoid(torch.randn((2 * ws - 1) ** 2, heads, generator=g))).to(gpu_device)
+    scale = (10.0 + 5 * torch.rand(heads, generator=g)).to(gpu_device)
+    if precision == "f32":
+        out = torch.empty(B * res * res, C, device=gpu_device)
+        op_window_attention(qkv, table, scale, out, B, res, ws, shift, heads, precision=PREC_F32)
+        got = out
+    else:
+        raw = torch.zeros(B * res * res * C * 2, dtype=torch.float16, device=gpu_device)
+        op_window_attention(qkv, table, scale, raw, B, res, ws, shift, heads, precision=PREC_F16X3)
+        got = x3_decode(raw.cpu(), (B * res * res, C)).float().to(gpu_device)
+    torch.cuda.synchronize()
+    ref = _attention_ref(qkv, table, scale, B, res, ws, shift, heads)
+    err = (got - ref).abs()
+    assert float(err.max()) < 2e-5 and float((got - ref).norm() / ref.norm()) < 3e-6, (float(err.max()), float((got - ref).norm() / ref.norm()))
+
+
 # ---------------- exact-f32 parity mode (SOCCDPT_PREC_F32) ----------------
 @pytest.mark.parametrize("M,N,K", [(300, 288, 96), (2048, 384, 1536), (512, 2304, 768)])
 def test_igemm_linear_f32(gpu_device, M, N, K):
