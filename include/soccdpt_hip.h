@@ -330,6 +330,11 @@ int soccdpt_bind_grad(void* handle, const char* key, float* dev_grad);
  * 2: fp16 operands (11-bit significand) -- the caller scales d_inv / d_seg like GradScaler scales the loss (the gradients come out scaled by the
  * same factor; values beyond +-65504 saturate in the operand conversion instead of becoming inf). */
 int soccdpt_train_set_amp(void* handle, int mode);
+/* Stochastic depth of the Swin-V2 encoder in the train-mode forward: timm's SwinTransformerV2 is created with drop_path_rate = 0.1 by default and
+ * model/backbones/swin2.py:15-30 does not override it, so under net.train() the reference drops each residual branch of block i per sample with
+ * probability rate * i / (blocks - 1) and scales the kept ones by 1 / (1 - p).  0 (the library default) disables it; the masks come from
+ * soccdpt_train_forward's seed (not torch's generator), and soccdpt_train_workspace_tensor("drop_path.<stage>.<block>") reads them back. */
+int soccdpt_train_set_drop_path(void* handle, float rate);
 /* GradScaler.unscale_ of the fp16 mode over n gradients: dev_grads[i] *= inv_scale; *dev_found_inf |= 1 when a result is not finite (the caller
  * zeroes the flag, skips its optimizer step when it is set and backs the scale off: scripts/train_SOccDPT.py:390-393). */
 int soccdpt_train_unscale(float* dev_grads, size_t n, float inv_scale, int* dev_found_inf, void* stream);

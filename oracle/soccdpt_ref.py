@@ -182,15 +182,22 @@ def window_attention(sd, pfx, x: Tensor, res: int, ws: int, shift: int, heads: i
     return out.reshape(B, L, C)
 
 
-def swin_block(sd, pfx, x, res, ws, shift, heads, pretrained_ws) -> Tensor:
-    """Residual post-norm block: x + LN(attn(x)); then + LN(mlp(.))."""
+def swin_block(sd, pfx, x, res, ws, shift, heads, pretrained_ws, drop_path=None) -> Tensor:
+    """Residual post-norm block: x + LN(attn(x)); then + LN(mlp(.)).  drop_path = (s1 [B], s2 [B]): the per-sample scales timm's DropPath applies
+    to the two normalised branches in train mode (0 or 1 / keep_prob; SwinTransformerV2Block.forward: x + drop_path1(norm1(attn(x))), ...)."""
     C = x.shape[-1]
     a = window_attention(sd, pfx + "attn.", x, res, ws, shift, heads, pretrained_ws)
-    x = x + F.layer_norm(a, (C,), sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"], 1e-5)
+    a = F.layer_norm(a, (C,), sd[pfx + "norm1.weight"], sd[pfx + "norm1.bias"], 1e-5)
+    if drop_path is not None:
+        a = a * drop_path[0].view(-1, 1, 1)
+    x = x + a
     m = F.linear(x, sd[pfx + "mlp.fc1.weight"], sd[pfx + "mlp.fc1.bias"])
     m = F.gelu(m)
     m = F.linear(m, sd[pfx + "mlp.fc2.weight"], sd[pfx + "mlp.fc2.bias"])
-    return x + F.layer_norm(m, (C,), sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"], 1e-5)
+    m = F.layer_norm(m, (C,), sd[pfx + "norm2.weight"], sd[pfx + "norm2.bias"], 1e-5)
+    if drop_path is not None:
+        m = m * drop_path[1].view(-1, 1, 1)
+    return x + m
 
 
 def patch_merging(sd, pfx, x, res) -> Tensor:
@@ -202,7 +209,7 @@ def patch_merging(sd, pfx, x, res) -> Tensor:
     return F.layer_norm(h, (2 * C,), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], 1e-5)
 
 
-def swin_encoder(sd: Dict[str, Tensor], x: Tensor, arch: SwinArch, pfx: str = "depth_net.pretrained.model.") -> List[Tensor]:
+def swin_encoder(sd: Dict[str, Tensor], x: Tensor, arch: SwinArch, pfx: str = "depth_net.pretrained.model.", drop_path=None) -> List[Tensor]:
     """forward_features with hooks on layers[i].blocks[hooks[i]]
     (backbones/swin_common.py:12-54, backbones/utils.py:54-81).
     Returns the four hooked tensors as NCHW maps."""
@@ -216,7 +223,8 @@ def swin_encoder(sd: Dict[str, Tensor], x: Tensor, arch: SwinArch, pfx: str = "d
     for s, depth in enumerate(arch.depths):
         for j in range(depth):
             ws, shift = window_geometry(res, arch.window, j)
-            t = swin_block(sd, f"{pfx}layers.{s}.blocks.{j}.", t, res, ws, shift, arch.heads[s], arch.pretrained_window[s])
+            t = swin_block(sd, f"{pfx}layers.{s}.blocks.{j}.", t, res, ws, shift, arch.heads[s], arch.pretrained_window[s],
+                           drop_path=None if drop_path is None else drop_path[(s, j)])   # {(stage, block): (s1 [B], s2 [B])}
             if j == arch.hooks[s]:
                 C = t.shape[-1]
                 outs.append(t.transpose(1, 2).reshape(B, C, res, res))

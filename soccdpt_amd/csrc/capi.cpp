@@ -119,6 +119,14 @@ int soccdpt_train_set_amp(void* handle, int on) {
     h->train_amp = on;
     return 0;
 }
+int soccdpt_train_set_drop_path(void* handle, float rate) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (!(rate >= 0.f && rate < 1.f)) return fail(h, "soccdpt_train_set_drop_path: rate must be in [0, 1)");
+    h->train_drop_path = rate;
+    return 0;
+}
+
 int soccdpt_train_unscale(float* dev_grads, size_t n, float inv_scale, int* dev_found_inf, void* stream) {
     if (!dev_grads || !dev_found_inf) return fail(nullptr, "soccdpt_train_unscale: null argument");
     if (n == 0) return 0;

@@ -141,7 +141,8 @@ template <int VPL, bool F16>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge, int x3) {
+                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge, int x3,
+                                                           const float* __restrict__ row_scale, int rows_per_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -182,6 +183,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
         const int c = lane + 64 * t;
         if (c < C) {
             float o = v[t] * rstd * gg[t] + bb[t];
+            if (row_scale) o *= row_scale[row / rows_per_scale];
             if (residual) o += xr[t];
             xf[(size_t)row * C + c] = o;
             if (x3) {   // xb / halo are x3 tensors (half16.h)
@@ -203,7 +205,8 @@ template <int V4, bool F16>  // float4 groups per lane = C / 256
 __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
                                                               bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                              int C, int residual, int res, int merge, int x3) {
+                                                              int C, int residual, int res, int merge, int x3,
+                                                              const float* __restrict__ row_scale, int rows_per_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -239,10 +242,12 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
     for (int t = 0; t < V4; ++t) {
         const int c = 4 * (lane + 64 * t);
         float4 o;
-        o.x = v[t].x * rstd * gg[t].x + bb[t].x + xr[t].x;
-        o.y = v[t].y * rstd * gg[t].y + bb[t].y + xr[t].y;
-        o.z = v[t].z * rstd * gg[t].z + bb[t].z + xr[t].z;
-        o.w = v[t].w * rstd * gg[t].w + bb[t].w + xr[t].w;
+        o.x = v[t].x * rstd * gg[t].x + bb[t].x;
+        o.y = v[t].y * rstd * gg[t].y + bb[t].y;
+        o.z = v[t].z * rstd * gg[t].z + bb[t].z;
+        o.w = v[t].w * rstd * gg[t].w + bb[t].w;
+        if (row_scale) { const float rs = row_scale[row / rows_per_scale]; o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs; }
+        o.x += xr[t].x; o.y += xr[t].y; o.z += xr[t].z; o.w += xr[t].w;
         *reinterpret_cast<float4*>(xf + (size_t)row * C + c) = o;
         if (x3) {
             if (xb) x3_store4(xb, boff + c, o.x, o.y, o.z, o.w);
@@ -259,7 +264,7 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
 }
 
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, int merge, hipStream_t st, std::string& err) {
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale, int rows_per_scale) {
     if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
     const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 (half16.h)
     if (x3 && (C % 16 || merge)) { err = "ln_residual: x3 rows are multiples of 16 elements, written unmerged"; return 1; }
@@ -269,8 +274,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     if (C % 256 == 0 && C <= 1024) {
 #define LN4_CASE(V)                                                                                                                       \
     do {                                                                                                                                  \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);  \
-        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);  \
+        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);    \
     } while (0)
         switch (C / 256) { case 1: LN4_CASE(1); break; case 2: LN4_CASE(2); break; case 3: LN4_CASE(3); break; default: LN4_CASE(4); break; }
 #undef LN4_CASE
@@ -278,8 +283,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     }
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);  \
-        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);  \
+        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);    \
     } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);

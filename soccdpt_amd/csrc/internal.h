@@ -140,6 +140,7 @@ struct Handle {
         int B = 0;
         float dropout_p = 0.f;
     } train_key;
+    float train_drop_path = 0.f;   // soccdpt_train_set_drop_path: timm drop_path_rate of the Swin-V2 encoder in train mode (0 = off)
     int train_amp = 0;        // soccdpt_train_set_amp: 16-bit MFMA operands for the gradient GEMMs (f32 accumulate, f32 weights / activations / gradients): 1 bf16, 2 fp16
     hipGraph_t graph = nullptr;
     hipGraphExec_t graph_exec = nullptr;

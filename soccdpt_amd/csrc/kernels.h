@@ -23,8 +23,10 @@ inline int check_launch(const char* what, std::string& err) {
 // elementwise.hip
 int launch_patch_embed(const float* x, const float* w, const float* bias, const float* g, const float* beta, float* xf, bf16_t* xb,
                        int hf, int B, int S, int C0, hipStream_t st, std::string& err);
+// row_scale (optional): the normalised branch of row m is multiplied by row_scale[m / rows_per_scale] before the residual add (stochastic depth
+// of the training step: per-sample DropPath scales)
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, int merge, hipStream_t st, std::string& err);
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale = nullptr, int rows_per_scale = 1);
 int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err);
 int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
                     int w, int H, int W, int C, hipStream_t st, std::string& err);

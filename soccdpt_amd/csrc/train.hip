@@ -972,6 +972,27 @@ __global__ void qv_bias_grad_kernel(const float* __restrict__ dqkv_bias, float* 
     if (dv) dv[i] = dqkv_bias[2 * C + i];
 }
 
+// Stochastic depth (timm DropPath, drop_path_rate of SwinTransformerV2 -- 0.1 by default in timm 0.6.12, not overridden by
+// /root/reference/SOccDPT/model/backbones/swin2.py:15-30): out[b] = keep_b / (1 - p), keep_b ~ Bernoulli(1 - p) from a counter hash of
+// (seed, stream_id, b).  The mask generator is not torch's (like the Dropout mask: parity runs use rate 0 or read the scales back).
+__global__ void drop_path_fill_kernel(float* __restrict__ out, int B, float p, unsigned seed, unsigned stream_id) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    unsigned h = seed * 0x9E3779B1u ^ (stream_id + 0x7F4A7C15u) * 0x85EBCA6Bu ^ (unsigned)b * 0xC2B2AE35u;
+    h ^= h >> 16; h *= 0x7FEB352Du; h ^= h >> 15; h *= 0x846CA68Bu; h ^= h >> 16;
+    const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+    out[b] = (p > 0.f && u < p) ? 0.f : 1.0f / (1.0f - p);
+}
+// out[m][:] = in[m][:] * scale[m / rows_per_scale]
+__global__ void scale_rows_kernel(const float* __restrict__ in, float* __restrict__ out, const float* __restrict__ scale, size_t n4, int C4, int rows_per_scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const float s = scale[(i / C4) / rows_per_scale];
+        float4 v = reinterpret_cast<const float4*>(in)[i];
+        v.x *= s; v.y *= s; v.z *= s; v.w *= s;
+        reinterpret_cast<float4*>(out)[i] = v;
+    }
+}
+
 // GradScaler.unscale_ + inf check of the fp16 amp mode, over a run of the flat gradient buffer: g *= inv_scale; *found |= any non-finite
 __global__ void unscale_check_kernel(float* __restrict__ g, size_t n, float inv_scale, int* __restrict__ found) {
     int bad = 0;
@@ -1199,6 +1220,15 @@ int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table,
         if (dw0 || db0) SOCCDPT_LAUNCH(cpb_reduce_kernel, dim3(8, 3), dim3(1024), 0, st, dhid, dt, dw0, db0, ws, pws, heads, 1);
     }
     TK("attn_param_grads");
+}
+int tr_drop_path_fill(float* out, int B, float p, unsigned seed, unsigned stream_id, hipStream_t st, std::string& err) {
+    SOCCDPT_LAUNCH(drop_path_fill_kernel, dim3((B + 63) / 64), dim3(64), 0, st, out, B, p, seed, stream_id);
+    TK("drop_path_fill");
+}
+int tr_scale_rows(const float* in, float* out, const float* scale, size_t M, int C, int rows_per_scale, hipStream_t st, std::string& err) {
+    const size_t n4 = M * (size_t)(C / 4);
+    SOCCDPT_LAUNCH(scale_rows_kernel, dim3(gs_blocks(n4)), dim3(256), 0, st, in, out, scale, n4, C / 4, rows_per_scale);
+    TK("scale_rows");
 }
 int tr_unscale_check(float* g, size_t n, float inv_scale, int* found, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(unscale_check_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, g, n, inv_scale, found);

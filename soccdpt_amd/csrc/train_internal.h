@@ -34,6 +34,7 @@ struct BlkT {
     float *qkv_bias, *scale, *table, *bias_acc;
     const float* xin;
     float *qkv, *attn, *a_pre, *x1, *hpre, *hact, *m_pre, *xout;
+    float* dp;   // stochastic depth: [2][B] per-sample scales of the attention / MLP branch (0 or 1 / (1 - p_block)); see train_forward
 };
 
 // ViT-hybrid encoder tape (train_hybrid_step.cpp)

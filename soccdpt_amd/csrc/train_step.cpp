@@ -7,6 +7,7 @@
 //
 // Gradients are WRITTEN (not accumulated) to the buffers bound with soccdpt_bind_grad; a weight without a bound gradient is frozen and its
 // weight-gradient GEMM is skipped (the reference freezes / partially unfreezes the encoder: model/loss.py:110-152).
+#include <cstdio>
 #include <cstdlib>
 
 #include "train_internal.h"
@@ -59,6 +60,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
             b.scale = ar.f(H);
             b.table = ar.f((size_t)(2 * ws - 1) * (2 * ws - 1) * H);
             b.bias_acc = ar.f(attn_bias_elems(ws, H));
+            b.dp = ar.f(2 * (size_t)B + 2);
             b.qkv = ar.f(M * 3 * C);
             b.attn = ar.f(M * C);
             b.a_pre = ar.f(M * C);
@@ -427,6 +429,10 @@ int train_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
     else if (k == "depth_conv2") { p = T.e; n = M0p * 32; }           // output_conv.2 output (pre-ReLU)
     else if (k == "depth_conv0") { p = T.d1; n = M1 * (size_t)(F / 2); }
     else if (k == "d_path1") { p = T.GP; n = M1 * F; }                // gradient w.r.t. path_1 (after the backward)
+    else if (k.compare(0, 10, "drop_path.") == 0 && !a.hybrid) {      // "drop_path.<stage>.<block>": the [2][B] DropPath scales of one Swin block
+        int s2 = -1, j2 = -1;
+        if (sscanf(k.c_str() + 10, "%d.%d", &s2, &j2) == 2 && s2 >= 0 && s2 < 4 && j2 >= 0 && j2 < a.depths[s2]) { p = T.blk[s2][j2].dp; n = 2 * (size_t)B; }
+    }
     else {
         for (int l = 0; l < 4 && !p; ++l) {
             const size_t M = (size_t)B * a.fres(l) * a.fres(l);
@@ -478,12 +484,22 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
                                st, err));
     }
     const float* xcur = T.x0;
+    int blk_index = 0;
+    const int nblk_total = a.depths[0] + a.depths[1] + a.depths[2] + a.depths[3];
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         for (int j = 0; j < a.depths[s]; ++j) {
             BlkT& b = T.blk[s][j];
             const std::string k = blk_key(s, j);
             b.xin = xcur;
+            // stochastic depth (timm DropPath on both residual branches; rate rising linearly over the blocks): per-sample scales for this block
+            const float dp_p = nblk_total > 1 ? h.train_drop_path * (float)blk_index / (float)(nblk_total - 1) : 0.f;
+            const bool dp_on = h.train_drop_path > 0.f;
+            if (dp_on) {
+                TRY(tr_drop_path_fill(b.dp, B, dp_p, seed, 2u * (unsigned)blk_index, st, err));
+                TRY(tr_drop_path_fill(b.dp + B, B, dp_p, seed, 2u * (unsigned)blk_index + 1u, st, err));
+            }
+            ++blk_index;
             TRY(launch_qkv_bias(c.W(k + "attn.q_bias"), c.W(k + "attn.v_bias"), b.qkv_bias, C, st, err));
             TRY(launch_logit_scale(c.W(k + "attn.logit_scale"), b.scale, H, st, err));
             TRY(launch_cpb_table(c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"), c.W(k + "attn.cpb_mlp.2.weight"), b.table, wsz, a.pretrained_window[s], H,
@@ -497,7 +513,8 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             d.X = b.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "attn.proj.bias"); d.out_f32 = b.a_pre;
             TRY(gemm(c, d));
             TRY(copy_d2d(c, b.x1, b.xin, (size_t)M * C * 4, "train_forward copy"));
-            TRY(launch_ln_residual(b.a_pre, c.W(k + "norm1.weight"), c.W(k + "norm1.bias"), b.x1, nullptr, nullptr, nullptr, 0, M, C, 1, res, 0, st, err));
+            TRY(launch_ln_residual(b.a_pre, c.W(k + "norm1.weight"), c.W(k + "norm1.bias"), b.x1, nullptr, nullptr, nullptr, 0, M, C, 1, res, 0, st, err,
+                                   dp_on ? b.dp : nullptr, res * res));
             d = IgemmDesc();
             d.X = b.x1; d.Wt = c.W(k + "mlp.fc1.weight"); d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "mlp.fc1.bias"); d.act = ACT_GELU;
             d.out_f32 = b.hpre; d.out_op = b.hact;
@@ -507,7 +524,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             TRY(gemm(c, d));
             TRY(copy_d2d(c, b.xout, b.x1, (size_t)M * C * 4, "train_forward copy"));
             TRY(launch_ln_residual(b.m_pre, c.W(k + "norm2.weight"), c.W(k + "norm2.bias"), b.xout, nullptr, nullptr, j == a.hooks[s] ? T.feat[s] : nullptr, 0, M, C, 1, res, 0,
-                                   st, err));
+                                   st, err, dp_on ? b.dp + B : nullptr, res * res));
             xcur = b.xout;
         }
         if (s < 3) {
@@ -644,13 +661,18 @@ static int encoder_backward(Ctx& c) {
             }
             if (!have) continue;   // blocks after the last hooked one do not reach the outputs
             if (!trains_upto(s, j)) return 0;
-            // xout = x1 + LN2(m_pre)
-            TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), T.GX, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
+            // xout = x1 + dp2 * LN2(m_pre)      (dp: the forward's per-sample DropPath scales; the gradient entering the branch is scaled alike)
+            const bool dp_on = h.train_drop_path > 0.f;
+            const float* g_mlp = T.GX;
+            if (dp_on) { TRY(tr_scale_rows(T.GX, G[4], b.dp + B, M, C, res * res, st, err)); g_mlp = G[4]; }
+            TRY(ln_bwd(c, b.m_pre, c.W(k + "norm2.weight"), g_mlp, G[0], G[1], M, C, c.Gd(k + "norm2.weight"), c.Gd(k + "norm2.bias")));
             TRY(linear_bwd(c, G[0], b.hact, c.W(k + "mlp.fc2.weight"), M, C, 4 * C, G[2], nullptr, c.Gd(k + "mlp.fc2.weight"), c.Gd(k + "mlp.fc2.bias")));
             TRY(tr_gelu_bwd(G[2], b.hpre, G[2], M * 4 * C, st, err));
             TRY(linear_bwd(c, G[2], b.x1, c.W(k + "mlp.fc1.weight"), M, 4 * C, C, G[3], T.GX, c.Gd(k + "mlp.fc1.weight"), c.Gd(k + "mlp.fc1.bias")));   // G3 = d x1
-            // x1 = xin + LN1(a_pre)
-            TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), G[3], G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
+            // x1 = xin + dp1 * LN1(a_pre)
+            const float* g_att = G[3];
+            if (dp_on) { TRY(tr_scale_rows(G[3], G[4], b.dp, M, C, res * res, st, err)); g_att = G[4]; }
+            TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), g_att, G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
             TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
             TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, T.attn_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
             {

@@ -133,6 +133,7 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_project.argtypes = [vp, vp, vp, ci, ci, ci, vp, vp, vp, vp, ci, vp]
     L.soccdpt_bind_grad.argtypes = [vp, ctypes.c_char_p, vp]
     L.soccdpt_train_set_amp.argtypes = [vp, ci]
+    L.soccdpt_train_set_drop_path.argtypes = [vp, ctypes.c_float]
     L.soccdpt_train_unscale.argtypes = [vp, cs, ctypes.c_float, vp, vp]
     L.soccdpt_train_workspace_bytes.argtypes = [vp, ci]
     L.soccdpt_train_workspace_bytes.restype = cs
@@ -418,6 +419,10 @@ class Engine:
         3 / "x3" / "f16x3": split-fp16 operands (three fp16 MFMAs per product): f32-grade gradients, no loss scaling needed."""
         code = {False: 0, True: 1, 0: 0, 1: 1, 2: 2, 3: 3, "bf16": 1, "f16": 2, "fp16": 2, "x3": 3, "f16x3": 3, None: 0}[mode]
         self._check(self.L.soccdpt_train_set_amp(self._h, code), "soccdpt_train_set_amp")
+
+    def train_set_drop_path(self, rate: float):
+        """Stochastic-depth rate of the Swin-V2 encoder's train-mode forward (timm drop_path_rate; 0 = off)."""
+        self._check(self.L.soccdpt_train_set_drop_path(self._h, float(rate)), "soccdpt_train_set_drop_path")
 
     def train_unscale(self, grads: torch.Tensor, inv_scale: float, found_inf: torch.Tensor):
         assert grads.is_contiguous() and grads.dtype == torch.float32 and found_inf.dtype == torch.int32

@@ -178,6 +178,9 @@ class SOccDPT_V3(SOccDPT):
             Interpolate(scale_factor=2, mode="bilinear", align_corners=True),
             activation,
         )
+        # Stochastic depth under net.train(): timm 0.6.12 builds SwinTransformerV2 with drop_path_rate = 0.1 and the reference's factory
+        # (model/backbones/swin2.py:15-30) does not override it; vit_base_resnet50_384 defaults to 0.  Set it to 0.0 for deterministic parity runs.
+        self.drop_path_rate = 0.1 if self.depth_net.backbone in SWIN_ARCHS else 0.0
         self.load_net(self.path)
 
     def _engine_backbone(self) -> str:
@@ -314,7 +317,8 @@ class SOccDPT_V3(SOccDPT):
         assert x.dim() == 4 and x.shape[1] == 3 and x.shape[2] == img and x.shape[3] == img, f"expected x [B,3,{img},{img}], got {tuple(x.shape)}"
         eng = self._engine(x.device)
         live, keys, st = self._bind_for_training(eng)
-        eng.train_set_amp(getattr(self, "train_amp", False))   # the reference's `amp` sweep parameter: False | True / "bf16" | "f16" (with a GradScaler)
+        eng.train_set_amp(getattr(self, "train_amp", False))   # the reference's `amp` sweep parameter: False | True / "bf16" | "f16" (with a GradScaler) | "x3"
+        eng.train_set_drop_path(float(getattr(self, "drop_path_rate", 0.0)))
         xin = x.detach().to(torch.float32).contiguous()
         B = xin.shape[0]
         inv = torch.empty((B, img, img), device=x.device)

@@ -23,6 +23,7 @@ dev = torch.device("cuda", local)
 torch.cuda.set_device(dev)
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
+net.drop_path_rate = 0.0   # deterministic comparisons: no stochastic depth
 net.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
 net = net.to(dev).train()
 net.seg_head[3].p = 0.0

@@ -27,6 +27,7 @@ def _make(gpu_device, compute_occ=False):
     m = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=compute_occ, precision=PREC_F32)
     sd = synth_state_dict(alias_pretrained=True)
     m.load_state_dict(sd, strict=False)
+    m.drop_path_rate = 0.0      # deterministic parity runs (the model's default follows timm: 0.1 for the Swin-V2 encoders)
     return m.to(gpu_device), sd
 
 

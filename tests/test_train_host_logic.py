@@ -29,6 +29,9 @@ class FakeEngine:
     def train_set_amp(self, on):
         self.amp = bool(on)
 
+    def train_set_drop_path(self, rate):
+        self.drop_path = float(rate)
+
     def train_forward(self, x, inv, seg, dropout_p=0.1, seed=0):
         self.calls.append(("fwd", float(dropout_p), int(seed)))
         inv.fill_(1.0)

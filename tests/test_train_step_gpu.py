@@ -33,6 +33,7 @@ def _make(gpu_device, sigmoid=False):
     m = SOccDPT_V3(sigmoid=sigmoid, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
     sd = synth_state_dict(alias_pretrained=True)
     m.load_state_dict(sd, strict=False)
+    m.drop_path_rate = 0.0     # parity runs: no stochastic depth (test_swin_encoder_backward_exact[0.3] covers it with the masks read back)
     return m.to(gpu_device), sd
 
 
@@ -452,7 +453,8 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
 
 
-def test_swin_encoder_backward_exact(gpu_device):
+@pytest.mark.parametrize("drop_path_rate", [0.0, 0.3])
+def test_swin_encoder_backward_exact(gpu_device, drop_path_rate):
     """The Swin-V2 encoder has no ReLU (the log-CPB MLP's ReLU sees weight-only inputs), so its backward can be compared with autograd free of
     the mask-flip floor: gradients w.r.t. the four hooked feature maps are injected directly (soccdpt_train_backward_encoder) and every
     encoder parameter gradient -- window attention with cosine similarity, clamped logit scale, relative-position-bias MLP, shifted-window masks,
@@ -463,17 +465,33 @@ def test_swin_encoder_backward_exact(gpu_device):
     m.train()
     for p in m.parameters():
         p.requires_grad_(True)
-    B = 2
+    B = 3 if drop_path_rate else 2
     x = synth_input(B, seed0=3)
     sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
-    feats = R.swin_encoder(sd_o, x, R.ARCHS["swin2t16_256"])
+    # stochastic depth (timm DropPath, rate rising linearly over the 12 blocks): the HIP forward draws the per-sample masks from its seed; they are
+    # read back from the training workspace and handed to the oracle, which then is the same function
+    m.drop_path_rate = drop_path_rate
+    m.train_forward(x.to(gpu_device), seed=11)
+    eng = m._engine(gpu_device)
+    arch = R.ARCHS["swin2t16_256"]
+    dp = None
+    if drop_path_rate:
+        dp, nb, i, dropped = {}, sum(arch.depths), 0, 0
+        for s_, depth in enumerate(arch.depths):
+            for j_ in range(depth):
+                t = eng.train_tensor(B, f"drop_path.{s_}.{j_}", B).cpu().clone()      # [2][B]
+                keep = 1.0 / (1.0 - drop_path_rate * i / (nb - 1))
+                assert all(abs(float(v)) < 1e-12 or abs(float(v) - keep) < 1e-6 for v in t.reshape(-1)), (s_, j_, t)
+                dropped += int((t == 0).sum())
+                dp[(s_, j_)] = (t[0], t[1])
+                i += 1
+        assert float(dp[(0, 0)][0].min()) == 1.0 and dropped >= 3          # block 0 never drops; some later branch did
+    feats = R.swin_encoder(sd_o, x, arch, drop_path=dp)
     g = torch.Generator().manual_seed(5)
     ws = [torch.randn(f.shape, generator=g) for f in feats]
     sum((f * w).sum() for f, w in zip(feats, ws)).backward()
-    m.train_forward(x.to(gpu_device))
     for p in m.parameters():
         p.grad = None
-    eng = m._engine(gpu_device)
     eng.train_backward_encoder(B, [_nhwc(w).to(gpu_device) for w in ws])
     torch.cuda.synchronize()
     st = m._train_state[id(eng)]
@@ -579,6 +597,7 @@ def test_training_step_gradients_with_criterion_other_models(gpu_device, model_t
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     m = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+    m.drop_path_rate = 0.0
     sd = synth_state_dict(backbone, alias_pretrained=True)
     m.load_state_dict(sd, strict=False)
     m = m.to(gpu_device).train()
@@ -640,6 +659,7 @@ def test_random_trainable_subsets_match_full_backward(gpu_device, model_type, ba
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+    m.drop_path_rate = 0.0
     m.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=False)
     m = m.to(gpu_device).train()
     m.seg_head[3].p = 0.0

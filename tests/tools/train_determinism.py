@@ -11,6 +11,7 @@ from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
 dev = torch.device("cuda:0")
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "c.yaml"))
 net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
+net.drop_path_rate = 0.0   # deterministic comparisons: no stochastic depth
 net.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
 net = net.to(dev).train(); net.train_amp = os.environ.get("AMP", "") or False
 x, _, md, yd, ms, ys = get_batch(SyntheticDepthSegDataset(4, 256), 4, 4)

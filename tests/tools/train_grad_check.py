@@ -23,6 +23,7 @@ mode = sys.argv[4] if len(sys.argv) > 4 else "random"
 dev = torch.device("cuda:0")
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 m = SOccDPT_V3(sigmoid=sigmoid, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=model_type)
+m.drop_path_rate = 0.0   # deterministic comparisons: no stochastic depth
 sd = synth_state_dict(backbone, alias_pretrained=True)
 m.load_state_dict(sd, strict=False)
 m = m.to(dev).train()

@@ -17,6 +17,7 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device("cuda:0")
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
+m.drop_path_rate = 0.0   # deterministic comparisons: no stochastic depth
 sd = synth_state_dict(alias_pretrained=True)
 m.load_state_dict(sd, strict=False)
 m = m.to(dev).train()

@@ -12,6 +12,7 @@ for mt, B, amp in (("dpt_swin2_tiny_256", 4, False), ("dpt_swin2_tiny_256", 4, T
     bb = MODEL_TYPE_TO_BACKBONE[mt]; S = backbone_image_size(bb)
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "c.yaml"))
     net = SOccDPT_V3(sigmoid=True, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32, model_type=mt)
+    net.drop_path_rate = 0.0   # deterministic comparisons: no stochastic depth
     net.load_state_dict(synth_state_dict(bb, alias_pretrained=True), strict=False)
     net = net.to(dev).train(); net.train_amp = amp
     ds = SyntheticDepthSegDataset(B, S)
