@@ -140,7 +140,12 @@ int soccdpt_train_backward_encoder(void* handle, int B, const float* const* dev_
     if (!h) return 1;
     if (h->train_key.ws != dev_workspace || h->train_key.B != B || !dev_workspace)
         return fail(h, "soccdpt_train_backward_encoder: no soccdpt_train_forward ran on this workspace with this batch size");
-    return train_backward_encoder(*h, B, dev_d_feat, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+    const int amp_now = h->train_amp;
+    const float dp_now = h->train_drop_path;
+    h->train_amp = h->train_key.amp; h->train_drop_path = h->train_key.drop_path;
+    const int rc = train_backward_encoder(*h, B, dev_d_feat, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+    h->train_amp = amp_now; h->train_drop_path = dp_now;
+    return rc;
 }
 int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems) {
     Handle* h = static_cast<Handle*>(handle);
@@ -156,6 +161,7 @@ int soccdpt_train_forward(void* handle, const float* dev_x, int B, float* dev_in
     h->train_key = Handle::TrainKey();
     if (train_forward(*h, dev_x, B, dev_inv, dev_seg, dev_workspace, workspace_bytes, dropout_p, seed, (hipStream_t)stream, h->err)) return 1;
     h->train_key.ws = dev_workspace; h->train_key.B = B; h->train_key.dropout_p = dropout_p;
+    h->train_key.amp = h->train_amp; h->train_key.drop_path = h->train_drop_path;
     return 0;
 }
 int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float* dev_d_inv, const float* dev_d_seg, void* dev_workspace,
@@ -165,7 +171,13 @@ int soccdpt_train_backward(void* handle, const float* dev_x, int B, const float*
     if (!dev_d_inv || !dev_d_seg) return fail(h, "soccdpt_train_backward: null argument");
     if (h->train_key.ws != dev_workspace || h->train_key.B != B || !dev_workspace)
         return fail(h, "soccdpt_train_backward: no soccdpt_train_forward ran on this workspace with this batch size");
-    return train_backward(*h, dev_x, B, dev_d_inv, dev_d_seg, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+    // the modes the forward ran with (a setter called between forward and backward takes effect at the next forward)
+    const int amp_now = h->train_amp;
+    const float dp_now = h->train_drop_path;
+    h->train_amp = h->train_key.amp; h->train_drop_path = h->train_key.drop_path;
+    const int rc = train_backward(*h, dev_x, B, dev_d_inv, dev_d_seg, dev_workspace, workspace_bytes, (hipStream_t)stream, h->err);
+    h->train_amp = amp_now; h->train_drop_path = dp_now;
+    return rc;
 }
 
 int soccdpt_project(void* handle, const float* dev_inv, const float* dev_seg, int B, int in_h, int in_w, float* dev_inv_up,

@@ -139,6 +139,8 @@ struct Handle {
         const void* ws = nullptr;
         int B = 0;
         float dropout_p = 0.f;
+        int amp = 0;              // amp mode and stochastic-depth rate LATCHED at the forward: the backward of that forward uses them even if the setters
+        float drop_path = 0.f;    // were called in between (the reuse_xt staged operands and the DropPath scales belong to the forward)
     } train_key;
     float train_drop_path = 0.f;   // soccdpt_train_set_drop_path: timm drop_path_rate of the Swin-V2 encoder in train mode (0 = off)
     int train_amp = 0;        // soccdpt_train_set_amp: 16-bit MFMA operands for the gradient GEMMs (f32 accumulate, f32 weights / activations / gradients): 1 bf16, 2 fp16

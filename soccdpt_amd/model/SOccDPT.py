@@ -347,7 +347,10 @@ class SOccDPT_V3(SOccDPT):
         carried = []
         for k in keys:
             g = st["grads"].get(k)
-            if g is not None and live[k].grad is g:
+            pg = live[k].grad
+            # "still the library's buffer" is decided by STORAGE, not object identity: _bind_for_training makes a new view of the same span whenever
+            # requires_grad toggles (PatchWiseInplace does on every patch), and an old view left in .grad aliases the memory the library overwrites
+            if g is not None and pg is not None and pg.data_ptr() == g.data_ptr():
                 carried.append((g, g.clone()))
         eng.train_backward(xin, d_inv.detach().to(torch.float32).contiguous(), d_seg.detach().to(torch.float32).contiguous())
         # contiguous runs of this step's trainable tensors in the flat gradient buffer (data-parallel exchange, GradScaler.unscale_)
@@ -373,9 +376,9 @@ class SOccDPT_V3(SOccDPT):
             if g is None or id(p) in seen:
                 continue
             seen.add(id(p))
-            if p.grad is None:
-                p.grad = g
-            elif p.grad is not g:
+            if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+                p.grad = g                      # (an alias of the same span already holds old + new: see `carried`)
+            else:
                 p.grad.add_(g)
         self._train_x = None
 

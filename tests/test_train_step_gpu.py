@@ -580,6 +580,21 @@ def test_backward_accumulates_without_zero_grad(gpu_device):
     for k, p in m.named_parameters():
         if p.grad is not None:
             assert torch.equal(p.grad, singles[0][k] + singles[1][k]), k
+    # ... also ACROSS a requires_grad toggle (what PatchWiseInplace does between patches): the toggle makes the binding create a fresh view of
+    # the same gradient span, so the old view left in .grad aliases the memory the library overwrites -- accumulation must still be old + new
+    for p in m.parameters():
+        p.grad = None
+    m.train_forward(xs[0])
+    m.backward(a, b)
+    w = dict(m.named_parameters())["seg_head.4.weight"]
+    w.requires_grad_(False)
+    m.train_forward(xs[1])          # re-binds: seg_head.4.weight frozen
+    w.requires_grad_(True)
+    m.train_forward(xs[1])          # re-binds again: a NEW view object over the same span, .grad still holds the old one
+    m.backward(a, b)
+    for k, p in m.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, singles[0][k] + singles[1][k]), k
 
 
 @pytest.mark.parametrize("model_type,backbone,size,tol,med_tol", [("dpt_swin2_base_384", "swin2b24_384", 384, 1e-3, 3e-4),
