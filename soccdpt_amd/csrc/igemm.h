@@ -81,6 +81,7 @@ struct IgemmDesc {
     int act_on_f32 = 0;
     void* out_op = nullptr;       // operand-typed copy (bf16 / f32): [M][N] plain (ld = N) or Halo image when out_halo != 0
     int out_halo = 0;
+    int out_op_f32 = 0;           // x3 launches only: out_op is a plain f32 tensor / halo image (the training tape keeps f32 activations), not an x3 operand
     // fused 1x1 tail of the depth head: out_dot[m] = relu(sum_n act(v)[n]*dot_w[n] + dot_b)   (N <= 32)
     const float* dot_w = nullptr;
     float dot_b = 0.f;

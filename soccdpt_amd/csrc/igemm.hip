@@ -636,7 +636,8 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                     p.y = pack_h2<F16>(a[2], a[3]);
                     *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
                 } else if constexpr (X3) {
-                    x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
+                    if (d.out_op_f32) *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
+                    else x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
                 } else {
                     *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
                 }
@@ -997,7 +998,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             err = "igemm: x3 weight-row views must start at multiples of 16 elements (wt_kx copies)";
             return 1;
         }
-        if (d.ldx % 16 || d.Cin % 32 || (d.out_op && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
+        if (d.ldx % 16 || d.Cin % 32 || (d.out_op && !d.out_op_f32 && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
         if (d.splitk > 1) {
             if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: x3 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
             if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true, false, true>(d, stream, err);

@@ -156,6 +156,22 @@ int gemm(Ctx& c, IgemmDesc d, bool x3) {
     return launch_igemm(d, c.st, c.err);
 }
 
+// Forward GEMM.  With train amp mode 3 ("x3") the operands -- f32 tape tensors and f32 (tap-major) weights -- are converted to the x3 split-fp16
+// format into backward scratch (S_T2 / S_wt, idle during the forward) and the product runs as three fp16 MFMAs per k-step; everything the launch
+// writes stays f32 (out_f32, and out_op as an f32 tensor: out_op_f32), so the tape and the backward are unchanged.  x_elems / w_elems: elements of
+// the X buffer (a halo image counts its border) and of the weight matrix.
+int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems) {
+    const bool x3 = c.h.train_amp == 3 && d.Cin % 32 == 0 && (d.taps == 9 || d.ldx % 16 == 0) && x_elems % 16 == 0 && w_elems % 16 == 0 && !d.ln_g && !d.gn_stats &&
+                    !d.grp_rows && !d.gather1 && d.stride == 1 && d.pad == 1 && d.in_halo == 1;
+    if (!x3) return gemm(c, d);
+    uint16_t* xs = reinterpret_cast<uint16_t*>(c.T.S_T2);
+    uint16_t* wsx = reinterpret_cast<uint16_t*>(c.T.S_wt);
+    TRY(launch_cvt_bf16(static_cast<const float*>(d.X), xs, x_elems, 3, c.st, c.err));
+    TRY(launch_cvt_bf16(static_cast<const float*>(d.Wt), wsx, w_elems, 3, c.st, c.err));
+    d.X = xs; d.Wt = wsx; d.out_op_f32 = 1;
+    return gemm(c, d, true);
+}
+
 // Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
 // in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.  amp: bf16 operands (K padded to 128 by the caller).
 int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3) {
@@ -479,7 +495,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
     {
         IgemmDesc d;
         d.X = T.patches; d.Wt = T.pe_wpad; d.M = (int)M0; d.N = C0; d.Cin = 64; d.ldx = 64; d.bias = c.W(ENC + "patch_embed.proj.bias"); d.out_f32 = T.pe_pre;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, M0 * 64, (size_t)C0 * 64));
         TRY(launch_ln_residual(T.pe_pre, c.W(ENC + "patch_embed.norm.weight"), c.W(ENC + "patch_embed.norm.bias"), T.x0, nullptr, nullptr, nullptr, 0, (int)M0, C0, 0, G, 0,
                                st, err));
     }
@@ -507,21 +523,21 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             TRY(launch_attn_bias(b.table, b.bias_acc, wsz, H, st, err));
             IgemmDesc d;
             d.X = b.xin; d.Wt = c.W(k + "attn.qkv.weight"); d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = b.qkv_bias; d.out_f32 = b.qkv;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * C, (size_t)3 * C * C));
             TRY(launch_window_attention_f32(b.qkv, b.bias_acc, b.table, b.scale, b.attn, B, res, wsz, a.shift(s, j), H, st, err));
             d = IgemmDesc();
             d.X = b.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "attn.proj.bias"); d.out_f32 = b.a_pre;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * C, (size_t)C * C));
             TRY(copy_d2d(c, b.x1, b.xin, (size_t)M * C * 4, "train_forward copy"));
             TRY(launch_ln_residual(b.a_pre, c.W(k + "norm1.weight"), c.W(k + "norm1.bias"), b.x1, nullptr, nullptr, nullptr, 0, M, C, 1, res, 0, st, err,
                                    dp_on ? b.dp : nullptr, res * res));
             d = IgemmDesc();
             d.X = b.x1; d.Wt = c.W(k + "mlp.fc1.weight"); d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = c.W(k + "mlp.fc1.bias"); d.act = ACT_GELU;
             d.out_f32 = b.hpre; d.out_op = b.hact;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * C, (size_t)4 * C * C));
             d = IgemmDesc();
             d.X = b.hact; d.Wt = c.W(k + "mlp.fc2.weight"); d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = c.W(k + "mlp.fc2.bias"); d.out_f32 = b.m_pre;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * 4 * C, (size_t)4 * C * C));
             TRY(copy_d2d(c, b.xout, b.x1, (size_t)M * C * 4, "train_forward copy"));
             TRY(launch_ln_residual(b.m_pre, c.W(k + "norm2.weight"), c.W(k + "norm2.bias"), b.xout, nullptr, nullptr, j == a.hooks[s] ? T.feat[s] : nullptr, 0, M, C, 1, res, 0,
                                    st, err, dp_on ? b.dp + B : nullptr, res * res));
@@ -532,7 +548,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             TRY(launch_merge_gather(xcur, T.mg[s], B, res, C, 4, st, err));
             IgemmDesc d;
             d.X = T.mg[s]; d.Wt = c.W(dk + "reduction.weight"); d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = T.mr_pre[s];
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * C, (size_t)8 * C * C));
             TRY(launch_ln_residual(T.mr_pre[s], c.W(dk + "norm.weight"), c.W(dk + "norm.bias"), T.mx[s], nullptr, nullptr, nullptr, 0, M / 4, 2 * C, 0, res / 2, 0, st, err));
             xcur = T.mx[s];
         }
@@ -555,7 +571,7 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
         {
             IgemmDesc d = conv_desc(T.feat[l], a.fdim(l), T.w_lrn[l], F, r, B);
             d.out_f32 = T.lrn_raw[l]; d.out_op = T.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, Halo{r, r, a.fdim(l)}.elems(B), (size_t)F * 9 * a.fdim(l)));
         }
         const float* fused_raw = T.lrn_raw[l];
         const float* fused_relu = T.lrn_relu[l];
@@ -563,12 +579,12 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             const std::string ub = rb + "resConfUnit1.";
             IgemmDesc d = conv_desc(T.lrn_relu[l], F, T.w_rcu[l][0][0], F, r, B);
             d.bias = c.W(ub + "conv1.bias"); d.act = ACT_RELU; d.out_op = T.t1[l]; d.out_halo = 1;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, Halo{r, r, F}.elems(B), (size_t)F * 9 * F));
             d = conv_desc(T.t1[l], F, T.w_rcu[l][0][1], F, r, B);
             d.bias = c.W(ub + "conv2.bias"); d.res1 = T.lrn_raw[l];
             d.res2 = T.oc[l + 1]; d.res2_h = a.fres(l + 1); d.res2_w = a.fres(l + 1);
             d.out_f32 = T.out_raw[l]; d.out_op = T.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, Halo{r, r, F}.elems(B), (size_t)F * 9 * F));
             fused_raw = T.out_raw[l];
             fused_relu = T.out_relu[l];
         }
@@ -576,15 +592,15 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
             const std::string ub = rb + "resConfUnit2.";
             IgemmDesc d = conv_desc(fused_relu, F, T.w_rcu[l][1][0], F, r, B);
             d.bias = c.W(ub + "conv1.bias"); d.act = ACT_RELU; d.out_op = T.t2[l]; d.out_halo = 1;
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, Halo{r, r, F}.elems(B), (size_t)F * 9 * F));
             d = conv_desc(T.t2[l], F, T.w_rcu[l][1][1], F, r, B);
             d.bias = c.W(ub + "conv2.bias"); d.res1 = fused_raw; d.out_f32 = T.u[l];
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, Halo{r, r, F}.elems(B), (size_t)F * 9 * F));
         }
         {
             IgemmDesc d;
             d.X = T.u[l]; d.Wt = c.W(rb + "out_conv.weight"); d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = c.W(rb + "out_conv.bias"); d.out_f32 = T.oc[l];
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)M * F, (size_t)F * F));
         }
         if (l == 0) TRY(launch_bilinear(T.oc[0], 0, nullptr, nullptr, T.path1, 1, 0, B, r, r, 2 * r, 2 * r, F, st, err));
     }
@@ -597,18 +613,18 @@ int train_forward(Handle& h, const float* x, int B, float* inv, float* seg, void
     {
         IgemmDesc d = conv_desc(T.path1, F, T.w_d0, F / 2, r1, B);
         d.bias = c.W(SCR + "output_conv.0.bias"); d.out_f32 = T.d1;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, Halo{r1, r1, F}.elems(B), (size_t)(F / 2) * 9 * F));
         TRY(launch_bilinear(T.d1, 0, nullptr, nullptr, T.d1u, 1, 0, B, r1, r1, r0, r0, F / 2, st, err));
         d = conv_desc(T.d1u, F / 2, T.w_d2, 32, r0, B);
         d.bias = c.W(SCR + "output_conv.2.bias"); d.out_f32 = T.e;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, Halo{r0, r0, F / 2}.elems(B), (size_t)32 * 9 * (F / 2)));
         TRY(tr_depth_tail_fwd(T.e, c.W(SCR + "output_conv.4.weight"), c.W(SCR + "output_conv.4.bias"), T.inv, M0p, 32, st, err));
         TRY(copy_d2d(c, inv, T.inv, M0p * 4, "train_forward inv"));
     }
     {
         IgemmDesc d = conv_desc(T.path1, F, T.w_s0, F, r1, B);
         d.out_f32 = T.c_raw;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, Halo{r1, r1, F}.elems(B), (size_t)F * 9 * F));
         TRY(tr_bn_stats(T.c_raw, T.bn_stats, const_cast<float*>(c.W("seg_head.1.running_mean")), const_cast<float*>(c.W("seg_head.1.running_var")), T.S_col, F, M1, 1e-5f,
                         0.1f, st, err));
         TRY(tr_bn_relu_dropout_fwd(T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), c.W("seg_head.1.bias"), T.r, T.keep, M1, F, dropout_p, seed, st, err));

@@ -418,7 +418,7 @@ def test_amp_gradients_with_criterion(gpu_device):
     for p in m.parameters():
         p.grad = None
     inv, seg = m.train_forward(x.to(dev))
-    assert torch.equal(inv, inv0)
+    assert _rel(inv.cpu(), inv0.cpu()) < 5e-6 and _rel(seg.cpu(), seg0.cpu()) < 5e-5     # the x3 mode also runs the FORWARD GEMMs on split-fp16 operands (f32-grade)
     r3 = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
     m.backward(r3["d_inv"], r3["d_seg"])
     torch.cuda.synchronize()
