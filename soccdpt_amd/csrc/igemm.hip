@@ -856,6 +856,21 @@ static int pick_cfg_f32(const IgemmDesc& d) {
         if (d.tune >= 8 && d.tune <= 10 && d.Cin % 64) return 1;   // 64-deep k-tiles
         return d.tune;
     }
+    // x3 launches with the GroupNorm-statistics epilogue / generalised addressing: instantiated for configurations 0, 1, 3, 4, 7 (statistics) and 1, 4 (addressing only)
+    if (d.x3 && d.tune >= 0 && d.splitk <= 1 && !d.ln_g && (d.gn_stats || need_gen(d))) {
+        const int t = d.tune;
+        const bool gen = need_gen(d);
+        const int bm = (t == 0 || t == 3 || t == 7) ? 128 : 64, bn = (t == 0 || t == 3) ? 128 : 64;
+        if (d.gn_stats && (t == 0 || t == 1 || t == 3 || t == 4 || t == 7) && d.gn_hw % bm == 0 && bn % d.gn_cpg == 0 && !(gen && t != 1 && t != 4)) return t;
+        if (!d.gn_stats && gen && (t == 1 || t == 4)) return t;
+    }
+    if (d.x3 && d.gn_stats && d.splitk <= 1 && !need_gen(d)) {
+        // in-network timings of the ResNetV2 convolutions of dpt_hybrid_384 (profiles/r03_autotune_x3_hyb_st.txt): the 8-wave 64 x 64 tile
+        // wins nearly everywhere (the statistics epilogue is per-wave work, and these launches are short of workgroups)
+        const long b64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+        if (d.gn_hw % 128 == 0 && 128 % d.gn_cpg == 0 && d.N >= 256 && d.M >= 32768) return 3;
+        if (d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0 && !(d.taps == 9 && b64 >= 256 && b64 < 512)) return 4;
+    }
     if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
     if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
     if (d.ln_g) return 0;  // 128x128 covers N <= 128 (host only fuses LayerNorm for N <= 128 in f32 mode)
@@ -1015,11 +1030,15 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, true, true>(d, stream, err)
                          : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, false, true>(d, stream, err)
                                        : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t>(d, stream, err);
-            case 3: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t>(d, stream, err);
-            case 4: return launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t>(d, stream, err);      // 8 waves, 32 x 16 per wave
+            case 3: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, false, true, true>(d, stream, err)
+                                      : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t>(d, stream, err);
+            case 4: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, true, true>(d, stream, err)      // 8 waves, 32 x 16 per wave
+                         : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, false, true>(d, stream, err)
+                                       : launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t>(d, stream, err);
             case 5: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 3>, x3_t>(d, stream, err);    // 3-stage ring (96 KB)
             case 6: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 4>, x3_t>(d, stream, err);    // 4-stage ring (128 KB)
-            case 7: return launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t>(d, stream, err);     // 4 waves, 64 x 32 per wave, two workgroups per CU
+            case 7: return d.gn_stats ? launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t, false, false, true, true>(d, stream, err)
+                                      : launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t>(d, stream, err);     // 4 waves, 64 x 32 per wave, two workgroups per CU
             case 8: return launch_cfg_t<Cfg<128, 128, 128, 2, 4, 2>, x3_t>(d, stream, err);   // 64-deep k-tiles (256-byte rows): half the barriers
             case 9: return launch_cfg_t<Cfg<64, 64, 128, 2, 2, 3>, x3_t>(d, stream, err);
             case 10: return launch_cfg_t<Cfg<32, 64, 128, 2, 4, 3>, x3_t>(d, stream, err);    // small grids, long K
