@@ -158,6 +158,9 @@ size_t soccdpt_occ_words(void* handle);
 
 /* Number of kernel launches issued by the last soccdpt_network call (diagnostics). */
 int soccdpt_last_launch_count(void* handle);
+/* Kernels the calling thread has launched from this library since it was loaded (forward, criterion, backward, optimizer: every launch goes
+ * through one macro, csrc/launch.h); the difference of two reads brackets a region, e.g. one training step (bench.py --train-step). */
+unsigned long long soccdpt_launch_counter(void);
 
 /* ---- evaluation metrics on the device (the step after the hot path; replaces the per-batch .cpu().numpy() round trip of
  * utils/__init__.py:161-332).  No handle: stateless; `scratch` = soccdpt_metrics_scratch_bytes(B, C) bytes of device memory.

@@ -18,6 +18,10 @@ LaunchTimer*& launch_timer() {
     static thread_local LaunchTimer* t = nullptr;
     return t;
 }
+unsigned long long& launch_counter() {
+    static thread_local unsigned long long n = 0;
+    return n;
+}
 }  // namespace soccdpt
 
 // algorithmic HBM bytes of the projection kernel: inputs once + every requested output once
@@ -257,6 +261,7 @@ int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, 
 }
 
 int soccdpt_last_launch_count(void* handle) { return static_cast<Handle*>(handle)->launches; }
+unsigned long long soccdpt_launch_counter(void) { return soccdpt::launch_counter(); }
 
 size_t soccdpt_metrics_scratch_bytes(int B, int C) { return metrics_scratch_bytes(B, C); }
 

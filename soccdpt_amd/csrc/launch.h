@@ -14,6 +14,7 @@ struct LaunchTimer {
     virtual ~LaunchTimer() {}
 };
 LaunchTimer*& launch_timer();   // the calling thread's open profiling scope, or nullptr (capi.cpp)
+unsigned long long& launch_counter();   // kernels this thread has launched through SOCCDPT_LAUNCH so far (soccdpt_launch_counter; capi.cpp)
 
 }  // namespace soccdpt
 
@@ -21,6 +22,7 @@ LaunchTimer*& launch_timer();   // the calling thread's open profiling scope, or
 #define SOCCDPT_LAUNCH(...) SOCCDPT_LAUNCH_I(__VA_ARGS__)
 #define SOCCDPT_LAUNCH_I(kernel, grid, block, lds, stream, ...)                                            \
     do {                                                                                                   \
+        ++::soccdpt::launch_counter();                                                                     \
         if (::soccdpt::LaunchTimer* _lt = ::soccdpt::launch_timer()) {                                     \
             hipEvent_t _e0 = nullptr, _e1 = nullptr;                                                       \
             _lt->next_pair(&_e0, &_e1);                                                                    \

@@ -154,6 +154,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_words.restype = cs
     L.soccdpt_last_launch_count.argtypes = [vp]
     L.soccdpt_last_launch_count.restype = ci
+    L.soccdpt_launch_counter.argtypes = []
+    L.soccdpt_launch_counter.restype = ctypes.c_ulonglong
     L.soccdpt_metrics_scratch_bytes.argtypes = [ci, ci]
     L.soccdpt_metrics_scratch_bytes.restype = cs
     L.soccdpt_metrics_depth.argtypes = [vp, vp, vp, ci, cs, vp, vp, vp]
