@@ -9,6 +9,7 @@
 //                                                                          shifted views of ONE transposed halo image, dy_halo_T_kernel; im2colT_kernel
 //                                                                          only where a 64-row weight tile would straddle two taps, C % 64 != 0)
 // Everything else here is an elementwise / row / column-reduction kernel, deterministic (no float atomics): fixed-order tree reductions.
+#include <type_traits>
 #include "half16.h"
 #include "kernels.h"
 
@@ -169,6 +170,38 @@ __global__ void to_halo_kernel(const float* __restrict__ in, OT* __restrict__ ou
         store_out<OT>(out, (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c, in[i]);
     }
 }
+// The same over the WHOLE halo image, 8 channels per thread (C % 8 == 0): border pixels are written as zeros, so the caller needs no memset of
+// the buffer, and every load / store is 16 or 32 bytes wide.
+template <typename OT>
+__global__ void to_halo_full8_kernel(const float* __restrict__ in, OT* __restrict__ out, int B, int H, int W, int C) {
+    const int C8 = C >> 3;
+    const size_t n = (size_t)B * (H + 2) * (W + 2) * C8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C8) * 8;
+        size_t r = i / C8;
+        const int x = (int)(r % (W + 2)) - 1;
+        r /= (W + 2);
+        const int y = (int)(r % (H + 2)) - 1, b = (int)(r / (H + 2));
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+        if (x >= 0 && x < W && y >= 0 && y < H) {
+            const float* p = in + (((size_t)b * H + y) * W + x) * C + c;
+            v0 = *reinterpret_cast<const float4*>(p);
+            v1 = *reinterpret_cast<const float4*>(p + 4);
+        }
+        const size_t o = i * 8;
+        if constexpr (sizeof(OT) == 4 && !std::is_same<OT, x3raw>::value) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o) = v0;
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o + 4) = v1;
+        } else if constexpr (std::is_same<OT, x3raw>::value) {
+            x3_store4(out, o, v0.x, v0.y, v0.z, v0.w);
+            x3_store4(out, o + 4, v1.x, v1.y, v1.z, v1.w);
+        } else {
+            const float f[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k) out[o + k] = cvt_out<OT>(f[k]);
+        }
+    }
+}
 // out[i] (+)= halo interior
 __global__ void from_halo_kernel(const float* __restrict__ halo, float* __restrict__ out, int B, int H, int W, int C, int accumulate) {
     const size_t n = (size_t)B * H * W * C;
@@ -186,32 +219,51 @@ __global__ void from_halo_kernel(const float* __restrict__ halo, float* __restri
 // ---------------- reductions ----------------
 // column sums of [M][N] (bias gradients, LayerNorm gamma / beta gradients): out[n] = sum_m a[m][n] (* b[m][n] when b != nullptr).
 // Two deterministic stages: a block = 64 columns x 4 row phases over one chunk of rows (partials per chunk), then the chunks in order.
+// TWO: a second output column set, the plain sum of a (LayerNorm: gamma and beta gradients from one pass over dout); part = [chunks][2N] then.
+// Four independent row streams per thread keep four loads in flight; the order of additions per output does not depend on TWO.
+template <bool TWO>
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part, size_t M, int N, int chunks) {
-    __shared__ float red[4][64];
+    __shared__ float red[TWO ? 2 : 1][4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + tx;
     const int ch = blockIdx.y;
     const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
-    float s = 0.f;
-    if (n < N)
-        for (size_t m = lo + ty; m < hi; m += 4) s += b ? a[m * N + n] * b[m * N + n] : a[m * N + n];
-    red[ty][tx] = s;
+    float s[4] = {0.f, 0.f, 0.f, 0.f}, t[4] = {0.f, 0.f, 0.f, 0.f};
+    if (n < N) {
+        size_t m = lo + ty;
+        for (; m + 12 < hi; m += 16) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = a[(m + 4 * u) * N + n]; bv[u] = b ? b[(m + 4 * u) * N + n] : 1.f; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { s[u] += b ? av[u] * bv[u] : av[u]; if (TWO) t[u] += av[u]; }
+        }
+        for (; m < hi; m += 4) { const float av = a[m * N + n]; s[0] += b ? av * b[m * N + n] : av; if (TWO) t[0] += av; }
+    }
+    red[0][ty][tx] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (TWO) red[TWO ? 1 : 0][ty][tx] = (t[0] + t[1]) + (t[2] + t[3]);
     __syncthreads();
-    if (ty == 0 && n < N) part[(size_t)ch * N + n] = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+    if (ty == 0 && n < N) {
+        const int NN = TWO ? 2 * N : N;
+        part[(size_t)ch * NN + n] = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
+        if (TWO) part[(size_t)ch * NN + N + n] = (red[TWO ? 1 : 0][0][tx] + red[TWO ? 1 : 0][1][tx]) + (red[TWO ? 1 : 0][2][tx] + red[TWO ? 1 : 0][3][tx]);
+    }
 }
-// second stage: the chunk partials [chunks][N] summed in chunk order, 64 columns x 4 phases per block (phase p takes chunks p, p+4, ...)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int chunks, int accumulate) {
+// second stage: the chunk partials [chunks][NN] summed in chunk order, 64 columns x 4 phases per block (phase p takes chunks p, p+4, ...); columns
+// >= N go to out2 (the TWO form above)
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2, int N, int NN, int chunks, int accumulate) {
     __shared__ float red[4][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + tx;
     float s = 0.f;
-    if (n < N)
-        for (int c = ty; c < chunks; c += 4) s += part[(size_t)c * N + n];
+    if (n < NN)
+        for (int c = ty; c < chunks; c += 4) s += part[(size_t)c * NN + n];
     red[ty][tx] = s;
     __syncthreads();
-    if (ty == 0 && n < N) {
+    if (ty == 0 && n < NN) {
         const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
-        out[n] = accumulate ? out[n] + v : v;
+        float* o = n < N ? out + n : out2 + (n - N);
+        *o = accumulate ? *o + v : v;
     }
 }
 // sum over the leading axis of [R][n] with n large (attention logit gradients summed over windows): one thread per column
@@ -1066,6 +1118,16 @@ int tr_wgrad_permute(const float* in, float* out, int N, int C, hipStream_t st, 
     SOCCDPT_LAUNCH(wgrad_permute_kernel, dim3(gs_blocks((size_t)N * C * 9)), dim3(256), 0, st, in, out, N, C);
     TK("wgrad_permute");
 }
+int tr_to_halo_full(const float* in, void* out, int B, int H, int W, int C, int fmt, hipStream_t st, std::string& err) {
+    // fmt: 0 f32, 1 bf16, 2 fp16, 3 x3.  Writes the border too (zeros): no memset needed.  C % 8 == 0.
+    if (C % 8) { err = "tr_to_halo_full: C must be a multiple of 8"; return 1; }
+    const dim3 g(gs_blocks((size_t)B * (H + 2) * (W + 2) * (C / 8))), b(256);
+    if (fmt == 0) SOCCDPT_LAUNCH(to_halo_full8_kernel<float>, g, b, 0, st, in, static_cast<float*>(out), B, H, W, C);
+    else if (fmt == 1) SOCCDPT_LAUNCH(to_halo_full8_kernel<uint16_t>, g, b, 0, st, in, static_cast<uint16_t*>(out), B, H, W, C);
+    else if (fmt == 2) SOCCDPT_LAUNCH(to_halo_full8_kernel<f16raw>, g, b, 0, st, in, static_cast<f16raw*>(out), B, H, W, C);
+    else SOCCDPT_LAUNCH(to_halo_full8_kernel<x3raw>, g, b, 0, st, in, static_cast<x3raw*>(out), B, H, W, C);
+    return check_launch("to_halo_full", err);
+}
 int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(to_halo_kernel<float>, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, in, out, B, H, W, C);
     TK("to_halo");
@@ -1086,9 +1148,19 @@ int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t
     int chunks = 512 / cb;
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
-    SOCCDPT_LAUNCH(colsum_part_kernel, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
-    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, N, chunks, accumulate);
+    SOCCDPT_LAUNCH(colsum_part_kernel<false>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, static_cast<float*>(nullptr), N, N, chunks, accumulate);
     TK("colsum");
+}
+// out_ab[n] = sum_m a b, out_a[n] = sum_m a from ONE pass over a (LayerNorm gamma / beta gradients).  scratch: up to 131072 + 2N floats
+int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, size_t M, int N, hipStream_t st, std::string& err) {
+    const int cb = (N + 63) / 64;
+    int chunks = 512 / cb;
+    if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
+    if (chunks < 1) chunks = 1;
+    SOCCDPT_LAUNCH(colsum_part_kernel<true>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((2 * N + 63) / 64), dim3(256), 0, st, scratch, out_ab, out_a, N, 2 * N, chunks, 0);
+    TK("colsum2");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);
@@ -1156,7 +1228,7 @@ int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, 
     if (K > 4) { err = "smallk_wgrad: K > 4"; return 1; }
     const int chunks = 256;
     SOCCDPT_LAUNCH(smallk_wgrad_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
-    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, K * C, chunks, 0);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, static_cast<float*>(nullptr), K * C, K * C, chunks, 0);
     TK("smallk_wgrad");
 }
 int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err) {

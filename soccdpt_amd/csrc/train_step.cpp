@@ -156,12 +156,12 @@ int gemm(Ctx& c, IgemmDesc d, bool x3) {
     return launch_igemm(d, c.st, c.err);
 }
 
-// Forward GEMM.  With train amp mode 3 ("x3") the operands -- f32 tape tensors and f32 (tap-major) weights -- are converted to the x3 split-fp16
+// Forward GEMM.  With any train amp mode (the 16-bit modes too: their forward stays f32-grade, so the ReLU masks are those of the f32 step) the operands -- f32 tape tensors and f32 (tap-major) weights -- are converted to the x3 split-fp16
 // format into backward scratch (S_T2 / S_wt, idle during the forward) and the product runs as three fp16 MFMAs per k-step; everything the launch
 // writes stays f32 (out_f32, and out_op as an f32 tensor: out_op_f32), so the tape and the backward are unchanged.  x_elems / w_elems: elements of
 // the X buffer (a halo image counts its border) and of the weight matrix.
 int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems) {
-    const bool x3 = c.h.train_amp == 3 && d.Cin % 32 == 0 && (d.taps == 9 || d.ldx % 16 == 0) && x_elems % 16 == 0 && w_elems % 16 == 0 && !d.ln_g && !d.gn_stats &&
+    const bool x3 = c.h.train_amp != 0 && d.Cin % 32 == 0 && (d.taps == 9 || d.ldx % 16 == 0) && x_elems % 16 == 0 && w_elems % 16 == 0 && !d.ln_g && !d.gn_stats &&
                     !d.grp_rows && !d.gather1 && d.stride == 1 && d.pad == 1 && d.in_halo == 1;
     if (!x3) return gemm(c, d);
     uint16_t* xs = reinterpret_cast<uint16_t*>(c.T.S_T2);
@@ -281,27 +281,31 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
     const bool amp = (c.h.train_amp == 1 || c.h.train_amp == 2) && N % 32 == 0 && C % 32 == 0;
     const int F16 = c.h.train_amp == 2 ? 1 : 0;
     if (dX_out) {
-        const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * (amp ? 2 : 4);
-        hipError_t e = hipMemsetAsync(T.S_halo, 0, hb, c.st);
-        if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+        const bool full = N % 8 == 0;   // the staging kernel writes the zero border itself; otherwise clear the buffer first
+        if (!full) {
+            const size_t hb = (size_t)B * (r + 2) * (r + 2) * N * (amp ? 2 : 4);
+            hipError_t e = hipMemsetAsync(T.S_halo, 0, hb, c.st);
+            if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+        }
         IgemmDesc d;
         d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
         if (x3) {
             uint16_t* h3 = reinterpret_cast<uint16_t*>(T.S_halo);
             uint16_t* w3 = reinterpret_cast<uint16_t*>(T.S_wt);
-            TRY(tr_to_halo16(dY, h3, B, r, r, N, 3, c.st, c.err));
+            TRY(tr_to_halo_full(dY, h3, B, r, r, N, 3, c.st, c.err));
             TRY(tr_conv_w_dgrad16(W, w3, N, C, 3, c.st, c.err));
             d.X = h3; d.Wt = w3;
             TRY(gemm(c, d, true));
         } else if (amp) {
             uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
             uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
-            TRY(tr_to_halo16(dY, h16, B, r, r, N, F16, c.st, c.err));
+            TRY(tr_to_halo_full(dY, h16, B, r, r, N, 1 + F16, c.st, c.err));
             TRY(tr_conv_w_dgrad16(W, w16, N, C, F16, c.st, c.err));
             d.X = h16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
-            TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
+            if (full) TRY(tr_to_halo_full(dY, T.S_halo, B, r, r, N, 0, c.st, c.err));
+            else TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
             TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err));   // [C][9][N], rotated
             d.X = T.S_halo; d.Wt = T.S_wt;
             TRY(gemm(c, d));
@@ -395,6 +399,7 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
 // out = LN(y) g + b backward: d y -> dy; gamma / beta gradients
 int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps) {
     TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, eps, c.st, c.err));
+    if (dg && dbeta) return tr_colsum2(dout, xhat, dg, dbeta, c.T.S_col, M, C, c.st, c.err);   // one pass over dout for both (same addition order as the single forms)
     if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, M, C, 0, c.st, c.err));
     if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, M, C, 0, c.st, c.err));
     return 0;

@@ -345,7 +345,8 @@ def test_amp_gradients_with_criterion(gpu_device):
     """net.train_amp = True (the reference's `amp` sweep parameter -> soccdpt_train_set_amp): the gradient GEMMs run with bf16 MFMA operands
     (f32 accumulate; forward, saved activations, weights and gradients stay f32).  Same whole-step comparison as above at B = 3; the bound is
     what bf16's 8-bit significand on dY / weights / activations allows: per tensor 5e-2, median 1e-2 (measured: median 5.7e-3, p90 7.5e-3,
-    worst 3.8e-2), and the forward is bit-identical to the f32 step's."""
+    worst 3.8e-2).  The forward's GEMMs take x3 split-fp16 operands in every amp mode (f32-grade: within 5e-6 of the exact-f32 step's outputs, so
+    the ReLU masks stay those of the f32 step up to its own rounding noise)."""
     from oracle import loss_ref
     from soccdpt_amd.scripts.train_SOccDPT import SyntheticDepthSegDataset, get_batch
     from soccdpt_amd.utils.loss import training_loss
@@ -368,7 +369,7 @@ def test_amp_gradients_with_criterion(gpu_device):
     m.train_amp = True
     m._engine(dev).train_workspace(B).fill_(0xA5)     # garbage: the bf16 staging buffers (two shifted copies, margins) must be fully initialised
     inv, seg = m.train_forward(x.to(dev))
-    assert torch.equal(inv, inv0) and torch.equal(seg, seg0)
+    assert _rel(inv, inv0) < 5e-6 and _rel(seg, seg0) < 5e-5, (_rel(inv, inv0), _rel(seg, seg0))
     r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
     m.backward(r["d_inv"], r["d_seg"])
     torch.cuda.synchronize()
@@ -388,8 +389,9 @@ def test_amp_gradients_with_criterion(gpu_device):
     scaler = GradScaler()
     for p in m.parameters():
         p.grad = None
+    inv_b = inv.clone()
     inv, seg = m.train_forward(x.to(dev))
-    assert torch.equal(inv, inv0)
+    assert torch.equal(inv, inv_b)          # the same x3 forward in both 16-bit amp modes
     r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
     m.backward(*scaler.scale(r["d_inv"], r["d_seg"]))
 
