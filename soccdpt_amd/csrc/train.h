@@ -42,7 +42,11 @@ int tr_merge_scatter(const float* dg, float* dx, int B, int R, int C, hipStream_
 int tr_patch_im2col(const float* x, float* out, int B, int S, hipStream_t st, std::string& err);
 int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream_t st, std::string& err);
 int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
-int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err);
+// MFMA form of tr_attention_bwd (train_attn.hip): no `part` scratch; rowstat holds {m + ln l, delta}; dscale_part has tr_attention_bwd_mfma_slots(ws) per (window, head)
+int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat,
+                          float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
+int tr_attention_bwd_mfma_slots(int ws);
+int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err, int dscale_slots = 0);
 int tr_drop_path_fill(float* out, int B, float p, unsigned seed, unsigned stream_id, hipStream_t st, std::string& err);
 int tr_scale_rows(const float* in, float* out, const float* scale, size_t M, int C, int rows_per_scale, hipStream_t st, std::string& err);
 int tr_unscale_check(float* g, size_t n, float inv_scale, int* found, hipStream_t st, std::string& err);

@@ -1277,9 +1277,10 @@ int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, c
 }
 // dS is overwritten by its sum over the windows (first nwin = 1 slab); hid: 2 * (2ws-1)^2 * 512 floats of scratch
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable,
-                        float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err) {
+                        float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err,
+                        int dscale_slots) {
     const int T2 = (2 * ws - 1) * (2 * ws - 1), N = ws * ws, nqb = (N + 63) / 64;
-    if (dls) SOCCDPT_LAUNCH(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, nqb * attn_nseg(ws));
+    if (dls) SOCCDPT_LAUNCH(attn_scale_reduce_kernel, dim3(heads), dim3(256), 0, st, dscale_part, ls, dls, nwin, heads, dscale_slots > 0 ? dscale_slots : nqb * attn_nseg(ws));
     if (dw0 || db0 || dw2) {
         const size_t n = (size_t)heads * N * N;
         // in place: column i of slab 0 is read before it is written, the other slabs are only read

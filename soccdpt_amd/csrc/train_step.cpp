@@ -695,7 +695,11 @@ static int encoder_backward(Ctx& c) {
             if (dp_on) { TRY(tr_scale_rows(G[3], G[4], b.dp, M, C, res * res, st, err)); g_att = G[4]; }
             TRY(ln_bwd(c, b.a_pre, c.W(k + "norm1.weight"), g_att, G[0], G[1], M, C, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias")));
             TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
-            TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, T.attn_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            // exact-f32 MFMA form (train_attn.hip); the VALU kernels of round 2 stay selectable for A/B and as the reference form
+            static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
+            const int dslots = attn_valu ? 0 : tr_attention_bwd_mfma_slots(wsz);
+            if (dslots) TRY(tr_attention_bwd_mfma(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            else TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, T.attn_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
             {
                 float* dls = c.Gd(k + "attn.logit_scale");
                 float* dw0 = c.Gd(k + "attn.cpb_mlp.0.weight");
@@ -704,7 +708,7 @@ static int encoder_backward(Ctx& c) {
                 if (dls || dw0 || db0 || dw2)
                     TRY(tr_attn_param_grads(T.dS, T.dscale_part, b.table, c.W(k + "attn.logit_scale"), c.W(k + "attn.cpb_mlp.0.weight"), c.W(k + "attn.cpb_mlp.0.bias"),
                                             c.W(k + "attn.cpb_mlp.2.weight"), T.dtable, T.dt, T.S_cpb, dls, dw0, db0, dw2, B * (res / wsz) * (res / wsz), wsz,
-                                            a.pretrained_window[s], H, st, err));
+                                            a.pretrained_window[s], H, st, err, dslots));
             }
             {
                 float* dq = c.Gd(k + "attn.q_bias");
