@@ -251,17 +251,19 @@ __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restric
 }
 // second stage: the chunk partials [chunks][NN] summed in chunk order, 64 columns x 4 phases per block (phase p takes chunks p, p+4, ...); columns
 // >= N go to out2 (the TWO form above)
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2, int N, int NN, int chunks, int accumulate) {
-    __shared__ float red[4][64];
+__global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ out2, int N, int NN, int chunks, int accumulate) {
+    __shared__ float red[16][64];   // 16 phases: a launch has only NN / 64 workgroups, so the chain of dependent loads per thread is what it costs
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + tx;
     float s = 0.f;
     if (n < NN)
-        for (int c = ty; c < chunks; c += 4) s += part[(size_t)c * NN + n];
+        for (int c = ty; c < chunks; c += 16) s += part[(size_t)c * NN + n];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && n < NN) {
-        const float v = (red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]);
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) v += (red[i][tx] + red[i + 1][tx]) + (red[i + 2][tx] + red[i + 3][tx]);
         float* o = n < N ? out + n : out2 + (n - N);
         *o = accumulate ? *o + v : v;
     }
@@ -379,6 +381,49 @@ __global__ void bilinear_bwd_kernel(const float* __restrict__ dhi, float* __rest
             }
         }
         dlo[i] = accumulate ? dlo[i] + acc : acc;
+    }
+}
+// four channels per thread (C % 4 == 0): the same taps, 16-byte loads
+__global__ void bilinear_bwd4_kernel(const float* __restrict__ dhi, float* __restrict__ dlo, int B, int h, int w, int H, int W, int C, int accumulate) {
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f, sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    const int C4 = C >> 2;
+    const size_t n = (size_t)B * h * w * C4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        size_t r = i / C4;
+        const int x = (int)(r % w);
+        r /= w;
+        const int y = (int)(r % h), b = (int)(r / h);
+        // candidate high-res rows: Y*sy in (y-1, y+1)
+        int Y0 = sy > 0.f ? (int)ceilf(((float)y - 1.0f) / sy) : 0, Y1 = sy > 0.f ? (int)floorf(((float)y + 1.0f) / sy) : H - 1;
+        int X0 = sx > 0.f ? (int)ceilf(((float)x - 1.0f) / sx) : 0, X1 = sx > 0.f ? (int)floorf(((float)x + 1.0f) / sx) : W - 1;
+        Y0 = Y0 < 0 ? 0 : Y0; X0 = X0 < 0 ? 0 : X0; Y1 = Y1 > H - 1 ? H - 1 : Y1; X1 = X1 > W - 1 ? W - 1 : X1;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int Y = Y0; Y <= Y1; ++Y) {
+            const float fy = sy * (float)Y;
+            const int y0 = (int)fy, y1 = y0 + (y0 < h - 1);
+            const float ly = fy - (float)y0;
+            float wy = 0.f;
+            if (y0 == y) wy += 1.f - ly;
+            if (y1 == y) wy += ly;
+            if (wy == 0.f) continue;
+            for (int X = X0; X <= X1; ++X) {
+                const float fx = sx * (float)X;
+                const int x0 = (int)fx, x1 = x0 + (x0 < w - 1);
+                const float lx = fx - (float)x0;
+                float wx = 0.f;
+                if (x0 == x) wx += 1.f - lx;
+                if (x1 == x) wx += lx;
+                if (wx != 0.f) {
+                    const float4 v = *reinterpret_cast<const float4*>(dhi + (((size_t)b * H + Y) * W + X) * C + c);
+                    const float ww = wy * wx;
+                    acc.x += ww * v.x; acc.y += ww * v.y; acc.z += ww * v.z; acc.w += ww * v.w;
+                }
+            }
+        }
+        float4* o = reinterpret_cast<float4*>(dlo + i * 4);
+        if (accumulate) { const float4 p = *o; acc.x += p.x; acc.y += p.y; acc.z += p.z; acc.w += p.w; }
+        *o = acc;
     }
 }
 
@@ -546,6 +591,35 @@ __global__ void depth_tail_bwd_kernel(const float* __restrict__ dinv, const floa
             rowterm[m * (K + 1) + k] = dz * fmaxf(ev, 0.f);
         }
         rowterm[m * (K + 1) + K] = dz;
+    }
+}
+
+// K = 32 forms: 8 threads per pixel, one float4 each (a thread per pixel walked a 128-byte row per lane: 617 us for the backward at B = 8)
+__global__ void depth_tail_fwd32_kernel(const float* __restrict__ e, const float* __restrict__ w4, const float* __restrict__ b4, float* __restrict__ inv, size_t M) {
+    const int c = threadIdx.x & 7;
+    const float4 w = *reinterpret_cast<const float4*>(w4 + 4 * c);
+    const float bias = b4[0];
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * 8; i += (size_t)gridDim.x * blockDim.x) {
+        const float4 v = *reinterpret_cast<const float4*>(e + i * 4);
+        float s = fmaxf(v.x, 0.f) * w.x + fmaxf(v.y, 0.f) * w.y + fmaxf(v.z, 0.f) * w.z + fmaxf(v.w, 0.f) * w.w;
+        s += __shfl_xor(s, 1);
+        s += __shfl_xor(s, 2);
+        s += __shfl_xor(s, 4);
+        if (c == 0) inv[i >> 3] = fmaxf(s + bias, 0.f);
+    }
+}
+__global__ void depth_tail_bwd32_kernel(const float* __restrict__ dinv, const float* __restrict__ inv, const float* __restrict__ e, const float* __restrict__ w4,
+                                        float* __restrict__ de, float* __restrict__ rowterm, size_t M) {
+    const int c = threadIdx.x & 7;
+    const float4 w = *reinterpret_cast<const float4*>(w4 + 4 * c);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M * 8; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t m = i >> 3;
+        const float dz = inv[m] > 0.f ? dinv[m] : 0.f;
+        const float4 v = *reinterpret_cast<const float4*>(e + i * 4);
+        *reinterpret_cast<float4*>(de + i * 4) = make_float4(v.x > 0.f ? dz * w.x : 0.f, v.y > 0.f ? dz * w.y : 0.f, v.z > 0.f ? dz * w.z : 0.f, v.w > 0.f ? dz * w.w : 0.f);
+        float* rt = rowterm + m * 33 + 4 * c;
+        rt[0] = dz * fmaxf(v.x, 0.f); rt[1] = dz * fmaxf(v.y, 0.f); rt[2] = dz * fmaxf(v.z, 0.f); rt[3] = dz * fmaxf(v.w, 0.f);
+        if (c == 7) rt[4] = dz;
     }
 }
 
@@ -995,17 +1069,23 @@ __global__ __launch_bounds__(1024) void cpb_reduce_kernel(const float* __restric
     const int T2 = (2 * ws - 1) * (2 * ws - 1);
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int j = blockIdx.x * 64 + tx, o = blockIdx.y;
-    float s = 0.f;
-    for (int r = ty; r < T2; r += 16) {
-        float coef;
-        if (mode == 0) coef = dt[(size_t)r * heads + o];
-        else {
-            float c0, c1;
-            cpb_coords(r, ws, pws, c0, c1);
-            coef = o == 0 ? c0 : (o == 1 ? c1 : 1.0f);
-        }
-        s += coef * mat[(size_t)r * 512 + j];
+    auto coef_of = [&](int r) -> float {
+        if (mode == 0) return dt[(size_t)r * heads + o];
+        float c0, c1;
+        cpb_coords(r, ws, pws, c0, c1);
+        return o == 0 ? c0 : (o == 1 ? c1 : 1.0f);
+    };
+    float s4[4] = {0.f, 0.f, 0.f, 0.f};   // four independent row streams: four loads in flight per thread
+    int r = ty;
+    for (; r + 48 < T2; r += 64) {
+        float cf[4], mv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { cf[u] = coef_of(r + 16 * u); mv[u] = mat[(size_t)(r + 16 * u) * 512 + j]; }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) s4[u] += cf[u] * mv[u];
     }
+    for (; r < T2; r += 16) s4[0] += coef_of(r) * mat[(size_t)r * 512 + j];
+    const float s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0) {
@@ -1149,7 +1229,7 @@ int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
     SOCCDPT_LAUNCH(colsum_part_kernel<false>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
-    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(256), 0, st, scratch, out, static_cast<float*>(nullptr), N, N, chunks, accumulate);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(1024), 0, st, scratch, out, static_cast<float*>(nullptr), N, N, chunks, accumulate);
     TK("colsum");
 }
 // out_ab[n] = sum_m a b, out_a[n] = sum_m a from ONE pass over a (LayerNorm gamma / beta gradients).  scratch: up to 131072 + 2N floats
@@ -1159,7 +1239,7 @@ int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, floa
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
     SOCCDPT_LAUNCH(colsum_part_kernel<true>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
-    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((2 * N + 63) / 64), dim3(256), 0, st, scratch, out_ab, out_a, N, 2 * N, chunks, 0);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((2 * N + 63) / 64), dim3(1024), 0, st, scratch, out_ab, out_a, N, 2 * N, chunks, 0);
     TK("colsum2");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
@@ -1183,7 +1263,8 @@ int tr_ln_bwd(const float* y, const float* g, const float* dout, float* dy, floa
     TK("ln_bwd");
 }
 int tr_bilinear_bwd(const float* dhi, float* dlo, int B, int h, int w, int H, int W, int C, int accumulate, hipStream_t st, std::string& err) {
-    SOCCDPT_LAUNCH(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
+    if (C % 4 == 0) SOCCDPT_LAUNCH(bilinear_bwd4_kernel, dim3(gs_blocks((size_t)B * h * w * (C / 4))), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
+    else SOCCDPT_LAUNCH(bilinear_bwd_kernel, dim3(gs_blocks((size_t)B * h * w * C)), dim3(256), 0, st, dhi, dlo, B, h, w, H, W, C, accumulate);
     TK("bilinear_bwd");
 }
 // scratch: (128 * C + C) doubles
@@ -1228,7 +1309,7 @@ int tr_smallk_wgrad(const float* dl, const float* x, float* dw, float* scratch, 
     if (K > 4) { err = "smallk_wgrad: K > 4"; return 1; }
     const int chunks = 256;
     SOCCDPT_LAUNCH(smallk_wgrad_part_kernel, dim3((C + 63) / 64, chunks), dim3(256), 0, st, dl, x, scratch, M, C, K, chunks);
-    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(256), 0, st, scratch, dw, static_cast<float*>(nullptr), K * C, K * C, chunks, 0);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((K * C + 63) / 64), dim3(1024), 0, st, scratch, dw, static_cast<float*>(nullptr), K * C, K * C, chunks, 0);
     TK("smallk_wgrad");
 }
 int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K, int S, int sigmoid, hipStream_t st, std::string& err) {
@@ -1236,11 +1317,13 @@ int tr_seg_act_bwd(const float* dseg, const float* seg, float* dup, int B, int K
     TK("seg_act_bwd");
 }
 int tr_depth_tail_fwd(const float* e, const float* w4, const float* b4, float* inv, size_t M, int K, hipStream_t st, std::string& err) {
-    SOCCDPT_LAUNCH(depth_tail_fwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, e, w4, b4, inv, M, K);
+    if (K == 32) SOCCDPT_LAUNCH(depth_tail_fwd32_kernel, dim3(gs_blocks(M * 8)), dim3(256), 0, st, e, w4, b4, inv, M);
+    else SOCCDPT_LAUNCH(depth_tail_fwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, e, w4, b4, inv, M, K);
     TK("depth_tail_fwd");
 }
 int tr_depth_tail_bwd(const float* dinv, const float* inv, const float* e, const float* w4, float* de, float* rowterm, size_t M, int K, hipStream_t st, std::string& err) {
-    SOCCDPT_LAUNCH(depth_tail_bwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M, K);
+    if (K == 32) SOCCDPT_LAUNCH(depth_tail_bwd32_kernel, dim3(gs_blocks(M * 8)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M);
+    else SOCCDPT_LAUNCH(depth_tail_bwd_kernel, dim3(gs_blocks(M)), dim3(256), 0, st, dinv, inv, e, w4, de, rowterm, M, K);
     TK("depth_tail_bwd");
 }
 int tr_merge_scatter(const float* dg, float* dx, int B, int R, int C, hipStream_t st, std::string& err) {
