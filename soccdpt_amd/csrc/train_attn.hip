@@ -311,6 +311,202 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Global softmax attention backward of the ViT-hybrid encoder (timm vision_transformer.Attention: P = softmax(q k^T / 8), head dimension 64, 577
+// tokens): the same two streaming passes without normalisation, bias or mask.  qkv [B*N][3E] (q | k | v, E = heads * 64), dqkv alike.
+// rowstat [B][heads][N][2] = {m + ln l, delta} (pass 0 -> pass 1; the forward's statistics are not needed).
+// ---------------------------------------------------------------------------------------------
+constexpr int VST = 68;   // floats per LDS row (272 B = 17 x 16)
+
+template <int PASS>
+__global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ attn_out,
+                                                                float* __restrict__ rowstat, float* __restrict__ dqkv, int N, int heads) {
+    constexpr float LOG2E = 1.4426950408889634f;
+    __shared__ __attribute__((aligned(16))) float X1[2][32 * VST];   // pass 0: k tile, pass 1: q / 8 tile
+    __shared__ __attribute__((aligned(16))) float X2[2][32 * VST];   // pass 0: v tile, pass 1: dO tile
+    __shared__ float ST[2][32][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int E = heads * 64, NT = (N + 31) / 32, NOB = (NT + 3) / 4;
+    int bid = blockIdx.x;
+    const int part = bid % NOB;
+    bid /= NOB;
+    const int head = bid % heads;
+    const int b = bid / heads;
+    const int r32 = lane & 31, h = lane >> 5;
+    const int ob = part * 4 + wave;
+    const bool active = ob < NT;
+    const int orow = ob * 32 + r32;
+    const int ocl = orow < N ? orow : N - 1;
+    const size_t bh = (size_t)b * heads + head;
+
+    // staging: thread -> (token tid >> 3, two 16-byte chunks c and c + 8 of the 64-float row)
+    float4 r1a, r1b, r2a, r2b;
+    float s0 = 0.f, s1 = 0.f;
+    auto gload = [&](int t) {
+        const int p = t * 32 + (tid >> 3), c = tid & 7;
+        r1a = make_float4(0.f, 0.f, 0.f, 0.f);
+        r1b = r1a; r2a = r1a; r2b = r1a;
+        s0 = 1.0e30f;
+        s1 = 0.f;
+        if (p < N) {
+            const size_t row = (size_t)b * N + p;
+            const float* src = qkv + row * (size_t)(3 * E) + head * 64 + c * 4;
+            if (PASS == 0) {
+                r1a = *reinterpret_cast<const float4*>(src + E);
+                r1b = *reinterpret_cast<const float4*>(src + E + 32);
+                r2a = *reinterpret_cast<const float4*>(src + 2 * E);
+                r2b = *reinterpret_cast<const float4*>(src + 2 * E + 32);
+            } else {
+                r1a = *reinterpret_cast<const float4*>(src);
+                r1b = *reinterpret_cast<const float4*>(src + 32);
+                r1a.x *= 0.125f; r1a.y *= 0.125f; r1a.z *= 0.125f; r1a.w *= 0.125f;
+                r1b.x *= 0.125f; r1b.y *= 0.125f; r1b.z *= 0.125f; r1b.w *= 0.125f;
+                const float* dsrc = dO + row * (size_t)E + head * 64 + c * 4;
+                r2a = *reinterpret_cast<const float4*>(dsrc);
+                r2b = *reinterpret_cast<const float4*>(dsrc + 32);
+                if (c == 0) {
+                    const float2 st = *reinterpret_cast<const float2*>(rowstat + (bh * N + p) * 2);
+                    s0 = st.x;
+                    s1 = st.y;
+                }
+            }
+        }
+    };
+    auto lstore = [&](int buf) {
+        const int kt = tid >> 3, c = tid & 7;
+        *reinterpret_cast<float4*>(&X1[buf][kt * VST + c * 4]) = r1a;
+        *reinterpret_cast<float4*>(&X1[buf][kt * VST + 32 + c * 4]) = r1b;
+        *reinterpret_cast<float4*>(&X2[buf][kt * VST + c * 4]) = r2a;
+        *reinterpret_cast<float4*>(&X2[buf][kt * VST + 32 + c * 4]) = r2b;
+        if (PASS == 1 && c == 0) { ST[buf][kt][0] = s0; ST[buf][kt][1] = s1; }
+    };
+
+    // owned fragments (B operand): lane (token r32, half h), step j <-> d = 32 h + j
+    float f1[32], f2[32];
+    float m_ln = 0.f, delta = 0.f;
+    {
+        const size_t row = (size_t)b * N + ocl;
+        const float* src = qkv + row * (size_t)(3 * E) + head * 64 + 32 * h + (PASS == 0 ? 0 : E);
+        const float* src2 = PASS == 0 ? dO + row * (size_t)E + head * 64 + 32 * h : qkv + row * (size_t)(3 * E) + head * 64 + 32 * h + 2 * E;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 a = *reinterpret_cast<const float4*>(src + 4 * j);
+            const float4 c4 = *reinterpret_cast<const float4*>(src2 + 4 * j);
+            const float sc = PASS == 0 ? 0.125f : 1.0f;
+            f1[4 * j] = a.x * sc; f1[4 * j + 1] = a.y * sc; f1[4 * j + 2] = a.z * sc; f1[4 * j + 3] = a.w * sc;
+            f2[4 * j] = c4.x; f2[4 * j + 1] = c4.y; f2[4 * j + 2] = c4.z; f2[4 * j + 3] = c4.w;
+        }
+        if (PASS == 0) {
+            const float* op = attn_out + row * (size_t)E + head * 64 + 32 * h;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float4 o4 = *reinterpret_cast<const float4*>(op + 4 * j);
+                delta = fmaf(f2[4 * j], o4.x, delta);
+                delta = fmaf(f2[4 * j + 1], o4.y, delta);
+                delta = fmaf(f2[4 * j + 2], o4.z, delta);
+                delta = fmaf(f2[4 * j + 3], o4.w, delta);
+            }
+            delta += __shfl_xor(delta, 32);
+        }
+    }
+    auto rows_dot = [&](const float* X, const float* f) -> f32x16 {   // rows = walked tokens of the tile, column = owned token
+        f32x16 acc;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+        const float* xrow = X + r32 * VST + 32 * h;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float4 k4 = *reinterpret_cast<const float4*>(xrow + 4 * j);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.x, f[4 * j], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.y, f[4 * j + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.z, f[4 * j + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(k4.w, f[4 * j + 3], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+
+    f32x16 g1a, g1b, g2a, g2b;   // rows d (a: 0..31, b: 32..63), column owned token
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) { g1a[rg] = 0.f; g1b[rg] = 0.f; g2a[rg] = 0.f; g2b[rg] = 0.f; }
+    float m = -3.0e38f, l = 0.f;
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+    const int ITERS = PASS == 0 ? 2 * NT : NT;
+#pragma unroll 1
+    for (int it = 0; it < ITERS; ++it) {
+        const int buf = it & 1;
+        const int t = it < NT ? it : it - NT;
+        const int tn = (it + 1) < NT ? it + 1 : it + 1 - NT;
+        if (it + 1 < ITERS) gload(tn);
+        if (active) {
+            f32x16 s = rows_dot(X1[buf], f1);
+            if (PASS == 0) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg)
+                    if (t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h >= N) s[rg] = -1.0e30f;
+            }
+            if (PASS == 0 && it < NT) {
+                float mt = s[0];
+#pragma unroll
+                for (int rg = 1; rg < 16; ++rg) mt = fmaxf(mt, s[rg]);
+                mt = fmaxf(mt, __shfl_xor(mt, 32));
+                const float mn = fmaxf(m, mt);
+                float psum = 0.f;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) psum += __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
+                l = l * __builtin_amdgcn_exp2f((m - mn) * LOG2E) + psum;
+                m = mn;
+                if (it == NT - 1) {
+                    l += __shfl_xor(l, 32);
+                    m_ln = m + __logf(l);
+                }
+            } else {
+                const f32x16 dp = rows_dot(X2[buf], f2);
+                f32x16 p, ds;
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int wl = (rg & 3) + 8 * (rg >> 2) + 4 * h;
+                    const float ml = PASS == 0 ? m_ln : ST[buf][wl][0];
+                    const float dl = PASS == 0 ? delta : ST[buf][wl][1];
+                    p[rg] = __builtin_amdgcn_exp2f((s[rg] - ml) * LOG2E);
+                    ds[rg] = p[rg] * (dp[rg] - dl);
+                }
+                const float* c1 = &X1[buf][(4 * h) * VST + r32];
+                const float* c2 = &X2[buf][(4 * h) * VST + r32];
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) {
+                    const int wl = (rg & 3) + 8 * (rg >> 2);
+                    g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST], ds[rg], g1a, 0, 0, 0);
+                    g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST + 32], ds[rg], g1b, 0, 0, 0);
+                    if (PASS == 1) {
+                        g2a = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST], p[rg], g2a, 0, 0, 0);
+                        g2b = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST + 32], p[rg], g2b, 0, 0, 0);
+                    }
+                }
+            }
+        }
+        if (it + 1 < ITERS) lstore(buf ^ 1);
+        __syncthreads();
+    }
+    if (!active || orow >= N) return;
+    const size_t row = (size_t)b * N + orow;
+    float* dst = dqkv + row * (size_t)(3 * E) + head * 64 + (PASS == 0 ? 0 : E);
+    const float gs = PASS == 0 ? 0.125f : 1.0f;   // pass 0: S = (q / 8) . k; pass 1 accumulated against q / 8 already
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        *reinterpret_cast<float4*>(dst + 8 * g + 4 * h) = make_float4(g1a[4 * g] * gs, g1a[4 * g + 1] * gs, g1a[4 * g + 2] * gs, g1a[4 * g + 3] * gs);
+        *reinterpret_cast<float4*>(dst + 32 + 8 * g + 4 * h) = make_float4(g1b[4 * g] * gs, g1b[4 * g + 1] * gs, g1b[4 * g + 2] * gs, g1b[4 * g + 3] * gs);
+        if (PASS == 1) {
+            *reinterpret_cast<float4*>(dst + E + 8 * g + 4 * h) = make_float4(g2a[4 * g], g2a[4 * g + 1], g2a[4 * g + 2], g2a[4 * g + 3]);
+            *reinterpret_cast<float4*>(dst + E + 32 + 8 * g + 4 * h) = make_float4(g2b[4 * g], g2b[4 * g + 1], g2b[4 * g + 2], g2b[4 * g + 3]);
+        }
+    }
+    if (PASS == 0 && h == 0) *reinterpret_cast<float2*>(rowstat + (bh * N + orow) * 2) = make_float2(m_ln, delta);
+}
+
 template <int WS>
 int launch_ws(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part,
               float* dqkv, int B, int res, int shift, int heads, hipStream_t st) {
@@ -345,6 +541,18 @@ int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* 
     }
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("attention_bwd_mfma: ") + hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+
+// ViT form: qkv [B*N][3E], O / dO [B*N][E], rowstat B * heads * N * 2 floats of scratch, dqkv [B*N][3E]
+int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err) {
+    const int NT = (N + 31) / 32, NOB = (NT + 3) / 4;
+    const unsigned blocks = (unsigned)(B * heads * NOB);
+    SOCCDPT_LAUNCH(vit_attn_bwd_mfma_kernel<0>, dim3(blocks), dim3(256), 0, st, qkv, dO, O, rowstat, dqkv, N, heads);
+    SOCCDPT_LAUNCH(vit_attn_bwd_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, qkv, dO, O, rowstat, dqkv, N, heads);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = std::string("vit_attention_bwd_mfma: ") + hipGetErrorString(e); return 1; }
     return 0;
 }
 

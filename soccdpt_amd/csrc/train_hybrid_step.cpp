@@ -24,6 +24,7 @@ int th_readout_cat_bwd(const float* dcat, float* dtok, int B, int NT, int E, int
 int th_tokens_to_patches(const float* dtok, float* dpatch, int B, int NT, int E, hipStream_t st, std::string& err);
 size_t th_vit_attention_part_floats(int B, int N, int heads);
 int th_vit_attention_fwd(const float* qkv, float* out, float* rowstat, float* part, int B, int N, int heads, hipStream_t st, std::string& err);
+int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err);   // train_attn.hip
 int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, const float* rowstat, float* part, float* dqkv, int B, int N, int heads, hipStream_t st,
                          std::string& err);
 
@@ -264,7 +265,10 @@ int hy_forward(Ctx& c, const float* x) {
         IgemmDesc d;
         d.X = v.ln1; d.Wt = c.W(k + "attn.qkv.weight"); d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.qkv.bias"); d.out_f32 = v.qkv;
         TRY(gemm(c, d));
-        TRY(th_vit_attention_fwd(v.qkv, v.attn, v.rowstat, Y.attn_part, B, NT, a.vit_heads, st, err));
+        // forward: the exact-f32 MFMA kernel of the inference path (vit_attention.hip); the VALU pair of round 2 stays behind SOCCDPT_ATTN_BWD_VALU
+        static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
+        if (attn_valu) TRY(th_vit_attention_fwd(v.qkv, v.attn, v.rowstat, Y.attn_part, B, NT, a.vit_heads, st, err));
+        else TRY(launch_vit_attention(v.qkv, v.attn, SOCCDPT_PREC_F32, B, NT, a.vit_heads, st, err));
         d = IgemmDesc();
         d.X = v.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.proj.bias"); d.res1 = v.xin; d.out_f32 = v.x1;
         TRY(gemm(c, d));
@@ -355,7 +359,9 @@ int hy_backward(Ctx& c) {
         TRY(tr_axpy(G[2], Y.GT, Mt * E, st, err));                                   // G2 = d x1
         // x1 = xin + proj(attn(qkv(LN1(xin))))
         TRY(linear_bwd(c, G[2], v.attn, c.W(k + "attn.proj.weight"), Mt, E, E, G[0], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
-        TRY(th_vit_attention_bwd(v.qkv, v.attn, G[0], v.rowstat, Y.attn_part, G[4], B, NT, a.vit_heads, st, err));
+        static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
+        if (attn_valu) TRY(th_vit_attention_bwd(v.qkv, v.attn, G[0], v.rowstat, Y.attn_part, G[4], B, NT, a.vit_heads, st, err));
+        else TRY(th_vit_attention_bwd_mfma(v.qkv, v.attn, G[0], v.rowstat, G[4], B, NT, a.vit_heads, st, err));
         TRY(linear_bwd(c, G[4], v.ln1, c.W(k + "attn.qkv.weight"), Mt, 3 * E, E, G[1], nullptr, c.Gd(k + "attn.qkv.weight"), c.Gd(k + "attn.qkv.bias")));
         TRY(ln_bwd(c, v.xin, c.W(k + "norm1.weight"), G[1], G[0], G[3], Mt, E, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias"), kLnEps));
         TRY(copy_d2d(c, Y.GT, G[2], Mt * E * 4, "hy_backward"));
