@@ -112,6 +112,7 @@ def test_training_entry_points_return_errors(gpu_device):
     m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, precision=PREC_F32)
     m.load_state_dict(synth_state_dict(alias_pretrained=True), strict=False)
     m = m.to(gpu_device).train()
+    m.drop_path_rate = 0.0        # the raw C calls below use the handle's default (no stochastic depth); the Python mirror must do the same step
     eng = m._engine(gpu_device)
     need = eng.L.soccdpt_train_workspace_bytes(eng._h, 1)
     big = torch.full((need,), 0xA5, dtype=torch.uint8, device=gpu_device)        # garbage: NaN patterns in every float
