@@ -99,6 +99,10 @@ struct IgemmDesc {
     float* sk_part = nullptr;
     unsigned* sk_count = nullptr;
     size_t sk_part_floats = 0, sk_count_words = 0;  // capacities, validated by launch_igemm
+    // sk_defer: every split only stores its partial tile (plain 16-byte stores) and a second launch sums the splits in order into out_f32 (nothing
+    // else of the epilogue applies).  For MANY splits of BIG tiles: the last-arriver reduction above is one workgroup walking splitk x tile floats
+    // with L2-bypassing loads (14 splits of a 128 x 128 tile: ~400 us), the deferred one is a chip-wide elementwise pass (~10 us).
+    int sk_defer = 0;
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
     // GroupNorm statistics of the raw output (the ST instantiation): with gn_stats != nullptr the epilogue also reduces sum / sum of
     // squares of v over every (sample, group of gn_cpg consecutive channels): per-tile partials go to gn_part ((M / BM) * (N / gn_cpg) * 2

@@ -397,6 +397,18 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         // (sc1, L2-bypassing) relaxed atomics, and "stored before counted" is enforced by s_waitcnt vmcnt(0) + the barrier.
         const size_t MN = (size_t)d.M * N;
         float* mine = d.sk_part + (size_t)split * MN;
+        if (d.sk_defer) {   // partial tile out with plain stores; launch_igemm's second launch (sk_reduce_kernel) sums the splits
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                const int m = m_of(j);
+#pragma unroll
+                for (int i = 0; i < TNE; ++i) {
+                    const int n = n_of(i);
+                    if (m < d.M && n < N) *reinterpret_cast<float4*>(mine + (size_t)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < TME; ++j) {
             const int m = m_of(j);
@@ -761,6 +773,18 @@ static bool need_gen(const IgemmDesc& d) {
     return d.stride != 1 || d.pad != 1 || d.in_halo != 1 || d.Hi || d.Wi || d.gather1 || d.grp_rows || d.seg2_k || d.stamps || d.wt_grp_rows;
 }
 
+// deferred split-K: out = sum over the splits (in order) of the partial tiles, 16 bytes per thread and iteration
+__global__ __launch_bounds__(256) void sk_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = *reinterpret_cast<const float4*>(part + i * 4);
+        for (int sp = 1; sp < splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)sp * n4 + i) * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        *reinterpret_cast<float4*>(out + i * 4) = s;
+    }
+}
+
 template <class C, typename T, bool LN = false, bool SK = false, bool ST = false, bool GEN = false>
 static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (!GEN && need_gen(d)) { err = "igemm: this configuration has no generalised-addressing instantiation (use 2, 20 or a GroupNorm-statistics launch)"; return 1; }
@@ -789,7 +813,14 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     const int splits = SK ? d.splitk : 1;
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
                (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
+    if (SK && d.sk_defer && (!d.out_f32 || d.out_op || d.bias || d.res1 || d.res2 || d.act || (d.N & 3))) { err = "igemm: deferred split-K writes out_f32 only"; return 1; }
     SOCCDPT_LAUNCH((igemm_kernel<C, T, LN, SK, ST, GEN>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    if (SK && d.sk_defer) {
+        const size_t n4 = (size_t)d.M * d.N / 4;
+        size_t blocks = (n4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        SOCCDPT_LAUNCH(sk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, d.sk_part, d.out_f32, splits, n4);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("igemm launch: ") + hipGetErrorString(e); return 1; }
     return 0;
@@ -1016,6 +1047,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         if (d.ldx % 16 || d.Cin % 32 || (d.out_op && !d.out_op_f32 && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
         if (d.splitk > 1) {
             if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: x3 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
+            if (need_gen(d) && d.tune == 3) return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, true, false, true>(d, stream, err);
             if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true, false, true>(d, stream, err);
             // tune 3 / 8: the 8-wave 128 x 128 tiles (32- / 64-deep k-tiles) for the long-K weight-gradient GEMMs of the training step: four times
             // the MFMA work per staged byte of the 64 x 64 tile, which the per-CU L2 -> LDS fill rate bounds (train_step.cpp: gemm_wgrad)
@@ -1050,6 +1082,9 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         // split-K in f32: the weight-gradient GEMMs of the training step (K = pixels, a handful of output tiles; train_step.cpp picks the split)
         if (d.splitk > 1) {
             if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: f32 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
+            if (d.tune == 3)   // 8-wave 128 x 128 tile (with sk_defer: the last-arriver reduction of many big partial tiles was what made it lose in round 2)
+                return need_gen(d) ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, float, false, true, false, true>(d, stream, err)
+                                   : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, float, false, true>(d, stream, err);
             if (need_gen(d)) return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, true, false, true>(d, stream, err);   // weight row groups (training wgrad)
             return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, float, false, true>(d, stream, err);
         }
@@ -1067,7 +1102,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if (id >= 30 && id <= 39) return launch_conv8p(d, id - 30, stream, err);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 45)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 46)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
@@ -1102,6 +1137,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 43: return launch_cfg<Cfg<128, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 64 x 64 per wave
         case 44: return launch_cfg<Cfg<256, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 128 x 64 per wave
         case 45: return launch_cfg<Cfg<128, 128, 64, 2, 2, 3, 32>>(d, stream, err);   // 4 waves, 3-stage ring
+        case 46:   // 8-wave 128 x 128 x 64 with split-K (training: weight gradients of the wide layers -- long K, few output tiles; tune-selected only)
+            if (d.splitk <= 1) { err = "igemm: configuration 46 is the split-K form"; return 1; }
+            if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, true, false, true>(d, stream, err)
+                                          : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, true, false, true>(d, stream, err);
+            return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, true>(d, stream, err) : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, true>(d, stream, err);
         case 20:
             if (d.gn_stats || (need_gen(d) && d.splitk <= 1)) return launch_cfg_gen<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, f16_t, false, true, false, true>(d, stream, err)

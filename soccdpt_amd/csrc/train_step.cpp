@@ -179,23 +179,31 @@ int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3) {
     d.f32 = (amp || x3) ? 0 : 1;
     d.x3 = x3 ? 1 : 0;
     d.f16 = c.h.train_amp == 2 ? 1 : 0;   // 16-bit format of the amp mode: bf16 (1) or fp16 with the caller's loss scaling (2)
-    // 64 x 64 tiles: the 128 x 128 split-K forms were measured slower (4 waves: 51.2 vs 45.2 ms per step at B = 8; 8 waves: 47.9 vs 42.2 --
-    // fewer, longer workgroups and a partial-tile exchange four times the size)
+    // Tiles.  Default for the wide layers (M, N multiples of 128, >= 8 tiles): the 8-wave 128 x 128 tile -- these launches are L2 -> LDS fill bound and it
+    // carries 64 FLOP per staged byte (16-bit) against 21 for 32 x 64 -- with the DEFERRED reduction (igemm.h sk_defer).  Rounds 2 and early 3 measured
+    // the big tiles slower (f32 4 waves 51.2 vs 45.2 ms, x3 37.5 vs 36.6 ms per step): that was the last-arriver reduction, one workgroup walking 14
+    // partial tiles of 64 KB with L2-bypassing loads (~400 us per launch).  SOCCDPT_SK_SMALL_TILES=1 selects the round-2 forms for A/B.
     long tiles = amp ? (long)((d.M + 31) / 32) * ((d.N + 63) / 64) : (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
     long nk = (long)d.taps * d.Cin / (amp ? 128 : 32);
-    static const int x3_sk_tile = getenv("SOCCDPT_X3_SK_TILE") ? atoi(getenv("SOCCDPT_X3_SK_TILE")) : 0;   // 0: 64 x 64 (default: the 128 x 128 forms measured slower, 37.5 / 40.3 vs 36.6 ms per step); 3 / 8: 128 x 128 (32- / 64-deep)
-    if (x3 && x3_sk_tile && d.M % 128 == 0 && d.N % 128 == 0 && d.Cin % 64 == 0 && (long)(d.M / 128) * (d.N / 128) >= 8) {
-        d.tune = x3_sk_tile;
+    static const bool small_tiles = getenv("SOCCDPT_SK_SMALL_TILES") != nullptr;
+    const bool big = !small_tiles && d.M % 128 == 0 && d.N % 128 == 0 && d.Cin % 64 == 0 && (long)(d.M / 128) * (d.N / 128) >= 8 &&
+                     (!d.wt_grp_rows || d.wt_grp_rows % 128 == 0);
+    if (big) {
+        d.tune = amp ? 46 : 3;
         tiles = (long)(d.M / 128) * (d.N / 128);
-        if (x3_sk_tile == 8) nk = (long)d.Cin / 64;
+        nk = (long)d.taps * d.Cin / (amp ? 64 : 32);
     }
     long S = (512 + tiles - 1) / tiles;
-    if (x3) S = 512 / tiles > 0 ? 512 / tiles : 1;   // x3 tiles are fill-bound at two workgroups per CU: at most ONE round of them (576 workgroups = 1.125 rounds cost 1 ms per step)
+    if (x3 || big) S = 512 / tiles > 0 ? 512 / tiles : 1;   // fill-bound at two workgroups per CU: at most ONE round of them (576 workgroups = 1.125 rounds cost 1 ms per step)
     if (S > nk / (amp ? 2 : 8)) S = nk / (amp ? 2 : 8);
     if (S > 64) S = 64;
     while (S > 1 && (size_t)S * d.M * d.N > kTrainSkPartFloats) --S;
     if (S > 1 && (size_t)tiles <= kTrainSkCountWords) {
         d.splitk = (int)S; d.sk_part = c.T.sk_part; d.sk_count = c.T.sk_count; d.sk_part_floats = kTrainSkPartFloats; d.sk_count_words = kTrainSkCountWords;
+        static const bool no_defer = getenv("SOCCDPT_SK_NO_DEFER") != nullptr;
+        if ((big || S >= 4) && !no_defer && d.N % 4 == 0) d.sk_defer = 1;   // many splits: sum them in a second chip-wide launch instead of in the last workgroup
+    } else if (big) {
+        d.tune = -1;
     }
     return launch_igemm(d, c.st, c.err);
 }
