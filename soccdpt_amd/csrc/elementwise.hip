@@ -266,9 +266,6 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
                        int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale, int rows_per_scale) {
     if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
-    // TIMING-ONLY ablation (wrong results): skip the launch, to bound what any fusion of these kernels into a neighbour could gain
-    static const bool ablate = getenv("SOCCDPT_ABLATE_LN") != nullptr;
-    if (ablate) return 0;
     const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 (half16.h)
     if (x3 && (C % 16 || merge)) { err = "ln_residual: x3 rows are multiples of 16 elements, written unmerged"; return 1; }
     hf = hf == 1;
