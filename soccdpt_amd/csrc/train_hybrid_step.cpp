@@ -264,22 +264,22 @@ int hy_forward(Ctx& c, const float* x) {
         if (i > 0) TRY(launch_ln_rows(const_cast<float*>(v.xin), c.W(k + "norm1.weight"), c.W(k + "norm1.bias"), v.ln1, 2, Mt, E, kLnEps, st, err));
         IgemmDesc d;
         d.X = v.ln1; d.Wt = c.W(k + "attn.qkv.weight"); d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.qkv.bias"); d.out_f32 = v.qkv;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, (size_t)Mt * E, (size_t)3 * E * E));   // x3 operands in the amp modes (train_step.cpp: gemm_fwd), exact f32 otherwise
         // forward: the exact-f32 MFMA kernel of the inference path (vit_attention.hip); the VALU pair of round 2 stays behind SOCCDPT_ATTN_BWD_VALU
         static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
         if (attn_valu) TRY(th_vit_attention_fwd(v.qkv, v.attn, v.rowstat, Y.attn_part, B, NT, a.vit_heads, st, err));
         else TRY(launch_vit_attention(v.qkv, v.attn, SOCCDPT_PREC_F32, B, NT, a.vit_heads, st, err));
         d = IgemmDesc();
         d.X = v.attn; d.Wt = c.W(k + "attn.proj.weight"); d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "attn.proj.bias"); d.res1 = v.xin; d.out_f32 = v.x1;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, (size_t)Mt * E, (size_t)E * E));
         TRY(launch_ln_rows(v.x1, c.W(k + "norm2.weight"), c.W(k + "norm2.bias"), v.ln2, 2, Mt, E, kLnEps, st, err));
         d = IgemmDesc();
         d.X = v.ln2; d.Wt = c.W(k + "mlp.fc1.weight"); d.M = Mt; d.N = 4 * E; d.Cin = E; d.ldx = E; d.bias = c.W(k + "mlp.fc1.bias"); d.act = ACT_GELU;
         d.out_f32 = v.hpre; d.out_op = v.hact;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, (size_t)Mt * E, (size_t)4 * E * E));
         d = IgemmDesc();
         d.X = v.hact; d.Wt = c.W(k + "mlp.fc2.weight"); d.M = Mt; d.N = E; d.Cin = 4 * E; d.ldx = 4 * E; d.bias = c.W(k + "mlp.fc2.bias"); d.res1 = v.x1; d.out_f32 = v.xout;
-        TRY(gemm(c, d));
+        TRY(gemm_fwd(c, d, (size_t)Mt * 4 * E, (size_t)4 * E * E));
         tcur = v.xout;
     }
     // ---- act_postprocess3 / 4: ProjectReadout -> Conv1x1 (-> Conv3x3 / 2) ----

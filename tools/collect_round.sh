@@ -1,0 +1,38 @@
+#!/bin/bash
+# One GPU call that collects everything profiles/ holds for a round tag (run through gpurun from the repo root, then tools/install_round.py <tag> here):
+#   tools/collect_profiles.sh for the three models (bench JSON, rocprofv3 kernel stats of the headline leg, three separate --pmc passes each),
+#   bench JSONs of the other arithmetic modes, the training-step bench lines and rocprofv3 kernel stats of one training step per amp mode.
+# usage: bash tools/collect_round.sh r03
+set -eo pipefail
+TAG=${1:-rXX}
+OUT=gpurun_out/${TAG}_extra
+mkdir -p $OUT
+bash tools/collect_profiles.sh ${TAG} > $OUT/collect_tiny.log 2>&1
+echo "tiny done"
+bash tools/collect_profiles.sh ${TAG}_base384 --config 3 > $OUT/collect_base.log 2>&1
+echo "base done"
+bash tools/collect_profiles.sh ${TAG}_hybrid384 --config 2 > $OUT/collect_hybrid.log 2>&1
+echo "hybrid done"
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+for p in f16 f16x3 f32; do python3 bench.py --precision $p --no-cpu-baseline > $OUT/bench_$p.json 2>> $OUT/bench.err; done
+python3 bench.py --config 2 --precision f16x3 --no-cpu-baseline > $OUT/bench_hybrid384_f16x3.json 2>> $OUT/bench.err
+python3 bench.py --config 2 --precision f32 --no-cpu-baseline > $OUT/bench_hybrid384_f32.json 2>> $OUT/bench.err
+python3 bench.py --config 3 --precision f16x3 --no-cpu-baseline > $OUT/bench_base384_f16x3.json 2>> $OUT/bench.err
+echo "modes done"
+python3 bench.py --train-step > $OUT/bench_train_step.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp x3 --no-cpu-baseline > $OUT/bench_train_step_x3.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp f16 --no-cpu-baseline > $OUT/bench_train_step_amp_f16.json 2>> $OUT/bench.err
+python3 bench.py --train-step --batch 3 --encoder-percentage 0.5 --patchwise-percentage 0.5 --no-cpu-baseline > $OUT/bench_train_step_B3_enc50_patch50.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --no-cpu-baseline > $OUT/bench_train_step_base384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp_base384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 --no-cpu-baseline > $OUT/bench_train_step_hybrid384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp_hybrid384.json 2>> $OUT/bench.err
+echo "train lines done"
+for a in 0 x3 bf16; do
+  TRAIN_AMP=$a rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_$a -o t -- python3 tools/train_bench.py 8 6 > $OUT/train_$a.json 2>> $OUT/bench.err
+  rm -f $OUT/train_$a/t_kernel_trace.csv
+done
+TRAIN_AMP=bf16 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_hybrid_bf16 -o t -- python3 tools/train_bench.py 4 4 1.0 1.0 dpt_hybrid_384 > $OUT/train_hybrid_bf16.json 2>> $OUT/bench.err
+rm -f $OUT/train_hybrid_bf16/t_kernel_trace.csv
+echo "all done"
