@@ -202,14 +202,14 @@ int hy_forward(Ctx& c, const float* x) {
             if (b.stride == 1) d.ldx = b.cin;
             else { d.gather1 = 1; d.stride = b.stride; d.pad = 0; d.in_halo = 0; d.Hi = b.rin; d.Wi = b.rin; d.H = b.rout; d.W = b.rout; }
             with_stats(c, d, b.ds_stats, b.cout, b.rout * b.rout);
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)Min * b.cin, (size_t)b.cout * b.cin));   // (x3 only for the un-strided form: gemm_fwd checks)
         }
         {
             TRY(launch_ws_conv_w(c.W(k + "conv1.weight"), b.w_c1, 2, b.mid, b.cin, 1, b.cin, kWsEps, st, err));
             IgemmDesc d;
             d.X = b.xin; d.Wt = b.w_c1; d.M = Min; d.N = b.mid; d.Cin = b.cin; d.ldx = b.cin; d.out_f32 = b.c1_raw;
             with_stats(c, d, b.c1_stats, b.mid, b.rin * b.rin);
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)Min * b.cin, (size_t)b.mid * b.cin));
             GnApplyArgs g;
             g.raw = b.c1_raw; g.stats = b.c1_stats; g.gamma = c.W(k + "norm1.weight"); g.beta = c.W(k + "norm1.bias"); g.out_halo = b.t1;
             g.M = (size_t)Min; g.HW = b.rin * b.rin; g.W = b.rin; g.C = b.mid; g.cpg = b.mid / 32;
@@ -221,7 +221,7 @@ int hy_forward(Ctx& c, const float* x) {
             d.X = b.t1; d.Wt = b.w_c2; d.M = Mout; d.N = b.mid; d.Cin = b.mid; d.taps = 9; d.H = b.rout; d.W = b.rout; d.Hi = b.rin; d.Wi = b.rin;
             d.stride = b.stride; d.pad = b.stride == 1 ? 1 : 0; d.in_halo = 1; d.out_f32 = b.c2_raw;
             with_stats(c, d, b.c2_stats, b.mid, b.rout * b.rout);
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)B * (b.rin + 2) * (b.rin + 2) * b.mid, (size_t)9 * b.mid * b.mid));
             GnApplyArgs g;
             g.raw = b.c2_raw; g.stats = b.c2_stats; g.gamma = c.W(k + "norm2.weight"); g.beta = c.W(k + "norm2.bias"); g.out_op = b.t2;
             g.M = (size_t)Mout; g.HW = b.rout * b.rout; g.W = b.rout; g.C = b.mid; g.cpg = b.mid / 32;
@@ -232,7 +232,7 @@ int hy_forward(Ctx& c, const float* x) {
             IgemmDesc d;
             d.X = b.t2; d.Wt = b.w_c3; d.M = Mout; d.N = b.cout; d.Cin = b.mid; d.ldx = b.mid; d.out_f32 = b.c3_raw;
             with_stats(c, d, b.c3_stats, b.cout, b.rout * b.rout);
-            TRY(gemm(c, d));
+            TRY(gemm_fwd(c, d, (size_t)Mout * b.mid, (size_t)b.cout * b.mid));
             GnApplyArgs g;
             g.raw = b.c3_raw; g.stats = b.c3_stats; g.gamma = c.W(k + "norm3.weight"); g.beta = c.W(k + "norm3.bias");
             if (b.proj) { g.raw2 = b.ds_raw; g.stats2 = b.ds_stats; g.gamma2 = c.W(k + "downsample.norm.weight"); g.beta2 = c.W(k + "downsample.norm.bias"); }

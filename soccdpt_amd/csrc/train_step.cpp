@@ -161,7 +161,7 @@ int gemm(Ctx& c, IgemmDesc d, bool x3) {
 // writes stays f32 (out_f32, and out_op as an f32 tensor: out_op_f32), so the tape and the backward are unchanged.  x_elems / w_elems: elements of
 // the X buffer (a halo image counts its border) and of the weight matrix.
 int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems) {
-    const bool x3 = c.h.train_amp != 0 && d.Cin % 32 == 0 && (d.taps == 9 || d.ldx % 16 == 0) && x_elems % 16 == 0 && w_elems % 16 == 0 && !d.ln_g && !d.gn_stats &&
+    const bool x3 = c.h.train_amp != 0 && d.Cin % 32 == 0 && (d.taps == 9 || d.ldx % 16 == 0) && x_elems % 16 == 0 && w_elems % 16 == 0 && !d.ln_g &&
                     !d.grp_rows && !d.gather1 && d.stride == 1 && d.pad == 1 && d.in_halo == 1;
     if (!x3) return gemm(c, d);
     uint16_t* xs = reinterpret_cast<uint16_t*>(c.T.S_T2);
