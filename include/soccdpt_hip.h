@@ -302,6 +302,9 @@ typedef struct soccdpt_igemm_args {
     size_t gn_part_floats, gn_count_words;
     uint64_t* stamps; /* diagnostics: 4 s_memrealtime stamps (100 MHz) per workgroup (entry, first k-tile landed, main loop done, stores
                          done); NULL = off (tools/igemm_stamps.py) */
+    int32_t sk_defer; /* with splitk > 1: every split only stores its partial tile and a second launch sums the splits in order into out_f32 (no
+                         bias / residual / activation / operand output); what the training step's weight-gradient GEMMs use with the 8-wave
+                         128 x 128 tiles (tune 46 for bf16 / fp16 operands, 3 for f32 / f16x3) */
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 

@@ -441,7 +441,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
     d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.x3 = a->precision == SOCCDPT_PREC_F16X3; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     d.splitk = a->splitk > 1 ? a->splitk : 1; d.sk_part = a->sk_part; d.sk_count = a->sk_count;
-    d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words;
+    d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words; d.sk_defer = a->sk_defer;
     if (a->conv_general) { d.stride = a->stride; d.pad = a->pad; d.in_halo = a->in_halo; d.Hi = a->Hi; d.Wi = a->Wi; d.gather1 = a->gather1; }
     d.grp_rows = a->grp_rows; d.grp_off = a->grp_off; d.grp_stride = a->grp_stride; d.seg2_k = a->seg2_k; d.seg2_off = a->seg2_off;
     d.gn_stats = a->gn_stats; d.gn_part = a->gn_part; d.gn_count = a->gn_count; d.gn_cpg = a->gn_cpg; d.gn_hw = a->gn_hw;

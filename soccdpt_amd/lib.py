@@ -66,7 +66,7 @@ class IgemmArgs(ctypes.Structure):
         ("grp_stride", ctypes.c_int64),
         ("gn_stats", ctypes.c_void_p), ("gn_part", ctypes.c_void_p), ("gn_count", ctypes.c_void_p),
         ("gn_cpg", ctypes.c_int32), ("gn_hw", ctypes.c_int32), ("gn_part_floats", ctypes.c_size_t), ("gn_count_words", ctypes.c_size_t),
-        ("stamps", ctypes.c_void_p),
+        ("stamps", ctypes.c_void_p), ("sk_defer", ctypes.c_int32),
     ]
 
 
@@ -536,7 +536,7 @@ class Engine:
 def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, res2=None, act=0, out_f32=None,
              act_on_f32=0, out_bf16=None, out_halo=0, dot_w=None, dot_b=0.0, out_dot=None, tune=-1, f32=0, precision=None, splitk=1, sk_part=None, sk_count=None,
              conv=None, gather1=0, grp_rows=0, grp_off=0, grp_stride=0, seg2_k=0, seg2_off=0, gn_stats=None, gn_part=None, gn_count=None, gn_cpg=0, gn_hw=0,
-             stamps=None):
+             stamps=None, sk_defer=0):
     """Kernel-level entry (tests): one implicit-GEMM launch on the current stream.  conv = dict(stride, pad, in_halo, Hi, Wi) selects
     the generalised convolution addressing."""
     L = load_library()
@@ -548,7 +548,7 @@ def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, re
                   1 if conv else 0, c.get("stride", 1), c.get("pad", 1), c.get("in_halo", 1), c.get("Hi", 0), c.get("Wi", 0), int(gather1),
                   int(grp_rows), int(grp_off), int(seg2_k), int(seg2_off), int(grp_stride),
                   _ptr(gn_stats), _ptr(gn_part), _ptr(gn_count), int(gn_cpg), int(gn_hw),
-                  0 if gn_part is None else gn_part.numel(), 0 if gn_count is None else gn_count.numel(), _ptr(stamps))
+                  0 if gn_part is None else gn_part.numel(), 0 if gn_count is None else gn_count.numel(), _ptr(stamps), int(sk_defer))
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())

@@ -208,6 +208,44 @@ def test_igemm_splitk(gpu_device, splitk):
     assert int(count.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f32", "f16x3"])
+def test_igemm_splitk_deferred_big_tiles(gpu_device, prec):
+    """The weight-gradient form of the training step: long K, a handful of 128 x 128 output tiles, many splits, every split storing its partial
+    tile and a second launch summing them in order (sk_defer).  Equal to the un-split product, bitwise reproducible, counters untouched,
+    epilogue options refused."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, PREC_F16X3, PREC_F32, op_igemm, x3_encode
+    g = torch.Generator().manual_seed(11)
+    M, N, K, S = 256, 384, 4096, 14
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    code, tune, tol = {"bf16": (PREC_BF16, 46, 1e-4), "f16": (PREC_F16, 46, 1e-4), "f32": (PREC_F32, 3, 2e-5), "f16x3": (PREC_F16X3, 3, 2e-5)}[prec]
+    if prec == "bf16":
+        x, w = _bf(x), _bf(w)
+        xd, wd = x.to(gpu_device), w.to(gpu_device)
+    elif prec == "f16":
+        x, w = x.half(), w.half()
+        xd, wd = x.to(gpu_device), w.to(gpu_device)
+    elif prec == "f32":
+        xd, wd = x.to(gpu_device), w.to(gpu_device)
+    else:
+        xd, wd = x3_encode(x.to(gpu_device)), x3_encode(w.to(gpu_device))
+    ref = (x.double() @ w.double().t()).float().to(gpu_device)
+    part = torch.full((S * M * N,), float("nan"), device=gpu_device)
+    count = torch.zeros(4096, dtype=torch.int32, device=gpu_device)
+    outs = []
+    for _ in range(2):
+        o = torch.empty(M, N, device=gpu_device)
+        op_igemm(xd, wd, M, N, K, ldx=K, out_f32=o, splitk=S, sk_part=part, sk_count=count, tune=tune, precision=code, sk_defer=1)
+        outs.append(o)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(outs[0], ref, rtol=tol, atol=tol)
+    assert torch.equal(outs[0], outs[1])
+    assert int(count.abs().sum()) == 0
+    with pytest.raises(RuntimeError):   # the deferred form writes out_f32 only
+        op_igemm(xd, wd, M, N, K, ldx=K, bias=torch.zeros(N, device=gpu_device), out_f32=outs[0], splitk=S, sk_part=part, sk_count=count, tune=tune,
+                 precision=code, sk_defer=1)
+
+
 # ---------------- fp16 operand mode (SOCCDPT_PREC_F16): same kernels, v_mfma_*_f16 ----------------
 def _hf(t):
     return t.to(torch.float16)
