@@ -7,11 +7,17 @@ import collections, csv, json, re, sys
 def family(kernel_name: str) -> str:
     """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
     n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
-    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)   # LN, SK[, ST, GEN]
+    m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)   # Cfg<BM, BN, BK, WM, WN, NS[, MF]>, T, LN, SK[, ST, GEN]
     if m:
+        mf32 = m.group(7) == "32"
+        m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)
         t = m.group(7)
-        if t == "float":
-            return f"igemm_f32_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(6)}"
+        if t == "float" or "x3_t" in t:   # 4 bytes per element: the k-tile holds BK / 2 elements (igemm.hip kCfgNamesF32 / kCfgNamesX3)
+            w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("64", "64"))
+            return (f"igemm_{'f32' if t == 'float' else 'x3'}_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(6)}" + ("_w8" if w8 else "") +
+                    ("_splitk" if m.group(9) == "true" else ""))
+        if mf32:
+            return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}_m32"
         # 8-wave forms of tiles that also exist with 4 waves carry a _w8 suffix in igemm.hip's kCfgNames
         w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("32", "64"), ("64", "64"))
         return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") +
