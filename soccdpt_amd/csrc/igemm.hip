@@ -874,7 +874,8 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "conv8p_bf16_256x256x64", "conv8p_bf16_128x256x64", "conv8p_bf16_256x128x64", "conv8p_var33", "conv8p_var34", "conv8p_var35", "conv8p_var36",
                                         "conv8p_var37", "conv8p_var38", "conv8p_var39",
                                         "igemm_bf16_128x128x64_s2_m32", "igemm_bf16_128x128x64_s2_w8_m32", "igemm_bf16_256x128x64_s2_m32", "igemm_bf16_128x256x64_s2_m32",
-                                        "igemm_bf16_256x256x64_s2_m32", "igemm_bf16_128x128x64_s3_m32"};
+                                        "igemm_bf16_256x256x64_s2_m32", "igemm_bf16_128x128x64_s3_m32",
+                                        "igemm_bf16_128x128x64_s2_w8_splitk"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
@@ -1007,10 +1008,11 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
 int igemm_config_id(const IgemmDesc& d) { return d.x3 ? pick_cfg_f32(d) : (d.f32 ? -1 : pick_cfg(d)); }
 
 const char* igemm_family(const IgemmDesc& d) {
-    if (d.x3) return d.splitk > 1 ? "igemm_x3_64x64x32_s4_splitk" : kCfgNamesX3[pick_cfg_f32(d)];
-    if (d.f32) return kCfgNamesF32[pick_cfg_f32(d)];
+    if (d.x3) return d.splitk > 1 ? (d.tune == 3 || d.tune == 8 ? "igemm_x3_128x128_w8_splitk" : "igemm_x3_64x64x32_s4_splitk") : kCfgNamesX3[pick_cfg_f32(d)];
+    if (d.f32) return d.splitk > 1 ? (d.tune == 3 ? "igemm_f32_128x128x32_s2_w8_splitk" : "igemm_f32_64x64x32_s4_splitk") : kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
     if (d.splitk > 1) {
+        if (id == 46) return d.f16 ? "igemm_f16_128x128x64_s2_w8_splitk" : "igemm_bf16_128x128x64_s2_w8_splitk";
         if (id == 20) return d.f16 ? "igemm_f16_32x64x128_s3_splitk" : "igemm_bf16_32x64x128_s3_splitk";
         return d.f16 ? "igemm_f16_32x64x64_s6_splitk" : "igemm_bf16_32x64x64_s6_splitk";
     }
@@ -1137,6 +1139,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 43: return launch_cfg<Cfg<128, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 64 x 64 per wave
         case 44: return launch_cfg<Cfg<256, 256, 64, 2, 4, 2, 32>>(d, stream, err);   // 8 waves, 128 x 64 per wave
         case 45: return launch_cfg<Cfg<128, 128, 64, 2, 2, 3, 32>>(d, stream, err);   // 4 waves, 3-stage ring
+        // (tried in round 3 and removed: 128-deep k-tiles on the 128 x 128 tile, 8 and 4 waves -- half the barriers, but 128 KB of LDS = one workgroup per
+        //  CU: 251 / 300 us against 198 us on the 64^2 256 -> 256 convolution in the network, 191 / 245 against 153 us on the seg-head convolution)
         case 46:   // 8-wave 128 x 128 x 64 with split-K (training: weight gradients of the wide layers -- long K, few output tiles; tune-selected only)
             if (d.splitk <= 1) { err = "igemm: configuration 46 is the split-K form"; return 1; }
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, true, false, true>(d, stream, err)
