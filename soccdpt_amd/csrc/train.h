@@ -46,6 +46,10 @@ int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, c
 int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat,
                           float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
 int tr_attention_bwd_mfma_slots(int ws);
+// Weight gradient from operands as stored (train_wgrad_tn.hip): out[Nout][taps * C] = sum_k A[k][n] B[k + shift(tap)][c], 16-bit operands
+bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps);
+int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
+                float* out, hipStream_t st, std::string& err);
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err, int dscale_slots = 0);
 int tr_drop_path_fill(float* out, int B, float p, unsigned seed, unsigned stream_id, hipStream_t st, std::string& err);
 int tr_scale_rows(const float* in, float* out, const float* scale, size_t M, int C, int rows_per_scale, hipStream_t st, std::string& err);

@@ -65,6 +65,7 @@ struct HyTape {
 
 struct Tape {
     HyTape hy;
+    const float* xt_tn_src = nullptr;   // the halo image whose 16-bit copy (train_wgrad_tn.hip layout) is in S_T2, or nullptr: conv3_bwd's reuse_xt only holds within one layout
     // encoder
     float *patches, *pe_wpad, *pe_pre, *x0;
     std::vector<BlkT> blk[4];

@@ -221,6 +221,12 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
     return 0;
 }
 
+// A/B switch: SOCCDPT_WGRAD_TRANSPOSE=1 keeps the transposing weight-gradient path of round 2 in the 16-bit amp modes
+static bool wgrad_tn_on() {
+    static const bool off = getenv("SOCCDPT_WGRAD_TRANSPOSE") != nullptr;
+    return !off;
+}
+
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
@@ -260,6 +266,15 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             TRY(tr_transpose16(dY, y3, (int)M, N, Mp, 3, c.st, c.err));
             TRY(tr_transpose16(X, x3p, (int)M, K, Mp, 3, c.st, c.err));
             d.X = y3; d.Wt = x3p; d.Cin = Mp; d.ldx = Mp;
+        } else if (amp && wgrad_tn_on() && tr_wgrad_tn_ok(M, N, K, 1)) {
+            // operands as stored (train_wgrad_tn.hip): dY in 16 bit is what the dgrad launch above already staged; X needs one conversion, no transposes
+            uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
+            uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
+            if (!dX_out) TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));
+            TRY(launch_cvt_bf16(X, x16, M * K, F16 ? 5 : 0, c.st, c.err));
+            TRY(tr_wgrad_tn(a16, N, x16, K, M, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            return 0;
         } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
             uint16_t* y16 = reinterpret_cast<uint16_t*>(T.S_T1);
@@ -319,7 +334,26 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(gemm(c, d));
         }
     }
-    if (dW && x3 && C % 64 == 0) {
+    if (dW && amp && wgrad_tn_on() && tr_wgrad_tn_ok((size_t)((size_t)B * (r + 2) * (r + 2) + 63) / 64 * 64, N, C, 9)) {
+        // Operands as stored, in halo pixel order (train_wgrad_tn.hip): A = dY as the zero-bordered 16-bit image the dgrad launch staged, B = the input's halo image
+        // converted to 16 bit; tap (ky, kx) reads B (ky - 1)(r + 2) + (kx - 1) rows further on.  K is padded to a k-tile with zero rows of A; B gets
+        // zero margins of r + 3 rows on both sides (border pixels of A are zero, but 0 * NaN is not).
+        const int rp = r + 2;
+        const size_t Kh = (size_t)B * rp * rp, Kp = (Kh + 63) / 64 * 64, mrg = (size_t)rp + 1;
+        uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
+        uint16_t* xb = reinterpret_cast<uint16_t*>(T.S_T2);
+        if (!dX_out) TRY(tr_to_halo_full(dY, h16, B, r, r, N, 1 + F16, c.st, c.err));
+        hipError_t e = Kp > Kh ? hipMemsetAsync(h16 + Kh * N, 0, (Kp - Kh) * N * 2, c.st) : hipSuccess;
+        if (!reuse_xt || T.xt_tn_src != Xhalo) {
+            T.xt_tn_src = Xhalo;
+            if (e == hipSuccess) e = hipMemsetAsync(xb, 0, mrg * C * 2, c.st);
+            if (e == hipSuccess) e = hipMemsetAsync(xb + (mrg + Kh) * C, 0, (Kp - Kh + mrg) * C * 2, c.st);
+            if (e == hipSuccess) TRY(launch_cvt_bf16(Xhalo, xb + mrg * C, Kh * C, F16 ? 5 : 0, c.st, c.err));
+        }
+        if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+        TRY(tr_wgrad_tn(h16, N, xb + mrg * C, C, Kp, N, C, 9, rp, F16, T.sk_part, kTrainSkPartFloats, T.S_dw, c.st, c.err));
+        TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+    } else if (dW && x3 && C % 64 == 0) {
         // x3, no im2col: like the f32 form below, but an x3 tensor is cut in 8-element units, so the views must start at multiples of 16 elements:
         // the pixel order pads every halo row to rpp = roundup(r + 2, 16) pixels (vertical taps = +- rpp) and the horizontal taps read three copies
         // of the transposed image pre-shifted by -1 / 0 / +1 pixel (x_halo_T_kernel).  9 views of 3 copies instead of a 9-fold im2col^T.
@@ -330,7 +364,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         char* yT = reinterpret_cast<char*>(T.S_T1);
         char* xT = reinterpret_cast<char*>(T.S_T2);
         TRY(tr_dy_halo_T(dY, yT, 3, B, r, N, margin, ld, c.st, c.err, rpp));
-        if (!reuse_xt) {
+        if (!reuse_xt || T.xt_tn_src) {
+            T.xt_tn_src = nullptr;
             for (int kx = 0; kx < 3; ++kx) {
                 char* base = xT + (size_t)kx * copy_elems * 4;
                 hipError_t e = hipMemsetAsync(base, 0, head * 4, c.st);
@@ -381,7 +416,8 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         const size_t copy_bytes = ((size_t)(C + 1) * ld + 64 + head) * esz;
         xT += head * esz;
         TRY(tr_dy_halo_T(dY, yT, amp ? 1 + F16 : 0, B, r, N, margin, ld, c.st, c.err));
-        if (!reuse_xt) {
+        if (!reuse_xt || T.xt_tn_src) {
+            T.xt_tn_src = nullptr;
             for (int cp = 0; cp < (amp ? 2 : 1); ++cp) {
                 char* base = xT + cp * copy_bytes;
                 // headroom + the first row's left margin; every other gap is the zero tail of a row (tr_transpose pads rows up to ld)
