@@ -266,13 +266,20 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             TRY(tr_transpose16(dY, y3, (int)M, N, Mp, 3, c.st, c.err));
             TRY(tr_transpose16(X, x3p, (int)M, K, Mp, 3, c.st, c.err));
             d.X = y3; d.Wt = x3p; d.Cin = Mp; d.ldx = Mp;
-        } else if (amp && wgrad_tn_on() && tr_wgrad_tn_ok(M, N, K, 1)) {
-            // operands as stored (train_wgrad_tn.hip): dY in 16 bit is what the dgrad launch above already staged; X needs one conversion, no transposes
+        } else if (amp && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1)) {
+            // operands as stored (train_wgrad_tn.hip): dY in 16 bit is what the dgrad launch above already staged; X needs one conversion, no transposes.
+            // Token counts that are not a k-tile multiple (577-token ViT sequences) get zero rows appended to both operands.
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
+            const size_t Mp = (M + 63) / 64 * 64;
             if (!dX_out) TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));
             TRY(launch_cvt_bf16(X, x16, M * K, F16 ? 5 : 0, c.st, c.err));
-            TRY(tr_wgrad_tn(a16, N, x16, K, M, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
+            if (Mp > M) {
+                hipError_t e = hipMemsetAsync(a16 + M * N, 0, (Mp - M) * N * 2, c.st);
+                if (e == hipSuccess) e = hipMemsetAsync(x16 + M * K, 0, (Mp - M) * K * 2, c.st);
+                if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
+            }
+            TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
             if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (amp) {
