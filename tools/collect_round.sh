@@ -7,18 +7,20 @@ set -eo pipefail
 TAG=${1:-rXX}
 OUT=gpurun_out/${TAG}_extra
 mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+if [ -z "$TRAIN_ONLY" ]; then   # TRAIN_ONLY=1: only the training-step lines and kernel tables (the forward's sources did not change)
 bash tools/collect_profiles.sh ${TAG} > $OUT/collect_tiny.log 2>&1
 echo "tiny done"
 bash tools/collect_profiles.sh ${TAG}_base384 --config 3 > $OUT/collect_base.log 2>&1
 echo "base done"
 bash tools/collect_profiles.sh ${TAG}_hybrid384 --config 2 > $OUT/collect_hybrid.log 2>&1
 echo "hybrid done"
-cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for p in f16 f16x3 f32; do python3 bench.py --precision $p --no-cpu-baseline > $OUT/bench_$p.json 2>> $OUT/bench.err; done
 python3 bench.py --config 2 --precision f16x3 --no-cpu-baseline > $OUT/bench_hybrid384_f16x3.json 2>> $OUT/bench.err
 python3 bench.py --config 2 --precision f32 --no-cpu-baseline > $OUT/bench_hybrid384_f32.json 2>> $OUT/bench.err
 python3 bench.py --config 3 --precision f16x3 --no-cpu-baseline > $OUT/bench_base384_f16x3.json 2>> $OUT/bench.err
 echo "modes done"
+fi
 python3 bench.py --train-step > $OUT/bench_train_step.json 2>> $OUT/bench.err
 python3 bench.py --train-step --amp x3 --no-cpu-baseline > $OUT/bench_train_step_x3.json 2>> $OUT/bench.err
 python3 bench.py --train-step --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err

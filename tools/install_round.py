@@ -13,4 +13,9 @@ for a, name in (("0", "f32"), ("x3", "x3"), ("bf16", "bf16"), ("hybrid_bf16", "h
     if os.path.exists(p):
         shutil.copy(p, os.path.join(dst, f"{tag}_train_{name}_kernel_stats.csv"))
         shutil.copy(os.path.join(src, f"train_{a}.json"), os.path.join(dst, f"{tag}_train_{name}_bench_under_rocprof.json"))
+# the bench lines re-run AFTER the PMC summaries were installed (only then can bench.py fill roofline.traffic from a matching file)
+for t in (tag, f"{tag}_base384", f"{tag}_hybrid384"):
+    p = f"gpurun_out/{t}_bench_final.json"
+    if os.path.exists(p) and os.path.getsize(p) > 0:
+        shutil.copy(p, os.path.join(dst, f"{t}_bench.json"))
 print("installed", tag)
