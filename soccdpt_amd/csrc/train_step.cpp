@@ -120,7 +120,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     for (int l = 0; l < 4; ++l) T.DF[l] = ar.f((size_t)B * a.fres(l) * a.fres(l) * a.fdim(l));
     T.S_T1 = ar.f(maxAct + 128 * 4 * Cmax0);
     T.S_T2 = ar.f(std::max(std::max(M1 * 9 * F, M0p * 9 * (size_t)(F / 2)), maxAct) + 128 * 9 * Cmax0);
-    T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)));
+    T.S_halo = ar.f(std::max((size_t)B * (r1 + 2) * (r1 + 2) * F, (size_t)B * (r0 + 2) * (r0 + 2) * (size_t)(F / 2)) + 64 * (size_t)F);   // + the k-tile padding rows of train_wgrad_tn.hip
     const size_t Cmax = a.hybrid ? 1024 : a.dim(3);
     const size_t wmax = std::max(std::max((size_t)9 * F * F, 4 * Cmax * Cmax), a.hybrid ? (size_t)9 * 768 * 768 : 0);
     T.S_wt = ar.f(wmax);
@@ -259,7 +259,22 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
     if (dW) {
         IgemmDesc d;
         d.M = N; d.N = K; d.out_f32 = dW;
-        if (x3) {
+        if (x3 && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1)) {
+            // x3 operands as stored (train_wgrad_tn.hip: wgrad_tn_x3_kernel); zero bytes are x3 zeros
+            char* a3 = reinterpret_cast<char*>(T.S_T1);
+            char* x3p = reinterpret_cast<char*>(T.S_T2);
+            const size_t Mp = (M + 63) / 64 * 64;
+            if (!dX_out) TRY(launch_cvt_bf16(dY, reinterpret_cast<uint16_t*>(a3), M * N, 3, c.st, c.err));
+            TRY(launch_cvt_bf16(X, reinterpret_cast<uint16_t*>(x3p), M * K, 3, c.st, c.err));
+            if (Mp > M) {
+                hipError_t e = hipMemsetAsync(a3 + M * N * 4, 0, (Mp - M) * N * 4, c.st);
+                if (e == hipSuccess) e = hipMemsetAsync(x3p + M * K * 4, 0, (Mp - M) * K * 4, c.st);
+                if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
+            }
+            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            return 0;
+        } else if (x3) {
             const int Mp = (int)((M + 31) / 32 * 32);
             uint16_t* y3 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x3p = reinterpret_cast<uint16_t*>(T.S_T2);
@@ -341,24 +356,27 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             TRY(gemm(c, d));
         }
     }
-    if (dW && amp && wgrad_tn_on() && tr_wgrad_tn_ok((size_t)((size_t)B * (r + 2) * (r + 2) + 63) / 64 * 64, N, C, 9)) {
+    if (dW && (amp || x3) && wgrad_tn_on() && tr_wgrad_tn_ok((size_t)((size_t)B * (r + 2) * (r + 2) + 63) / 64 * 64, N, C, 9)) {
         // Operands as stored, in halo pixel order (train_wgrad_tn.hip): A = dY as the zero-bordered 16-bit image the dgrad launch staged, B = the input's halo image
         // converted to 16 bit; tap (ky, kx) reads B (ky - 1)(r + 2) + (kx - 1) rows further on.  K is padded to a k-tile with zero rows of A; B gets
         // zero margins of r + 3 rows on both sides (border pixels of A are zero, but 0 * NaN is not).
         const int rp = r + 2;
         const size_t Kh = (size_t)B * rp * rp, Kp = (Kh + 63) / 64 * 64, mrg = (size_t)rp + 1;
-        uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
-        uint16_t* xb = reinterpret_cast<uint16_t*>(T.S_T2);
-        if (!dX_out) TRY(tr_to_halo_full(dY, h16, B, r, r, N, 1 + F16, c.st, c.err));
-        hipError_t e = Kp > Kh ? hipMemsetAsync(h16 + Kh * N, 0, (Kp - Kh) * N * 2, c.st) : hipSuccess;
+        const size_t es = x3 ? 4 : 2;                              // bytes per operand element
+        const int fmt = x3 ? 3 : 1 + F16, cvt = x3 ? 3 : (F16 ? 5 : 0);
+        char* h16 = reinterpret_cast<char*>(T.S_halo);
+        char* xb = reinterpret_cast<char*>(T.S_T2);
+        if (!dX_out) TRY(tr_to_halo_full(dY, h16, B, r, r, N, fmt, c.st, c.err));
+        hipError_t e = Kp > Kh ? hipMemsetAsync(h16 + Kh * N * es, 0, (Kp - Kh) * N * es, c.st) : hipSuccess;
         if (!reuse_xt || T.xt_tn_src != Xhalo) {
             T.xt_tn_src = Xhalo;
-            if (e == hipSuccess) e = hipMemsetAsync(xb, 0, mrg * C * 2, c.st);
-            if (e == hipSuccess) e = hipMemsetAsync(xb + (mrg + Kh) * C, 0, (Kp - Kh + mrg) * C * 2, c.st);
-            if (e == hipSuccess) TRY(launch_cvt_bf16(Xhalo, xb + mrg * C, Kh * C, F16 ? 5 : 0, c.st, c.err));
+            if (e == hipSuccess) e = hipMemsetAsync(xb, 0, mrg * C * es, c.st);
+            if (e == hipSuccess) e = hipMemsetAsync(xb + (mrg + Kh) * C * es, 0, (Kp - Kh + mrg) * C * es, c.st);
+            if (e == hipSuccess) TRY(launch_cvt_bf16(Xhalo, reinterpret_cast<uint16_t*>(xb + mrg * C * es), Kh * C, cvt, c.st, c.err));
         }
         if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
-        TRY(tr_wgrad_tn(h16, N, xb + mrg * C, C, Kp, N, C, 9, rp, F16, T.sk_part, kTrainSkPartFloats, T.S_dw, c.st, c.err));
+        TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(h16), N, reinterpret_cast<uint16_t*>(xb + mrg * C * es), C, Kp, N, C, 9, rp, x3 ? 3 : F16, T.sk_part, kTrainSkPartFloats,
+                        T.S_dw, c.st, c.err));
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     } else if (dW && x3 && C % 64 == 0) {
         // x3, no im2col: like the f32 form below, but an x3 tensor is cut in 8-element units, so the views must start at multiples of 16 elements:

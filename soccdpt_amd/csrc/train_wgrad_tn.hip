@@ -139,6 +139,113 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnArgs a) {
     }
 }
 
+
+// ---- x3 (split-fp16, half16.h) operands: 4 bytes per element, 8-element units of [hi x 8][lo x 8] (order swapped in odd units).  Tile 128 x 128 x 32:
+// 512-byte LDS rows, 32 reduction rows per k-tile (one k-step of the fp16 MFMA), the 16-byte chunks XOR-swizzled in their low four index bits.  A 16-column
+// fragment group spans units 2cg (hi at chunk 4cg, lo at 4cg + 1) and 2cg + 1 (lo at 4cg + 2, hi at 4cg + 3); three MFMAs per fragment pair, two
+// accumulator sets folded at the end (igemm.hip X3).
+__global__ __launch_bounds__(512) void wgrad_tn_x3_kernel(TnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int TILE = 32 * 512, STAGE = 2 * TILE;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int ntiles = (a.Ncols + 127) / 128;
+    int bid = blockIdx.x;
+    const int split = bid % a.splits;
+    bid /= a.splits;
+    const int nt = bid % ntiles, mt = bid / ntiles;
+    const int n0 = mt * 128, col0 = nt * 128;
+    const int tap = a.taps > 1 ? col0 / a.C : 0, cc0 = a.taps > 1 ? col0 - tap * a.C : col0;
+    const long shift = a.taps > 1 ? (long)(tap / 3 - 1) * a.rp + (tap % 3 - 1) : 0;
+    const int nk = a.K / 32;
+    const int kt0 = (int)((long)split * nk / a.splits), kt1 = (int)((long)(split + 1) * nk / a.splits);
+    const char* Ab = reinterpret_cast<const char*>(a.A);
+    const char* Bb = reinterpret_cast<const char*>(a.B);
+
+    const char* ga[2];
+    const char* gb[2];
+    uint32_t lds_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int rb = wave * 2 + i, row = 2 * rb + (lane >> 5), pch = lane & 31, ch = (pch & 16) | ((pch & 15) ^ swz(row));
+        ga[i] = Ab + ((long)row * a.ldA + n0) * 4 + 16 * ch;
+        gb[i] = Bb + (((long)row + shift) * a.ldB + cc0) * 4 + 16 * ch;
+        lds_off[i] = (uint32_t)(rb * 1024);
+    }
+    auto stage = [&](int kt, int slot) {
+        char* sb = smem + slot * STAGE;
+        const long ka = (long)kt * 32 * a.ldA * 4, kb = (long)kt * 32 * a.ldB * 4;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + ka),
+                                             (__attribute__((address_space(3))) void*)(sb + lds_off[i]), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + kb),
+                                             (__attribute__((address_space(3))) void*)(sb + TILE + lds_off[i]), 16, 0, 0);
+        }
+    };
+    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    // hi (lo == 0) or lo (lo == 1) fragment of 16-column group cg: rows 8 g + 4 h2 + q
+    auto frag = [&](const char* tile, int cg, int lo) -> h16x8 {
+        h16x8 f;
+        const int odd = p >> 1;                                  // unit 2 cg + odd
+        const int ch = 4 * cg + (odd ? (lo ? 2 : 3) : (lo ? 1 : 0));
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2) {
+            const int row = 8 * g + 4 * h2 + q;
+            const char* ptr = tile + row * 512 + 16 * ((ch & 16) | ((ch & 15) ^ swz(row))) + 8 * (p & 1);
+            const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)ptr);
+            f[4 * h2] = v[0]; f[4 * h2 + 1] = v[1]; f[4 * h2 + 2] = v[2]; f[4 * h2 + 3] = v[3];
+        }
+        return f;
+    };
+    f32x4 acc[2][4], accx[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) { acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+    if (kt0 < kt1) stage(kt0, 0);
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int slot = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (kt + 1 < kt1) stage(kt + 1, slot ^ 1);
+        const char* ta = smem + slot * STAGE;
+        const char* tb = ta + TILE;
+        h16x8 fah[2], fal[2], fbh[4], fbl[4];
+#pragma unroll
+        for (int it = 0; it < 2; ++it) { fah[it] = frag(tb, wn * 2 + it, 0); fal[it] = frag(tb, wn * 2 + it, 1); }
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) { fbh[jt] = frag(ta, wm * 4 + jt, 0); fbl[jt] = frag(ta, wm * 4 + jt, 1); }
+#pragma unroll
+        for (int it = 0; it < 2; ++it)
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                acc[it][jt] = mfma_16x16x32<true>(fah[it], fbh[jt], acc[it][jt]);
+                accx[it][jt] = mfma_16x16x32<true>(fah[it], fbl[jt], accx[it][jt]);
+                accx[it][jt] = mfma_16x16x32<true>(fal[it], fbh[jt], accx[it][jt]);
+            }
+    }
+    float* mine = a.part + (size_t)split * a.Nout * a.Ncols;
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) {
+        const int n = n0 + wm * 64 + 16 * jt + (lane & 15);
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int col = col0 + wn * 32 + 16 * it + 4 * g;
+            if (n < a.Nout && col < a.Ncols) {
+                float4 o;
+                o.x = fmaf(accx[it][jt][0], 1.0f / 2048.f, acc[it][jt][0]);
+                o.y = fmaf(accx[it][jt][1], 1.0f / 2048.f, acc[it][jt][1]);
+                o.z = fmaf(accx[it][jt][2], 1.0f / 2048.f, acc[it][jt][2]);
+                o.w = fmaf(accx[it][jt][3], 1.0f / 2048.f, acc[it][jt][3]);
+                *reinterpret_cast<float4*>(mine + (size_t)n * a.Ncols + col) = o;
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = *reinterpret_cast<const float4*>(part + i * 4);
@@ -159,16 +266,17 @@ bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps) {
     return taps == 1 && Nout % 32 == 0 && C % 32 == 0;         // edge tiles are masked (the operands are over-read by up to 127 columns: callers keep them inside scratch)
 }
 
-// out [Nout][taps * C] f32 (tap-major for taps == 9).  A = dY [K][ldA] and B = X [K][ldB] are 16-bit (bf16, or fp16 when f16 != 0); for taps == 9 both are
+// out [Nout][taps * C] f32 (tap-major for taps == 9).  A = dY [K][ldA] and B = X [K][ldB] are 16-bit (bf16, or fp16 when f16 == 1) or x3 tensors (f16 == 3); for taps == 9 both are
 // in halo pixel order with pitch rp and B must be readable (finite) from row -(rp + 1) to row K + rp: zero margins.  part: at least
 // splits * Nout * taps * C floats.  Returns the number of splits used through *splits_out.
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
                 float* out, hipStream_t st, std::string& err) {
     if (!tr_wgrad_tn_ok(K, Nout, C, taps)) { err = "wgrad_tn: unsupported shape"; return 1; }
-    if ((ldA & 7) || (ldB & 7)) { err = "wgrad_tn: row strides must be multiples of 8 elements"; return 1; }
+    const bool x3 = f16 == 3;   // x3 operands: 4 bytes per element, rows start at multiples of 16 elements, 32-row k-tiles
+    if (x3 ? ((ldA & 15) || (ldB & 15)) : ((ldA & 7) || (ldB & 7))) { err = "wgrad_tn: row strides must be multiples of 8 (x3: 16) elements"; return 1; }
     TnArgs a;
     a.A = A; a.B = B; a.ldA = ldA; a.ldB = ldB; a.K = (int)K; a.Nout = Nout; a.C = C; a.taps = taps; a.Ncols = taps * C; a.rp = rp; a.part = part;
-    const long tiles = (long)((Nout + 127) / 128) * ((a.Ncols + 127) / 128), nk = (long)K / 64;
+    const long tiles = (long)((Nout + 127) / 128) * ((a.Ncols + 127) / 128), nk = (long)K / (x3 ? 32 : 64);
     long S = 512 / tiles > 0 ? 512 / tiles : 1;   // one round of two workgroups per CU
     if (S > nk / 2) S = nk / 2 > 0 ? nk / 2 : 1;
     if (S > 64) S = 64;
@@ -177,7 +285,8 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     a.splits = (int)S;
     const dim3 grid((unsigned)(tiles * S)), block(512);
     const size_t lds = 2 * 2 * 64 * 256;
-    if (f16) SOCCDPT_LAUNCH(wgrad_tn_kernel<true>, grid, block, lds, st, a);
+    if (x3) SOCCDPT_LAUNCH(wgrad_tn_x3_kernel, grid, block, lds, st, a);
+    else if (f16) SOCCDPT_LAUNCH(wgrad_tn_kernel<true>, grid, block, lds, st, a);
     else SOCCDPT_LAUNCH(wgrad_tn_kernel<false>, grid, block, lds, st, a);
     const size_t n4 = (size_t)Nout * a.Ncols / 4;
     size_t blocks = (n4 + 255) / 256;
