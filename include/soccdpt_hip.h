@@ -313,6 +313,15 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
  * bf16 / f32 / fp16 by `precision`.  N <= 608 (dpt_hybrid_384: N = 577). */
 int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, int B, int N, int heads, void* stream);
 
+/* Weight-gradient GEMM from operands as stored (kernel-level entry, tests): out [Nout][taps * C] f32 = sum over k of A[k][n] * B[k + shift(tap)][c] with
+ * A [K][ldA] (the output gradient: rows = tokens, or halo pixels of a 3x3 convolution) and B [K][ldB] (the layer input alike), elements bf16 / fp16 / x3 by
+ * `precision` (SOCCDPT_PREC_BF16 / _F16 / _F16X3); taps 1 or 9, shift(tap) = (tap / 3 - 1) * rp + (tap % 3 - 1) rows (B must be readable and finite from row
+ * -(rp + 1) to K + rp).  K % 64 == 0; taps == 9: Nout, C % 128 == 0; taps == 1: Nout, C % 32 == 0 and both operands readable 127 columns past their rows.
+ * scratch: at least 64 * Nout * taps * C floats is always enough (fewer splits are used when less is given).  What the training step's 16-bit and x3 amp
+ * modes run instead of transposing both operands (csrc/train_wgrad_tn.hip; autograd of nn.Linear / nn.Conv2d weights, scripts/train_SOccDPT.py:360-393). */
+int soccdpt_op_wgrad_tn(const void* dev_a, long lda, const void* dev_b, long ldb, size_t K, int Nout, int C, int taps, int rp, int precision,
+                        float* dev_scratch, size_t scratch_floats, float* dev_out, void* stream);
+
 /* Swin-V2 cosine window attention of one block (timm WindowAttention + shift/partition/reverse):
  * qkv [B*res*res][3*heads*32] -> out [B*res*res][heads*32], elements bf16 / f32 / fp16 by `precision` (SOCCDPT_PREC_*).  cpb_table [(2ws-1)^2][heads] f32 is
  * 16*sigmoid(cpb_mlp(coords)); scale[heads] = exp(min(logit_scale, ln 100)); bias_scratch: heads*ceil(ws*ws/32)^2*1024

@@ -452,6 +452,18 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     return 0;
 }
 
+int soccdpt_op_wgrad_tn(const void* dev_a, long lda, const void* dev_b, long ldb, size_t K, int Nout, int C, int taps, int rp, int precision, float* dev_scratch,
+                        size_t scratch_floats, float* dev_out, void* stream) {
+    std::string err;
+    if (!dev_a || !dev_b || !dev_scratch || !dev_out) return fail(nullptr, "soccdpt_op_wgrad_tn: null argument");
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16 && precision != SOCCDPT_PREC_F16X3) return fail(nullptr, "soccdpt_op_wgrad_tn: bf16, fp16 or f16x3 operands");
+    const int f16 = precision == SOCCDPT_PREC_F16X3 ? 3 : (precision == SOCCDPT_PREC_F16 ? 1 : 0);
+    if (tr_wgrad_tn(static_cast<const uint16_t*>(dev_a), lda, static_cast<const uint16_t*>(dev_b), ldb, K, Nout, C, taps, rp, f16, dev_scratch, scratch_floats, dev_out,
+                    (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_op_vit_attention(const void* dev_qkv, void* dev_out, int precision, int B, int N, int heads, void* stream) {
     std::string err;
     if (!dev_qkv || !dev_out) return fail(nullptr, "soccdpt_op_vit_attention: null argument");

@@ -196,6 +196,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_op_vit_attention.restype = ci
     L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.soccdpt_op_window_attention.restype = ci
+    L.soccdpt_op_wgrad_tn.argtypes = [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_size_t, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp]
+    L.soccdpt_op_wgrad_tn.restype = ci
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
                                            ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.soccdpt_workspace_tensor.restype = ci
@@ -584,6 +586,20 @@ def op_mlp_ln(x_op, x_f32, w1, b1, w2, b2, ln_g, ln_b, x_op_out=None, halo=None,
                              int(precision), M, C, H, W, _stream_ptr(x_op.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_mlp_ln failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_wgrad_tn(a, lda, b, ldb, K, Nout, C, taps=1, rp=0, precision=PREC_BF16, b_row0=0):
+    """Kernel-level entry (tests): weight gradient out [Nout][taps * C] from operands as stored (include/soccdpt_hip.h soccdpt_op_wgrad_tn).  a, b: flat device
+    tensors (bf16 / fp16, or x3 bytes from x3_encode); b_row0: element offset of row 0 of b inside its tensor (margins in front for taps == 9)."""
+    L = load_library()
+    out = torch.empty((Nout, taps * C), dtype=torch.float32, device=a.device)
+    scratch = torch.empty((64 * Nout * taps * C,), dtype=torch.float32, device=a.device)
+    es = 4 if precision == PREC_F16X3 else 2
+    rc = L.soccdpt_op_wgrad_tn(_ptr(a), lda, b.data_ptr() + b_row0 * es, ldb, K, Nout, C, taps, rp, int(precision), _ptr(scratch), scratch.numel(), _ptr(out),
+                               _stream_ptr(a.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_wgrad_tn failed: " + L.soccdpt_last_error(None).decode())
+    return out
 
 
 def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads, precision=PREC_BF16):

@@ -448,3 +448,65 @@ def test_conv8p_matches_torch(gpu_device, tune, Cout, prec):
         op_igemm(xh, wt, B * H * H, Cout, Cin, taps=9, H=H, W=H, bias=bias, res1=res1, res2=res2, act=1, out_f32=o2, tune=21, precision=P)
         torch.cuda.synchronize()
         assert torch.equal(o2, out), f"tune={tune}: differs from configuration 21"
+
+
+# ---------------- weight gradient from operands as stored (csrc/train_wgrad_tn.hip: LDS transpose reads) ----------------
+@pytest.mark.parametrize("prec", ["bf16", "f16", "f16x3"])
+def test_wgrad_tn_linear(gpu_device, prec):
+    """dW[n][c] = sum_k dY[k][n] X[k][c] with both operands row-major over k (no transposes).  Nout = 192 and C = 96 exercise the masked edge tiles
+    (operands over-read past their rows), K = 1600 * ... a multiple of 64 that is not a multiple of the split count."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, PREC_F16X3, op_wgrad_tn, x3_encode
+    g = torch.Generator().manual_seed(5)
+    for K, Nout, C in ((4096, 256, 384), (1600 * 4, 192, 96), (576, 128, 128)):
+        dy = torch.randn(K, Nout, generator=g)
+        x = torch.randn(K, C, generator=g)
+        if prec == "bf16":
+            dy, x = _bf(dy), _bf(x)
+            a, b, code, tol = dy.to(gpu_device), x.to(gpu_device), PREC_BF16, 2e-5
+        elif prec == "f16":
+            dy, x = dy.half(), x.half()
+            a, b, code, tol = dy.to(gpu_device), x.to(gpu_device), PREC_F16, 2e-5
+        else:
+            a, b, code, tol = x3_encode(dy.to(gpu_device)), x3_encode(x.to(gpu_device)), PREC_F16X3, 2e-6
+        # the edge tiles over-read up to 127 columns past a row: give the flat tensors room behind the last row
+        pad = torch.zeros(4096, dtype=a.dtype, device=gpu_device)
+        a, b = torch.cat([a.reshape(-1), pad]), torch.cat([b.reshape(-1), pad])
+        ref = (dy.double().t() @ x.double()).float().to(gpu_device)
+        out = op_wgrad_tn(a, Nout, b, C, K, Nout, C, precision=code)
+        out2 = op_wgrad_tn(a, Nout, b, C, K, Nout, C, precision=code)
+        torch.cuda.synchronize()
+        err = float((out - ref).norm() / ref.norm())
+        assert err < tol, (prec, K, Nout, C, err)
+        assert torch.equal(out, out2)          # deterministic split-K
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16x3"])
+def test_wgrad_tn_conv3x3(gpu_device, prec):
+    """The 3x3 convolution's weight gradient in halo pixel order: tap (ky, kx) = the same GEMM over the input's halo image read (ky - 1)(r + 2) + (kx - 1) rows
+    further on.  Against torch autograd of conv2d."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16X3, op_wgrad_tn, x3_encode
+    g = torch.Generator().manual_seed(7)
+    B, r, C, N = 2, 12, 128, 128
+    x = torch.randn(B, C, r, r, generator=g)
+    dy = torch.randn(B, N, r, r, generator=g)
+    if prec == "bf16":
+        x, dy = _bf(x).float(), _bf(dy).float()
+    w = torch.zeros(N, C, 3, 3, requires_grad=True)
+    F.conv2d(x, w, padding=1).backward(dy)
+    ref = w.grad.permute(0, 2, 3, 1).reshape(N, 9 * C).contiguous().to(gpu_device)     # tap-major [N][9][C]
+    rp = r + 2
+    Kh = B * rp * rp
+    Kp = (Kh + 63) // 64 * 64
+    mrg = rp + 1
+    xh = torch.zeros(Kp + 2 * mrg, C)
+    xh[mrg:mrg + Kh] = _halo(x.permute(0, 2, 3, 1).contiguous().to(torch.float32)).reshape(Kh, C)
+    dyh = torch.zeros(Kp, N)
+    dyh[:Kh] = _halo(dy.permute(0, 2, 3, 1).contiguous().to(torch.float32)).reshape(Kh, N)
+    if prec == "bf16":
+        a, b, code, tol = dyh.to(torch.bfloat16).to(gpu_device).reshape(-1), xh.to(torch.bfloat16).to(gpu_device).reshape(-1), PREC_BF16, 2e-5
+    else:
+        a, b, code, tol = x3_encode(dyh.to(gpu_device)), x3_encode(xh.to(gpu_device)), PREC_F16X3, 2e-6
+    out = op_wgrad_tn(a, N, b, C, Kp, N, C, taps=9, rp=rp, precision=code, b_row0=mrg * C)
+    torch.cuda.synchronize()
+    err = float((out - ref).norm() / ref.norm())
+    assert err < tol, (prec, err)
