@@ -46,6 +46,7 @@ int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, c
 int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat,
                           float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
 int tr_attention_bwd_mfma_slots(int ws);
+int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, void* out1, size_t n1, hipStream_t st, std::string& err);   // two f32 -> x3 conversions, one launch
 // Weight gradient from operands as stored (train_wgrad_tn.hip): out[Nout][taps * C] = sum_k A[k][n] B[k + shift(tap)][c], 16-bit operands
 bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps);
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,

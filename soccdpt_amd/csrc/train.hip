@@ -277,6 +277,23 @@ __global__ void rowsum_kernel(const float* a, float* out, int R, size_t n) {
     }
 }
 
+// f32 -> x3 of TWO tensors in one launch (the X and W operands of a forward GEMM, train_step.cpp gemm_fwd): the conversions are a few microseconds each,
+// so the second launch cost as much as its work
+__global__ void cvt_x3_pair_kernel(const float* __restrict__ in0, void* __restrict__ out0, size_t n0, const float* __restrict__ in1, void* __restrict__ out1,
+                                   size_t n1) {   // n0, n1 % 4 == 0
+    const size_t total = n0 + n1;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+        if (i < n0) {
+            const float4 v = *reinterpret_cast<const float4*>(in0 + i);
+            x3_store4(out0, i, v.x, v.y, v.z, v.w);
+        } else {
+            const size_t j = i - n0;
+            const float4 v = *reinterpret_cast<const float4*>(in1 + j);
+            x3_store4(out1, j, v.x, v.y, v.z, v.w);
+        }
+    }
+}
+
 // ---------------- elementwise ----------------
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {   // y += x
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
@@ -1241,6 +1258,13 @@ int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, floa
     SOCCDPT_LAUNCH(colsum_part_kernel<true>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
     SOCCDPT_LAUNCH(colsum_final_kernel, dim3((2 * N + 63) / 64), dim3(1024), 0, st, scratch, out_ab, out_a, N, 2 * N, chunks, 0);
     TK("colsum2");
+}
+int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, void* out1, size_t n1, hipStream_t st, std::string& err) {
+    if ((n0 | n1) % 16) { err = "cvt_x3_pair: x3 tensors are multiples of 16 elements"; return 1; }
+    size_t blocks = ((n0 + n1) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    SOCCDPT_LAUNCH(cvt_x3_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in0, out0, n0, in1, out1, n1);
+    TK("cvt_x3_pair");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);

@@ -166,8 +166,7 @@ int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems) {
     if (!x3) return gemm(c, d);
     uint16_t* xs = reinterpret_cast<uint16_t*>(c.T.S_T2);
     uint16_t* wsx = reinterpret_cast<uint16_t*>(c.T.S_wt);
-    TRY(launch_cvt_bf16(static_cast<const float*>(d.X), xs, x_elems, 3, c.st, c.err));
-    TRY(launch_cvt_bf16(static_cast<const float*>(d.Wt), wsx, w_elems, 3, c.st, c.err));
+    TRY(tr_cvt_x3_pair(static_cast<const float*>(d.X), xs, x_elems, static_cast<const float*>(d.Wt), wsx, w_elems, c.st, c.err));
     d.X = xs; d.Wt = wsx; d.out_op_f32 = 1;
     return gemm(c, d, true);
 }
