@@ -24,7 +24,7 @@ constexpr int S_ROWB = CIN * 2;               // 256 B per source pixel
 constexpr int S_BYTES = SRH * SRW * S_ROWB;   // 24576
 constexpr int T_BYTES = 512;                   // per-tile row / column interpolation tables
 constexpr int R_BYTES = TH * TW * 4;            // cross-wave reduction of the two channel tiles
-constexpr int LDS_BYTES = P_BYTES + S_BYTES + T_BYTES + R_BYTES;  // 74560
+constexpr int LDS_BYTES = P_BYTES + 2 * S_BYTES + T_BYTES + R_BYTES;  // 99136: two source windows (the next tile's arrives by LDS-DMA while this one is built / multiplied)
 constexpr int NTHR = 512;                      // 8 waves: one output row of the 8 x 16 tile each
 }  // namespace
 
@@ -34,8 +34,8 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
                                                           const float* __restrict__ w4, float b4, float* __restrict__ out, int B, int h, int w) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Ps = smem;
-    char* Ss = smem + P_BYTES;
-    int* Ti = reinterpret_cast<int*>(smem + P_BYTES + S_BYTES);  // [0..9] row: src offset (bytes) of the upper row | valid<<30 ; [32..49] col
+    char* Ss0 = smem + P_BYTES;
+    int* Ti = reinterpret_cast<int*>(smem + P_BYTES + 2 * S_BYTES);  // [0..9] row: src offset (bytes) of the upper row | valid<<30 ; [32..49] col
     float* Tf = reinterpret_cast<float*>(Ti) + 64;                          // [0..9] ly ; [32..49] lx
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = 2 * h, W = 2 * w;
@@ -51,25 +51,43 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
     const float sy = (float)(h - 1) / (float)(H - 1), sx = (float)(w - 1) / (float)(W - 1);
     const float4 bia = *reinterpret_cast<const float4*>(bias + ntile * 16 + fq * 4);
     const float4 w4v = *reinterpret_cast<const float4*>(w4 + ntile * 16 + fq * 4);
-    float* red = reinterpret_cast<float*>(smem + P_BYTES + S_BYTES + T_BYTES);  // [8 rows][16 px] partial dots of channel tile 1
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    float* red = reinterpret_cast<float*>(smem + P_BYTES + 2 * S_BYTES + T_BYTES);  // [8 rows][16 px] partial dots of channel tile 1
+    // low-res source window of a tile -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, nobody waits for it until the tile's turn): the window's
+    // 96 pixels x 256 B are 24 wave-sized pieces of 4 pixels, three per wave; lane = (pixel of the piece, 16-byte chunk)
+    auto issue_window = [&](int tile, int buf) {
+        const int tx = tile % tiles_x;
+        int r = tile / tiles_x;
+        const int ty = r % tiles_y;
+        const int b = r / tiles_y;
+        const int y0 = ty * TH - 1, x0 = tx * TW - 1;
+        const bf16_t* src = d1 + (size_t)b * h * w * CIN;
+        const int Yc0 = y0 < 0 ? 0 : y0, Xc0 = x0 < 0 ? 0 : x0;
+        const int sy0 = (int)(sy * (float)Yc0), sx0 = (int)(sx * (float)Xc0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int piece = wave * 3 + i, p = piece * 4 + (lane >> 4), ch = lane & 15;
+            int yy = sy0 + p / SRW, xx = sx0 + p % SRW;
+            yy = yy > h - 1 ? h - 1 : yy;
+            xx = xx > w - 1 ? w - 1 : xx;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + ((size_t)yy * w + xx) * CIN + ch * 8),
+                                             (__attribute__((address_space(3))) void*)(Ss0 + buf * S_BYTES + piece * 1024), 16, 0, 0);
+        }
+    };
+    if ((int)blockIdx.x < ntiles) issue_window(blockIdx.x, 0);
+    int iter = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++iter) {
         const int tx = tile % tiles_x;
         int r = tile / tiles_x;
         const int ty = r % tiles_y;
         const int b = r / tiles_y;
         const int y0 = ty * TH - 1, x0 = tx * TW - 1;  // up-sampled coordinates of the patch origin
-        __syncthreads();                               // previous tile's MFMAs are done with the patch (and the weights are in)
-        // ---- low-res source window -> LDS (each source pixel once, coalesced) + interpolation tables ----
-        const bf16_t* src = d1 + (size_t)b * h * w * CIN;
+        const char* Ss = Ss0 + (iter & 1) * S_BYTES;
+        // raw barriers from here on: __syncthreads() would also drain the LDS-DMA of the NEXT tile's window, which is the latency being hidden
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                  // previous tile's MFMAs are done with the patch, its build with the tables (and the weights are in)
+        // ---- interpolation tables of this tile ----
         const int Yc0 = y0 < 0 ? 0 : y0, Xc0 = x0 < 0 ? 0 : x0;
         const int sy0 = (int)(sy * (float)Yc0), sx0 = (int)(sx * (float)Xc0);  // first source row / column any patch pixel touches
-        for (int it = tid; it < SRH * SRW * (CIN / 8); it += NTHR) {
-            const int ch = it % (CIN / 8), p = it / (CIN / 8);
-            int yy = sy0 + p / SRW, xx = sx0 + p % SRW;
-            yy = yy > h - 1 ? h - 1 : yy;
-            xx = xx > w - 1 ? w - 1 : xx;
-            *reinterpret_cast<uint4*>(Ss + p * S_ROWB + ch * 16) = *reinterpret_cast<const uint4*>(src + ((size_t)yy * w + xx) * CIN + ch * 8);
-        }
         if (tid < PH) {  // rows: byte offset of source row yy0 inside the window, step to yy1, weight
             const int Y = y0 + tid;
             const bool ok = Y >= 0 && Y < H;
@@ -85,7 +103,10 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
             Ti[tid] = ((xx0 - sx0) * S_ROWB) | ((xx0 < w - 1) ? (1 << 28) : 0) | (ok ? (1 << 30) : 0);
             Tf[tid] = fx - (float)xx0;
         }
-        __syncthreads();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // this wave's pieces of THIS tile's window have landed, its table entries are written
+        __builtin_amdgcn_s_barrier();                                  // ... everybody's
+        // the other window buffer was last read by the build of the previous tile, which every wave has left: fetch the next tile's window into it
+        if (tile + (int)gridDim.x < ntiles) issue_window(tile + gridDim.x, (iter & 1) ^ 1);
         // ---- build the up-sampled halo patch from the staged window: thread = fixed 8-channel chunk, strided pixels ----
         {
             const int ch = tid & 15;
@@ -116,7 +137,8 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
                 *reinterpret_cast<uint4*>(Ps + p * P_ROWB + ch * 16) = o;
             }
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         // ---- 9 taps x 4 k-steps: wave = 2 output rows x 16 channels, weights from registers, patch rows from LDS ----
         f32x4 acc[2];
         acc[0] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -148,7 +170,8 @@ __global__ __launch_bounds__(512) void depth_tail_kernel(const bf16_t* __restric
             red[(2 * rowpair + 0) * TW + frow] = part[0];
             red[(2 * rowpair + 1) * TW + frow] = part[1];
         }
-        __syncthreads();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         if (ntile == 0 && fq == 0) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
