@@ -38,26 +38,27 @@ def load(path, counter):
             a[1] += float(r["Counter_Value_Sum"]) if "Counter_Value_Sum" in r else float(r["Counter_Value"])
     return agg
 
-f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
-out = {}
-for k in f:
-    fl, wl = f[k], w.get(k, [1, 0.0])
-    out[k] = dict(launches=fl[0], fetch_bytes_per_launch_raw=fl[1] / fl[0] * 1024, fetch_bytes_per_launch=2 * fl[1] / fl[0] * 1024,
-                  write_bytes_per_launch=wl[1] / max(wl[0], 1) * 1024)
-    out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
-if len(sys.argv) > 4:  # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -> MFMA pipe utilisation per kernel family
-    mf, ga = load(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), load(sys.argv[4], "GRBM_GUI_ACTIVE")
-    for k in out:
-        if k in mf and k in ga and ga[k][1] > 0:
-            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 256 CUs x 4 SIMDs (16 cycles per v_mfma_f32_16x16x32: checked against the
-            # analytic MFMA count of the 256x256 conv, 9,437,184 x 16 = 150,994,944); GRBM_GUI_ACTIVE is summed over the 8 XCDs
-            out[k]["mfma_busy_cycles_per_launch"] = mf[k][1] / mf[k][0]
-            out[k]["gpu_active_cycles_per_launch_sum_of_8_xcds"] = ga[k][1] / ga[k][0]
-            out[k]["mfma_util"] = mf[k][1] / (ga[k][1] / 8.0 * 256 * 4)
-import os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from soccdpt_amd.lib import csrc_sha  # noqa: E402
-json.dump(dict(csrc_sha=csrc_sha(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --headline-only --steps 3 --warmup 1`; KiB->bytes; "
-                    "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads)", kernels=out),
-          open(sys.argv[3], "w"), indent=1)
-print("wrote", sys.argv[3], len(out), "kernels")
+if __name__ == "__main__":
+    f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
+    out = {}
+    for k in f:
+        fl, wl = f[k], w.get(k, [1, 0.0])
+        out[k] = dict(launches=fl[0], fetch_bytes_per_launch_raw=fl[1] / fl[0] * 1024, fetch_bytes_per_launch=2 * fl[1] / fl[0] * 1024,
+                      write_bytes_per_launch=wl[1] / max(wl[0], 1) * 1024)
+        out[k]["hbm_bytes_per_launch"] = out[k]["fetch_bytes_per_launch"] + out[k]["write_bytes_per_launch"]
+    if len(sys.argv) > 4:  # optional third pass: SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -> MFMA pipe utilisation per kernel family
+        mf, ga = load(sys.argv[4], "SQ_VALU_MFMA_BUSY_CYCLES"), load(sys.argv[4], "GRBM_GUI_ACTIVE")
+        for k in out:
+            if k in mf and k in ga and ga[k][1] > 0:
+                # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 256 CUs x 4 SIMDs (16 cycles per v_mfma_f32_16x16x32: checked against the
+                # analytic MFMA count of the 256x256 conv, 9,437,184 x 16 = 150,994,944); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                out[k]["mfma_busy_cycles_per_launch"] = mf[k][1] / mf[k][0]
+                out[k]["gpu_active_cycles_per_launch_sum_of_8_xcds"] = ga[k][1] / ga[k][0]
+                out[k]["mfma_util"] = mf[k][1] / (ga[k][1] / 8.0 * 256 * 4)
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from soccdpt_amd.lib import csrc_sha  # noqa: E402
+    json.dump(dict(csrc_sha=csrc_sha(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --headline-only --steps 3 --warmup 1`; KiB->bytes; "
+                        "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads)", kernels=out),
+              open(sys.argv[3], "w"), indent=1)
+    print("wrote", sys.argv[3], len(out), "kernels")
