@@ -1,9 +1,12 @@
 // Training step of SOccDPT_V3 (Swin-V2 encoders here, the ViT-hybrid encoder in train_hybrid_step.cpp; decoder and heads shared): train-mode
 // forward that keeps every activation the backward needs (the "tape"),
 // and the backward that autograd runs for the reference (scripts/train_SOccDPT.py:360-393 over model/SOccDPT.py:660-685, model/dpt.py:142-232,
-// model/blocks.py:391-497 and timm's SwinTransformerV2).  Exact f32 (SOCCDPT_PREC_F32): every GEMM-shaped gradient goes through the f32
-// MFMA igemm (igemm.hip), the rest through train.hip.  Train mode differs from eval in the seg head only (model/SOccDPT.py:660-671):
-// BatchNorm2d uses batch statistics and updates its running buffers, Dropout(0.1) is live; drop_path is 0 in the reference's encoders.
+// model/blocks.py:391-497 and timm's SwinTransformerV2).  Arithmetic by soccdpt_train_set_amp: 0 = exact f32 (every GEMM-shaped gradient through the f32
+// MFMA igemm), 3 = x3 split-fp16 operands in every GEMM of the step (f32-grade), 1 / 2 = bf16 / fp16 operands in the gradient GEMMs with an x3 forward;
+// the tape, the weights and the gradients are f32 in every mode.  Weight gradients: split-K igemm over transposed operands (gemm_wgrad), or -- 16-bit and x3
+// modes, shapes permitting -- from the operands as stored (train_wgrad_tn.hip).  Attention backward: train_attn.hip.  The rest: train.hip.
+// Train mode differs from eval in the seg head (model/SOccDPT.py:660-671: BatchNorm2d on batch statistics with running-buffer updates, Dropout(0.1) live)
+// and in the encoder's stochastic depth (timm's drop_path_rate = 0.1, soccdpt_train_set_drop_path).
 //
 // Gradients are WRITTEN (not accumulated) to the buffers bound with soccdpt_bind_grad; a weight without a bound gradient is frozen and its
 // weight-gradient GEMM is skipped (the reference freezes / partially unfreezes the encoder: model/loss.py:110-152).
@@ -171,8 +174,9 @@ int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems) {
     return gemm(c, d, true);
 }
 
-// Weight-gradient GEMM: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are summed
-// in split order by the last workgroup to arrive (igemm.hip, SK): deterministic.  amp: bf16 operands (K padded to 128 by the caller).
+// Weight-gradient GEMM over TRANSPOSED operands: few output tiles, K = pixels.  Split K so that about two workgroups per CU exist; the partial tiles are
+// summed in split order -- by a second launch (sk_defer) for the big tiles and for >= 4 splits, by the last workgroup to arrive otherwise: deterministic
+// either way.  amp: bf16 / fp16 operands (K padded to 128 by the caller).
 int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3) {
     const bool amp = bf16_operands;   // the CALLER says what its staging kernels wrote (amp applies per GEMM: shapes that do not fit stay f32)
     d.f32 = (amp || x3) ? 0 : 1;
