@@ -6,6 +6,7 @@ so GEMM/conv results agree to fp32 summation-order noise (rtol 2e-3 on the bf16-
 1e-4 on f32 outputs).  The attention kernel additionally rounds q-hat, k-hat and the softmax
 numerators to bf16: atol 3e-2 on outputs of magnitude O(1)."""
 import math
+import os
 
 import pytest
 import torch
@@ -510,3 +511,18 @@ def test_wgrad_tn_conv3x3(gpu_device, prec):
     torch.cuda.synchronize()
     err = float((out - ref).norm() / ref.norm())
     assert err < tol, (prec, err)
+
+
+def test_lds_transpose_read_semantics(gpu_device, tmp_path):
+    """ds_read_b64_tr_b16 as train_wgrad_tn.hip uses it: per 16-lane group a 4-row x 16-column block of 16-bit elements, lane 4q + p addresses row q columns
+    4p..4p+3, lane i receives column i of the four rows.  tests/tools/tr_read_probe.hip is compiled with the box's hipcc and run as a child process."""
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("no hipcc on this box")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "tr_read_probe.hip")
+    exe = str(tmp_path / "tr_read_probe")
+    subprocess.run([hipcc, "-O3", "--offload-arch=gfx950", src, "-o", exe], check=True, capture_output=True, timeout=300)
+    out = subprocess.run([exe], check=True, capture_output=True, text=True, timeout=120).stdout
+    assert "mismatches vs 'lane i gets column i of rows 4g..4g+3': 0" in out, out
