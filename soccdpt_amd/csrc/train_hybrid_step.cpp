@@ -62,6 +62,40 @@ int conv_gen_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* Wtap,
     Tape& T = c.T;
     const int B = c.B;
     const size_t Mo = (size_t)B * Ho * Ho;
+    {
+        // 16-bit amp modes, un-strided convolutions of the wide stages (N, C multiples of 128): dgrad on the 16-bit igemm over the zero-bordered dY image, weight
+        // gradient from the operands as stored in halo pixel order (train_wgrad_tn.hip) -- the path the decoder convolutions take in conv3_bwd, with the
+        // tap-major standardised weights of this encoder on both ends.  SOCCDPT_WGRAD_TRANSPOSE=1 keeps the f32 path below.
+        static const bool tn_off = getenv("SOCCDPT_WGRAD_TRANSPOSE") != nullptr;
+        const int amp = c.h.train_amp;
+        const int rp = Ho + 2;
+        const size_t Kh = (size_t)B * rp * rp, Kp = (Kh + 63) / 64 * 64, mrg = (size_t)rp + 1;
+        if (!tn_off && (amp == 1 || amp == 2) && stride == 1 && pad == 1 && Hi == Ho && N % 128 == 0 && C % 128 == 0 && tr_wgrad_tn_ok(Kp, N, C, 9)) {
+            const int F16 = amp == 2 ? 1 : 0, cvt = F16 ? 5 : 0;
+            uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
+            TRY(tr_to_halo_full(dY, h16, B, Ho, Ho, N, 1 + F16, c.st, c.err));
+            if (dX_out) {
+                uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
+                TRY(th_conv_w_dgrad_tap(Wtap, T.S_dw, N, C, c.st, c.err));                         // [C][9][N] f32, rotated
+                TRY(launch_cvt_bf16(T.S_dw, w16, (size_t)C * 9 * N, cvt, c.st, c.err));
+                IgemmDesc d;
+                d.X = h16; d.Wt = w16; d.M = (int)Mo; d.N = C; d.Cin = N; d.taps = 9; d.H = Ho; d.W = Ho; d.out_f32 = dX_out;
+                TRY(gemm16(c, d));
+            }
+            if (dWtap_out) {
+                uint16_t* xb = reinterpret_cast<uint16_t*>(T.S_T2);
+                hipError_t e = Kp > Kh ? hipMemsetAsync(h16 + Kh * N, 0, (Kp - Kh) * N * 2, c.st) : hipSuccess;
+                if (e == hipSuccess) e = hipMemsetAsync(xb, 0, mrg * C * 2, c.st);
+                if (e == hipSuccess) e = hipMemsetAsync(xb + (mrg + Kh) * C, 0, (Kp - Kh + mrg) * C * 2, c.st);
+                if (e != hipSuccess) { c.err = std::string("conv_gen_bwd memset: ") + hipGetErrorString(e); return 1; }
+                TRY(launch_cvt_bf16(Xhalo, xb + mrg * C, Kh * C, cvt, c.st, c.err));
+                c.T.xt_tn_src = nullptr;   // S_T2 no longer holds conv3_bwd's staged image
+                TRY(tr_wgrad_tn(h16, N, xb + mrg * C, C, Kp, N, C, 9, rp, F16, T.sk_part, kTrainSkPartFloats, dWtap_out, c.st, c.err));
+            }
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, Mo, N, 0, c.st, c.err));
+            return 0;
+        }
+    }
     if (dX_out) {
         if (stride == 1 && pad == 1) {
             const size_t hb = (size_t)B * (Ho + 2) * (Ho + 2) * N * sizeof(float);

@@ -107,6 +107,7 @@ struct Ctx {
 int gemm(Ctx& c, IgemmDesc d, bool x3 = false);
 // a GEMM of the train-mode FORWARD: exact f32, or -- train amp mode 3 -- its operands converted to x3 into scratch first (outputs stay f32)
 int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems);
+int gemm16(Ctx& c, IgemmDesc d);   // 16-bit operands of the amp mode (bf16 / fp16), f32 outputs
 int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3 = false);   // operands as written by the caller's staging kernels
 int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what);
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
