@@ -427,12 +427,55 @@ __global__ __launch_bounds__(256) void bilinear_f32_to_halo8_kernel(const float*
     }
 }
 
+// The same launch in the F16X3 mode: f32 [B,h,w,C] -> x3 halo image, one 8-element unit (two 16-byte stores) per thread
+__global__ __launch_bounds__(256) void bilinear_f32_to_halo8_x3_kernel(const float* __restrict__ in, void* __restrict__ out, int B, int h, int w, int H, int W, int C) {
+    const int c8 = C / 8;
+    const size_t total = (size_t)B * H * W * c8;
+    const float sy = H > 1 ? (float)(h - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(w - 1) / (float)(W - 1) : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int cc = (int)(i % c8) * 8;
+        size_t r = i / c8;
+        const int ox = (int)(r % W);
+        r /= W;
+        const int oy = (int)(r % H);
+        const int b = (int)(r / H);
+        const float fy = sy * (float)oy, fx = sx * (float)ox;
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = y0 + (y0 < h - 1), x1 = x0 + (x0 < w - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = in + (size_t)b * h * w * C + cc;
+        float o[8];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * w + x0) * C + 4 * half);
+            const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)y0 * w + x1) * C + 4 * half);
+            const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * w + x0) * C + 4 * half);
+            const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)y1 * w + x1) * C + 4 * half);
+            // same expression as bilinear_kernel: identical results
+            o[4 * half] = hy * (hx * v00.x + lx * v01.x) + ly * (hx * v10.x + lx * v11.x);
+            o[4 * half + 1] = hy * (hx * v00.y + lx * v01.y) + ly * (hx * v10.y + lx * v11.y);
+            o[4 * half + 2] = hy * (hx * v00.z + lx * v01.z) + ly * (hx * v10.z + lx * v11.z);
+            o[4 * half + 3] = hy * (hx * v00.w + lx * v01.w) + ly * (hx * v10.w + lx * v11.w);
+        }
+        x3_store8(out, ((size_t)(b * (H + 2) + oy + 1) * (W + 2) + ox + 1) * C + cc, o);
+    }
+}
+
 int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
                     int w, int H, int W, int C, hipStream_t st, std::string& err) {
     if (C % 4) { err = "bilinear: C % 4 != 0"; return 1; }
     const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 output in out_bf16 (half16.h)
     if (x3 && (C % 16 || in_is_bf16)) { err = "bilinear: x3 output needs f32 input and C % 16 == 0"; return 1; }
     hf = hf == 1;
+    if (x3 && out_bf16 && out_halo && !out_f32 && !out_f32_halo) {
+        const size_t total8 = (size_t)B * H * W * (C / 8);
+        size_t blocks8 = (total8 + 255) / 256;
+        if (blocks8 > 8192) blocks8 = 8192;
+        SOCCDPT_LAUNCH(bilinear_f32_to_halo8_x3_kernel, dim3((unsigned)blocks8), dim3(256), 0, st, (const float*)in, static_cast<void*>(out_bf16), B, h, w, H, W, C);
+        return check_launch("bilinear", err);
+    }
     if (!x3 && !in_is_bf16 && out_bf16 && out_halo && !out_f32 && !out_f32_halo && C % 8 == 0) {
         const size_t total8 = (size_t)B * H * W * (C / 8);
         size_t blocks8 = (total8 + 255) / 256;

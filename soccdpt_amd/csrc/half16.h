@@ -96,6 +96,21 @@ __device__ __forceinline__ void x3_store4(void* base, size_t e, float a, float b
     *reinterpret_cast<uint2*>(p + x3_hi_off(e)) = ph;
     *reinterpret_cast<uint2*>(p + x3_lo_off(e)) = pl;
 }
+// store one whole unit, elements e .. e+7 (e % 8 == 0): two 16-byte stores
+__device__ __forceinline__ void x3_store8(void* base, size_t e, const float (&v)[8]) {
+    uint32_t ph[4], pl[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        _Float16 h0, l0, h1, l1;
+        x3_split(v[2 * k], h0, l0);
+        x3_split(v[2 * k + 1], h1, l1);
+        ph[k] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+        pl[k] = (uint32_t)__builtin_bit_cast(uint16_t, l0) | ((uint32_t)__builtin_bit_cast(uint16_t, l1) << 16);
+    }
+    char* p = static_cast<char*>(base);
+    *reinterpret_cast<uint4*>(p + x3_hi_off(e)) = make_uint4(ph[0], ph[1], ph[2], ph[3]);
+    *reinterpret_cast<uint4*>(p + x3_lo_off(e)) = make_uint4(pl[0], pl[1], pl[2], pl[3]);
+}
 __device__ __forceinline__ void x3_store1(void* base, size_t e, float a) {
     _Float16 h, l;
     x3_split(a, h, l);
