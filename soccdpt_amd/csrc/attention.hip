@@ -839,11 +839,17 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
     const int nw = res / ws;
     static const bool force_any = getenv("SOCCDPT_ATTN_F32_ANY") != nullptr;   // A/B switch: the one-thread-per-query kernel
-    if ((ws == 24 || ws == 12) && !force_any) {   // dpt_swin2_base_384: the streaming MFMA-f32 kernel
+    // 16 x 16 / 8 x 8 windows too (round 3, late): 0.507 -> 0.296 ms per tiny_256 forward at B = 8 against the whole-score-matrix kernel below
+    // (SOCCDPT_ATTN_F32_FLASH16=0 selects that one for A/B)
+    static const int flash_small = getenv("SOCCDPT_ATTN_F32_FLASH16") ? atoi(getenv("SOCCDPT_ATTN_F32_FLASH16")) : 1;
+    const bool flash = (ws == 24 || ws == 12) || ((ws == 16 || ws == 8) && flash_small == 1);
+    if (flash && !force_any) {   // the streaming MFMA-f32 kernel
         const int NT = (ws * ws + 31) / 32, NQB = (NT + 3) / 4;
         const unsigned blocksf = (unsigned)(B * nw * nw * heads * NQB);
         if (ws == 24) SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<24>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
-        else SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<12>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
+        else if (ws == 12) SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<12>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
+        else if (ws == 16) SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<16>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
+        else SOCCDPT_LAUNCH((window_attention_f32_flash_kernel<8>), dim3(blocksf), dim3(256), 0, st, qkv, bias_acc, scale, out, res, shift, heads, x3);
         return check_launch("window_attention_f32_flash", err);
     }
     if (ws != 16 && !(ws == 8 && shift == 0)) {  // any other window size: the generic exact kernel (parity mode of base_384)
