@@ -5,8 +5,13 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 th
 under torch.distributed.run, one rank per GPU (RCCL).  One "step" = one forward of one batch of
 synthetic 256x256 frames per rank (weak scaling: per-GPU batch fixed).  Rank 0 prints ONE JSON line.
 
-Workload at N = 1: BASELINE.json configs[1] — SOccDPT_V3 dpt_swin2_tiny_256, bf16 MFMA operands,
-batch 8, compute_occ=True, eval mode, synthetic weights/inputs/camera.
+Workload at N = 1: BASELINE.json configs[1] — SOccDPT_V3 dpt_swin2_tiny_256, batch 8, compute_occ=True,
+eval mode, synthetic weights/inputs/camera.  `value` is timed in the default arithmetic
+`--precision mixed` (SOCCDPT_PREC_MIXED: fp16 MFMA operands, x3 split where the shipped precision map asks
+for it), the fastest mode whose outputs are measured -- in this same run, against the library's own
+exact-f32 mode -- inside HALF the north star's 1e-3 (`tolerance`); the bf16 figure BASELINE configs[1]
+names and the plain-fp16 figure are side fields (`bf16_operands`, `f16_operands`), each with its own
+measured errors and roofline fraction.
 
 Extra objects:
   roofline     dominant kernel family of the forward (by summed device time), timed live with HIP
@@ -101,12 +106,17 @@ def train_step_bench(args):
     torch.cuda.synchronize()
     all_trainable = args.encoder_percentage >= 1.0 and args.patchwise_percentage >= 1.0
     roof = None
-    if all_trainable and args.amp in (None, False, "x3"):
-        # f32: the exact-f32 MFMA peak; x3: every GEMM of the step (forward, dgrad, wgrad) runs three fp16 MFMAs per product -> a third of the fp16 peak
-        peak = PEAK_F32_TFLOPS if not args.amp else round(2500.0 / 3.0, 1)
+    if all_trainable:
+        # f32: the exact-f32 MFMA peak; x3: every GEMM of the step (forward, dgrad, wgrad) runs three fp16 MFMAs per product -> a third of the fp16 peak;
+        # bf16 / f16 amp: the train forward runs x3 operands (its outputs feed the f32 tape), dgrad and wgrad run 16-bit operands -> one third of the
+        # algorithmic FLOPs against 833.3, two thirds against 2500: the FLOP-weighted harmonic mean 3 / (1 / 833.3 + 2 / 2500) = 1500
+        x3_peak = PEAK_BF16_TFLOPS / 3.0
+        peak = PEAK_F32_TFLOPS if not args.amp else (round(x3_peak, 1) if args.amp == "x3" else round(3.0 / (1.0 / x3_peak + 2.0 / PEAK_BF16_TFLOPS), 1))
         ach = 3.0 * FWD_GFLOP_PER_FRAME[args.model_type] * sps / 1e3
         roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
-                "kernel": "whole step (igemm forward + dgrad + split-K wgrad; profiles/r03_train_*kernel_stats.csv split it per kernel)",
+                "kernel": "whole step (igemm forward + dgrad + split-K wgrad; profiles/r04_train_*kernel_stats.csv split it per kernel)",
+                "peak_note": ("exact-f32 MFMA" if not args.amp else "x3: a third of the 16-bit MFMA peak" if args.amp == "x3" else
+                              "x3 forward (1/3 of the FLOPs at 833.3) + 16-bit dgrad / wgrad (2/3 at 2500): FLOP-weighted harmonic mean"),
                 "flops_per_sample_gflop": round(3.0 * FWD_GFLOP_PER_FRAME[args.model_type], 1)}
     cpu = None
     if not args.no_cpu_baseline and not args.headline_only:
@@ -133,6 +143,47 @@ def train_step_bench(args):
     os.dup2(real_stdout, 1)
     print(json.dumps(result), flush=True)
     return 0
+
+
+PREC_CODE = {"bf16": 0, "f32": 1, "f16": 2, "f16x3": 3, "mixed": 4}
+QUANTITIES = ("feat0", "feat1", "feat2", "feat3", "path1", "inv", "seg_logits")
+
+
+def igemm_roofline(stats, prof_steps, precision, pmc=None):
+    """The igemm_kernel template as a whole: algorithmic FLOPs / summed launch durations against the MFMA peak.  x3 launches spend three
+    fp16 MFMAs per algorithmic product, so their peak for ALGORITHMIC FLOPs is a third of the dense 16-bit peak; a mixed-precision forward is
+    priced against the FLOP-weighted harmonic mean of its members' peaks (what the same launches would take at their own peaks)."""
+    mem = {n: v for n, v in stats.items() if n.startswith("igemm_") and v["flops"] > 0}
+    if not mem:
+        return None
+    def peak_of(name):
+        if name.startswith("igemm_f32"):
+            return PEAK_F32_TFLOPS
+        return PEAK_BF16_TFLOPS / 3.0 if name.startswith("igemm_x3") else PEAK_BF16_TFLOPS
+    flops, ms, launches = sum(v["flops"] for v in mem.values()), sum(v["ms"] for v in mem.values()), sum(v["launches"] for v in mem.values())
+    peak = flops / sum(v["flops"] / peak_of(n) for n, v in mem.items())
+    ach = flops / (ms * 1e-3) / 1e12
+    total_ms = sum(v["ms"] for v in stats.values())
+    roof = dict(bound="mfma", kernel="igemm_kernel (all tile configurations)", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+                traffic=None, avg_launch_us=round(ms * 1e3 / launches, 2), share_of_device_time=round(ms / total_ms, 4),
+                flops_per_step=flops / prof_steps, launches_per_step=launches / prof_steps)
+    if precision == "mixed":
+        roof["peak_note"] = "FLOP-weighted harmonic mean of 2500 (fp16 launches) and 833.3 (x3 launches: three MFMAs per algorithmic product)"
+    by = []
+    for name in sorted(mem, key=lambda n: -mem[n]["ms"]):
+        v = mem[name]
+        e = dict(config=name, launches_per_step=v["launches"] / prof_steps, avg_launch_us=round(v["ms"] * 1e3 / v["launches"], 2),
+                 achieved=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(name), 4))
+        if pmc and name in pmc:
+            e["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
+            if "mfma_util" in pmc[name]:
+                e["mfma_util_pmc"] = round(pmc[name]["mfma_util"], 4)
+        by.append(e)
+    if len(by) > 1:
+        roof["by_config"] = by
+    if pmc and all(n in pmc for n in mem):
+        roof["traffic"] = round(sum(pmc[n]["hbm_bytes_per_launch"] * mem[n]["launches"] for n in mem) / launches)   # HBM bytes per launch, launch-weighted
+    return roof
 
 
 def launch_ranks(args):
@@ -180,10 +231,12 @@ def main():
     ap.add_argument("--model-type", default="dpt_swin2_tiny_256", choices=["dpt_swin2_tiny_256", "dpt_swin2_base_384", "dpt_hybrid_384"],
                     help="dpt_swin2_tiny_256 = BASELINE metric config (configs[1]); dpt_swin2_base_384 --batch 8 = configs[3]'s per-GPU shape "
                          "(64 frames over 8 GPUs); dpt_hybrid_384 --batch 4 = configs[2]")
-    ap.add_argument("--precision", choices=["bf16", "f16", "f32", "f16x3"], default="bf16",
-                    help="bf16: bf16 MFMA operands (BASELINE config); f16: IEEE fp16 operands, same kernels and MFMA rate, "
-                         "meets the 1e-3 tolerance on the Swin-V2 models; f32: exact-f32 parity mode (1/16 MFMA rate); f16x3: split-operand fp16 "
-                         "(three fp16 MFMAs per product, ~22 significand bits at 1/3 of the 16-bit rate): the fast parity-grade mode")
+    ap.add_argument("--precision", choices=["mixed", "bf16", "f16", "f32", "f16x3"], default="mixed",
+                    help="mixed (default): fp16 MFMA operands, x3 split where the shipped precision map asks for it -- the fastest mode inside half the "
+                         "north star's 1e-3; bf16: bf16 operands (what BASELINE configs[1] names; 3e-3, fails the tolerance); f16: IEEE fp16 operands, "
+                         "same kernels and MFMA rate, meets 1e-3 on the Swin-V2 models without margin; f32: exact-f32 parity mode (1/16 MFMA rate); "
+                         "f16x3: split-operand fp16 everywhere (three fp16 MFMAs per product, ~22 significand bits at 1/3 of the 16-bit rate)")
+    ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 / fp16 side legs and the live error measurement")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: slower than eager)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -244,7 +297,7 @@ def main():
     with contextlib.redirect_stdout(io.StringIO()):
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
                          model_type=args.model_type,
-                         graph=args.graph, precision={"bf16": 0, "f32": 1, "f16": 2, "f16x3": 3}[args.precision])
+                         graph=args.graph, precision=PREC_CODE[args.precision])
     from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
     backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
     img = backbone_image_size(backbone)
@@ -313,75 +366,47 @@ def main():
     stats = eng.profile_collect()
     eng.profile_enable(False)
 
-    result = None
-    if rank == 0:
-        total_ms = sum(s["ms"] for s in stats.values())
-        kernels = []
-        for name, s in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]):
-            k = dict(name=name, launches_per_step=s["launches"] / prof_steps, ms_per_step=round(s["ms"] / prof_steps, 4),
-                     share=round(s["ms"] / total_ms, 4))
-            if s["flops"] > 0:
-                k["tflops"] = round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2)
-            if s["bytes"] > 0:
-                k["gbs"] = round(s["bytes"] / (s["ms"] * 1e-3) / 1e9, 1)
-            kernels.append(k)
-        # The dominant KERNEL is the igemm_kernel template (igemm.hip): every Linear layer and convolution of the network is one
-        # of its tile instantiations ("igemm_<dtype>_<BM>x<BN>x<BK>_s<stages>" families).  The roofline object prices the template
-        # as a whole (sum of algorithmic FLOPs / sum of launch durations) and lists every instantiation under by_config; when a
-        # non-igemm kernel dominates (it does not at these sizes) that kernel is reported instead.
-        groups = {}
-        for name, s in stats.items():
-            gname = "igemm_kernel" if name.startswith("igemm_") else name
-            g = groups.setdefault(gname, dict(ms=0.0, flops=0.0, bytes=0.0, launches=0, members=[]))
-            g["ms"] += s["ms"]; g["flops"] += s["flops"]; g["bytes"] += s["bytes"]; g["launches"] += s["launches"]; g["members"].append(name)
-        fam, dom = max(groups.items(), key=lambda kv: kv[1]["ms"])
-        # f16x3: three fp16 MFMAs per algorithmic product -> the roofline for ALGORITHMIC FLOPs is a third of the dense 16-bit peak
-        peak = PEAK_F32_TFLOPS if args.precision == "f32" else (round(PEAK_BF16_TFLOPS / 3.0, 1) if args.precision == "f16x3" else PEAK_BF16_TFLOPS)
-        pmc, pmc_file, pmc_stale = {}, None, None
-        try:   # HBM bytes / MFMA-pipe utilisation per launch: PMC counters cannot be read inside this process; they come from the
-               # committed rocprofv3 --pmc passes over this same command (profiles/, tools/collect_profiles.sh, tools/pmc_summary.py).
-               # A file is only used when it was collected from the CURRENT kernel sources (csrc_sha); otherwise traffic is null.
+    def load_pmc():
+        """HBM bytes / MFMA-pipe utilisation per launch: PMC counters cannot be read inside this process; they come from the committed rocprofv3
+        --pmc passes over this same command (profiles/, tools/collect_profiles.sh, tools/pmc_summary.py).  A file is only used when it was
+        collected from the CURRENT kernel sources (csrc_sha); otherwise traffic is null and traffic_note says why."""
+        try:
             import glob
             from soccdpt_amd.lib import csrc_sha
             tagsfx = {"dpt_swin2_tiny_256": "", "dpt_swin2_base_384": "_base384", "dpt_hybrid_384": "_hybrid384"}[args.model_type]
             cands = sorted(glob.glob(os.path.join(REPO, "profiles", f"r*{tagsfx}_pmc_traffic.json")))
             cands = [c for c in cands if tagsfx or not any(t in os.path.basename(c) for t in ("_base384", "_hybrid384"))]
-            pmc_file = cands[-1]
-            pj = json.load(open(pmc_file))
-            if pj.get("csrc_sha") == csrc_sha():
-                pmc = pj["kernels"]
-            else:
-                pmc_stale = f"{os.path.basename(pmc_file)} was collected from other kernel sources (csrc_sha {pj.get('csrc_sha')} != {csrc_sha()})"
+            pj = json.load(open(cands[-1]))
+            if pj.get("csrc_sha") == csrc_sha() and pj.get("precision", "bf16") == args.precision:
+                return pj["kernels"], os.path.basename(cands[-1]), None
+            return {}, None, (f"{os.path.basename(cands[-1])} was collected from other kernel sources or another precision (csrc_sha {pj.get('csrc_sha')} vs "
+                              f"{csrc_sha()}, precision {pj.get('precision', 'bf16')} vs {args.precision})")
         except Exception:
-            pmc_file = None
-        if dom["flops"] > 0:
-            ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-            roofline = dict(bound="mfma", kernel=fam + (" (all tile configurations)" if fam == "igemm_kernel" else ""),
-                            achieved=round(ach, 2), peak=peak, unit="TFLOP/s", frac=round(ach / peak, 4), traffic=None,
-                            avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2), share_of_device_time=round(dom["ms"] / total_ms, 4),
-                            flops_per_step=dom["flops"] / prof_steps, launches_per_step=dom["launches"] / prof_steps)
-            by = []
-            for name in sorted(dom["members"], key=lambda n: -stats[n]["ms"]):
-                s = stats[name]
-                e = dict(config=name, launches_per_step=s["launches"] / prof_steps, avg_launch_us=round(s["ms"] * 1e3 / s["launches"], 2),
-                         achieved=round(s["flops"] / (s["ms"] * 1e-3) / 1e12, 2), frac=round(s["flops"] / (s["ms"] * 1e-3) / 1e12 / peak, 4))
-                if name in pmc:
-                    e["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
-                    if "mfma_util" in pmc[name]:
-                        e["mfma_util_pmc"] = round(pmc[name]["mfma_util"], 4)
-                by.append(e)
-            if len(by) > 1:
-                roofline["by_config"] = by
-        else:
-            ach = dom["bytes"] / (dom["ms"] * 1e-3) / 1e9
-            roofline = dict(bound="hbm", kernel=fam, achieved=round(ach, 1), peak=PEAK_HBM_GBS, unit="GB/s",
-                            frac=round(ach / PEAK_HBM_GBS, 4), traffic=None,
-                            avg_launch_us=round(dom["ms"] * 1e3 / dom["launches"], 2))
-        tr = [pmc[n]["hbm_bytes_per_launch"] * stats[n]["launches"] for n in dom["members"] if n in pmc]
-        if tr and len(tr) == len(dom["members"]):
-            roofline["traffic"] = round(sum(tr) / dom["launches"])     # HBM bytes per launch, launch-weighted over the members
-            roofline["traffic_source"] = os.path.basename(pmc_file)
-        elif pmc_stale:
+            return {}, None, None
+
+    def kernel_table(stats, steps):
+        total = sum(v["ms"] for v in stats.values())
+        rows = []
+        for name, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"]):
+            k = dict(name=name, launches_per_step=v["launches"] / steps, ms_per_step=round(v["ms"] / steps, 4), share=round(v["ms"] / total, 4))
+            if v["flops"] > 0:
+                k["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
+            if v["bytes"] > 0:
+                k["gbs"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
+            rows.append(k)
+        return rows, total
+
+    result = None
+    if rank == 0:
+        kernels, total_ms = kernel_table(stats, prof_steps)
+        # The dominant KERNEL is the igemm_kernel template (igemm.hip): every Linear layer and convolution of the network is one of its tile
+        # instantiations ("igemm_<dtype>_<BM>x<BN>x<BK>_s<stages>" families).  The roofline object prices the template as a whole (sum of
+        # algorithmic FLOPs / sum of launch durations) and lists every instantiation under by_config.
+        pmc, pmc_file, pmc_stale = load_pmc()
+        roofline = igemm_roofline(stats, prof_steps, args.precision, pmc)
+        if pmc_file and roofline and roofline.get("traffic") is not None:
+            roofline["traffic_source"] = pmc_file
+        elif roofline is not None and pmc_stale:
             roofline["traffic_note"] = "null: " + pmc_stale
         # second regime (SURVEY.md 8d "two regimes, report both"): the HBM-bound projection + occupancy expansion
         hb = {n: stats[n] for n in ("project_voxelise", "occ_expand") if n in stats and stats[n]["bytes"] > 0}
@@ -396,6 +421,7 @@ def main():
                                                 **({"traffic": round(pmc[n]["hbm_bytes_per_launch"])} if n in pmc else {})) for n, v in hb.items()])
             if all(n in pmc for n in hb):
                 roofline_hbm["traffic"] = round(sum(pmc[n]["hbm_bytes_per_launch"] * hb[n]["launches"] for n in hb) / hb_l)
+        dtype_name = {"mixed": "mixed fp16 + f16x3 (SOCCDPT_PREC_MIXED: fp16 MFMA operands, x3 split per the shipped precision map; f32 accumulate)"}.get(args.precision, args.precision)
         result = {
             "metric": f"frames/sec SOccDPT_V3 {args.model_type.replace('dpt_', '')} @{img}px (depth+seg+points+occupancy forward)",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -403,11 +429,12 @@ def main():
             "repeats": {"count": repeats, "steps_each": args.steps, "ms_per_step": [round(e / args.steps * 1e3, 4) for e in rep_elapsed],
                         "min_ms_per_step": round(min(rep_elapsed) / args.steps * 1e3, 4), "median_ms_per_step": round(elapsed / args.steps * 1e3, 4),
                         "note": "value / ms_per_step are the median repeat (rank-0 clock; with N > 1 the maximum over ranks of each rank's median)"},
-            "vs_baseline": None, "dtype": args.precision, "data": "synthetic",
+            "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": f"SOccDPT_V3 {args.model_type} full forward, compute_occ=True, camera 1920x1080",
                        "batch_per_gpu": B, "global_batch": B * world, "image": img, "streams_per_gpu": args.streams, "hip_graph": args.graph,
                        "parallelism": f"dp{world}" if world > 1 else "single", "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
-                       "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none"},
+                       "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none",
+                       "precision_map_x3_groups": (sorted(g for g, f in eng.prec_map().items() if f == 3) if args.precision == "mixed" else None)},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,
@@ -415,50 +442,122 @@ def main():
             "device_ms_per_step": round(total_ms / prof_steps, 3),
             "ms_per_step_with_events": round(elapsed_prof / prof_steps * 1e3, 3),
             "launches_per_step": eng.launch_count() + 2,
-            "paper_hz": 47.0, "x_paper_hz": round(fps / 47.0, 2),
         }
+        if world > 1 and getattr(net, "occ_exchange", None) is not None and hasattr(net.occ_exchange, "window_ms"):
+            wms = net.occ_exchange.window_ms()   # issue of the all-gather -> end of the OR kernel, device time, with the rows' zero-fill overlapped (soccdpt_amd/dist.py)
+            result["exchange_window_ms"] = None if wms is None else round(wms, 4)
 
-    # ---- the same workload with IEEE fp16 MFMA operands (SOCCDPT_PREC_F16): same kernels and MFMA rate; this is the mode that
-    # meets the north star's 1e-3 tolerance (tests/test_network_gpu.py::test_f16_mode_meets_1e3_relative).  N = 1 only.
-    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and not args.headline_only:
+    single = rank == 0 and world == 1 and not args.graph and args.streams == 1
+    side_ok = single and not args.headline_only and not args.no_side_modes
+
+    def build(prec_name, streams=1):
         with contextlib.redirect_stdout(io.StringIO()):
-            net16 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
-                               model_type=args.model_type, precision=2)
-        net16.load_state_dict(sd, strict=False)
-        net16 = net16.eval().to(dev)
-        for _ in range(args.warmup):
-            out = net16(x)
+            m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=streams,
+                           model_type=args.model_type, precision=PREC_CODE[prec_name])
+        m.load_state_dict(sd, strict=False)
+        return m.eval().to(dev)
+
+    # ---- B = 1 latency: the protocol behind the paper's 47 Hz (/root/reference/SOccDPT/scripts/eval_SOccDPT.py:246-259: 50 forwards of ONE frame,
+    # fps = 50 / elapsed), here WITH a device synchronisation on both sides of the 50 forwards.  x_paper_hz compares like with like.
+    if single and not args.headline_only:
+        x1 = x[:1].contiguous()
+        for _ in range(10):
+            net(x1)
         torch.cuda.synchronize()
-        t3 = time.perf_counter()
-        for _ in range(args.steps):
-            out = net16(x)
+        t5 = time.perf_counter()
+        for _ in range(50):
+            out = net(x1)
         torch.cuda.synchronize()
-        e16 = time.perf_counter() - t3
-        result["f16_operands"] = {"value": round(B * args.steps / e16, 2), "unit": "frames/s", "ms_per_step": round(e16 / args.steps * 1e3, 3),
-                                  "note": "same forward with fp16 instead of bf16 MFMA operands (f32 accumulate); depth / logits / features "
-                                          "within 1e-3 rel-L2 of the fp32 CPU oracle, bf16 is at 3e-3"}
-        del net16
+        e1 = time.perf_counter() - t5
+        result["latency_b1"] = {"ms_per_frame": round(e1 / 50 * 1e3, 4), "hz": round(50 / e1, 1), "forwards": 50, "dtype": args.precision,
+                                "protocol": "50 forwards of one frame, compute_occ=True, device-synchronised on both sides (scripts/eval_SOccDPT.py:246-259 without its missing sync)"}
+        result["paper_hz"] = 47.0
+        result["x_paper_hz"] = round(50 / e1 / 47.0, 2)
+        result["x_paper_hz_note"] = "B = 1 latency protocol against the paper's B = 1 figure; the B = 8 throughput `value` is not divided by 47 any more"
+        for _ in range(5):
+            net(x)   # back to the benchmark's batch (workspace layout, clocks)
+
+    # ---- live error measurement against the library's own exact-f32 mode (product path only; the CPU oracle checks the same quantities in
+    # tests/test_mixed_gpu.py and tests/test_network_gpu.py), and the side modes: the bf16 figure BASELINE configs[1] names and plain fp16 ----
+    measured = {}
+    if side_ok:
+        xe = x[:2].contiguous()
+
+        def quantities(m):
+            inv, _ = m.network(xe)
+            e = m._engine(dev)
+            q = {k: e.workspace_tensor(2, k).double() for k in QUANTITIES if k != "inv"}
+            q["inv"] = inv.double()
+            return q
+
+        ref_net = build("f32")
+        ref = quantities(ref_net)
+        del ref_net
+
+        def errors(m):
+            q = quantities(m)
+            e = {k: float((q[k] - ref[k]).norm() / ref[k].norm()) for k in QUANTITIES}
+            pix = ((q["inv"] - ref["inv"]).abs() / ref["inv"].abs().clamp_min(1e-6)).flatten()
+            e["inv_per_pixel_p999"] = float(pix.kthvalue(max(1, int(0.999 * pix.numel()))).values)
+            m(x)   # restore the benchmark batch's workspace layout
+            return {k: float(f"{v:.3e}") for k, v in e.items()}
+
+        measured[args.precision] = errors(net)
+        for side in [p for p in ("mixed", "f16", "bf16") if p != args.precision]:
+            m = build(side)
+            err_side = errors(m)
+            for _ in range(args.warmup):
+                out = m(x)
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(args.steps):
+                out = m(x)
+            torch.cuda.synchronize()
+            es = time.perf_counter() - t3
+            es_eng = m._engine(dev)
+            es_eng.profile_enable(True)
+            for _ in range(prof_steps):
+                out = m(x)
+            torch.cuda.synchronize()
+            st_side = es_eng.profile_collect()
+            es_eng.profile_enable(False)
+            rs = igemm_roofline(st_side, prof_steps, side)
+            measured[side] = err_side
+            result[f"{side}_operands"] = {"value": round(B * args.steps / es, 2), "unit": "frames/s", "ms_per_step": round(es / args.steps * 1e3, 3),
+                                          "device_ms_per_step": round(sum(v["ms"] for v in st_side.values()) / prof_steps, 3),
+                                          "roofline": {k: rs[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")} if rs else None,
+                                          "errors_vs_f32_mode": err_side}
+            del m
     if rank == 0 and result is not None:
-        # Which arithmetic meets the north star's tolerance (1e-3 relative on depth maps / class logits, tests/test_network_gpu.py):
-        # stated as top-level fields, not in a note (VERDICT r1 #5e)
-        meets = {"bf16": False, "f16": args.model_type != "dpt_hybrid_384", "f32": True, "f16x3": True}   # tests/test_network_gpu.py, tests/test_hybrid_gpu.py
+        # Which arithmetic meets the north star's tolerance (1e-3 relative on depth maps / class logits), stated as top-level fields (VERDICT r1 #5e)
+        # and, since round 4, MEASURED in this run: relative L2 of every hooked feature map, path_1, inverse depth and the class logits against the
+        # library's exact-f32 mode on the same weights and frames (that mode is pinned to the fp32 CPU oracle at 1e-5 by tests/).  The bar for
+        # `value` is HALF the north star (margin: VERDICT r3 #1); dpt_hybrid_384, whose fp16 error is 5.7e-3, is held to the north star itself.
+        bar = 1e-3 if args.model_type == "dpt_hybrid_384" else 5e-4
+        static = {"bf16": False, "f16": args.model_type != "dpt_hybrid_384", "f32": True, "f16x3": True, "mixed": True}   # tests/test_network_gpu.py, test_hybrid_gpu.py, test_mixed_gpu.py
+        def worst(p):
+            return max(v for k, v in measured[p].items() if k in QUANTITIES) if p in measured else None
+        meets = {p: (worst(p) <= bar if p in measured else static[p]) for p in set(list(measured) + [args.precision])}
+        cands = {args.precision: result["value"]}
+        for p in ("mixed", "f16", "bf16"):
+            if f"{p}_operands" in result:
+                cands[p] = result[f"{p}_operands"]["value"]
+        ok = {p: v for p, v in cands.items() if meets.get(p)}
         result["tolerance"] = {"north_star": "1e-3 relative (depth, logits), voxel indices bit-exact at the projection boundary",
-                               "dtype_of_value": args.precision, "value_meets_tolerance": meets[args.precision],
-                               "dtype_meeting_tolerance_at_full_mfma_rate": "f16" if args.model_type != "dpt_hybrid_384" else None,
-                               "fastest_dtype_meeting_tolerance": "f16" if args.model_type != "dpt_hybrid_384" else "f16x3 (a third of the fp16 MFMA rate; --precision f16x3)",
-                               "value_meeting_tolerance": result["value"] if meets[args.precision] else
-                               (result.get("f16_operands", {}).get("value") if args.model_type != "dpt_hybrid_384" else None)}
+                               "bar_for_value": bar, "bar_note": "relative L2 of feat0-3, path_1, inverse depth, class logits vs the exact-f32 mode, measured in this run"
+                               if measured else "not measured in this run (side modes off): the static table of tests/ applies",
+                               "dtype_of_value": args.precision, "value_meets_tolerance": bool(meets[args.precision]),
+                               "worst_measured": {p: worst(p) for p in measured}, "measured": measured,
+                               "meets_north_star_1e-3": {p: (worst(p) <= 1e-3) for p in measured},
+                               "fastest_dtype_meeting_tolerance": (max(ok, key=ok.get) if ok else None),
+                               "value_meeting_tolerance": (max(ok.values()) if ok else None)}
 
     # ---- the same workload dealt to two concurrent sub-batches on internal streams (soccdpt_set_streams(2), eager): bit for bit the
     # result of running the two sub-batches one after the other (tools/multistream_split_check.py; equal to the whole-batch result too
     # unless the sub-batch size flips a split-K decision, which moves last bits), faster because the latency-bound launches of one half overlap the other half's.  Reported
     # beside `value`, which stays on one stream so that the per-kernel durations behind `roofline` are those of kernels running alone.
-    if rank == 0 and world == 1 and args.precision == "bf16" and not args.graph and args.streams == 1 and B >= 2 and args.with_two_streams and not args.headline_only:
-        with contextlib.redirect_stdout(io.StringIO()):
-            net2 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=2,
-                              model_type=args.model_type, precision=0)
-        net2.load_state_dict(sd, strict=False)
-        net2 = net2.eval().to(dev)
+    if single and B >= 2 and args.with_two_streams and not args.headline_only:
+        net2 = build(args.precision, streams=2)
         for _ in range(args.warmup):
             out = net2(x)
         torch.cuda.synchronize()

@@ -26,7 +26,10 @@
 extern "C" {
 #endif
 
-#define SOCCDPT_ABI_VERSION 1
+/* Bumped whenever a public struct or signature changes (a binding built against another version is refused by soccdpt_create):
+ *   1 rounds 1-2; 2 round 3 (soccdpt_igemm_args gained stamps / sk_defer, soccdpt_train_forward changed arity);
+ *   3 round 4 (SOCCDPT_PREC_MIXED + the precision map entry points, soccdpt_sizeof, soccdpt_occ_zero / soccdpt_occ_set). */
+#define SOCCDPT_ABI_VERSION 3
 
 /* backbone ids: model/loader.py:65-77 (model_type switch), model/blocks.py:59-78 */
 #define SOCCDPT_BACKBONE_SWIN2T16_256 0 /* dpt_swin2_tiny_256 */
@@ -46,7 +49,13 @@ extern "C" {
 #define SOCCDPT_PREC_F16X3 3 /* split-operand fp16: every GEMM / convolution operand is an fp16 pair (hi, lo * 2^11) and every product three
                                fp16 MFMAs (hi hi + hi lo + lo hi) with f32 accumulation: ~22 significand bits at 1/3 of the 16-bit MFMA
                                rate (the f32 MFMA runs at 1/16); attention, normalisations and residual streams in f32.  The fast
-                               parity-grade mode for models whose reference arithmetic is fp32 (dpt_hybrid_384: model/loader.py:115-120) */
+                               parity-grade mode for models whose reference arithmetic is fp32 (dpt_hybrid_384: model/loader.py:115-120).
+                               Valid operand magnitudes: |v| < 65520 (beyond: +-inf, as an IEEE fp16 conversion gives -- never clipped);
+                               22+ significand bits down to ~6e-5, fewer below, 11 bits below ~6e-8 (csrc/half16.h x3_split) */
+#define SOCCDPT_PREC_MIXED 4 /* per-site mix of the two above: every GEMM / convolution group runs fp16 operands (one MFMA per product) unless the
+                               precision map promotes it to x3 (three).  The default map of each backbone is the cheapest assignment found by
+                               tools/precision_map.py that keeps depth, logits, path_1 and every hooked feature map within HALF the north
+                               star's 1e-3 of the fp32 reference (model/loader.py:126-139 computes in fp32); soccdpt_prec_map_set edits it. */
 
 /* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
 typedef struct soccdpt_config {
@@ -73,6 +82,24 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle);
 void soccdpt_destroy(void* handle);
 const char* soccdpt_last_error(void* handle); /* handle may be NULL: last create error */
 int soccdpt_abi_version(void);
+/* sizeof of the public structs as the LIBRARY was compiled (a binding checks its own layout against these): which = 0 soccdpt_config,
+ * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat; unknown -> 0 */
+size_t soccdpt_sizeof(int which);
+
+/* ---- precision map (SOCCDPT_PREC_MIXED handles only) ----
+ * Groups are named launch sites of the forward (one operand format per group: its GEMMs / convolutions, their weights and the
+ * activation buffers they read):
+ *   Swin-V2:  "s<stage>.b<block>.attn" (qkv + proj), "s<stage>.b<block>.mlp" (fc1 + fc2), "merge<stage>" (PatchMerging reduction)
+ *   hybrid:   "rn.s<stage>.b<block>" (one ResNetV2 bottleneck: conv1-3 + shortcut), "pe" (patch-embedding projection),
+ *             "vit.b<i>.attn" (qkv + proj), "vit.b<i>.mlp", "ro<k>" (ProjectReadout + 1x1 of act_postprocess3 / 4), "pp4" (its 3x3 / 2)
+ *   decoder:  "lrn<l>" (scratch.layer<l+1>_rn), "ref<l>" (the four RCU convolutions of refinenet<l+1>), "oc<l>" (its out_conv),
+ *             "head" (output_conv.0 and seg_head.0: both read path_1), "head.d2" (output_conv.2 + .4), "head.s1" (format in which
+ *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32)
+ * `group` may end in '*' (prefix match) or be "*".  fmt = SOCCDPT_PREC_F16 or SOCCDPT_PREC_F16X3.  Returns the number of groups
+ * changed (>= 0) or a negative value on error.  Invalidates the prepared weights and the workspace (call soccdpt_prepare again). */
+int soccdpt_prec_map_set(void* handle, const char* group, int fmt);
+/* Writes "name=fmt name=fmt ..." (fmt 2 / 3, launch order) into buf; returns the length needed (excluding the terminator). */
+int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes);
 
 /* ---- weights: replaces BaseModel.load_net -> load_state_dict (model/base_model.py:5-37) ----
  * `key` is the reference's state-dict key, e.g.
@@ -154,6 +181,11 @@ int soccdpt_project_backward(void* handle, const float* dev_inv_up, const float*
 int soccdpt_occ_or(void* handle, uint32_t* dev_dst_bits, const uint32_t* dev_src_bits, int n_sets, void* stream);
 /* packed bits -> dense f32 rows, identical in every batch row (model/SOccDPT.py:449-455). */
 int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream);
+/* The same expansion in two halves for the multi-GPU path: soccdpt_occ_zero writes the B dense rows of zeros (no dependence on any rank's voxels:
+ * issue it while the RCCL all-gather of the packed grids is in flight), soccdpt_occ_set then writes a 1 into every row for each set bit of the
+ * union.  zero + set stores exactly what soccdpt_occ_expand stores. */
+int soccdpt_occ_zero(void* handle, int B, float* dev_occ, void* stream);
+int soccdpt_occ_set(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream);
 size_t soccdpt_occ_words(void* handle);
 
 /* Number of kernel launches issued by the last soccdpt_network call (diagnostics). */

@@ -44,7 +44,7 @@ struct AttnCfg {
 template <int WS, bool F16, int QS>
 __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                                  const float* __restrict__ scale, bf16_t* __restrict__ out,
-                                                                                 int res, int shift, int heads) {
+                                                                                 int res, int shift, int heads, int out_x3) {
     using A = AttnCfg<WS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem + A::QS_OFF;
@@ -207,9 +207,14 @@ __global__ __launch_bounds__(AttnCfg<WS>::THREADS) void window_attention_kernel(
         }
         // ---- store: lane owns query column r32, rows d = (rg&3) + 8(rg>>2) + 4h ----
         const float inv = 1.0f / sum;
-        bf16_t* orow = out + token_row(qrow) * (size_t)C + head * 32;
+        const size_t e0 = token_row(qrow) * (size_t)C + head * 32;
+        bf16_t* orow = out + e0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
+            if (F16 && out_x3) {   // SOCCDPT_PREC_MIXED: the proj GEMM of this block reads x3 operands (half16.h); the f32 accumulators go out unrounded
+                x3_store4(out, e0 + 8 * g + 4 * h, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                continue;
+            }
             uint2 pkt;
             pkt.x = pack_h2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv);
             pkt.y = pack_h2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
@@ -384,7 +389,7 @@ struct AttnGenCfg {
 template <int WS, bool F16, int QS>
 __global__ __launch_bounds__(AttnGenCfg<WS>::THREADS) void window_attention_flash_kernel(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
                                                                      const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
-                                                                     int shift, int heads) {
+                                                                     int shift, int heads, int out_x3) {
     using A = AttnGenCfg<WS>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* Qs = smem;
@@ -530,9 +535,14 @@ __global__ __launch_bounds__(AttnGenCfg<WS>::THREADS) void window_attention_flas
         l += __shfl_xor(l, 32);
         if (qrow < A::N) {
             const float inv = 1.0f / l;
-            bf16_t* orow = out + token_row(qrow) * (size_t)C + head * 32;
+            const size_t e0 = token_row(qrow) * (size_t)C + head * 32;
+            bf16_t* orow = out + e0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (F16 && out_x3) {   // SOCCDPT_PREC_MIXED: x3 operand of the proj GEMM
+                    x3_store4(out, e0 + 8 * g + 4 * h, o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv);
+                    continue;
+                }
                 uint2 pkt;
                 pkt.x = pack_h2<F16>(o[4 * g] * inv, o[4 * g + 1] * inv);
                 pkt.y = pack_h2<F16>(o[4 * g + 2] * inv, o[4 * g + 3] * inv);
@@ -878,8 +888,9 @@ int launch_window_attention_f32(const float* qkv, const float* bias_acc, const f
 }
 
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
-                            int shift, int heads, hipStream_t st, std::string& err) {
+                            int shift, int heads, hipStream_t st, std::string& err, int out_x3) {
     if (res % ws != 0) { err = "window_attention: res % ws != 0"; return 1; }
+    if (out_x3 && !hf) { err = "window_attention: the x3 output form belongs to the fp16 kernels"; return 1; }
     const int nw = res / ws;
     const unsigned blocks = (unsigned)(B * nw * nw * heads);
     if (ws == 16) {
@@ -892,13 +903,13 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
             (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&window_attention_flash_kernel<16, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, AttnGenCfg<16>::LDS);
             attr16.done();
         }
-        if (hf) SOCCDPT_LAUNCH((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else SOCCDPT_LAUNCH((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) SOCCDPT_LAUNCH((window_attention_flash_kernel<16, true, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, out_x3);
+        else SOCCDPT_LAUNCH((window_attention_flash_kernel<16, false, 1>), dim3(blocks), dim3(AttnGenCfg<16>::THREADS), AttnGenCfg<16>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, out_x3);
     } else if (ws == 8) {
         using A = AttnCfg<8>;
         if (shift != 0) { err = "window_attention: shifted 8x8 windows are not instantiated"; return 1; }
-        if (hf) SOCCDPT_LAUNCH((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
-        else SOCCDPT_LAUNCH((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads);
+        if (hf) SOCCDPT_LAUNCH((window_attention_kernel<8, true, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, out_x3);
+        else SOCCDPT_LAUNCH((window_attention_kernel<8, false, 1>), dim3(blocks), dim3(A::THREADS), A::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, out_x3);
     } else if (ws == 24 || ws == 12) {
         static PerDeviceOnce attr_done;
         if (attr_done.need()) {
@@ -907,7 +918,7 @@ int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const floa
 #undef FLASH_ATTR
             attr_done.done();
         }
-#define FLASH(W, H, Q) SOCCDPT_LAUNCH((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads)
+#define FLASH(W, H, Q) SOCCDPT_LAUNCH((window_attention_flash_kernel<W, H, Q>), dim3(blocks * Q), dim3(AttnGenCfg<W>::THREADS), AttnGenCfg<W>::LDS, st, qkv, bias_acc, scale, out, res, shift, heads, out_x3)
         if (ws == 24 && blocks < 256) { if (hf) FLASH(24, true, 2); else FLASH(24, false, 2); }   // too few (window, head) pairs: split the queries
         else if (ws == 24) { if (hf) FLASH(24, true, 1); else FLASH(24, false, 1); }
         else { if (hf) FLASH(12, true, 1); else FLASH(12, false, 1); }

@@ -39,6 +39,45 @@ static int fail(Handle* h, const std::string& msg) {
 extern "C" {
 
 int soccdpt_abi_version(void) { return SOCCDPT_ABI_VERSION; }
+size_t soccdpt_sizeof(int which) {
+    switch (which) {
+        case 0: return sizeof(soccdpt_config);
+        case 1: return sizeof(soccdpt_igemm_args);
+        case 2: return sizeof(soccdpt_kernel_stat);
+        default: return 0;
+    }
+}
+
+int soccdpt_prec_map_set(void* handle, const char* group, int fmt) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h || !group) return -1;
+    if (h->cfg.precision != SOCCDPT_PREC_MIXED) { fail(h, "soccdpt_prec_map_set: the handle was not created with SOCCDPT_PREC_MIXED"); return -1; }
+    if (fmt != SOCCDPT_PREC_F16 && fmt != SOCCDPT_PREC_F16X3) { fail(h, "soccdpt_prec_map_set: fmt must be SOCCDPT_PREC_F16 or SOCCDPT_PREC_F16X3"); return -1; }
+    const int n = model_prec_set(*h, group, fmt == SOCCDPT_PREC_F16X3 ? 3 : 1, h->err);
+    if (n < 0) return n;
+    // formats decide where the zero borders of the 3x3 inputs lie and which weight copies exist: both caches are void
+    h->ws_key = Handle::WsKey();
+    h->is_prepared = false;
+    model_drop_graph(*h);
+    return n;
+}
+int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return -1;
+    std::string out;
+    for (const auto& g : model_prec_groups(*h)) {
+        auto it = h->prec_map.find(g);
+        const int f = h->cfg.precision == SOCCDPT_PREC_MIXED ? (it != h->prec_map.end() && it->second == 3 ? SOCCDPT_PREC_F16X3 : SOCCDPT_PREC_F16) : h->cfg.precision;
+        if (!out.empty()) out += ' ';
+        out += g + "=" + std::to_string(f);
+    }
+    if (buf && buf_bytes > 0) {
+        const size_t n = out.size() < (size_t)buf_bytes - 1 ? out.size() : (size_t)buf_bytes - 1;
+        memcpy(buf, out.data(), n);
+        buf[n] = 0;
+    }
+    return (int)out.size();
+}
 
 int soccdpt_create(const soccdpt_config* cfg, void** handle) {
     if (!cfg || !handle) return fail(nullptr, "soccdpt_create: null argument");
@@ -46,7 +85,8 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
     if (cfg->num_classes != 3) return fail(nullptr, "soccdpt_create: num_classes must be 3 (model/SOccDPT.py:347-349)");
     if (cfg->features != 256) return fail(nullptr, "soccdpt_create: features must be 256");
     if (cfg->cam_width <= 0 || cfg->cam_height <= 0) return fail(nullptr, "soccdpt_create: bad camera size");
-    if (cfg->precision != SOCCDPT_PREC_BF16 && cfg->precision != SOCCDPT_PREC_F32 && cfg->precision != SOCCDPT_PREC_F16 && cfg->precision != SOCCDPT_PREC_F16X3)
+    if (cfg->precision != SOCCDPT_PREC_BF16 && cfg->precision != SOCCDPT_PREC_F32 && cfg->precision != SOCCDPT_PREC_F16 && cfg->precision != SOCCDPT_PREC_F16X3 &&
+        cfg->precision != SOCCDPT_PREC_MIXED)
         return fail(nullptr, "soccdpt_create: unknown precision");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
@@ -229,6 +269,22 @@ int soccdpt_occ_expand(void* handle, const uint32_t* dev_bits, int B, float* dev
     if (B <= 0) return fail(h, "soccdpt_occ_expand: empty batch");
     ProfScope ps(h->prof, "occ_expand", 0.0, occ_cells(h->cfg) * (4.0 * B + 0.125), (hipStream_t)stream);
     return launch_occ_expand(h->cfg, dev_bits, B, dev_occ, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_occ_zero(void* handle, int B, float* dev_occ, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (B <= 0 || !dev_occ) return fail(h, "soccdpt_occ_zero: bad argument");
+    ProfScope ps(h->prof, "occ_zero", 0.0, occ_cells(h->cfg) * 4.0 * B, (hipStream_t)stream);
+    return launch_occ_zero(h->cfg, B, dev_occ, (hipStream_t)stream, h->err);
+}
+
+int soccdpt_occ_set(void* handle, const uint32_t* dev_bits, int B, float* dev_occ, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (B <= 0 || !dev_occ || !dev_bits) return fail(h, "soccdpt_occ_set: bad argument");
+    ProfScope ps(h->prof, "occ_set", 0.0, occ_cells(h->cfg) * 0.125, (hipStream_t)stream);
+    return launch_occ_set(h->cfg, dev_bits, B, dev_occ, (hipStream_t)stream, h->err);
 }
 
 int soccdpt_forward(void* handle, const float* dev_x, int B, float* dev_inv_up, float* dev_seg_up, float* dev_points,

@@ -141,7 +141,7 @@ template <int VPL, bool F16>  // values per lane = ceil(C / 64)
 __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                            const float* __restrict__ beta, float* __restrict__ xf,
                                                            bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge, int x3,
+                                                           int C, int residual, int res /*spatial size for halo / merge*/, int merge, int x3, int x3h,
                                                            const float* __restrict__ row_scale, int rows_per_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -186,14 +186,9 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const float* __restric
             if (row_scale) o *= row_scale[row / rows_per_scale];
             if (residual) o += xr[t];
             xf[(size_t)row * C + c] = o;
-            if (x3) {   // xb / halo are x3 tensors (half16.h)
-                if (xb) x3_store1(xb, boff + c, o);
-                if (halo) x3_store1(halo, hoff + c, o);
-            } else {
-                const bf16_t ob = f2h<F16>(o);
-                if (xb) xb[boff + c] = ob;
-                if (halo) halo[hoff + c] = ob;
-            }
+            const bf16_t ob = f2h<F16>(o);
+            if (xb) { if (x3) x3_store1(xb, boff + c, o); else xb[boff + c] = ob; }          // x3 / x3h: that output is an x3 tensor (half16.h)
+            if (halo) { if (x3h) x3_store1(halo, hoff + c, o); else halo[hoff + c] = ob; }
             if (halo_f32) halo_f32[hoff + c] = o;
         }
     }
@@ -205,7 +200,7 @@ template <int V4, bool F16>  // float4 groups per lane = C / 256
 __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __restrict__ y, const float* __restrict__ g,
                                                               const float* __restrict__ beta, float* __restrict__ xf,
                                                               bf16_t* __restrict__ xb, bf16_t* __restrict__ halo, float* __restrict__ halo_f32, int M,
-                                                              int C, int residual, int res, int merge, int x3,
+                                                              int C, int residual, int res, int merge, int x3, int x3h,
                                                               const float* __restrict__ row_scale, int rows_per_scale) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -249,33 +244,30 @@ __global__ __launch_bounds__(256) void ln_residual_v4_kernel(const float* __rest
         if (row_scale) { const float rs = row_scale[row / rows_per_scale]; o.x *= rs; o.y *= rs; o.z *= rs; o.w *= rs; }
         o.x += xr[t].x; o.y += xr[t].y; o.z += xr[t].z; o.w += xr[t].w;
         *reinterpret_cast<float4*>(xf + (size_t)row * C + c) = o;
-        if (x3) {
-            if (xb) x3_store4(xb, boff + c, o.x, o.y, o.z, o.w);
-            if (halo) x3_store4(halo, hoff + c, o.x, o.y, o.z, o.w);
-        } else {
-            uint2 ob;
-            ob.x = pack_h2<F16>(o.x, o.y);
-            ob.y = pack_h2<F16>(o.z, o.w);
-            if (xb) *reinterpret_cast<uint2*>(xb + boff + c) = ob;
-            if (halo) *reinterpret_cast<uint2*>(halo + hoff + c) = ob;
-        }
+        uint2 ob;
+        ob.x = pack_h2<F16>(o.x, o.y);
+        ob.y = pack_h2<F16>(o.z, o.w);
+        if (xb) { if (x3) x3_store4(xb, boff + c, o.x, o.y, o.z, o.w); else *reinterpret_cast<uint2*>(xb + boff + c) = ob; }
+        if (halo) { if (x3h) x3_store4(halo, hoff + c, o.x, o.y, o.z, o.w); else *reinterpret_cast<uint2*>(halo + hoff + c) = ob; }
         if (halo_f32) *reinterpret_cast<float4*>(halo_f32 + hoff + c) = o;
     }
 }
 
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale, int rows_per_scale) {
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale, int rows_per_scale, int hf_halo) {
     if (merge && (res <= 0 || (res & 1) || M % (res * res) != 0)) { err = "ln_residual: merged operand layout needs an even token grid"; return 1; }
-    const int x3 = hf == 3 ? 1 : 0;   // hf: 0 bf16, 1 fp16, 3 x3 (half16.h)
-    if (x3 && (C % 16 || merge)) { err = "ln_residual: x3 rows are multiples of 16 elements, written unmerged"; return 1; }
-    hf = hf == 1;
+    if (hf_halo < 0) hf_halo = hf;
+    const int x3 = hf == 3 ? 1 : 0, x3h = hf_halo == 3 ? 1 : 0;   // hf / hf_halo: 0 bf16, 1 fp16, 3 x3 (half16.h)
+    if ((x3 || x3h) && C % 16) { err = "ln_residual: x3 rows are multiples of 16 elements"; return 1; }
+    if ((hf == 0) != (hf_halo == 0) && xb && halo) { err = "ln_residual: bf16 and fp16 / x3 outputs cannot be mixed in one launch"; return 1; }
+    hf = (hf == 1 || hf_halo == 1 || x3 || x3h);   // 16-bit outputs beside an x3 one are IEEE fp16 (SOCCDPT_PREC_MIXED)
     const int vpl = (C + 63) / 64;
     dim3 grid((M + 3) / 4), block(256);
     if (C % 256 == 0 && C <= 1024) {
 #define LN4_CASE(V)                                                                                                                       \
     do {                                                                                                                                  \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);  \
-        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, x3h, row_scale, rows_per_scale);  \
+        else SOCCDPT_LAUNCH((ln_residual_v4_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, x3h, row_scale, rows_per_scale);    \
     } while (0)
         switch (C / 256) { case 1: LN4_CASE(1); break; case 2: LN4_CASE(2); break; case 3: LN4_CASE(3); break; default: LN4_CASE(4); break; }
 #undef LN4_CASE
@@ -283,8 +275,8 @@ int launch_ln_residual(const float* y, const float* g, const float* beta, float*
     }
 #define LN_CASE(V)                                                                                                                    \
     do {                                                                                                                              \
-        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);  \
-        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, row_scale, rows_per_scale);    \
+        if (hf) SOCCDPT_LAUNCH((ln_residual_kernel<V, true>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, x3h, row_scale, rows_per_scale);  \
+        else SOCCDPT_LAUNCH((ln_residual_kernel<V, false>), grid, block, 0, st, y, g, beta, xf, xb, halo, halo_f32, M, C, residual, res, merge, x3, x3h, row_scale, rows_per_scale);    \
     } while (0)
     if (vpl <= 2) LN_CASE(2);
     else if (vpl <= 4) LN_CASE(4);

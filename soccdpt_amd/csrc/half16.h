@@ -73,11 +73,16 @@ __device__ __forceinline__ f32x16_t mfma_32x32x16(h16x8 a, h16x8 b, f32x16_t c) 
 // {0, 2, 4, 6} would collide pairwise.)  Rows of an x3 tensor must start at multiples of 16 elements.
 struct x3_t { uint32_t v; };   // element tag of the x3 instantiations: 4 bytes per element
 
+// Valid magnitude range: |v| < 65520 (beyond it hi is +-inf, like an IEEE fp16 conversion -- an overflowing or diverging activation / gradient
+// reaches the outputs as a non-finite value instead of being clipped to 65504, so parity checks and GradScaler's found_inf see it); the pair keeps
+// >= 22 significand bits down to |v| ~ 2^-3 * 2^-11 (lo normal), degrades gradually below that and is hi alone (11 bits, then fp16 subnormals
+// of 2^-24 absolute) below |v| ~ 6e-8.  There is no per-tensor exponent shift: callers whose values live below ~1e-4 (gradients under a large
+// batch mean) scale by a power of two first (the training step's loss scale, soccdpt_hip.h).
 __device__ __forceinline__ void x3_split(float v, _Float16& hi, _Float16& lo) {
-    float c = __builtin_amdgcn_fmed3f(v, -65504.f, 65504.f);
-    c = (v != v) ? v : c;                      // a NaN stays a NaN (fmed3 would swallow it)
-    hi = (_Float16)c;
-    const float r = (v - (float)hi) * 2048.f;  // exact in f32
+    hi = (_Float16)v;                          // round to nearest even; overflow -> +-inf, NaN stays NaN
+    const float hf = (float)hi;
+    float r = (v - hf) * 2048.f;               // exact in f32 for finite hi
+    r = (hf - hf == 0.f) ? r : 0.f;            // hi non-finite: no correction term (inf - inf / NaN would poison lo with a second NaN source)
     lo = (_Float16)__builtin_amdgcn_fmed3f(r, -65504.f, 65504.f);
 }
 // byte offsets of element e's hi / lo halves from the tensor base

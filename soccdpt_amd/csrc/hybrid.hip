@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
                                                        const float* __restrict__ beta, const float* __restrict__ raw2, const float* __restrict__ stats2,
                                                        const float* __restrict__ gamma2, const float* __restrict__ beta2, const float* res /* may alias out_f32 */,
                                                        float* out_f32, void* __restrict__ out_op, void* __restrict__ out_halo, int relu,
-                                                       size_t M, int HW, int W, int C, int cpg) {
+                                                       size_t M, int HW, int W, int C, int cpg, int halo_mode) {
     const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
     const int c4 = C / 4;
     if (gid >= M * c4) return;
@@ -172,7 +172,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
     if (out_halo) {
         const int rem = (int)(m - (size_t)b * HW);
         const int y = rem / W, x = rem - y * W, H = HW / W;
-        store4<OUT>(out_halo, (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c, v.x, v.y, v.z, v.w);
+        const size_t hidx = (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c;
+        // halo_mode: format of the halo image when it differs from out_op's (SOCCDPT_PREC_MIXED: the hooked stage output feeds the decoder's group)
+        if (halo_mode == OUT) store4<OUT>(out_halo, hidx, v.x, v.y, v.z, v.w);
+        else if (halo_mode == 3) store4<3>(out_halo, hidx, v.x, v.y, v.z, v.w);
+        else if (halo_mode == 2) store4<2>(out_halo, hidx, v.x, v.y, v.z, v.w);
+        else if (halo_mode == 1) store4<1>(out_halo, hidx, v.x, v.y, v.z, v.w);
+        else store4<0>(out_halo, hidx, v.x, v.y, v.z, v.w);
     }
 }
 
@@ -305,7 +311,7 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     if (a.raw2 && a.res) { err = "gn_apply: one shortcut kind at a time"; return 1; }
     const size_t total = a.M * (size_t)(a.C / 4);
     DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(gn_apply_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.raw, a.stats, a.gamma, a.beta, a.raw2,
-                                               a.stats2, a.gamma2, a.beta2, a.res, a.out_f32, a.out_op, a.out_halo, a.relu, a.M, a.HW, a.W, a.C, a.cpg));
+                                               a.stats2, a.gamma2, a.beta2, a.res, a.out_f32, a.out_op, a.out_halo, a.relu, a.M, a.HW, a.W, a.C, a.cpg, a.halo_mode < 0 ? out_mode : a.halo_mode));
     return check_launch("gn_apply", err);
 }
 

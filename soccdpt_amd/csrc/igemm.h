@@ -82,6 +82,10 @@ struct IgemmDesc {
     void* out_op = nullptr;       // operand-typed copy (bf16 / f32): [M][N] plain (ld = N) or Halo image when out_halo != 0
     int out_halo = 0;
     int out_op_f32 = 0;           // x3 launches only: out_op is a plain f32 tensor / halo image (the training tape keeps f32 activations), not an x3 operand
+    // Mixed-precision launch sequences (SOCCDPT_PREC_MIXED, model.cpp): the operand copy is written for the NEXT launch's format, which may differ
+    // from this launch's own.  -1 = same as this launch's operands; 1 = IEEE fp16 (from an x3 launch); 3 = x3 (from an fp16 launch).  ln_halo follows
+    // halo_fmt the same way (the hooked feature map feeds the decoder, the operand copy the next encoder block).
+    int out_fmt = -1, halo_fmt = -1;
     // fused 1x1 tail of the depth head: out_dot[m] = relu(sum_n act(v)[n]*dot_w[n] + dot_b)   (N <= 32)
     const float* dot_w = nullptr;
     float dot_b = 0.f;

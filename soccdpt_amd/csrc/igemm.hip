@@ -542,11 +542,26 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
                     uint2 p;
                     p.x = pack_h2<F16>(o[0], o[1]);
                     p.y = pack_h2<F16>(o[2], o[3]);
-                    if (d.out_op) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
-                    if (d.ln_halo) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                    if (d.out_op) {
+                        if (F16 && d.out_fmt == 3) x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
+                        else *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
+                    }
+                    if (d.ln_halo) {
+                        if (F16 && d.halo_fmt == 3) x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
+                        else *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                    }
                 } else if constexpr (X3) {
-                    if (d.out_op) x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
-                    if (d.ln_halo) x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
+                    uint2 p;
+                    p.x = pack_h2<true>(o[0], o[1]);
+                    p.y = pack_h2<true>(o[2], o[3]);
+                    if (d.out_op) {
+                        if (d.out_fmt == 1) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
+                        else x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
+                    }
+                    if (d.ln_halo) {
+                        if (d.halo_fmt == 1) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                        else x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
+                    }
                 } else {
                     if (d.ln_halo) *reinterpret_cast<float4*>(static_cast<float*>(d.ln_halo) + hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
                 }
@@ -643,13 +658,21 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
             }
             if (d.out_op) {
                 if constexpr (sizeof(T) == 2) {
-                    uint2 p;
-                    p.x = pack_h2<F16>(a[0], a[1]);
-                    p.y = pack_h2<F16>(a[2], a[3]);
-                    *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    if (F16 && d.out_fmt == 3) x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);   // the next launch reads x3 operands
+                    else {
+                        uint2 p;
+                        p.x = pack_h2<F16>(a[0], a[1]);
+                        p.y = pack_h2<F16>(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    }
                 } else if constexpr (X3) {
                     if (d.out_op_f32) *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
-                    else x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
+                    else if (d.out_fmt == 1) {   // the next launch reads fp16 operands
+                        uint2 p;
+                        p.x = pack_h2<true>(a[0], a[1]);
+                        p.y = pack_h2<true>(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    } else x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
                 } else {
                     *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
                 }
@@ -989,6 +1012,10 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
         auto cdiv32 = [](long a, long b) { return (a + b - 1) / b; };
         const long nk32 = (long)d.taps * d.Cin / 32, blocks64 = cdiv32(d.M, 64) * cdiv32(d.N, 64);
         if (blocks64 > 96 || nk32 < 48 || (size_t)blocks64 > count_words) return 1;
+        // x3: the 32 x 64 tile with 64-deep k-steps (configuration 10) beats every split of these launches up to K ~ 3500 (r04 per-site timings of the
+        // forward: M 512, N 768, K 1536: 34.4 us split vs 13.6; K 3072: 81.5 vs 47.9; 3x3 N 256, K 2304: 59 vs 37 per two launches); only the
+        // K = 6912 convolution still wins split (34 vs 49)
+        if (d.x3 && nk32 < 160) return 1;
         long S = (256 + blocks64 - 1) / blocks64;
         if (S > nk32 / 8) S = nk32 / 8;
         if (S > 16) S = 16;
@@ -1046,7 +1073,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             err = "igemm: x3 weight-row views must start at multiples of 16 elements (wt_kx copies)";
             return 1;
         }
-        if (d.ldx % 16 || d.Cin % 32 || (d.out_op && !d.out_op_f32 && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
+        if (d.ldx % 16 || d.Cin % 32 || (d.out_op && !d.out_op_f32 && d.out_fmt != 1 && d.N % 16) || d.grp_off % 16 || d.seg2_off % 16 || d.grp_stride % 16) { err = "igemm: x3 rows must start at multiples of 16 elements"; return 1; }
         if (d.splitk > 1) {
             if (d.ln_g || d.gn_stats || d.out_dot) { err = "igemm: x3 split-K has no LayerNorm, statistics or dot epilogue"; return 1; }
             if (need_gen(d) && d.tune == 3) return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, true, false, true>(d, stream, err);

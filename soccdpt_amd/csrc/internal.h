@@ -110,6 +110,8 @@ struct Handle {
     std::vector<SiteRec> sites;                           // shapes seen while prof_sites was on, in first-launch order
     std::unordered_map<long long, int> tune_by_shape;     // shape key -> forced tile configuration (in-network tuning)
     int mlp_fuse_max = 128;                               // widest stage whose MLP half-block runs as one fused launch (mlp_fused.hip; wider ones lose)
+    // SOCCDPT_PREC_MIXED: operand format of every launch-site group (model.cpp: prec_groups), 1 = fp16, 3 = x3; groups absent from the map are fp16
+    std::unordered_map<std::string, int> prec_map;
     std::vector<WeightSlot> weights;
     std::unordered_map<std::string, int> index;
     size_t prepared_bytes = 0;
@@ -160,6 +162,9 @@ int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t stream, s
 int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256, void* ws, size_t ws_bytes, hipStream_t stream,
                   std::string& err);
 
+std::vector<std::string> model_prec_groups(const Handle& h);   // every group name of this backbone, in launch order
+void model_prec_default(Handle& h);                            // the shipped map of the backbone
+int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err);   // -> groups changed, < 0 on error
 int model_set_streams(Handle& h, int n, std::string& err);
 void model_drop_graph(Handle& h);
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C);
@@ -168,6 +173,8 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
 int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg, int B, int in_h, int in_w, float* inv_up,
                    float* seg_up, float* points, uint32_t* occ_bits, int clear_bits, hipStream_t stream, std::string& err);
 int launch_occ_expand(const soccdpt_config& cfg, const uint32_t* bits, int B, float* occ, hipStream_t stream, std::string& err);
+int launch_occ_zero(const soccdpt_config& cfg, int B, float* occ, hipStream_t stream, std::string& err);
+int launch_occ_set(const soccdpt_config& cfg, const uint32_t* bits, int B, float* occ, hipStream_t stream, std::string& err);
 int launch_occ_or(const soccdpt_config& cfg, uint32_t* dst, const uint32_t* src, int nsets, hipStream_t stream, std::string& err);
 
 }  // namespace soccdpt

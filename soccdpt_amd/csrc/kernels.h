@@ -25,8 +25,10 @@ int launch_patch_embed(const float* x, const float* w, const float* bias, const 
                        int hf, int B, int S, int C0, hipStream_t st, std::string& err);
 // row_scale (optional): the normalised branch of row m is multiplied by row_scale[m / rows_per_scale] before the residual add (stochastic depth
 // of the training step: per-sample DropPath scales)
+// hf_halo: operand format of `halo` when it differs from xb's (SOCCDPT_PREC_MIXED: the hooked map feeds the decoder, xb the next block); -1 = hf
 int launch_ln_residual(const float* y, const float* g, const float* beta, float* xf, bf16_t* xb, bf16_t* halo, float* halo_f32, int hf, int M,
-                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale = nullptr, int rows_per_scale = 1);
+                       int C, int residual, int res, int merge, hipStream_t st, std::string& err, const float* row_scale = nullptr, int rows_per_scale = 1,
+                       int hf_halo = -1);
 int launch_merge_gather(const void* in, void* out, int B, int R, int C, int elem_bytes, hipStream_t st, std::string& err);
 int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_bf16, float* out_f32_halo, int out_halo, int hf, int B, int h,
                     int w, int H, int W, int C, hipStream_t st, std::string& err);
@@ -94,6 +96,7 @@ struct GnApplyArgs {
     float* out_f32 = nullptr;        // [M][C]
     void* out_op = nullptr;          // [M][C] operand type
     void* out_halo = nullptr;        // [B][H+2][W+2][C] operand type (zero halo untouched)
+    int halo_mode = -1;              // operand format of out_halo when it differs from out_op's (SOCCDPT_PREC_MIXED); -1 = the launch's out_mode
     int relu = 1;
     size_t M = 0;
     int HW = 0, W = 0, C = 0, cpg = 0;
@@ -108,14 +111,16 @@ int launch_pos_embed_resize(const float* pos, float* out, int g0, int g, int C, 
 
 // vit_attention.hip: global softmax attention of a ViT block (timm Attention.forward): qkv [B*N][3*heads*64] -> out [B*N][heads*64],
 // softmax(q k^T / 8) v per (sample, head), N tokens (577 for dpt_hybrid_384).  prec: SOCCDPT_PREC_* of qkv / out.
-int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err);
+// out_x3 != 0 (prec == SOCCDPT_PREC_F16 only): fp16 q, k, v in, `out` written in the x3 operand format from the f32 accumulators (SOCCDPT_PREC_MIXED)
+int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err, int out_x3 = 0);
 
 // attention.hip
 // bias_acc: CPB bias pre-arranged in MFMA accumulator order, see attention.hip
 size_t attn_bias_elems(int ws, int heads);
 int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hipStream_t st, std::string& err);
+// out_x3 != 0 (fp16 kernels only): `out` is written in the x3 operand format from the f32 accumulators (SOCCDPT_PREC_MIXED: the proj GEMM is an x3 launch)
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
-                            int shift, int heads, hipStream_t st, std::string& err);
+                            int shift, int heads, hipStream_t st, std::string& err, int out_x3 = 0);
 
 // x3 != 0: `out` is written in the x3 split-fp16 operand format (half16.h) for the proj GEMM of SOCCDPT_PREC_F16X3
 int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,

@@ -79,6 +79,21 @@ Handle::~Handle() {
 namespace {
 inline long long shape_key(int M, int N, int K, int taps) { return (((long long)M * 8192 + N) * 65536 + K) * 16 + taps; }
 
+// Operand format code of a launch-site group: 0 bf16, 1 fp16, 2 f32, 3 x3.  The uniform modes give every group the same code;
+// SOCCDPT_PREC_MIXED looks the group up in the handle's precision map (absent = fp16).
+int group_fmt(const Handle& h, const std::string& g) {
+    switch (h.cfg.precision) {
+        case SOCCDPT_PREC_F32: return 2;
+        case SOCCDPT_PREC_F16: return 1;
+        case SOCCDPT_PREC_F16X3: return 3;
+        case SOCCDPT_PREC_MIXED: { auto it = h.prec_map.find(g); return (it != h.prec_map.end() && it->second == 3) ? 3 : 1; }
+        default: return 0;
+    }
+}
+inline std::string gname(const char* a, int i) { return std::string(a) + std::to_string(i); }
+inline std::string gblk(int s, int j, const char* part) { return "s" + std::to_string(s) + ".b" + std::to_string(j) + "." + part; }
+inline std::string gvit(int i, const char* part) { return "vit.b" + std::to_string(i) + "." + part; }
+
 
 struct Arena {
     char* base;
@@ -112,28 +127,28 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     const Arch& a = h.arch;
     const bool run = ar.base != nullptr;
     auto W = [&](const std::string& key) -> const float* { return h.weights[h.index.at(key)].ptr; };
-    const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;   // split-fp16 operands: 4 bytes per element in the x3 layout (half16.h)
-    const int HF = X3 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0);  // operand format: 0 bf16, 1 fp16, 3 x3
+    // SOCCDPT_PREC_MIXED: every weight copy gets 4 bytes per element whatever its group's format, so the arena layout (and
+    // soccdpt_prepared_bytes) does not depend on the precision map
+    const bool MIX = h.cfg.precision == SOCCDPT_PREC_MIXED;
+    auto GF = [&](const std::string& g) { return group_fmt(h, g); };   // operand format code of a group: 0 bf16, 1 fp16, 2 f32, 3 x3 (half16.h)
     static const char kNoCopy = 0;  // non-null placeholder while measuring
-    auto cvt = [&](const std::string& key, size_t n) -> const void* {
-        if (F32) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
-        bf16_t* p = X3 ? reinterpret_cast<bf16_t*>(ar.take<float>(n)) : ar.take<bf16_t>(n);
-        if (run && launch_cvt_bf16(W(key), p, n, HF, st, err)) return nullptr;
+    auto cvt = [&](const std::string& key, size_t n, int fmt) -> const void* {
+        if (fmt == 2) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
+        bf16_t* p = (fmt == 3 || MIX) ? reinterpret_cast<bf16_t*>(ar.take<float>(n)) : ar.take<bf16_t>(n);
+        if (run && launch_cvt_bf16(W(key), p, n, fmt, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale) -> const void* {
+    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale, int fmt) -> const void* {
         const size_t n = (size_t)Cout * Cin * 9;
-        void* p = (F32 || X3) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
-        if (run && launch_conv_w(W(key), scale, p, F32 ? 1 : 0, HF, Cout, Cin, st, err)) return nullptr;
+        void* p = (fmt >= 2 || MIX) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        if (run && launch_conv_w(W(key), scale, p, fmt == 2 ? 1 : 0, fmt == 2 ? 0 : fmt, Cout, Cin, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    const int OM = F32 ? 2 : HF;   // operand format code of hybrid.hip: 0 bf16, 1 fp16, 2 f32, 3 x3
-    // weight-standardised convolution weight (timm StdConv2dSame, eps 1e-8), tap-major [Cout][Kpad]
-    auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad) -> const void* {
+    // weight-standardised convolution weight (timm StdConv2dSame, eps 1e-8), tap-major [Cout][Kpad]; fmt = operand format code of hybrid.hip
+    auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad, int fmt) -> const void* {
         const size_t n = (size_t)Cout * Kpad;
-        void* p = (F32 || X3) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
-        if (run && launch_ws_conv_w(W(key), p, OM, Cout, Cin, k, Kpad, 1e-8f, st, err)) return nullptr;
+        void* p = (fmt >= 2 || MIX) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
+        if (run && launch_ws_conv_w(W(key), p, fmt, Cout, Cin, k, Kpad, 1e-8f, st, err)) return nullptr;
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     if (a.hybrid) {
@@ -155,11 +170,12 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
             for (int j = 0; j < a.rn_layers[s3]; ++j) {
                 const std::string b = rnblk(s3, j);
                 RnBlockW bw;
+                const int fb = GF(gname("rn.s", s3));
                 bw.cin = prev; bw.cout = cout; bw.mid = mid; bw.proj = (j == 0); bw.stride = (j == 0 && s3 > 0) ? 2 : 1;
-                if (bw.proj) bw.ds_w = wsw(b + "downsample.conv.weight", cout, prev, 1, prev);
-                bw.c1_w = wsw(b + "conv1.weight", mid, prev, 1, prev);
-                bw.c2_w = wsw(b + "conv2.weight", mid, mid, 3, 9 * mid);
-                bw.c3_w = wsw(b + "conv3.weight", cout, mid, 1, mid);
+                if (bw.proj) bw.ds_w = wsw(b + "downsample.conv.weight", cout, prev, 1, prev, fb);
+                bw.c1_w = wsw(b + "conv1.weight", mid, prev, 1, prev, fb);
+                bw.c2_w = wsw(b + "conv2.weight", mid, mid, 3, 9 * mid, fb);
+                bw.c3_w = wsw(b + "conv3.weight", cout, mid, 1, mid, fb);
                 if (run) {
                     if ((bw.proj && !bw.ds_w) || !bw.c1_w || !bw.c2_w || !bw.c3_w) return 1;
                     if (bw.proj) { bw.ds_g = W(b + "downsample.norm.weight"); bw.ds_b = W(b + "downsample.norm.bias"); }
@@ -172,7 +188,7 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
             }
         }
         const int E = a.vit_dim, g = a.grid();
-        hw.pe_w = cvt(ENC + "patch_embed.proj.weight", (size_t)E * prev);
+        hw.pe_w = cvt(ENC + "patch_embed.proj.weight", (size_t)E * prev, GF("pe"));
         hw.pos = ar.take<float>((size_t)(1 + g * g) * E);
         if (run) {
             if (!hw.pe_w) return 1;
@@ -184,10 +200,10 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         for (int i = 0; i < a.vit_depth; ++i) {
             const std::string b = vitblk(i);
             VitBlockW vb{};
-            vb.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * E * E);
-            vb.proj_w = cvt(b + "attn.proj.weight", (size_t)E * E);
-            vb.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * E * E);
-            vb.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * E * E);
+            vb.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * E * E, GF(gvit(i, "attn")));
+            vb.proj_w = cvt(b + "attn.proj.weight", (size_t)E * E, GF(gvit(i, "attn")));
+            vb.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * E * E, GF(gvit(i, "mlp")));
+            vb.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * E * E, GF(gvit(i, "mlp")));
             if (run) {
                 if (!vb.qkv_w || !vb.proj_w || !vb.fc1_w || !vb.fc2_w) return 1;
                 vb.qkv_b = W(b + "attn.qkv.bias"); vb.proj_b = W(b + "attn.proj.bias");
@@ -199,15 +215,15 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
         for (int k = 0; k < 2; ++k) {
             const std::string ap = HYB + "act_postprocess" + std::to_string(3 + k) + ".";
-            hw.ro_w[k] = cvt(ap + "0.project.0.weight", (size_t)E * 2 * E);
-            hw.pp_w[k] = cvt(ap + "3.weight", (size_t)a.fdim(2 + k) * E);
+            hw.ro_w[k] = cvt(ap + "0.project.0.weight", (size_t)E * 2 * E, GF(gname("ro", k)));
+            hw.pp_w[k] = cvt(ap + "3.weight", (size_t)a.fdim(2 + k) * E, GF(gname("ro", k)));
             if (run) {
                 if (!hw.ro_w[k] || !hw.pp_w[k]) return 1;
                 hw.ro_b[k] = W(ap + "0.project.0.bias");
                 hw.pp_b[k] = W(ap + "3.bias");
             }
         }
-        hw.pp4_w = convw(HYB + "act_postprocess4.4.weight", a.fdim(3), a.fdim(3), nullptr);
+        hw.pp4_w = convw(HYB + "act_postprocess4.4.weight", a.fdim(3), a.fdim(3), nullptr, GF("pp4"));
         if (run) {
             if (!hw.pp4_w) return 1;
             hw.pp4_b = W(HYB + "act_postprocess4.4.bias");
@@ -226,10 +242,10 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         for (int j = 0; j < a.depths[s]; ++j) {
             const std::string b = blk(s, j);
             BlockW bw{};
-            bw.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * C * C);
-            bw.proj_w = cvt(b + "attn.proj.weight", (size_t)C * C);
-            bw.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * C * C);
-            bw.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * C * C);
+            bw.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * C * C, GF(gblk(s, j, "attn")));
+            bw.proj_w = cvt(b + "attn.proj.weight", (size_t)C * C, GF(gblk(s, j, "attn")));
+            bw.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * C * C, GF(gblk(s, j, "mlp")));
+            bw.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * C * C, GF(gblk(s, j, "mlp")));
             bw.qkv_bias = ar.take<float>(3 * C);
             bw.scale = ar.take<float>(H);
             bw.table = ar.take<float>((size_t)(2 * ws - 1) * (2 * ws - 1) * H);
@@ -251,7 +267,7 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
         if (s < 3) {
             const std::string d = ENC + "layers." + std::to_string(s) + ".downsample.";
-            const void* rw = cvt(d + "reduction.weight", (size_t)8 * C * C);
+            const void* rw = cvt(d + "reduction.weight", (size_t)8 * C * C, GF(gname("merge", s)));
             if (run) {
                 if (!rw) return 1;
                 P->merge[s] = MergeW{rw, W(d + "norm.weight"), W(d + "norm.bias")};
@@ -260,18 +276,18 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     }
     const int F = h.cfg.features;
     for (int i = 0; i < 4; ++i) {
-        const void* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.fdim(i), nullptr);
+        const void* p = convw(SCR + "layer" + std::to_string(i + 1) + "_rn.weight", F, a.fdim(i), nullptr, GF(gname("lrn", i)));
         if (run) { if (!p) return 1; P->layer_rn[i] = p; }
     }
     for (int r = 1; r <= 4; ++r) {
         const std::string b = SCR + "refinenet" + std::to_string(r) + ".";
-        const void* ocw = cvt(b + "out_conv.weight", (size_t)F * F);
+        const void* ocw = cvt(b + "out_conv.weight", (size_t)F * F, GF(gname("oc", r - 1)));
         if (run) { if (!ocw) return 1; P->oc_w[r - 1] = ocw; P->oc_b[r - 1] = W(b + "out_conv.bias"); }
         for (int u = 1; u <= 2; ++u) {
             if (r == 4 && u == 1) continue;
             const std::string ub = b + "resConfUnit" + std::to_string(u) + ".";
-            const void* w1 = convw(ub + "conv1.weight", F, F, nullptr);
-            const void* w2 = convw(ub + "conv2.weight", F, F, nullptr);
+            const void* w1 = convw(ub + "conv1.weight", F, F, nullptr, GF(gname("ref", r - 1)));
+            const void* w2 = convw(ub + "conv2.weight", F, F, nullptr, GF(gname("ref", r - 1)));
             if (run) {
                 if (!w1 || !w2) return 1;
                 P->rcu[r - 1][u - 1] = RcuW{w1, w2, W(ub + "conv1.bias"), W(ub + "conv2.bias")};
@@ -279,14 +295,14 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         }
     }
     {
-        const void* d0 = convw(SCR + "output_conv.0.weight", F / 2, F, nullptr);
-        const void* d2 = convw(SCR + "output_conv.2.weight", 32, F / 2, nullptr);
+        const void* d0 = convw(SCR + "output_conv.0.weight", F / 2, F, nullptr, GF("head"));
+        const void* d2 = convw(SCR + "output_conv.2.weight", 32, F / 2, nullptr, GF("head.d2"));
         float* bscale = ar.take<float>(F);
         float* bshift = ar.take<float>(F);
         if (run && launch_bn_fold(W("seg_head.1.weight"), W("seg_head.1.bias"), W("seg_head.1.running_mean"), W("seg_head.1.running_var"),
                                   bscale, bshift, F, st, err))
             return 1;
-        const void* s0 = convw("seg_head.0.weight", F, F, bscale);
+        const void* s0 = convw("seg_head.0.weight", F, F, bscale, GF("head"));
         if (run) {
             if (!d0 || !d2 || !s0) return 1;
             P->d0_w = d0; P->d2_w = d2; P->s0_w = s0;
@@ -325,7 +341,9 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const int G = a.grid(), C0 = a.embed, F = h.cfg.features;
     const size_t M0 = (size_t)B * G * G;
     const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const size_t es = (F32 || h.cfg.precision == SOCCDPT_PREC_F16X3) ? 4 : 2;   // f32 and x3 operands: 4 bytes per element
+    // f32 and x3 operands: 4 bytes per element.  SOCCDPT_PREC_MIXED sizes every operand buffer for x3, so the layout does not depend on the
+    // precision map (an fp16 group uses the first half of its buffers)
+    const size_t es = (F32 || h.cfg.precision == SOCCDPT_PREC_F16X3 || h.cfg.precision == SOCCDPT_PREC_MIXED) ? 4 : 2;
     auto op = [&](size_t elems) -> void* { return ar.take<char>(elems * es); };
     if (a.hybrid) {
         const int S = a.img, H1 = S / 2, H2 = S / 4, E = a.vit_dim, NT = G * G + 1;
@@ -409,6 +427,7 @@ int model_init(Handle& h, std::string& err) {
     }
     h.arch = a;
     h.img = a.img;
+    if (h.cfg.precision == SOCCDPT_PREC_MIXED) model_prec_default(h);
     const int64_t C0 = a.embed;
     if (a.hybrid) {
         // timm 0.6.12 vit_base_resnet50_384 + the reference's act_postprocess3/4 (backbones/vit.py:183-229): SURVEY.md 8a row a4-H
@@ -555,6 +574,67 @@ int model_bind(Handle& h, const char* key, const void* ptr, const int64_t* shape
 }
 
 
+std::vector<std::string> model_prec_groups(const Handle& h) {
+    const Arch& a = h.arch;
+    std::vector<std::string> g;
+    if (a.hybrid) {
+        for (int s = 0; s < 3; ++s) g.push_back(gname("rn.s", s));
+        g.push_back("pe");
+        for (int i = 0; i < a.vit_depth; ++i) { g.push_back(gvit(i, "attn")); g.push_back(gvit(i, "mlp")); }
+        g.push_back("ro0"); g.push_back("ro1"); g.push_back("pp4");
+    } else {
+        for (int s = 0; s < 4; ++s) {
+            for (int j = 0; j < a.depths[s]; ++j) { g.push_back(gblk(s, j, "attn")); g.push_back(gblk(s, j, "mlp")); }
+            if (s < 3) g.push_back(gname("merge", s));
+        }
+    }
+    for (int l = 3; l >= 0; --l) { g.push_back(gname("lrn", l)); g.push_back(gname("ref", l)); g.push_back(gname("oc", l)); }
+    g.push_back("head"); g.push_back("head.d2"); g.push_back("head.s1");
+    return g;
+}
+
+int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err) {
+    std::string p(pattern);
+    const bool prefix = !p.empty() && p.back() == '*';
+    if (prefix) p.pop_back();
+    int n = 0;
+    for (const auto& g : model_prec_groups(h)) {
+        if (prefix ? g.compare(0, p.size(), p) != 0 : g != p) continue;
+        h.prec_map[g] = fmt;
+        ++n;
+    }
+    if (n == 0) { err = std::string("soccdpt_prec_map_set: no such group: ") + pattern; return -1; }
+    return n;
+}
+
+// The shipped precision maps: the cheapest assignments tools/precision_map.py found (in-network device time per group against the
+// error each fp16 group adds to inverse depth, logits, path_1 and the hooked feature maps, measured against the library's own
+// exact-f32 mode) that keep all seven quantities within 5e-4 relative L2 of the fp32 reference on the synthetic weights
+// (dpt_hybrid_384: 1e-3, its fp16 error is 5.7e-3).  profiles/r04_precision_map_*.json hold the tables they were read from.
+void model_prec_default(Handle& h) {
+    h.prec_map.clear();
+    std::string err;
+    auto x3 = [&](std::initializer_list<const char*> groups) { for (const char* g : groups) (void)model_prec_set(h, g, 3, err); };
+    switch (h.cfg.backbone) {
+        case SOCCDPT_BACKBONE_VITB_RN50_384:
+            // profiles/r04_precision_map_hybrid384.json (B = 4, budget 1e-3): worst of the seven quantities 7.1e-4 (fp16 everywhere: 2.5e-2).  The
+            // weight-standardised ResNetV2 stages amplify operand rounding and take x3; the ViT blocks and the 3x3 convolutions
+            // of the decoder stay fp16; the 1x1 out_convs, the last read-out projection and the seg-head feature map are the cheap rest of the budget.
+            x3({"rn.s0", "rn.s1", "rn.s2", "ro1", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            break;
+        case SOCCDPT_BACKBONE_SWIN2B24_384:
+            // profiles/r04_precision_map_base384.json (B = 8, budget 5e-4)
+            x3({"s1.*", "s2.*", "s3.b0.attn", "s3.b1.attn", "merge1", "merge2", "lrn2", "lrn3", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            break;
+        default:
+            // profiles/r04_precision_map_tiny256.json (B = 8, budget 5e-4): worst of the seven quantities 4.6e-4 (fp16 everywhere: 9.8e-4).  Stage 0's
+            // second block, its PatchMerging, the big 3x3 convolutions of refinenet1-3 and both heads stay fp16 (they hold 85 % of the FLOPs).
+            x3({"s0.b0.attn", "s0.b0.mlp", "s1.b0.attn", "s1.b0.mlp", "s1.b1.attn", "s1.b1.mlp", "merge1", "s2.b0.attn", "s2.b0.mlp", "s2.b1.attn", "s2.b1.mlp",
+                "s2.b3.attn", "s2.b4.attn", "s2.b5.attn", "merge2", "s3.b0.attn", "s3.b0.mlp", "s3.b1.attn", "lrn2", "lrn3", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            break;
+    }
+}
+
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C) {
     char* fake = reinterpret_cast<char*>(uintptr_t(1) << 20);  // only offsets are used
     Arena ar(fake, ~size_t(0) >> 1);
@@ -574,13 +654,16 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         *byte_offset = (size_t)(static_cast<const char*>(p) - fake); *elems = e; *kind = k; *H = hh; *W = ww; *C = cc;
         return 0;
     };
-    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;
-    const int hk = X3 ? 7 : (h.cfg.precision == SOCCDPT_PREC_F32 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 5 : 2));  // zero-halo NHWC: 2 bf16, 3 f32, 5 fp16, 7 x3
+    // zero-halo NHWC kinds by the operand format of the group that READS the tensor: 2 bf16, 3 f32, 5 fp16, 7 x3 (plain: kind - 1, f32 = 0)
+    auto halo_kind = [&](const std::string& g) { const int f = group_fmt(h, g); return f == 3 ? 7 : (f == 2 ? 3 : (f == 1 ? 5 : 2)); };
     for (int s = 0; s < 4; ++s)
-        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.fres(s), a.fres(s), a.fdim(s)}.elems(B), hk, a.fres(s), a.fres(s), a.fdim(s));
+        if (n == "feat" + std::to_string(s)) return set(w.feat[s], Halo{a.fres(s), a.fres(s), a.fdim(s)}.elems(B), halo_kind(gname("lrn", s)), a.fres(s), a.fres(s), a.fdim(s));
     const int r1 = 2 * a.fres(0);
-    if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), hk, r1, r1, h.cfg.features);
-    if (n == "seg_feat") return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, (hk == 3 || X3) ? 0 : hk - 1, r1, r1, h.cfg.features);  // seg head conv3x3 + BN + ReLU output
+    if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), halo_kind("head"), r1, r1, h.cfg.features);
+    if (n == "seg_feat") {   // seg head conv3x3 + BN + ReLU output
+        const int fs = h.cfg.precision == SOCCDPT_PREC_MIXED ? group_fmt(h, "head.s1") : group_fmt(h, "head");
+        return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, fs >= 2 ? 0 : (fs == 1 ? 4 : 1), r1, r1, h.cfg.features);
+    }
     if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
     if (n == "xf" && !a.hybrid) return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));
     if (n == "vit_tokens" && a.hybrid) return set(w.vt_xf, (size_t)B * (a.grid() * a.grid() + 1) * a.vit_dim, 0, 1, a.grid() * a.grid() + 1, a.vit_dim);  // residual stream after the last block
@@ -611,20 +694,18 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     const Arch& a = h.arch;
     const Prepared& P = *h.prep;
     const int F = h.cfg.features;
-    const bool F32 = h.cfg.precision == SOCCDPT_PREC_F32;
-    const bool X3 = h.cfg.precision == SOCCDPT_PREC_F16X3;   // GEMM / conv operands in the x3 split-fp16 format; everything else as in the f32 mode
-    const bool W4 = F32 || X3;                               // 4-byte operand elements: the launch sequence of the f32 mode
-    const int es = W4 ? 4 : 2;
-    const int HF = X3 ? 3 : (h.cfg.precision == SOCCDPT_PREC_F16 ? 1 : 0);  // operand format: 0 bf16, 1 fp16, 3 x3
-    // a GEMM output that a NON-GEMM kernel consumes (attention, bilinear, the seg tail) is plain f32 in both 4-byte modes: f32 operands ARE
-    // plain f32, in the x3 mode it goes to out_f32 instead of out_op
-    auto to_plain = [&](IgemmDesc& d, void* buf) { if (X3) { d.out_f32 = static_cast<float*>(buf); d.act_on_f32 = 1; } else d.out_op = buf; };
+    const bool MIX = h.cfg.precision == SOCCDPT_PREC_MIXED;  // per-group fp16 / x3 operands (the precision map); 4-byte operand buffers
+    auto GF = [&](const std::string& g) { return group_fmt(h, g); };   // operand format code of a launch-site group: 0 bf16, 1 fp16, 2 f32, 3 x3
+    // a GEMM output that a NON-GEMM kernel consumes as plain f32 (attention of the 4-byte modes, bilinear, the seg tail): f32 operands ARE plain
+    // f32 (out_op of an f32 launch); every other launch type writes it through out_f32 (fmt = operand format code of the launch)
+    auto to_plain = [&](IgemmDesc& d, void* buf, int fmt) {
+        if (fmt == 3 || (MIX && fmt == 1)) { d.out_f32 = static_cast<float*>(buf); d.act_on_f32 = 1; } else d.out_op = buf; };
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
-    auto gemm = [&](IgemmDesc d) {
-        if (!d.f32) { d.f32 = F32 ? 1 : 0; d.f16 = HF == 1; d.x3 = X3 ? 1 : 0; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
-        const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps);
-        if (!h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py)
+    auto gemm = [&](IgemmDesc d, int fmt) {   // fmt: operand format code of the launch's group
+        if (!d.f32) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
+        const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps + ((MIX && fmt == 3) ? 16 : 0));   // mixed mode: the x3 launches of a shape are their own site
+        if (!MIX && !h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py; uniform modes: tile ids are per format)
             auto it = h.tune_by_shape.find(key);
             if (it != h.tune_by_shape.end()) d.tune = it->second;
         }
@@ -634,11 +715,11 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         if (h.prof_sites && h.prof.on) {
             size_t i = 0;
             for (; i < h.sites.size(); ++i)
-                if (shape_key(h.sites[i].M, h.sites[i].N, h.sites[i].K, h.sites[i].taps) == key) break;
+                if (shape_key(h.sites[i].M, h.sites[i].N, h.sites[i].K, h.sites[i].taps + (h.sites[i].name[7] == 'x' ? 16 : 0)) == key) break;
             if (i == h.sites.size() && h.sites.size() >= 1024) { err = "soccdpt: too many distinct igemm shapes for site profiling"; return 1; }
             if (i == h.sites.size()) {
                 SiteRec r{d.M, d.N, d.taps * d.Cin, d.taps, igemm_config_id(d), 0, {0}};
-                snprintf(r.name, sizeof(r.name), "site%03zu", i);
+                snprintf(r.name, sizeof(r.name), (MIX && fmt == 3) ? "site%03zux" : "site%03zu", i);
                 h.sites.push_back(r);
             }
             h.sites[i].count++;
@@ -652,16 +733,19 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         // forward_flex (/root/reference/SOccDPT/model/backbones/vit.py:44-85) + forward_adapted_unflatten (backbones/utils.py:84-133);
         // launch for launch what oracle/soccdpt_ref.py hybrid_encoder() states.
         const HybridW& Y = P.hy;
-        const int OM = F32 ? 2 : HF;   // 0 bf16, 1 fp16, 2 f32, 3 x3
         const int S = a.img, H1 = S / 2, H2 = S / 4;
+        // Per-group operand formats (uniform modes: one code everywhere): a ResNetV2 stage "rn.s<k>" (its bottlenecks share the zero-halo images
+        // of their 3x3 inputs, so the stage is the unit), "pe", the ViT blocks' "vit.b<i>.attn" / ".mlp", "ro<k>", "pp4".
+        const int fRn[3] = {GF("rn.s0"), GF("rn.s1"), GF("rn.s2")}, fPe = GF("pe");
         // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
         auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
             d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part; d.gn_count = w.hy_count; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
             d.gn_part_floats = w.hy_part_floats; d.gn_count_words = (size_t)B + 8;
         };
-        auto gn = [&](GnApplyArgs g) {
-            PROF("gn_apply", 0.0, (double)g.M * g.C * (4.0 + (g.raw2 || g.res ? 4.0 : 0.0) + (g.out_f32 ? 4.0 : 0.0) + (g.out_op ? es : 0) + (g.out_halo ? es : 0)));
-            return launch_gn_apply(g, OM, st, err);
+        auto gn = [&](GnApplyArgs g, int om) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise)
+            const int eo = om >= 2 ? 4 : 2;
+            PROF("gn_apply", 0.0, (double)g.M * g.C * (4.0 + (g.raw2 || g.res ? 4.0 : 0.0) + (g.out_f32 ? 4.0 : 0.0) + (g.out_op ? eo : 0) + (g.out_halo ? eo : 0)));
+            return launch_gn_apply(g, om, st, err);
         };
         {   // stem: Conv 7x7 / 2 'SAME' (im2col + igemm) -> GroupNorm + ReLU -> MaxPool 3x3 / 2 'SAME'
             { PROF("stem_im2col", 0.0, (double)B * S * S * 12.0 + (double)B * H1 * H1 * 160.0 * 4.0);
@@ -670,17 +754,19 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.f32 = 1;
             d.X = w.hy_a0; d.Wt = Y.stem_w; d.M = B * H1 * H1; d.N = a.stem_ch; d.Cin = 160; d.ldx = 160; d.out_f32 = w.hy_r[0];
             with_stats(d, 0, a.stem_ch, H1 * H1);
-            RUN(gemm(d));
-            { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * es);
-              RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, OM, B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
+            RUN(gemm(d, 2));
+            { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * (fRn[0] >= 2 ? 4 : 2));
+              RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, fRn[0], B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
         }
         int rcur = H2;
         for (int s3 = 0; s3 < 3; ++s3) {
             const int nb = (int)Y.stages[s3].size();
+            const int fb = fRn[s3];
             for (int j = 0; j < nb; ++j) {
                 const RnBlockW& bw = Y.stages[s3][j];
                 const int rin = rcur, rout = rin / bw.stride;
                 const int Min = B * rin * rin, Mout = B * rout * rout;
+                const int fnext = j + 1 < nb ? fb : (s3 < 2 ? fRn[s3 + 1] : fPe);   // who reads this bottleneck's output
                 // zero-halo image for this (resolution, width): see carve()
                 const int ti = s3 == 0 ? 0 : (s3 == 1 ? (j == 0 ? 1 : 2) : (j == 0 ? 3 : 4));
                 if (bw.proj) {   // shortcut: GN(1x1 stride-s conv)
@@ -689,42 +775,42 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                     if (bw.stride == 1) { d.ldx = bw.cin; }
                     else { d.gather1 = 1; d.stride = bw.stride; d.pad = 0; d.in_halo = 0; d.Hi = rin; d.Wi = rin; d.H = rout; d.W = rout; }
                     with_stats(d, 3, bw.cout, rout * rout);
-                    RUN(gemm(d));
+                    RUN(gemm(d, fb));
                 }
                 {   // conv1 1x1 -> GN + ReLU -> halo image
                     IgemmDesc d;
                     d.X = w.hy_xop; d.Wt = bw.c1_w; d.M = Min; d.N = bw.mid; d.Cin = bw.cin; d.ldx = bw.cin; d.out_f32 = w.hy_r[0];
                     with_stats(d, 0, bw.mid, rin * rin);
-                    RUN(gemm(d));
+                    RUN(gemm(d, fb));
                     GnApplyArgs g;
                     g.raw = w.hy_r[0]; g.stats = w.hy_stats[0]; g.gamma = bw.n1_g; g.beta = bw.n1_b; g.out_halo = w.hy_t1[ti];
                     g.M = (size_t)Min; g.HW = rin * rin; g.W = rin; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g));
+                    RUN(gn(g, fb));
                 }
                 {   // conv2 3x3 (stride on this conv; 'SAME': pad 1 at stride 1, the extra pixel right / bottom at stride 2) -> GN + ReLU
                     IgemmDesc d;
                     d.X = w.hy_t1[ti]; d.Wt = bw.c2_w; d.M = Mout; d.N = bw.mid; d.Cin = bw.mid; d.taps = 9; d.H = rout; d.W = rout; d.Hi = rin; d.Wi = rin;
                     d.stride = bw.stride; d.pad = bw.stride == 1 ? 1 : 0; d.in_halo = 1; d.out_f32 = w.hy_r[1];
                     with_stats(d, 1, bw.mid, rout * rout);
-                    RUN(gemm(d));
+                    RUN(gemm(d, fb));
                     GnApplyArgs g;
                     g.raw = w.hy_r[1]; g.stats = w.hy_stats[1]; g.gamma = bw.n2_g; g.beta = bw.n2_b; g.out_op = w.hy_t2;
                     g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g));
+                    RUN(gn(g, fb));
                 }
                 {   // conv3 1x1 -> GN, + shortcut, ReLU: the new residual stream (f32) and its operand copy; hooked stages also as a halo image
                     IgemmDesc d;
                     d.X = w.hy_t2; d.Wt = bw.c3_w; d.M = Mout; d.N = bw.cout; d.Cin = bw.mid; d.ldx = bw.mid; d.out_f32 = w.hy_r[2];
                     with_stats(d, 2, bw.cout, rout * rout);
-                    RUN(gemm(d));
+                    RUN(gemm(d, fb));
                     GnApplyArgs g;
                     g.raw = w.hy_r[2]; g.stats = w.hy_stats[2]; g.gamma = bw.n3_g; g.beta = bw.n3_b;
                     if (bw.proj) { g.raw2 = w.hy_r[3]; g.stats2 = w.hy_stats[3]; g.gamma2 = bw.ds_g; g.beta2 = bw.ds_b; }
                     else g.res = w.hy_xf;
                     g.out_f32 = w.hy_xf; g.out_op = w.hy_xop;
-                    if (j == nb - 1 && s3 < 2) g.out_halo = w.feat[s3];   // hooks on patch_embed.backbone.stages[0], [1] (vit.py:164-167)
+                    if (j == nb - 1 && s3 < 2) { g.out_halo = w.feat[s3]; g.halo_mode = GF(gname("lrn", s3)); }   // hooks on patch_embed.backbone.stages[0], [1] (vit.py:164-167)
                     g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.cout; g.cpg = bw.cout / 32;
-                    RUN(gn(g));
+                    RUN(gn(g, fnext));
                 }
                 rcur = rout;
             }
@@ -734,121 +820,138 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         {
             IgemmDesc d;
             d.X = w.hy_xop; d.Wt = Y.pe_w; d.M = Mp; d.N = E; d.Cin = 1024; d.ldx = 1024; d.bias = Y.pe_b; d.out_f32 = w.vt_y;
-            RUN(gemm(d));
-            PROF("vit_tokens_ln", 0.0, (double)Mt * E * (8.0 + 4.0 + es));
-            RUN(launch_vit_tokens_ln(w.vt_y, Y.cls, Y.pos, w.vt_xf, Y.blocks[0].n1_g, Y.blocks[0].n1_b, w.vt_xb, OM, B, NT, E, 1e-6f, st, err));
+            RUN(gemm(d, fPe));
+            const int f0 = GF(gvit(0, "attn"));
+            PROF("vit_tokens_ln", 0.0, (double)Mt * E * (8.0 + 4.0 + (f0 >= 2 ? 4 : 2)));
+            RUN(launch_vit_tokens_ln(w.vt_y, Y.cls, Y.pos, w.vt_xf, Y.blocks[0].n1_g, Y.blocks[0].n1_b, w.vt_xb, f0, B, NT, E, 1e-6f, st, err));
         }
         for (int i = 0; i < a.vit_depth; ++i) {
             const VitBlockW& vb = Y.blocks[i];
+            const int fa = GF(gvit(i, "attn")), fm = GF(gvit(i, "mlp"));
             IgemmDesc d;
-            d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b; to_plain(d, w.vt_qkv);
-            RUN(gemm(d));
-            { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * es);
-              RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, h.cfg.precision, B, NT, a.vit_heads, st, err)); }
+            d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b;
+            if (MIX) { d.out_op = w.vt_qkv; d.out_fmt = 1; }   // mixed mode: fp16 q, k, v for the fp16 attention kernel
+            else to_plain(d, w.vt_qkv, fa);
+            RUN(gemm(d, fa));
+            { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * (fa >= 2 && !MIX ? 4 : 2));
+              const int aprec = MIX ? SOCCDPT_PREC_F16 : h.cfg.precision;
+              RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, aprec, B, NT, a.vit_heads, st, err, (MIX && fa == 3) ? 1 : 0)); }
             d = IgemmDesc();
             d.X = w.vt_attn; d.Wt = vb.proj_w; d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = vb.proj_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;   // x += attn (in place)
-            RUN(gemm(d));
-            { PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + es));
-              RUN(launch_ln_rows(w.vt_xf, vb.n2_g, vb.n2_b, w.vt_xb, OM, Mt, E, 1e-6f, st, err)); }
+            RUN(gemm(d, fa));
+            { PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + (fm >= 2 ? 4 : 2)));
+              RUN(launch_ln_rows(w.vt_xf, vb.n2_g, vb.n2_b, w.vt_xb, fm, Mt, E, 1e-6f, st, err)); }
             d = IgemmDesc();
             d.X = w.vt_xb; d.Wt = vb.fc1_w; d.M = Mt; d.N = 4 * E; d.Cin = E; d.ldx = E; d.bias = vb.fc1_b; d.act = ACT_GELU; d.out_op = w.vt_h;
-            RUN(gemm(d));
+            RUN(gemm(d, fm));
             d = IgemmDesc();
             d.X = w.vt_h; d.Wt = vb.fc2_w; d.M = Mt; d.N = E; d.Cin = 4 * E; d.ldx = 4 * E; d.bias = vb.fc2_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;      // x += mlp (in place)
             for (int k = 0; k < 2; ++k)
-                if (i == a.vit_hooks[k]) d.out_op = w.vt_tok[k];   // hooks on blocks[8], blocks[11] (vit.py:168-171): operand copy for the readout GEMM
-            RUN(gemm(d));
+                if (i == a.vit_hooks[k]) { d.out_op = w.vt_tok[k]; d.out_fmt = MIX ? GF(gname("ro", k)) : -1; }   // hooks on blocks[8], blocks[11] (vit.py:168-171): operand copy for the readout GEMM
+            RUN(gemm(d, fm));
             if (i + 1 < a.vit_depth) {
-                PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + es));
-                RUN(launch_ln_rows(w.vt_xf, Y.blocks[i + 1].n1_g, Y.blocks[i + 1].n1_b, w.vt_xb, OM, Mt, E, 1e-6f, st, err));
+                const int fn = GF(gvit(i + 1, "attn"));
+                PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + (fn >= 2 ? 4 : 2)));
+                RUN(launch_ln_rows(w.vt_xf, Y.blocks[i + 1].n1_g, Y.blocks[i + 1].n1_b, w.vt_xb, fn, Mt, E, 1e-6f, st, err));
             }
         }
         // ---- act_postprocess3 / 4: ProjectReadout (cat(token, cls) @ W^T + GELU, the cat never materialises) -> Conv1x1 (-> Conv3x3 / 2) ----
         for (int k = 0; k < 2; ++k) {
+            const int fr = GF(gname("ro", k)), fp4 = GF("pp4");
             IgemmDesc d;
             d.X = w.vt_tok[k]; d.Wt = Y.ro_w[k]; d.M = Mp; d.N = E; d.Cin = 2 * E; d.ldx = E; d.bias = Y.ro_b[k]; d.act = ACT_GELU; d.out_op = w.vt_ro;
             d.grp_rows = G * G; d.grp_stride = (long long)NT * E; d.grp_off = E; d.seg2_k = E; d.seg2_off = 0;
-            RUN(gemm(d));
+            RUN(gemm(d, fr));
             d = IgemmDesc();
             d.X = w.vt_ro; d.Wt = Y.pp_w[k]; d.M = Mp; d.N = a.fdim(2 + k); d.Cin = E; d.ldx = E; d.bias = Y.pp_b[k]; d.H = G; d.W = G;
-            d.out_op = k == 0 ? w.feat[2] : w.vt_pp4; d.out_halo = 1;
-            RUN(gemm(d));
+            d.out_op = k == 0 ? w.feat[2] : w.vt_pp4; d.out_halo = 1; d.out_fmt = MIX ? (k == 0 ? GF("lrn2") : fp4) : -1;
+            RUN(gemm(d, fr));
             if (k == 1) {
                 d = IgemmDesc();
                 d.X = w.vt_pp4; d.Wt = Y.pp4_w; d.M = B * (G / 2) * (G / 2); d.N = a.fdim(3); d.Cin = a.fdim(3); d.taps = 9; d.H = G / 2; d.W = G / 2; d.Hi = G; d.Wi = G;
-                d.stride = 2; d.pad = 1; d.in_halo = 1; d.bias = Y.pp4_b; d.out_op = w.feat[3]; d.out_halo = 1;
-                RUN(gemm(d));
+                d.stride = 2; d.pad = 1; d.in_halo = 1; d.bias = Y.pp4_b; d.out_op = w.feat[3]; d.out_halo = 1; d.out_fmt = MIX ? GF("lrn3") : -1;
+                RUN(gemm(d, fp4));
             }
         }
     } else {
     // ---------------- encoder ----------------
-    { PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
+    // Every launch-site group carries its own operand format (uniform modes: the same one everywhere).  A producer writes each operand
+    // copy in the format of the group that READS it: fa / fm = this block's attention / MLP group, fnext = the group that reads the
+    // block's output (the next block's attention, or the PatchMerging reduction), fhook = the decoder's layer_rn conv of this stage.
+    { const int f0 = GF(gblk(0, 0, "attn"));
+      PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
-                           W(ENC + "patch_embed.norm.bias"), w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), HF, B, a.img, a.embed, st, err)); }
+                           W(ENC + "patch_embed.norm.bias"), w.xf, f0 == 2 ? nullptr : static_cast<bf16_t*>(w.xb), f0 == 2 ? 0 : f0, B, a.img, a.embed, st, err)); }
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         bool merged = false;   // the stage's last block wrote its operand copy straight into the PatchMerging layout (w.hbuf)
+        const int fhook = GF(gname("lrn", s));
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
-            const bool to_merge = !W4 && s < 3 && j == a.depths[s] - 1;
+            const bool last = j == a.depths[s] - 1;
+            const int fa = GF(gblk(s, j, "attn")), fm = GF(gblk(s, j, "mlp"));
+            const int fnext = !last ? GF(gblk(s, j + 1, "attn")) : (s < 3 ? GF(gname("merge", s)) : fm);
+            // the operand copy goes straight into the PatchMerging layout where the reduction GEMM reads 16-bit (or, mixed mode, x3) operands
+            const bool to_merge = s < 3 && last && (fnext <= 1 || (MIX && fnext == 3));
+            const bool hook = (j == a.hooks[s]);
             IgemmDesc d;
-            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias; to_plain(d, w.qkv);
-            RUN(gemm(d));
+            d.X = w.xb; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias;
+            if (MIX) { d.out_op = w.qkv; d.out_fmt = 1; }   // mixed mode: fp16 q, k, v for the fp16 attention kernel whatever the GEMM ran in
+            else to_plain(d, w.qkv, fa);
+            RUN(gemm(d, fa));
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
-              if (W4) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
-                                                       a.shift(s, j), H, st, err, X3 ? 1 : 0));
-              else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), HF, B, res, wsz,
-                                               a.shift(s, j), H, st, err)); }
+              if (!MIX && fa >= 2) RUN(launch_window_attention_f32(static_cast<const float*>(w.qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(w.attn), B, res, wsz,
+                                                       a.shift(s, j), H, st, err, fa == 3 ? 1 : 0));
+              else RUN(launch_window_attention(static_cast<const bf16_t*>(w.qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(w.attn), MIX ? 1 : fa, B, res, wsz,
+                                               a.shift(s, j), H, st, err, (MIX && fa == 3) ? 1 : 0)); }
             const bool fuse_ln = C <= 128;  // whole rows fit one igemm tile; measured: a win for C = 96, a wash at 192, a loss beyond
             d = IgemmDesc();
             d.X = w.attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b;
             if (fuse_ln) {
-                d.ln_g = bw.n1_g; d.ln_b = bw.n1_b; d.ln_xf = w.xf; d.out_op = F32 ? nullptr : w.xb;
-                RUN(gemm(d));
+                d.ln_g = bw.n1_g; d.ln_b = bw.n1_b; d.ln_xf = w.xf; d.out_op = fm == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fm : -1;
+                RUN(gemm(d, fa));
             } else {
                 d.out_f32 = w.y;
-                RUN(gemm(d));
+                RUN(gemm(d, fa));
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M, C, 1, res, 0, st, err)); }
+                  RUN(launch_ln_residual(w.y, bw.n1_g, bw.n1_b, w.xf, fm == 2 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, fm == 2 ? 0 : fm, M, C, 1, res, 0, st, err)); }
             }
-            if (!W4 && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
-                const bool hook = (j == a.hooks[s]);
+            if (fm <= 1 && fnext == fm && (!hook || fhook == fm) && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
                 PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
                 RUN(launch_mlp_ln(static_cast<const bf16_t*>(w.xb), w.xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
-                                  bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, HF,
+                                  bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, fm,
                                   M, C, res, res, to_merge ? 1 : 0, st, err));
                 merged = to_merge;
                 continue;
             }
             d = IgemmDesc();
             d.X = w.xb; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = w.hbuf;
-            RUN(gemm(d));
+            RUN(gemm(d, fm));
             d = IgemmDesc();
             d.X = w.hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b;
             if (fuse_ln) {
-                const bool hook = (j == a.hooks[s]);
-                d.ln_g = bw.n2_g; d.ln_b = bw.n2_b; d.ln_xf = w.xf; d.out_op = F32 ? nullptr : w.xb;
-                if (hook) { d.ln_halo = w.feat[s]; d.H = res; d.W = res; }
-                RUN(gemm(d));
+                d.ln_g = bw.n2_g; d.ln_b = bw.n2_b; d.ln_xf = w.xf; d.out_op = fnext == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fnext : -1;
+                if (hook) { d.ln_halo = w.feat[s]; d.H = res; d.W = res; d.halo_fmt = MIX ? fhook : -1; }
+                RUN(gemm(d, fm));
             } else {
             d.out_f32 = w.y;
-            RUN(gemm(d));
+            RUN(gemm(d, fm));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
-              const bool hook = (j == a.hooks[s]);
-              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb),
-                                     (hook && !F32) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && F32) ? static_cast<float*>(w.feat[s]) : nullptr, HF, M, C,
-                                     1, res, to_merge ? 1 : 0, st, err));
+              RUN(launch_ln_residual(w.y, bw.n2_g, bw.n2_b, w.xf, fnext == 2 ? nullptr : static_cast<bf16_t*>(to_merge ? w.hbuf : w.xb),
+                                     (hook && fhook != 2) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && fhook == 2) ? static_cast<float*>(w.feat[s]) : nullptr,
+                                     fnext == 2 ? 0 : fnext, M, C, 1, res, to_merge ? 1 : 0, st, err, nullptr, 1, fhook == 2 ? -1 : fhook));
               merged = to_merge; }
             }
         }
         if (s < 3) {
+            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "attn"));
             if (!merged) { PROF("merge_gather", 0.0, (double)M * C * 4.0);
-              RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, es, st, err)); }
+              RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, fg >= 2 ? 4 : 2, st, err)); }
             IgemmDesc d;
             d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
-            RUN(gemm(d));
+            RUN(gemm(d, fg));
             { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
-              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, F32 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, HF, M / 4, 2 * C, 0,
+              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, fn == 2 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr, fn == 2 ? 0 : fn, M / 4, 2 * C, 0,
                                      res / 2, 0, st, err)); }
         }
     }
@@ -859,12 +962,14 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         d.X = X; d.Wt = Wt; d.M = B * r * r; d.N = N; d.Cin = Cin; d.taps = 9; d.H = r; d.W = r;
         return d;
     };
+    const int fH = GF("head"), fD2 = GF("head.d2");
     for (int l = 3; l >= 0; --l) {
         const int r = a.fres(l), M = B * r * r;
-        {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd bf16 halo (RCU conv1 input)
+        const int fL = GF(gname("lrn", l)), fR = GF(gname("ref", l)), fO = GF(gname("oc", l));
+        {   // layer{l+1}_rn: 3x3, no bias.  raw f32 (residual) + relu'd operand halo image (RCU conv1 input)
             IgemmDesc d = conv(w.feat[l], a.fdim(l), P.layer_rn[l], F, r);
-            d.out_f32 = w.lrn_raw[l]; d.out_op = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            RUN(gemm(d));
+            d.out_f32 = w.lrn_raw[l]; d.out_op = w.lrn_relu[l]; d.out_halo = 1; d.act = ACT_RELU; d.out_fmt = MIX ? fR : -1;
+            RUN(gemm(d, fL));
         }
         const float* fused_raw = w.lrn_raw[l];
         const void* fused_relu = w.lrn_relu[l];
@@ -872,12 +977,12 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             const RcuW& u1 = P.rcu[l][0];
             IgemmDesc d = conv(w.lrn_relu[l], F, u1.w1, F, r);
             d.bias = u1.b1; d.act = ACT_RELU; d.out_op = w.t_relu[l]; d.out_halo = 1;
-            RUN(gemm(d));
+            RUN(gemm(d, fR));
             d = conv(w.t_relu[l], F, u1.w2, F, r);
             d.bias = u1.b2; d.res1 = w.lrn_raw[l];
             d.res2 = w.oc[l + 1]; d.res2_h = a.fres(l + 1); d.res2_w = a.fres(l + 1);  // bilinear(out_conv output of the coarser level), on the fly
             d.out_f32 = w.out_raw[l]; d.out_op = w.out_relu[l]; d.out_halo = 1; d.act = ACT_RELU;
-            RUN(gemm(d));
+            RUN(gemm(d, fR));
             fused_raw = w.out_raw[l];
             fused_relu = w.out_relu[l];
         }
@@ -885,43 +990,52 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             const RcuW& u2 = P.rcu[l][1];
             IgemmDesc d = conv(fused_relu, F, u2.w1, F, r);
             d.bias = u2.b1; d.act = ACT_RELU; d.out_op = w.t_relu[l]; d.out_halo = 1;
-            RUN(gemm(d));
+            RUN(gemm(d, fR));
             d = conv(w.t_relu[l], F, u2.w2, F, r);
-            d.bias = u2.b2; d.res1 = fused_raw; d.out_op = w.u[l];
-            RUN(gemm(d));
+            d.bias = u2.b2; d.res1 = fused_raw; d.out_op = w.u[l]; d.out_fmt = MIX ? fO : -1;
+            RUN(gemm(d, fR));
         }
         {   // out_conv (1x1) BEFORE the bilinear resize: both are linear and the interpolation weights sum to 1
             IgemmDesc d;
             d.X = w.u[l]; d.Wt = P.oc_w[l]; d.M = M; d.N = F; d.Cin = F; d.ldx = F; d.bias = P.oc_b[l]; d.out_f32 = w.oc[l];
-            RUN(gemm(d));
+            RUN(gemm(d, fO));
         }
         if (l == 0) { PROF("bilinear_resize", 0.0, (double)M * F * (4.0 + 8.0));
-               RUN(launch_bilinear(w.oc[0], 0, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.path1), F32 ? static_cast<float*>(w.path1) : nullptr, 1, HF, B, r, r,
+               RUN(launch_bilinear(w.oc[0], 0, nullptr, fH == 2 ? nullptr : static_cast<bf16_t*>(w.path1), fH == 2 ? static_cast<float*>(w.path1) : nullptr, 1, fH == 2 ? 0 : fH, B, r, r,
                                    2 * r, 2 * r, F, st, err)); }
     }
     // ---------------- heads ----------------
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
     {
         IgemmDesc d = conv(w.path1, F, P.d0_w, F / 2, r1);
-        d.bias = P.d0_b; to_plain(d, w.d1);
-        RUN(gemm(d));
-        if (!W4 && F == 256) {
-            // fused: up-sample + conv3x3(128->32) + ReLU + 1x1 + ReLU straight from the half-resolution map
+        d.bias = P.d0_b;
+        if (fD2 <= 1 && F == 256) {
+            // fused: up-sample + conv3x3(128->32) + ReLU + 1x1 + ReLU straight from the half-resolution map (16-bit operands)
+            d.out_op = w.d1; d.out_fmt = MIX ? fD2 : -1;
+            RUN(gemm(d, fH));
             PROF("depth_tail_fused", 2.0 * B * r0 * r0 * 32.0 * 9.0 * (F / 2), 0.0);
-            RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, HF, B, r1, r1, st, err));
+            RUN(launch_depth_tail(static_cast<const bf16_t*>(w.d1), static_cast<const bf16_t*>(P.d2_w), P.d2_b, P.d4_w, P.d4_b, inv256, fD2, B, r1, r1, st, err));
         } else {
+            const bool d1_16 = fH <= 1 && !MIX;   // uniform 16-bit mode with F != 256: the half-resolution map stays a 16-bit operand
+            if (d1_16) d.out_op = w.d1; else to_plain(d, w.d1, fH);
+            RUN(gemm(d, fH));
             { PROF("bilinear_resize", 0.0, (double)B * r1 * r1 * (F / 2) * (2.0 + 8.0));
-              RUN(launch_bilinear(w.d1, W4 ? 0 : 1, nullptr, F32 ? nullptr : static_cast<bf16_t*>(w.d1u), F32 ? static_cast<float*>(w.d1u) : nullptr, 1, HF, B, r1,
+              RUN(launch_bilinear(w.d1, d1_16 ? 1 : 0, nullptr, fD2 == 2 ? nullptr : static_cast<bf16_t*>(w.d1u), fD2 == 2 ? static_cast<float*>(w.d1u) : nullptr, 1, fD2 == 2 ? 0 : fD2, B, r1,
                                   r1, r0, r0, F / 2, st, err)); }
             d = conv(w.d1u, F / 2, P.d2_w, 32, r0);
             d.bias = P.d2_b; d.act = ACT_RELU; d.dot_w = P.d4_w; d.dot_b = P.d4_b; d.out_dot = inv256;
-            RUN(gemm(d));
+            RUN(gemm(d, fD2));
         }
+        // seg head: conv3x3 + folded BN + ReLU, then the 1x1 classifier + up-sampling + activation (f32 VALU).  The feature map between them is
+        // a 16-bit operand in the 16-bit modes, plain f32 in the 4-byte modes; in the mixed mode the "head.s1" entry of the map chooses.
+        const int fS1 = MIX ? GF("head.s1") : fH;
+        const bool s1_f32 = fS1 >= 2;
         d = conv(w.path1, F, P.s0_w, F, r1);
-        d.bias = P.bn_shift; d.act = ACT_RELU; to_plain(d, w.s1);
-        RUN(gemm(d));
+        d.bias = P.bn_shift; d.act = ACT_RELU;
+        if (s1_f32) to_plain(d, w.s1, fH); else { d.out_op = w.s1; d.out_fmt = MIX ? 1 : -1; }
+        RUN(gemm(d, fH));
         { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
-          RUN(launch_seg_tail(w.s1, W4 ? 1 : 0, HF == 1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
+          RUN(launch_seg_tail(w.s1, s1_f32 ? 1 : 0, fS1 == 1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
         ++launches;
     }
 #undef RUN

@@ -586,6 +586,27 @@ __global__ __launch_bounds__(256) void occ_expand_kernel(const uint32_t* __restr
     }
 }
 
+// The same expansion in two halves, for the multi-GPU path (soccdpt_amd/dist.py): occ_zero_kernel writes the B x ncell zeros -- independent of every
+// rank's voxels, so it runs WHILE the RCCL all-gather of the packed grids is in flight -- and occ_set_kernel, after the union, writes a 1 into every
+// row for each set bit (~1e4 of 6.3 M cells).  Together they store exactly what occ_expand_kernel stores.
+__global__ __launch_bounds__(256) void occ_zero_kernel(float* __restrict__ occ, size_t n4) {
+    typedef __attribute__((ext_vector_type(4))) float v4f;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (size_t)gridDim.x * blockDim.x)
+        __builtin_nontemporal_store(v4f{0.f, 0.f, 0.f, 0.f}, reinterpret_cast<v4f*>(occ) + q);
+}
+__global__ __launch_bounds__(256) void occ_set_kernel(const uint32_t* __restrict__ bits, float* __restrict__ occ, size_t ncell, size_t nwords, int B) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t wv = bits[i];
+        while (wv) {
+            const int k = __builtin_ctz(wv);
+            wv &= wv - 1;
+            const size_t n = i * 32 + (size_t)k;
+            if (n < ncell)
+                for (int b = 0; b < B; ++b) occ[(size_t)b * ncell + n] = 1.0f;
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void occ_or_kernel(uint32_t* __restrict__ dst, const uint32_t* __restrict__ src, size_t nwords, int nsets) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x) {
         uint32_t v = dst[i];
@@ -665,6 +686,27 @@ int launch_occ_expand(const soccdpt_config& cfg, const uint32_t* bits, int B, fl
     size_t blocks = (ncell / 4 + 255) / 256;
     if (blocks > 256 * 16) blocks = 256 * 16;
     SOCCDPT_LAUNCH(occ_expand_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, bits, occ, ncell, B);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+int launch_occ_zero(const soccdpt_config& cfg, int B, float* occ, hipStream_t stream, std::string& err) {
+    const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
+    if (ncell % 4 != 0) { err = "occupancy cell count must be a multiple of 4"; return 1; }
+    const size_t n4 = ncell / 4 * (size_t)B;
+    size_t blocks = (n4 + 255) / 256;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    SOCCDPT_LAUNCH(occ_zero_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, occ, n4);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
+    return 0;
+}
+
+int launch_occ_set(const soccdpt_config& cfg, const uint32_t* bits, int B, float* occ, hipStream_t stream, std::string& err) {
+    const size_t ncell = (size_t)cfg.grid[0] * cfg.grid[1] * cfg.grid[2] * cfg.num_classes;
+    const size_t nwords = (ncell + 31) / 32;
+    SOCCDPT_LAUNCH(occ_set_kernel, dim3((unsigned)((nwords + 255) / 256)), dim3(256), 0, stream, bits, occ, ncell, nwords, B);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = hipGetErrorString(e); return 1; }
     return 0;

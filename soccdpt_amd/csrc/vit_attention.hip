@@ -26,7 +26,7 @@ constexpr int D = 64;            // head dimension
 constexpr int KROW = D * 2;      // bytes per K row in LDS
 
 template <bool F16>
-__global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int NPAD, int heads, int QS) {
+__global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int NPAD, int heads, int QS, int out_x3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VT_STRIDE = NPAD * 2 + 8;
     char* Ks = smem;
@@ -146,9 +146,15 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
         l += __shfl_xor(l, 32);
         if (qrow < N) {   // lane owns query column r32; accumulator register rg is d = (rg&3) + 8(rg>>2) + 4h (+32 for o1)
             const float inv = 1.0f / l;
-            uint16_t* orow = out + ((size_t)b * N + qrow) * C + head * D;
+            const size_t e0 = ((size_t)b * N + qrow) * C + head * D;
+            uint16_t* orow = out + e0;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
+                if (F16 && out_x3) {   // SOCCDPT_PREC_MIXED: the proj GEMM of this block is an x3 launch (half16.h); the f32 accumulators go out unrounded
+                    x3_store4(out, e0 + 8 * g + 4 * h, o0[4 * g] * inv, o0[4 * g + 1] * inv, o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
+                    x3_store4(out, e0 + 32 + 8 * g + 4 * h, o1[4 * g] * inv, o1[4 * g + 1] * inv, o1[4 * g + 2] * inv, o1[4 * g + 3] * inv);
+                    continue;
+                }
                 uint2 p0, p1;
                 p0.x = pack_h2<F16>(o0[4 * g] * inv, o0[4 * g + 1] * inv);
                 p0.y = pack_h2<F16>(o0[4 * g + 2] * inv, o0[4 * g + 3] * inv);
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __r
 
 }  // namespace
 
-int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err) {
+int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int heads, hipStream_t st, std::string& err, int out_x3) {
     if (B <= 0 || N <= 0 || heads <= 0) { err = "vit_attention: bad geometry"; return 1; }
     if (prec == SOCCDPT_PREC_F32 || prec == SOCCDPT_PREC_F16X3) {   // qkv plain f32 in both; the F16X3 mode wants its output in the x3 operand format
         const int NQB = (N + 127) / 128;
@@ -324,6 +330,7 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
         else SOCCDPT_LAUNCH(vit_attention_f32_kernel<2>, dim3(blocks), dim3(256), 0, st, static_cast<const float*>(qkv), out, N, heads, NQB);
         return check_launch("vit_attention_f32", err);
     }
+    if (out_x3 && prec != SOCCDPT_PREC_F16) { err = "vit_attention: the x3 output form belongs to the fp16 kernel"; return 1; }
     const int NPAD = (N + 31) / 32 * 32, NT = NPAD / 32;
     const size_t lds = (size_t)NPAD * KROW + (size_t)D * (NPAD * 2 + 8);
     if (lds > 160 * 1024) { err = "vit_attention: sequence too long for the LDS-resident K / V^T form (max 608 tokens)"; return 1; }
@@ -341,9 +348,9 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
     }
     const unsigned blocks = (unsigned)(B * heads * QS);
     if (prec == SOCCDPT_PREC_F16)
-        SOCCDPT_LAUNCH(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+        SOCCDPT_LAUNCH(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
     else
-        SOCCDPT_LAUNCH(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS);
+        SOCCDPT_LAUNCH(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
     return check_launch("vit_attention", err);
 }
 

@@ -63,6 +63,7 @@ class OccExchange:
         self.group = group
         self._or_reduce = or_reduce  # tests on CPU (gloo) inject a reducer; on GPU the HIP kernel is used
         self._flat: Optional[torch.Tensor] = None   # reused receive buffer (world x 786,432 B)
+        self.windows = []                           # (start, end) event pairs of the last exchanges (window_ms)
 
     def __call__(self, eng, bits: torch.Tensor) -> torch.Tensor:
         gathered = gather_occ_bits(bits, self.group, out=self._flat)
@@ -71,6 +72,49 @@ class OccExchange:
             return self._or_reduce(gathered)
         eng.occ_or(bits, gathered, gathered.shape[0])   # in place: bits |= every rank's grid (its own is among them)
         return bits
+
+    # ---- split form: the collective in flight while the caller zero-fills the dense rows (SOccDPT._finish_occupancy) ----
+    def start(self, bits: torch.Tensor):
+        """Issue the all-gather of the packed grids WITHOUT blocking the caller's stream: RCCL runs it on the process group's own stream (ordered
+        after the projection kernel that wrote `bits`), so whatever the caller launches next -- the zero-fill of the B dense rows, which depends
+        on no rank's voxels -- overlaps the exchange.  Returns a ticket for finish().  gloo (CPU tests, the one-GPU rehearsal) gathers synchronously."""
+        world = dist.get_world_size(self.group)
+        n = world * bits.numel()
+        ev = None
+        if bits.is_cuda:
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
+        if bits.is_cuda and dist.get_backend(self.group) == "nccl":
+            if self._flat is None or self._flat.numel() != n or self._flat.device != bits.device:
+                self._flat = torch.empty((n,), dtype=bits.dtype, device=bits.device)
+            work = dist.all_gather_into_tensor(self._flat, bits.contiguous().reshape(-1), group=self.group, async_op=True)
+            return (work, self._flat.reshape(world, bits.numel()), ev)
+        gathered = gather_occ_bits(bits, self.group, out=self._flat)
+        self._flat = gathered.reshape(-1)
+        return (None, gathered, ev)
+
+    def finish(self, eng, bits: torch.Tensor, ticket) -> torch.Tensor:
+        work, gathered, ev = ticket
+        if work is not None:
+            work.wait()            # stream-level: the caller's stream waits for the collective, the host does not
+        if self._or_reduce is not None:
+            out = self._or_reduce(gathered)
+        else:
+            eng.occ_or(bits, gathered, gathered.shape[0])
+            out = bits
+        if ev is not None:
+            ev[1].record()
+            self.windows.append(ev)
+            del self.windows[:-32]
+        return out
+
+    def window_ms(self):
+        """Mean device time from the issue of the all-gather to the end of the OR kernel over the recorded steps (the exchange window
+        bench.py reports at N > 1); includes whatever the caller overlapped with it.  Synchronises."""
+        if not self.windows:
+            return None
+        torch.cuda.synchronize()
+        return sum(a.elapsed_time(b) for a, b in self.windows) / len(self.windows)
 
 
 class GradExchange:

@@ -15,12 +15,13 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SOCCDPT_LIB_PATH") or os.path.join(_HERE, "libsoccdpt_hip.so")   # override: A/B of two builds in one GPU call (tools/ab_bench.sh)
 
-ABI_VERSION = 1
+ABI_VERSION = 3
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}
 PREC_BF16 = 0
 PREC_F32 = 1
 PREC_F16 = 2
 PREC_F16X3 = 3
+PREC_MIXED = 4   # fp16 operands, x3 where the precision map says so (include/soccdpt_hip.h)
 
 
 class SoccdptConfig(ctypes.Structure):
@@ -201,8 +202,22 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
                                            ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci), ctypes.POINTER(ci)]
     L.soccdpt_workspace_tensor.restype = ci
+    L.soccdpt_occ_zero.argtypes = [vp, ci, vp, vp]
+    L.soccdpt_occ_zero.restype = ci
+    L.soccdpt_occ_set.argtypes = [vp, vp, ci, vp, vp]
+    L.soccdpt_occ_set.restype = ci
+    L.soccdpt_sizeof.argtypes = [ci]
+    L.soccdpt_sizeof.restype = cs
+    L.soccdpt_prec_map_set.argtypes = [vp, ctypes.c_char_p, ci]
+    L.soccdpt_prec_map_set.restype = ci
+    L.soccdpt_prec_map_get.argtypes = [vp, ctypes.c_char_p, ci]
+    L.soccdpt_prec_map_get.restype = ci
     if L.soccdpt_abi_version() != ABI_VERSION:
         raise RuntimeError("libsoccdpt_hip.so ABI version mismatch; rebuild the library")
+    # the ctypes mirrors of the public structs must have the layout the library was compiled with (include/soccdpt_hip.h)
+    for which, cls in ((0, SoccdptConfig), (1, IgemmArgs), (2, KernelStat)):
+        if L.soccdpt_sizeof(which) != ctypes.sizeof(cls):
+            raise RuntimeError(f"libsoccdpt_hip.so: sizeof mismatch for {cls.__name__}: library {L.soccdpt_sizeof(which)}, binding {ctypes.sizeof(cls)}")
     _lib = L
     return L
 
@@ -335,6 +350,23 @@ class Engine:
             self._check(self.L.soccdpt_prepare(self._h, self._prepared.data_ptr(), nbytes, _stream_ptr(self.device)),
                         "soccdpt_prepare")
 
+    # ---- precision map (PREC_MIXED handles) ----
+    def prec_map(self) -> dict:
+        """{group: PREC_F16 | PREC_F16X3} in launch order (uniform-precision handles report their one format for every group)."""
+        n = self.L.soccdpt_prec_map_get(self._h, None, 0)
+        buf = ctypes.create_string_buffer(n + 1)
+        self.L.soccdpt_prec_map_get(self._h, buf, n + 1)
+        return {k: int(v) for k, v in (kv.split("=") for kv in buf.value.decode().split())}
+
+    def prec_map_set(self, group: str, fmt: int) -> int:
+        """Set one group ('s2.b0.attn'), a prefix ('s2.*') or everything ('*') to PREC_F16 / PREC_F16X3; re-prepares the weights."""
+        n = self.L.soccdpt_prec_map_set(self._h, group.encode(), int(fmt))
+        if n < 0:
+            raise RuntimeError("soccdpt_prec_map_set failed: " + self.L.soccdpt_last_error(self._h).decode())
+        if self._bound:
+            self.prepare()
+        return n
+
     def workspace(self, B: int) -> torch.Tensor:
         """Per-forward scratch.  The library zero-fills it itself whenever (buffer, B, streams) changes (include/soccdpt_hip.h,
         workspace contract), so any allocation will do; the buffer only grows."""
@@ -401,6 +433,14 @@ class Engine:
         with torch.cuda.device(self.device):
             self._check(self.L.soccdpt_occ_expand(self._h, _ptr(bits), B, _ptr(occ), _stream_ptr(self.device)),
                         "soccdpt_occ_expand")
+
+    def occ_zero(self, B: int, occ: torch.Tensor):
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_occ_zero(self._h, B, _ptr(occ), _stream_ptr(self.device)), "soccdpt_occ_zero")
+
+    def occ_set(self, bits: torch.Tensor, B: int, occ: torch.Tensor):
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_occ_set(self._h, _ptr(bits), B, _ptr(occ), _stream_ptr(self.device)), "soccdpt_occ_set")
 
     def network(self, x: torch.Tensor, inv256: torch.Tensor, seg256: torch.Tensor):
         B = x.shape[0]

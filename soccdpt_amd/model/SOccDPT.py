@@ -39,9 +39,10 @@ class SOccDPT(BaseModel):
                  camera_intrinsics_yaml=DEFAULT_CALIB, point_compute_method="torch",
                  grid_size=(256, 256, 32), scale=(2.0, 2.0, 0.666), shift=(0.0, 0.0, 0.0),
                  pc_scale=(10000.0, 50000.0, 800.0), pc_shift=(55.0, -20.0, 15.0), correction_angle=(7.0, 0, 0),
-                 compute_occ=False, precision: int = PREC_BF16, streams: int = 1, graph: bool = False, **kwargs):
+                 compute_occ=False, precision: int = PREC_BF16, streams: int = 1, graph: bool = False, share_occupancy_rows: bool = False, **kwargs):
         super().__init__()
         self.compute_occ = compute_occ
+        self.share_occupancy_rows = bool(share_occupancy_rows)   # occupancy returned as a stride-0 expand of one row (read-only callers)
         self.grid_size = grid_size
         self.scale = scale
         self.shift = shift
@@ -145,13 +146,25 @@ class SOccDPT(BaseModel):
         return self._shape_outputs(inv_up, seg_up, points, occ)
 
     def _finish_occupancy(self, eng: Engine, bits: torch.Tensor, B: int):
-        if self.occ_exchange is not None:  # multi-GPU: union over every rank's frames
-            bits = self.occ_exchange(eng, bits)
         g = self.grid_size
-        occ = torch.empty((B, g[0], g[1], g[2], self.num_classes), device=bits.device)
-        eng.occ_expand(bits, B, occ)
+        rows = 1 if self.share_occupancy_rows else B
+        occ = torch.empty((rows, g[0], g[1], g[2], self.num_classes), device=bits.device)
+        ex = self.occ_exchange
+        if ex is not None and hasattr(ex, "start"):
+            # multi-GPU: union over every rank's frames.  The all-gather of the packed grids runs on RCCL's stream while this
+            # stream writes the rows' zeros (the bulk of the expansion's 25 MB per row); after the OR only the set voxels are written.
+            ticket = ex.start(bits)
+            eng.occ_zero(rows, occ)
+            bits = ex.finish(eng, bits, ticket)
+            eng.occ_set(bits, rows, occ)
+        else:
+            if ex is not None:
+                bits = ex(eng, bits)
+            eng.occ_expand(bits, rows, occ)
         self.last_occ_bits = bits
-        return occ
+        # opt-in: ONE dense row viewed B times (stride 0).  The reference writes the same union grid into every batch row
+        # (/root/reference/SOccDPT/model/SOccDPT.py:449-455); a caller that only reads it saves (B - 1) x 25 MB of stores per step.
+        return occ.expand(B, -1, -1, -1, -1) if self.share_occupancy_rows else occ
 
 
 class SOccDPT_V3(SOccDPT):
@@ -241,11 +254,11 @@ class SOccDPT_V3(SOccDPT):
         bits = None
         if self.compute_occ:
             bits = torch.empty((eng.occ_words(),), dtype=torch.int32, device=dev)
-            if self.occ_exchange is None:
+            if self.occ_exchange is None and not self.share_occupancy_rows:
                 g = self.grid_size
                 occ = torch.empty((B, g[0], g[1], g[2], C), device=dev)
         eng.forward(xin, inv_up, seg_up, points, occ, bits)
-        if self.compute_occ and self.occ_exchange is not None:
+        if self.compute_occ and occ is None:
             occ = self._finish_occupancy(eng, bits, B)
         self.last_occ_bits = bits
         return self._shape_outputs(inv_up, seg_up, points, occ)

@@ -26,7 +26,22 @@ def test_header_symbols_exported():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/soccdpt_hip.h but not exported"
     lib.soccdpt_abi_version.restype = ctypes.c_int
-    assert lib.soccdpt_abi_version() == 1
+    header = open(os.path.join(REPO, "include", "soccdpt_hip.h")).read()
+    declared_version = int(re.search(r"#define\s+SOCCDPT_ABI_VERSION\s+(\d+)", header).group(1))
+    from soccdpt_amd import lib as binding
+    # one version number in three places: the header, the compiled library, the ctypes binding (it had never moved)
+    assert lib.soccdpt_abi_version() == declared_version == binding.ABI_VERSION >= 3
+
+
+def test_binding_struct_sizes_match_the_library():
+    """The ctypes mirrors of the public structs have exactly the size the LIBRARY was compiled with (soccdpt_sizeof): a field added to
+    soccdpt_igemm_args / soccdpt_config without the binding following is caught here and at load_library()."""
+    from soccdpt_amd.lib import IgemmArgs, KernelStat, SoccdptConfig, load_library
+    L = load_library()
+    assert L.soccdpt_sizeof(0) == ctypes.sizeof(SoccdptConfig)
+    assert L.soccdpt_sizeof(1) == ctypes.sizeof(IgemmArgs)
+    assert L.soccdpt_sizeof(2) == ctypes.sizeof(KernelStat)
+    assert L.soccdpt_sizeof(99) == 0
 
 
 def test_binding_struct_matches_header():

@@ -193,3 +193,46 @@ def test_training_loss_is_all_reduced_before_the_scheduler(tmp_path):
     a, b = np.load(tmp_path / "lrs_0.npy"), np.load(tmp_path / "lrs_1.npy")
     assert np.array_equal(a, b)
     assert a[-1, 1] < a[0, 1]           # the plateau was detected (identically)
+
+
+def _worker_split(rank, world, port, outdir, gb):
+    """The split exchange SOccDPT._finish_occupancy drives at N > 1: start() (all-gather issued), the caller's zero-fill, finish() (wait + OR)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    from oracle import cref
+    from tests.golden_inputs import proj_inputs
+    inv, seg = proj_inputs(seed=13, B=gb, S=64)
+    lo, hi = shard_range(gb, rank, world)
+    bits = torch.from_numpy(cref.project(inv[lo:hi], seg[lo:hi], want=("occ_bits",))["occ_bits"].view(np.int32).copy())
+
+    def or_reduce(g):
+        out = g[0].clone()
+        for i in range(1, g.shape[0]):
+            out |= g[i]
+        return out
+    ex = OccExchange(or_reduce=or_reduce)
+    for _ in range(2):
+        ticket = ex.start(bits)
+        union = ex.finish(None, bits, ticket)
+    assert ex.window_ms() is None            # CPU tensors carry no device events
+    np.save(os.path.join(outdir, f"union_{rank}.npy"), union.numpy())
+    np.save(os.path.join(outdir, f"shard_{rank}.npy"), np.array([lo, hi]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_ranks_split_exchange_64_frames(tmp_path):
+    """BASELINE configs[3]'s shape of the job: a 64-frame global batch over world_size 8 shards 8 x 8 (contiguous, in rank order), and the split
+    exchange (start / finish) leaves every rank with the single-rank union grid.  (The frames here are small synthetic maps; the grid is the real one.)"""
+    gb, world = 64, 8
+    assert [shard_range(gb, r, world) for r in range(world)] == [(8 * r, 8 * r + 8) for r in range(world)]
+    mp.spawn(_worker_split, args=(world, _free_port(), str(tmp_path), gb), nprocs=world, join=True)
+    from oracle import cref
+    from tests.golden_inputs import proj_inputs
+    inv, seg = proj_inputs(seed=13, B=gb, S=64)
+    whole = cref.project(inv, seg, want=("occ_bits",))["occ_bits"].view(np.int32)
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"union_{r}.npy"), whole), r
+        assert list(np.load(tmp_path / f"shard_{r}.npy")) == [8 * r, 8 * r + 8]

@@ -56,6 +56,56 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
     assert "cpu_baseline" not in d                                                         # N = 1 only
 
 
+def test_bench_config3_four_rank_rehearsal_on_one_gpu(gpu_device):
+    """`python bench.py --gpus N --config 3` (dpt_swin2_base_384, 8 frames per rank: BASELINE configs[3] is N = 8, 64 frames) rehearsed with FOUR gloo
+    ranks on the one GPU of a test box -- the pool allows at most 6 processes on a card, so the 8-rank job itself cannot be rehearsed here; the
+    8 x 8 sharding and the 8-rank exchange are covered on CPU (tests/test_dist_cpu.py::test_eight_ranks_split_exchange_64_frames).  The line must
+    name the model, report four ranks, 32 frames, and the exchange window (all-gather + OR, with the rows' zero-fill overlapped)."""
+    import json
+    env = dict(os.environ, SOCCDPT_DIST_REHEARSAL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    bench = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py")
+    r = subprocess.run([sys.executable, bench, "--gpus", "4", "--config", "3", "--steps", "3", "--warmup", "1", "--prewarm", "2"],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["rccl_ranks"] == 4 and len(d["per_rank_ms_per_step"]) == 4
+    assert "swin2_base_384" in d["metric"] and d["config"]["global_batch"] == 32 and d["config"]["batch_per_gpu"] == 8
+    assert d["exchange_window_ms"] is not None and d["exchange_window_ms"] > 0
+    assert d["dtype"].startswith("mixed") and d["tolerance"]["value_meets_tolerance"] is True
+
+
+def test_split_exchange_and_shared_rows_match_the_plain_forward(gpu_device):
+    """One forced rank over RCCL: the split exchange (async all-gather, zero-fill of the dense rows meanwhile, OR, set bits) returns the occupancy
+    grid of the plain forward bit for bit; share_occupancy_rows=True returns the same values as a stride-0 expand of one row."""
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    sd = synth_state_dict(alias_pretrained=True)
+    x = synth_input(3, seed0=41).to(gpu_device)
+
+    def build(**kw):
+        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, **kw)
+        net.load_state_dict(sd, strict=False)
+        return net.eval().to(gpu_device)
+    occ = build()(x)[3]
+    shared = build(share_occupancy_rows=True)(x)[3]
+    torch.cuda.synchronize()
+    assert shared.shape == occ.shape and shared.stride(0) == 0 and torch.equal(shared, occ)
+    # zero + set == expand on the same bits (the two halves the multi-GPU path runs around the collective)
+    net = build()
+    out = net(x)
+    eng = net._engine(gpu_device)
+    occ2 = torch.full_like(out[3], 7.0)
+    eng.occ_zero(3, occ2)
+    eng.occ_set(net.last_occ_bits, 3, occ2)
+    torch.cuda.synchronize()
+    assert torch.equal(occ2, out[3])
+
+
 def test_data_parallel_training_rehearsal(gpu_device):
     """Data-parallel training (soccdpt_amd.dist.attach_training) with TWO ranks on the one GPU of a test box (gloo rehearsal): the exchanged
     gradient equals the mean of the ranks' local gradients, and after two Adam steps both replicas hold bit-identical weights and BatchNorm

@@ -1,0 +1,148 @@
+"""GPU: SOCCDPT_PREC_MIXED -- fp16 MFMA operands with the x3 split only where the precision map asks for it.
+
+Checked against the fp32 CPU oracle on the same synthetic weights: the shipped map keeps every hooked feature map, path_1, inverse depth
+and the class logits within HALF the north star's 1e-3 (relative L2), the depth map also per pixel; the map's two corner cases reproduce
+the uniform modes (all fp16 == SOCCDPT_PREC_F16 bit for bit; all x3 is parity-grade like SOCCDPT_PREC_F16X3)."""
+import os
+import tempfile
+
+import pytest
+import torch
+
+from oracle import soccdpt_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel_l2(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+def _build(prec, model_type="dpt_swin2_tiny_256", backbone="swin2t16_256", dev="cuda:0"):
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, precision=prec, model_type=model_type)
+    sd = synth_state_dict(backbone, alias_pretrained=True)
+    m.load_state_dict(sd, strict=False)
+    return m.eval().to(dev), sd
+
+
+def _errors(m, sd, x, gpu_device, layers, o_inv, o_p1):
+    inv, seg = m.network(x.to(gpu_device))
+    torch.cuda.synchronize()
+    eng = m._engine(gpu_device)
+    B = x.shape[0]
+    errs = {f"feat{s}": _rel_l2(eng.workspace_tensor(B, f"feat{s}").cpu().permute(0, 3, 1, 2), layers[s]) for s in range(4)}
+    errs["path1"] = _rel_l2(eng.workspace_tensor(B, "path1").cpu().permute(0, 3, 1, 2), o_p1)
+    errs["inv"] = _rel_l2(inv.cpu(), o_inv)
+    errs["seg_logits"] = _rel_l2(eng.workspace_tensor(B, "seg_logits").cpu().permute(0, 3, 1, 2), R.seg_logits(sd, o_p1))
+    return errs, inv.cpu(), seg.cpu()
+
+
+@pytest.fixture(scope="module")
+def tiny_oracle():
+    from soccdpt_amd.utils.synth import synth_input, synth_state_dict
+    sd = synth_state_dict(alias_pretrained=True)
+    x = synth_input(2, seed0=4)
+    with torch.no_grad():
+        layers = R.swin_encoder(sd, x, R.ARCHS["swin2t16_256"])
+        o_inv, o_p1 = R.dpt_decoder(sd, layers)
+    return x, layers, o_inv, o_p1
+
+
+def test_mixed_default_map_within_half_the_tolerance(gpu_device, tiny_oracle):
+    """The shipped map of dpt_swin2_tiny_256: all seven quantities <= 5e-4 relative L2 of the fp32 oracle (the north star allows 1e-3), the
+    inverse depth also per pixel: 99.9 % of the pixels within 1e-3 relative, none beyond 3e-3."""
+    from soccdpt_amd.lib import PREC_F16X3, PREC_MIXED
+    x, layers, o_inv, o_p1 = tiny_oracle
+    m, sd = _build(PREC_MIXED)
+    pm = m._engine(gpu_device).prec_map()
+    assert any(v == PREC_F16X3 for v in pm.values()) and not all(v == PREC_F16X3 for v in pm.values())
+    errs, inv, seg = _errors(m, sd, x, gpu_device, layers, o_inv, o_p1)
+    pix = ((inv - o_inv).abs() / o_inv.abs().clamp_min(1e-6)).flatten()
+    p999 = float(pix.kthvalue(int(0.999 * pix.numel())).values)
+    print("mixed (shipped map), relative L2 vs fp32 CPU oracle:", {k: f"{v:.2e}" for k, v in errs.items()},
+          f"inv per pixel: p99.9 {p999:.2e} max {float(pix.max()):.2e}; x3 groups: {sorted(g for g, v in pm.items() if v == PREC_F16X3)}")
+    for k, v in errs.items():
+        assert v <= 5e-4, (k, errs)
+    assert p999 < 1e-3 and float(pix.max()) < 3e-3
+
+
+def test_mixed_all_fp16_is_the_f16_mode_bit_for_bit(gpu_device):
+    from soccdpt_amd.lib import PREC_F16, PREC_MIXED
+    from soccdpt_amd.utils.synth import synth_input
+    x = synth_input(3, seed0=11).to(gpu_device)
+    m, _ = _build(PREC_MIXED)
+    m._engine(gpu_device).prec_map_set("*", PREC_F16)
+    a = [t.clone() for t in m(x)]
+    m16, _ = _build(PREC_F16)
+    b = m16(x)
+    torch.cuda.synchronize()
+    for u, v in zip(a, b):
+        assert torch.equal(torch.nan_to_num(u, nan=-7.0), torch.nan_to_num(v, nan=-7.0))
+
+
+def test_mixed_all_x3_is_parity_grade(gpu_device, tiny_oracle):
+    """Every group promoted: the GEMMs are those of SOCCDPT_PREC_F16X3; what stays fp16 is the attention core (q, k, v operands and the
+    probabilities), so the errors sit between the two uniform modes -- an order of magnitude under the fp16 mode's."""
+    from soccdpt_amd.lib import PREC_F16X3, PREC_MIXED
+    x, layers, o_inv, o_p1 = tiny_oracle
+    m, sd = _build(PREC_MIXED)
+    eng = m._engine(gpu_device)
+    n = eng.prec_map_set("*", PREC_F16X3)
+    assert n == len(eng.prec_map()) and all(v == PREC_F16X3 for v in eng.prec_map().values())
+    errs, _, _ = _errors(m, sd, x, gpu_device, layers, o_inv, o_p1)
+    print("mixed (all x3), relative L2 vs fp32 CPU oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 2e-4, (k, errs)
+
+
+def test_mixed_map_changes_keep_the_zero_halos(gpu_device, tiny_oracle):
+    """A map change moves the zero borders of the 3x3 inputs (2- vs 4-byte elements in the same buffers): the library re-zeroes the
+    workspace itself.  Going x3 -> fp16 -> x3 on one handle must reproduce the first result exactly."""
+    from soccdpt_amd.lib import PREC_F16, PREC_F16X3, PREC_MIXED
+    x = tiny_oracle[0].to(gpu_device)
+    m, _ = _build(PREC_MIXED)
+    eng = m._engine(gpu_device)
+    eng.prec_map_set("*", PREC_F16X3)
+    a = m.network(x)[0].clone()
+    z0 = eng.workspace_zero_fills()
+    eng.prec_map_set("ref*", PREC_F16)
+    m.network(x)
+    eng.prec_map_set("ref*", PREC_F16X3)
+    b = m.network(x)[0]
+    torch.cuda.synchronize()
+    assert eng.workspace_zero_fills() == z0 + 2
+    assert torch.equal(a, b)
+
+
+def test_prec_map_errors(gpu_device):
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, PREC_F16X3, PREC_MIXED
+    m, _ = _build(PREC_MIXED)
+    eng = m._engine(gpu_device)
+    with pytest.raises(RuntimeError, match="no such group"):
+        eng.prec_map_set("s9.b0.attn", PREC_F16X3)
+    with pytest.raises(RuntimeError, match="fmt must be"):
+        eng.prec_map_set("*", PREC_BF16)
+    m16, _ = _build(PREC_F16)
+    with pytest.raises(RuntimeError, match="SOCCDPT_PREC_MIXED"):
+        m16._engine(gpu_device).prec_map_set("*", PREC_F16X3)
+    assert set(m16._engine(gpu_device).prec_map().values()) == {PREC_F16}
+
+
+def test_mixed_hybrid_384_within_tolerance(gpu_device):
+    """dpt_hybrid_384 (BASELINE configs[2]): plain fp16 is at 5.7e-3; the shipped map (x3 where the weight-standardised ResNetV2 bottlenecks
+    amplify operand rounding) keeps all seven quantities inside the north star's 1e-3."""
+    from soccdpt_amd.lib import PREC_MIXED
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _build(PREC_MIXED, "dpt_hybrid_384", "vitb_rn50_384")
+    x = synth_input(1, size=384, seed0=8)
+    torch.set_num_threads(16)
+    with torch.no_grad():
+        layers = R.hybrid_encoder(sd, x)
+        o_inv, o_p1 = R.dpt_decoder(sd, layers)
+    errs, _, _ = _errors(m, sd, x, gpu_device, layers, o_inv, o_p1)
+    print("hybrid_384 mixed (shipped map), relative L2 vs fp32 CPU oracle:", {k: f"{v:.2e}" for k, v in errs.items()})
+    for k, v in errs.items():
+        assert v <= 1e-3, (k, errs)

@@ -1,0 +1,167 @@
+"""The precision map of SOCCDPT_PREC_MIXED: which launch-site groups must run x3 (three fp16 MFMAs per product) and which
+may run plain fp16 so that every output stays inside an error budget at the least device time.
+
+Everything runs through the product path (the C ABI); the reference is the library's own exact-f32 mode on the same weights and inputs.
+
+  1. error side: all groups x3 except ONE in fp16 -> the squared relative-L2 error that group adds to each of the seven quantities
+     (hooked feature maps 0-3, path_1, inverse depth, class logits);
+  2. cost side: all groups fp16 except ONE in x3 -> the device time that promotion costs (median of repeated timed loops);
+  3. greedy selection by error removed per microsecond until every quantity's predicted error (root sum of squares of the fp16 groups)
+     is under the budget, then pruning; the chosen map is run and its real errors / frames/s are reported.
+
+    python tools/precision_map.py [model_type] [batch] [budget] > gpurun_out/precision_map_<model>.json
+"""
+import json
+import math
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from soccdpt_amd.lib import PREC_F16, PREC_F16X3, PREC_F32, PREC_MIXED
+from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
+from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+
+model_type = sys.argv[1] if len(sys.argv) > 1 else "dpt_swin2_tiny_256"
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+budget = float(sys.argv[3]) if len(sys.argv) > 3 else 5e-4
+EB = 2                      # frames of the error runs
+QUANT = ["feat0", "feat1", "feat2", "feat3", "path1", "inv", "seg_logits"]
+dev = torch.device("cuda:0")
+backbone = MODEL_TYPE_TO_BACKBONE[model_type]
+img = backbone_image_size(backbone)
+calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+sd = synth_state_dict(backbone, alias_pretrained=True)
+
+
+def build(prec):
+    net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type=model_type, precision=prec)
+    net.load_state_dict(sd, strict=False)
+    return net.eval().to(dev)
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def quantities(net, x):
+    inv, seg = net.network(x)
+    eng = net._engine(dev)
+    out = {q: eng.workspace_tensor(x.shape[0], q).double() for q in QUANT if q != "inv"}
+    out["inv"] = inv.double()
+    return out
+
+
+def rel(a, b):
+    return float((a - b).norm() / b.norm())
+
+
+xe = synth_input(EB, size=img, seed0=4).to(dev)
+xt = synth_input(B, size=img, seed0=0).to(dev)
+ref = quantities(build(PREC_F32), xe)
+net = build(PREC_MIXED)
+eng = net._engine(dev)
+default_map = eng.prec_map()
+groups = list(default_map)
+
+
+def errors():
+    q = quantities(net, xe)
+    return {k: rel(q[k], ref[k]) for k in QUANT}
+
+
+def step_us(reps=5, steps=40):
+    for _ in range(10):
+        net(xt)
+    ts = []
+    for _ in range(reps):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            net(xt)
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) / steps * 1e6)
+    ts.sort()
+    return ts[len(ts) // 2]
+
+
+eng.prec_map_set("*", PREC_F16X3)
+base_err = errors()
+t_x3 = step_us()
+log("all x3:", {k: f"{v:.2e}" for k, v in base_err.items()}, f"{t_x3:.0f} us/step")
+eng.prec_map_set("*", PREC_F16)
+f16_err = errors()
+t_f16 = step_us()
+log("all fp16:", {k: f"{v:.2e}" for k, v in f16_err.items()}, f"{t_f16:.0f} us/step")
+
+table = {}
+for g in groups:   # error side: one fp16 group among x3
+    eng.prec_map_set("*", PREC_F16X3)
+    eng.prec_map_set(g, PREC_F16)
+    e = errors()
+    table[g] = {"var": {k: max(e[k] ** 2 - base_err[k] ** 2, 0.0) for k in QUANT}}
+for g in groups:   # cost side: one x3 group among fp16
+    eng.prec_map_set("*", PREC_F16)
+    eng.prec_map_set(g, PREC_F16X3)
+    table[g]["cost_us"] = step_us(reps=3, steps=30) - t_f16
+    log(f"{g:14s} +{table[g]['cost_us']:7.1f} us  " + " ".join(f"{math.sqrt(table[g]['var'][k]):.1e}" for k in QUANT))
+
+
+def predict(promoted):
+    return {k: math.sqrt(base_err[k] ** 2 + sum(table[g]["var"][k] for g in groups if g not in promoted)) for k in QUANT}
+
+
+def solve(target):
+    prom = set()
+    cost = lambda g: max(table[g]["cost_us"], 0.5)
+    while True:
+        e = predict(prom)
+        viol = [k for k in QUANT if e[k] > target]
+        if not viol:
+            break
+        best = None
+        for g in groups:
+            if g in prom:
+                continue
+            gain = sum(min(table[g]["var"][k], max(0.0, e[k] ** 2 - target ** 2)) for k in viol)
+            if gain > 0 and (best is None or gain / cost(g) > best[0]):
+                best = (gain / cost(g), g)
+        if best is None:
+            break
+        prom.add(best[1])
+    for g in sorted(prom, key=lambda g: -cost(g)):   # prune what the later picks made redundant
+        if all(v <= target for v in predict(prom - {g}).values()):
+            prom.discard(g)
+    return prom
+
+
+def apply(prom):
+    eng.prec_map_set("*", PREC_F16)
+    for g in prom:
+        eng.prec_map_set(g, PREC_F16X3)
+
+
+results = []
+target = budget * 0.94   # head-room: the variance model is additive, the real errors are not exactly
+for attempt in range(4):
+    prom = solve(target)
+    apply(prom)
+    e = errors()
+    t = step_us()
+    results.append({"target": target, "x3_groups": sorted(prom), "errors": e, "predicted": predict(prom), "us_per_step": t, "frames_per_s": B / t * 1e6})
+    log(f"target {target:.2e}: {len(prom)} x3 groups, {t:.0f} us/step = {B / t * 1e6:.0f} frames/s, worst {max(e.values()):.2e}")
+    if max(e.values()) <= budget:
+        break
+    target *= 0.9
+eng.prec_map_set("*", PREC_F16)
+for g, f in default_map.items():
+    eng.prec_map_set(g, f)
+e = errors()
+t = step_us()
+shipped = {"x3_groups": sorted(g for g, f in default_map.items() if f == PREC_F16X3), "errors": e, "us_per_step": t, "frames_per_s": B / t * 1e6}
+log(f"shipped map: {t:.0f} us/step = {B / t * 1e6:.0f} frames/s, worst {max(e.values()):.2e}")
+print(json.dumps({"model": model_type, "B": B, "budget": budget, "all_x3": {"errors": base_err, "us_per_step": t_x3},
+                  "all_fp16": {"errors": f16_err, "us_per_step": t_f16}, "groups": table, "solutions": results, "shipped": shipped}, indent=1))
