@@ -1,0 +1,784 @@
+// The implicit-GEMM tile of igemm.hip as a device function, shared by the stand-alone kernel (igemm.hip: one workgroup = one tile) and the
+// XCD-local persistent stage kernel (stage_xcd.hip: a workgroup walks the tiles of one phase after another).  Design notes: igemm.hip.
+#pragma once
+#include <type_traits>
+
+#include "gelu.h"
+#include "half16.h"
+#include "igemm.h"
+
+namespace soccdpt {
+
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+struct f16_t { uint16_t v; };  // element tag of the fp16 instantiations (SOCCDPT_PREC_F16); bf16_t tags bf16, float exact f32
+
+// BK_ is the k-tile depth in bf16 elements; a tile row is ROWB = 2*BK_ bytes (128 or 64).  With f32 operands
+// (SOCCDPT_PREC_F32) the same byte geometry holds BK_/2 elements per row.
+// MF_: MFMA shape of the 16-bit instantiations: 16 = v_mfma_f32_16x16x32 (a wave tile is TM x TN tiles of 16 x 16), 32 = v_mfma_f32_32x32x16 (a wave tile
+// is (BM/WM/32) x (BN/WN/32) tiles of 32 x 32; half the MFMA issue slots per FLOP).  Same LDS bytes per FLOP for the same wave tile.
+template <int BM_, int BN_, int BK_, int WM_, int WN_, int NS_, int MF_ = 16>
+struct Cfg {
+    static constexpr int BM = BM_, BN = BN_, BK = BK_, WM = WM_, WN = WN_, NS = NS_, MF = MF_;  // NS: LDS stages (tiles in flight + 1)
+    static constexpr int THREADS = WM * WN * 64;
+    static constexpr int ROWB = BK * 2;    // bytes per LDS tile row
+    static constexpr int CPR = ROWB / 16;  // 16-byte chunks per row
+    static constexpr int X_BYTES = BM * ROWB, W_BYTES = BN * ROWB;
+    static constexpr int STAGE = X_BYTES + W_BYTES;
+    static constexpr int X_LOADS = X_BYTES / 16 / THREADS;
+    static constexpr int W_LOADS = W_BYTES / 16 / THREADS;
+    static constexpr int TM = BM / WM / 16, TN = BN / WN / 16;  // 16x16 tiles per wave
+    static constexpr int KS = BK / 32;
+    static constexpr int LOADS = X_LOADS + W_LOADS;  // LDS-DMA instructions per thread per k-tile
+    static_assert(X_LOADS * THREADS * 16 == X_BYTES && W_LOADS * THREADS * 16 == W_BYTES, "tile/threads mismatch");
+    static_assert(NS >= 2 && (NS - 2) * LOADS <= 63, "vmcnt immediate is 6 bits");
+};
+
+template <int BK, int MF = 16>
+__device__ __forceinline__ int swz_of_row(int row) {
+    // 32 x 32 MFMA fragments: the 32 lanes of a half-wave read 32 ROWS at ONE chunk; ds_read_b128 serves lane groups {0-3, 12-15, 20-27} /
+    // {4-11, 16-19, 28-31}: rows of equal parity share a 128-byte bank half, (row >> 1) & 7 gives each of a group's 8 such rows its own slot
+    if constexpr (MF == 32 && BK == 64) return (row >> 1) & 7;
+    if constexpr (BK == 128) return row & 15;        // 256-byte rows (one full bank sweep each): 16 chunks
+    else if constexpr (BK == 64) return row & 7;     // 128-byte rows: 8 chunks
+    else return (-(row >> 2)) & 3;                   // 64-byte rows: 4 chunks, rows r and r+4 share banks
+}
+
+// T = bf16_t (v_mfma_f32_16x16x32_bf16), f16_t (v_mfma_f32_16x16x32_f16), float (v_mfma_f32_16x16x4_f32, exact f32) or x3_t: split-fp16 operands
+// (half16.h: every element an fp16 pair hi, lo * 2^11 in the 4-byte-per-element x3 layout; three v_mfma_f32_16x16x32_f16 per product --
+// hi hi into `acc`, hi lo + lo hi into a second accumulator set folded in with 2^-11 after the k-loop: SOCCDPT_PREC_F16X3).  The x3 tiles share
+// the f32 tiles' byte geometry (128-byte LDS rows = 32 elements = one MFMA k-step), staging code and epilogues.
+// LN: the fused post-norm LayerNorm + residual epilogue (d.ln_g) instead of the generic one; a separate instantiation so that
+// its registers (row statistics) do not inflate the generic kernels (measured: 110 -> 158 VGPRs, one block per CU less).
+// SK: split-K.  gridDim.x = tiles x d.splitk; every workgroup accumulates its slice of the k-tiles, stores the f32 partial
+// tile to d.sk_part[split][M][N], and the LAST workgroup to arrive at the tile (a counter in d.sk_count, left at 0 again) sums
+// the splitk partials in split order -- deterministic, no float atomics -- and runs the epilogue.  No workgroup ever waits
+// for another one.  For long-K problems whose output grid cannot fill the 256 CUs (coarse decoder levels, stage-3 fc2).
+// ST: GroupNorm statistics of the raw output (d.gn_stats): per-tile per-group partial sums, finished by the last workgroup of each
+// sample (same fence-free sc1 exchange as SK).  ResNetV2 stages of the ViT-hybrid encoder (csrc/hybrid.hip applies the normalisation).
+// GEN: the generalised addressing (strided / un-haloed / gathered convolution, row groups, second A segment) and the diagnostics stamps.
+// A separate instantiation: carried by every launch they cost the Swin models 1.5 % of the forward (A/B in one GPU call, tools/ab_bench.sh).
+// One output tile `bid` (logical id: n-tile fastest, split fastest of all under SK) of the launch described by d.  `smem`: C::NS * C::STAGE bytes
+// of LDS, free on entry (callers that run several tiles in a row put a workgroup barrier between them).
+template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
+__device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, int ntiles, int bid, char* smem) {
+    constexpr int BM = C::BM, BN = C::BN;
+    constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
+    constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
+    constexpr bool F16 = std::is_same<T, f16_t>::value;
+    constexpr bool X3 = std::is_same<T, x3_t>::value;
+    static_assert(!X3 || C::ROWB >= 128, "an x3 k-step (32 elements) is 128 bytes of a tile row");
+    constexpr int MF = C::MF;
+    static_assert(MF == 16 || (MF == 32 && sizeof(T) == 2 && C::BK == 64 && !LN && !SK && !ST), "32x32x16 tiles: 16-bit operands, 64-deep k-tiles, plain epilogue");
+    // epilogue view of a wave's accumulators, common to both MFMA shapes: TME m-tiles x TNE groups of 4 consecutive channels per lane;
+    // m_of(j) / n_of(i) = the pixel / first channel a lane owns in group (i, j)
+    constexpr int TME = MF == 32 ? BM / C::WM / 32 : C::TM;
+    constexpr int TNE = MF == 32 ? (BN / C::WN / 32) * 4 : C::TN;
+    const T* const Xp = static_cast<const T*>(d.X);
+    const T* const Wtp = static_cast<const T*>(d.Wt);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WN, wn = wave % C::WN;
+    if (GEN && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
+
+    int split = 0, kbase = 0;
+    if constexpr (SK) {  // splits of one tile are consecutive logical ids: same XCD, their partials meet in one L2
+        split = bid % d.splitk;
+        bid /= d.splitk;
+        kbase = (int)((long)split * nk / d.splitk);
+        nk = (int)((long)(split + 1) * nk / d.splitk) - kbase;
+    }
+    const int tile_id = bid;
+    const int nt = bid % ntiles, mt = bid / ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    auto m_of = [&](int j) { return m0 + wm * (BM / C::WM) + (MF == 32 ? j * 32 + (lane & 31) : j * 16 + (lane & 15)); };
+    auto n_of = [&](int i) { return n0 + wn * (BN / C::WN) + (MF == 32 ? (i >> 2) * 32 + (i & 3) * 8 + (lane >> 5) * 4 : i * 16 + (lane >> 4) * 4); };
+    const int Ktot = d.taps * d.Cin;
+    const int Wp = d.W + 2;                 // OUTPUT halo geometry (out_halo / ln_halo stores)
+    const bool conv_addr = d.taps == 9 || (GEN && d.gather1);
+    const int Wpi = GEN ? (d.Wi ? d.Wi : d.W) + 2 * d.in_halo : d.W + 2;   // INPUT image geometry
+    const int Hpi = GEN ? (d.Hi ? d.Hi : d.H) + 2 * d.in_halo : d.H + 2;
+
+    // ---- per-thread staging sources (element offsets) ----
+    uint32_t x_off[C::X_LOADS], x_off2[C::X_LOADS], w_off[C::W_LOADS];
+#pragma unroll
+    for (int i = 0; i < C::X_LOADS; ++i) {
+        const int cid = i * C::THREADS + tid;
+        const int row = cid / C::CPR, c = cid % C::CPR;
+        int m = m0 + row;
+        m = m < d.M ? m : d.M - 1;
+        uint32_t base, base2 = 0;
+        if (conv_addr) {
+            const int hw = d.H * d.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / d.W, x = rem - y * d.W;
+            if constexpr (GEN) base = (uint32_t)(((b * Hpi + y * d.stride + d.in_halo - d.pad) * Wpi + x * d.stride + d.in_halo - d.pad) * d.Cin);
+            else base = (uint32_t)(((b * Hpi + y) * Wpi + x) * d.Cin);
+        } else if (GEN && d.grp_rows) {
+            const int g = m / d.grp_rows, r = m - g * d.grp_rows;
+            const uint32_t gb = (uint32_t)((long long)g * d.grp_stride);
+            base = gb + (uint32_t)d.grp_off + (uint32_t)r * (uint32_t)d.ldx;
+            base2 = gb + (uint32_t)d.seg2_off;
+        } else {
+            base = (uint32_t)m * (uint32_t)d.ldx;
+        }
+        const uint32_t sw = (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
+        x_off[i] = base + sw;
+        x_off2[i] = base2 - base;   // delta to the second-segment row (mod 2^32), added when the k-tile lies in the second segment
+    }
+#pragma unroll
+    for (int i = 0; i < C::W_LOADS; ++i) {
+        const int cid = i * C::THREADS + tid;
+        const int row = cid / C::CPR, c = cid % C::CPR;
+        int n = n0 + row;
+        n = n < d.N ? n : d.N - 1;
+        if (GEN && d.wt_grp_rows) {   // weight row groups: the tile's rows belong to ONE group (wt_grp_rows % BN == 0): a shifted view of the same matrix
+            const int g = n0 / d.wt_grp_rows, ky = g / 3, kx = g - ky * 3;
+            const uint32_t shift = d.wt_kx ? (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + kx * d.wt_kx)
+                                           : (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + (kx - 1) + (kx != 1 ? d.wt_odd : 0));
+            w_off[i] = (uint32_t)(n - g * d.wt_grp_rows) * (uint32_t)Ktot + shift + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
+        } else
+        w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK, C::MF>(row)) * EPC);
+    }
+
+    auto stage = [&](int kt, int buf) {
+        kt += kbase;
+        uint32_t xk, wk = (uint32_t)kt * BK;  // elements of T
+        bool seg2 = false;
+        if (d.taps == 9) {
+            const int tap = kt / kpt, kc = kt - tap * kpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            xk = (uint32_t)((ky * Wpi + kx) * d.Cin + kc * BK);
+        } else if (GEN && d.seg2_k && (int)wk >= d.seg2_k) {   // wave-uniform: the per-group row (ViT readout token)
+            seg2 = true;
+            xk = wk - (uint32_t)d.seg2_k;
+        } else {
+            xk = wk;
+        }
+        char* sb = smem + buf * C::STAGE;
+#pragma unroll
+        for (int i = 0; i < C::X_LOADS; ++i) {
+            const T* g = Xp + (x_off[i] + ((GEN && seg2) ? x_off2[i] : 0u)) + xk;   // a VALUE select: selecting between the two arrays demotes them (and d) to scratch
+            char* l = sb + (i * C::THREADS + wave * 64) * 16;  // wave-uniform base; HW adds lane*16
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < C::W_LOADS; ++i) {
+            const T* g = Wtp + w_off[i] + wk;
+            char* l = sb + C::X_BYTES + (i * C::THREADS + wave * 64) * 16;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)l, 16, 0, 0);
+        }
+    };
+
+    f32x4 acc[TNE][TME];
+#pragma unroll
+    for (int i = 0; i < TNE; ++i)
+#pragma unroll
+        for (int j = 0; j < TME; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 accx[X3 ? TNE : 1][X3 ? TME : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
+    if constexpr (X3) {
+#pragma unroll
+        for (int i = 0; i < TNE; ++i)
+#pragma unroll
+            for (int j = 0; j < TME; ++j) accx[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+    constexpr int TN32 = MF == 32 ? BN / C::WN / 32 : 1, TM32 = MF == 32 ? BM / C::WM / 32 : 1;
+    f32x16_t acc32[TN32][TM32];   // MF == 32: the 32 x 32 accumulators of the main loop (re-viewed as `acc` groups for the epilogue)
+    if constexpr (MF == 32) {
+#pragma unroll
+        for (int i = 0; i < TN32; ++i)
+#pragma unroll
+            for (int j = 0; j < TM32; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc32[i][j][r] = 0.f;
+    }
+
+    // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
+    // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
+    // its own.  Big tiles prefetch only the bias (their residual rows would cost 64 registers).
+    constexpr bool PRE = !SK && (TNE * TME <= 8);
+    constexpr bool PREB = !SK;   // the bias alone is cheap enough (TN x 4 registers) for every tile size: 128x128 convs 338 -> 323 us
+    float4 bias_pre[PREB ? TNE : 1];
+    float4 res1_pre[PRE ? TNE : 1][PRE ? TME : 1];
+    if constexpr (PREB) {
+#pragma unroll
+        for (int i = 0; i < TNE; ++i) {
+            int n = n_of(i);
+            n = n < d.N ? n : 0;
+            bias_pre[i] = d.bias ? *reinterpret_cast<const float4*>(d.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PRE)
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                int m = m_of(j);
+                m = m < d.M ? m : d.M - 1;
+                res1_pre[i][j] = d.res1 ? *reinterpret_cast<const float4*>(d.res1 + (size_t)m * d.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        asm volatile("" ::: "memory");
+    }
+
+    // fragment read offsets (bytes within a stage), constant per lane
+    const int frow = lane & 15, fq = lane >> 4;
+    const int fswz = swz_of_row<C::BK, C::MF>(frow);
+    int xr_off[C::KS], wr_off[C::KS];
+#pragma unroll
+    for (int ks = 0; ks < C::KS; ++ks) {
+        const int q = ((ks * 4 + fq) ^ fswz) * 16;
+        xr_off[ks] = (wm * C::TM * 16 + frow) * C::ROWB + q;
+        wr_off[ks] = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB + q;
+    }
+    // x3: k-step s of a row covers units 4s .. 4s+3 (8 elements each); lane quarter fq takes unit u = 4s + fq, whose hi chunk is 2u + (u & 1)
+    // and lo chunk 2u + 1 - (u & 1) (half16.h) -- with the row's XOR swizzle the 16-lane groups of ds_read_b128 hit 16 distinct bank slots
+    constexpr int KSX = X3 ? C::ROWB / 128 : 1;
+    int x3h_off[KSX], x3l_off[KSX];   // byte offsets of the hi / lo chunk inside a tile row (before the row base)
+    if constexpr (X3) {
+#pragma unroll
+        for (int ks = 0; ks < KSX; ++ks) {
+            const int u = ks * 4 + fq;
+            x3h_off[ks] = ((2 * u + (u & 1)) ^ fswz) * 16;
+            x3l_off[ks] = ((2 * u + 1 - (u & 1)) ^ fswz) * 16;
+        }
+    }
+    const int x_row0 = (wm * C::TM * 16 + frow) * C::ROWB, w_row0 = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB;
+    // 32 x 32 x 16 fragments: lane (row r32, half h2) reads chunk 2 ks + h2 of k-step ks (16 elements per step)
+    constexpr int KS32 = MF == 32 ? C::BK / 16 : 1;
+    int x32_off[KS32], w32_off[KS32];
+    if constexpr (MF == 32) {
+        const int r32 = lane & 31, h2 = lane >> 5, sw32 = swz_of_row<C::BK, C::MF>(r32);
+#pragma unroll
+        for (int ks = 0; ks < KS32; ++ks) {
+            const int q = ((ks * 2 + h2) ^ sw32) * 16;
+            x32_off[ks] = (wm * (BM / C::WM) + r32) * C::ROWB + q;
+            w32_off[ks] = C::X_BYTES + (wn * (BN / C::WN) + r32) * C::ROWB + q;
+        }
+    }
+
+    // ---- NS-stage LDS ring: up to NS-1 k-tiles of LDS-DMA in flight, ONE raw barrier per k-tile.
+    // Tile kt is waited for with a COUNTED vmcnt (the NS-2 younger tiles stay in flight), then the barrier
+    // both publishes it to the other waves and retires everybody's reads of ring slot (kt-1)%NS, which the
+    // next LDS-DMA group overwrites.  (__syncthreads() would drain vmcnt(0): cdna_hip_programming.md §5.)
+    auto wait_tile = [&](int kt) {
+        if (kt + C::NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::NS - 2) * C::LOADS) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+#pragma unroll
+    for (int s0 = 0; s0 < C::NS - 1; ++s0)
+        if (s0 < nk) stage(s0, s0);
+    // (Tried and removed: running the wm == 1 wave row of the 8-wave tiles half a k-step out of phase, | M1' R0 M0 R1 | against
+    //  | R0 M0 R1 M1 |, so that the two waves of a SIMD alternate load and MFMA halves: 5-8 % on the 256x256 / 128x256 convs.
+    //  It was dropped when wrong seg pixels showed up in the eager two-stream mode; the same signature was later traced to
+    //  packed-f32 math in the seg head's 1x1 kernel under co-residency, so the schedule was probably
+    //  innocent -- but the retuned heuristics no longer pick the tiles it applied to.)
+    {
+    for (int kt = 0; kt < nk; ++kt) {
+        wait_tile(kt);
+        __builtin_amdgcn_s_barrier();
+        if (GEN && kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
+        if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
+        const char* sb = smem + (kt % C::NS) * C::STAGE;
+        if constexpr (X3) {
+#pragma unroll
+            for (int ks = 0; ks < KSX; ++ks) {
+                h16x8 wh[C::TN], wl[C::TN], xh[C::TM], xl[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) {
+                    wh[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + x3h_off[ks] + i * 16 * C::ROWB);
+                    wl[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + x3l_off[ks] + i * 16 * C::ROWB);
+                }
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) {
+                    xh[j] = *reinterpret_cast<const h16x8*>(sb + x_row0 + x3h_off[ks] + j * 16 * C::ROWB);
+                    xl[j] = *reinterpret_cast<const h16x8*>(sb + x_row0 + x3l_off[ks] + j * 16 * C::ROWB);
+                }
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TM; ++j) {
+                        acc[i][j] = mfma_16x16x32<true>(wh[i], xh[j], acc[i][j]);
+                        accx[i][j] = mfma_16x16x32<true>(wh[i], xl[j], accx[i][j]);
+                        accx[i][j] = mfma_16x16x32<true>(wl[i], xh[j], accx[i][j]);
+                    }
+            }
+        } else if constexpr (MF == 32) {
+#pragma unroll
+            for (int ks = 0; ks < KS32; ++ks) {
+                h16x8 wf[TN32], xf[TM32];
+#pragma unroll
+                for (int i = 0; i < TN32; ++i) wf[i] = *reinterpret_cast<const h16x8*>(sb + w32_off[ks] + i * 32 * C::ROWB);
+#pragma unroll
+                for (int j = 0; j < TM32; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + x32_off[ks] + j * 32 * C::ROWB);
+#pragma unroll
+                for (int i = 0; i < TN32; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM32; ++j) acc32[i][j] = mfma_32x32x16<F16>(wf[i], xf[j], acc32[i][j]);
+            }
+        } else {
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            if constexpr (sizeof(T) == 2) {
+                h16x8 wf[C::TN], xf[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const h16x8*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TM; ++j)
+                        acc[i][j] = mfma_16x16x32<F16>(wf[i], xf[j], acc[i][j]);
+            } else {
+                // f32: the lane's 16-byte chunk holds 4 consecutive k; element e of every lane forms MFMA k-step e
+                // (A and B use the same lane->k map, so any k permutation is a valid dot product order)
+                f32x4 wf[C::TN], xf[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) wf[i] = *reinterpret_cast<const f32x4*>(sb + wr_off[ks] + i * 16 * C::ROWB);
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const f32x4*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                        for (int j = 0; j < C::TM; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i][e], xf[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        }
+    }
+    }
+    if constexpr (MF == 32) {   // accumulator register 4 g + r of tile (i, j) = channel 8 g + 4 h2 + r of pixel (lane & 31): epilogue group (4 i + g, j)
+#pragma unroll
+        for (int i = 0; i < TN32; ++i)
+#pragma unroll
+            for (int j = 0; j < TM32; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i * 4 + g][j][r] = acc32[i][j][4 * g + r];
+    }
+    if constexpr (X3) {   // fold the cross terms in: a b = hi hi + 2^-11 (hi lo + lo hi)
+#pragma unroll
+        for (int i = 0; i < TNE; ++i)
+#pragma unroll
+            for (int j = 0; j < TME; ++j)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaf(accx[i][j][r], 1.0f / 2048.f, acc[i][j][r]);
+    }
+
+    const int N = d.N;
+    if (GEN && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
+    if constexpr (SK) {
+        // Cross-workgroup exchange WITHOUT fences: a release/acquire fence at agent scope writes back / invalidates the whole
+        // per-XCD L2 on gfx950 (measured: ~30 us per split).  Instead every partial is stored and loaded with agent-scope
+        // (sc1, L2-bypassing) relaxed atomics, and "stored before counted" is enforced by s_waitcnt vmcnt(0) + the barrier.
+        const size_t MN = (size_t)d.M * N;
+        float* mine = d.sk_part + (size_t)split * MN;
+        if (d.sk_defer) {   // partial tile out with plain stores; launch_igemm's second launch (sk_reduce_kernel) sums the splits
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                const int m = m_of(j);
+#pragma unroll
+                for (int i = 0; i < TNE; ++i) {
+                    const int n = n_of(i);
+                    if (m < d.M && n < N) *reinterpret_cast<float4*>(mine + (size_t)m * N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                }
+            }
+            return;
+        }
+#pragma unroll
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
+#pragma unroll
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
+                if (m < d.M && n < N) {
+                    float* q = mine + (size_t)m * N + n;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) __hip_atomic_store(q + r, acc[i][j][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this lane's partial stores are acknowledged at device scope
+        __syncthreads();                                   // ... and so are everybody else's in this workgroup
+        unsigned* arrival = reinterpret_cast<unsigned*>(smem);  // the staging ring is free after the barrier above
+        if (tid == 0) *arrival = __hip_atomic_fetch_add(d.sk_count + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*arrival != (unsigned)d.splitk - 1) return;   // not the last split of this tile: done (nobody waits)
+        if (tid == 0) __hip_atomic_store(d.sk_count + tile_id, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+#pragma unroll
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
+#pragma unroll
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
+                f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+                if (m < d.M && n < N) {
+                    for (int sp = 0; sp < d.splitk; ++sp) {   // fixed order: bitwise reproducible
+                        const float* q = d.sk_part + (size_t)sp * MN + (size_t)m * N + n;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[r] += __hip_atomic_load(q + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                }
+                acc[i][j] = sum;
+            }
+        }
+    }
+    if constexpr (LN) {
+        // ---- fused post-norm epilogue: out = (x +) LayerNorm(acc + bias) over the N (<= BN) channels of each row.
+        // A row's channels are spread over the TN tiles x 4 lane groups of a wave and over the WN waves: two-pass mean /
+        // variance with an in-wave shuffle reduction and a cross-wave exchange through LDS (the staging ring is free now).
+        float* red = reinterpret_cast<float*>(smem);  // [BM][WN]
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < TNE; ++i) {
+            const int n = n_of(i);
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if constexpr (PREB) { if (n < N) b4 = bias_pre[i]; }
+            else if (d.bias && n < N) b4 = *reinterpret_cast<const float4*>(d.bias + n);
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
+            }
+        }
+        // the residual rows are requested before the two reduction passes (their latency hides behind the barriers)
+        float4 xres[TNE][TME];
+        if (d.ln_residual) {
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                int m = m_of(j);
+                m = m < d.M ? m : d.M - 1;
+#pragma unroll
+                for (int i = 0; i < TNE; ++i) {
+                    int n = n_of(i);
+                    n = n < N ? n : 0;
+                    xres[i][j] = *reinterpret_cast<const float4*>(d.ln_xf + (size_t)m * N + n);
+                }
+            }
+        }
+        float mean[TME], rstd[TME];
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                float sum = 0.f;
+#pragma unroll
+                for (int i = 0; i < TNE; ++i) {
+                    const int n = n_of(i);
+                    if (n < N) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float t = pass == 0 ? acc[i][j][r] : (acc[i][j][r] - mean[j]) * (acc[i][j][r] - mean[j]);
+                            sum += t;
+                        }
+                    }
+                }
+                sum += __shfl_xor(sum, 16);
+                sum += __shfl_xor(sum, 32);
+                if ((lane >> 4) == 0) red[(wm * TME * 16 + j * 16 + (lane & 15)) * C::WN + wn] = sum;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TME; ++j) {
+                float tot = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < C::WN; ++wv) tot += red[(wm * TME * 16 + j * 16 + (lane & 15)) * C::WN + wv];
+                if (pass == 0) mean[j] = tot / (float)N;
+                else rstd[j] = rsqrtf(tot / (float)N + 1e-5f);
+            }
+            __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < TME; ++j) {
+            const int m = m_of(j);
+            if (m >= d.M) continue;
+            const size_t orow = (size_t)m * N;
+            size_t hrow = 0;
+            if (d.ln_halo) {
+                const int hw = d.H * d.W;
+                const int b = m / hw, rem = m - b * hw;
+                const int y = rem / d.W, x = rem - y * d.W;
+                hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+            }
+#pragma unroll
+            for (int i = 0; i < TNE; ++i) {
+                const int n = n_of(i);
+                if (n >= N) continue;
+                const float4 g4 = *reinterpret_cast<const float4*>(d.ln_g + n), e4 = *reinterpret_cast<const float4*>(d.ln_b + n);
+                float o[4];
+                o[0] = (acc[i][j][0] - mean[j]) * rstd[j] * g4.x + e4.x;
+                o[1] = (acc[i][j][1] - mean[j]) * rstd[j] * g4.y + e4.y;
+                o[2] = (acc[i][j][2] - mean[j]) * rstd[j] * g4.z + e4.z;
+                o[3] = (acc[i][j][3] - mean[j]) * rstd[j] * g4.w + e4.w;
+                if (d.ln_residual) {
+                    const float4 x4 = xres[i][j];
+                    o[0] += x4.x; o[1] += x4.y; o[2] += x4.z; o[3] += x4.w;
+                }
+                *reinterpret_cast<float4*>(d.ln_xf + orow + n) = make_float4(o[0], o[1], o[2], o[3]);
+                if constexpr (sizeof(T) == 2) {
+                    uint2 p;
+                    p.x = pack_h2<F16>(o[0], o[1]);
+                    p.y = pack_h2<F16>(o[2], o[3]);
+                    if (d.out_op) {
+                        if (F16 && d.out_fmt == 3) x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
+                        else *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
+                    }
+                    if (d.ln_halo) {
+                        if (F16 && d.halo_fmt == 3) x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
+                        else *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                    }
+                } else if constexpr (X3) {
+                    uint2 p;
+                    p.x = pack_h2<true>(o[0], o[1]);
+                    p.y = pack_h2<true>(o[2], o[3]);
+                    if (d.out_op) {
+                        if (d.out_fmt == 1) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + orow + n) = p;
+                        else x3_store4(d.out_op, orow + n, o[0], o[1], o[2], o[3]);
+                    }
+                    if (d.ln_halo) {
+                        if (d.halo_fmt == 1) *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.ln_halo) + hrow + n) = p;
+                        else x3_store4(d.ln_halo, hrow + n, o[0], o[1], o[2], o[3]);
+                    }
+                } else {
+                    if (d.ln_halo) *reinterpret_cast<float4*>(static_cast<float*>(d.ln_halo) + hrow + n) = make_float4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        return;
+    } else {
+    // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
+    float dot_part[TME];
+#pragma unroll
+    for (int j = 0; j < TME; ++j) dot_part[j] = 0.f;
+    float gsum[ST ? TNE : 1][4], gsq[ST ? TNE : 1][4];   // ST: per-lane sums over this wave's pixel rows of its 4 channels per n-tile
+    if constexpr (ST) {
+#pragma unroll
+        for (int i = 0; i < TNE; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gsum[i][r] = 0.f; gsq[i][r] = 0.f; }
+    }
+#pragma unroll
+    for (int j = 0; j < TME; ++j) {
+        const int m = m_of(j);
+        const bool mv = m < d.M;
+        size_t orow = (size_t)m * N;
+        size_t hrow = 0;
+        // bilinear source of res2 (4 low-res pixels + weights), computed once per pixel
+        size_t up00 = 0, up01 = 0, up10 = 0, up11 = 0;
+        float uly = 0.f, ulx = 0.f;
+        if ((d.out_halo || d.res2_h) && mv) {
+            const int hw = d.H * d.W;
+            const int b = m / hw, rem = m - b * hw;
+            const int y = rem / d.W, x = rem - y * d.W;
+            hrow = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+            if (d.res2_h) {
+                const float sy = d.H > 1 ? (float)(d.res2_h - 1) / (float)(d.H - 1) : 0.f;
+                const float sx = d.W > 1 ? (float)(d.res2_w - 1) / (float)(d.W - 1) : 0.f;
+                const float fy = sy * (float)y, fx = sx * (float)x;
+                const int y0 = (int)fy, x0 = (int)fx;
+                const int y1 = y0 + (y0 < d.res2_h - 1), x1 = x0 + (x0 < d.res2_w - 1);
+                uly = fy - (float)y0;
+                ulx = fx - (float)x0;
+                const size_t pb = (size_t)b * d.res2_h * d.res2_w;
+                up00 = (pb + (size_t)y0 * d.res2_w + x0) * N;
+                up01 = (pb + (size_t)y0 * d.res2_w + x1) * N;
+                up10 = (pb + (size_t)y1 * d.res2_w + x0) * N;
+                up11 = (pb + (size_t)y1 * d.res2_w + x1) * N;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < TNE; ++i) {
+            const int n = n_of(i);
+            if (!mv || n >= N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if constexpr (PRE) {
+                const float4 b4 = bias_pre[i], r4 = res1_pre[i][j];   // zeros when absent; same (acc + bias) + res1 order as the other branch
+                v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            } else {
+                if constexpr (PREB) {
+                    const float4 b4 = bias_pre[i];
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                } else if (d.bias) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(d.bias + n);
+                    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+                }
+                if (d.res1) {
+                    const float4 r4 = *reinterpret_cast<const float4*>(d.res1 + orow + n);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+            }
+            if (d.res2 && d.res2_h) {
+                const float4 a00 = *reinterpret_cast<const float4*>(d.res2 + up00 + n), a01 = *reinterpret_cast<const float4*>(d.res2 + up01 + n);
+                const float4 a10 = *reinterpret_cast<const float4*>(d.res2 + up10 + n), a11 = *reinterpret_cast<const float4*>(d.res2 + up11 + n);
+                const float hy = 1.f - uly, hx = 1.f - ulx;
+                v[0] += hy * (hx * a00.x + ulx * a01.x) + uly * (hx * a10.x + ulx * a11.x);
+                v[1] += hy * (hx * a00.y + ulx * a01.y) + uly * (hx * a10.y + ulx * a11.y);
+                v[2] += hy * (hx * a00.z + ulx * a01.z) + uly * (hx * a10.z + ulx * a11.z);
+                v[3] += hy * (hx * a00.w + ulx * a01.w) + uly * (hx * a10.w + ulx * a11.w);
+            } else if (d.res2) {
+                const float4 r4 = *reinterpret_cast<const float4*>(d.res2 + orow + n);
+                v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+            }
+            if constexpr (ST) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { gsum[i][r] += v[r]; gsq[i][r] = fmaf(v[r], v[r], gsq[i][r]); }
+            }
+            float a[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                a[r] = d.act == ACT_RELU ? fmaxf(v[r], 0.f) : (d.act == ACT_GELU ? (sizeof(T) == 2 ? gelu_fast(v[r]) : gelu_erf(v[r])) : v[r]);
+            }
+            if (d.out_f32) {
+                const float* s = d.act_on_f32 ? a : v;
+                *reinterpret_cast<float4*>(d.out_f32 + orow + n) = make_float4(s[0], s[1], s[2], s[3]);
+            }
+            if (d.out_op) {
+                if constexpr (sizeof(T) == 2) {
+                    if (F16 && d.out_fmt == 3) x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);   // the next launch reads x3 operands
+                    else {
+                        uint2 p;
+                        p.x = pack_h2<F16>(a[0], a[1]);
+                        p.y = pack_h2<F16>(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    }
+                } else if constexpr (X3) {
+                    if (d.out_op_f32) *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
+                    else if (d.out_fmt == 1) {   // the next launch reads fp16 operands
+                        uint2 p;
+                        p.x = pack_h2<true>(a[0], a[1]);
+                        p.y = pack_h2<true>(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(static_cast<uint16_t*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = p;
+                    } else x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);
+                } else {
+                    *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
+                }
+            }
+            if (d.out_dot) {
+                const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
+                dot_part[j] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+            }
+        }
+    }
+    if constexpr (ST) {
+        // ---- GroupNorm statistics.  (1) in-wave: the 16 lanes that share (lane >> 4) hold the same 4 channels of 16 different pixels.
+        // (2) per-channel sums of the WM wave rows meet in LDS (the staging ring is free after the barrier), (3) one thread per group adds
+        // its gn_cpg channels in a fixed order and publishes the tile's partial with an L2-bypassing store, (4) the last workgroup of the
+        // sample to arrive adds the tile partials in tile order in f64 and writes {mean, rstd}.  Fixed orders everywhere: bitwise
+        // reproducible; no workgroup waits for another one.
+#pragma unroll
+        for (int i = 0; i < TNE; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float a = gsum[i][r], q = gsq[i][r];
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) { a += __shfl_xor(a, o); q += __shfl_xor(q, o); }
+                gsum[i][r] = a; gsq[i][r] = q;
+            }
+        float* red = reinterpret_cast<float*>(smem);   // [WM][BN][2]
+        __syncthreads();
+        if ((lane & 15) == 0) {
+#pragma unroll
+            for (int i = 0; i < TNE; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int ch = wn * TNE * 16 + i * 16 + (lane >> 4) * 4 + r;
+                    red[(wm * BN + ch) * 2] = gsum[i][r];
+                    red[(wm * BN + ch) * 2 + 1] = gsq[i][r];
+                }
+        }
+        __syncthreads();
+        const int cpg = d.gn_cpg, G = N / cpg, gpt = BN / cpg;   // groups in total / per n-tile
+        if (tid < gpt && n0 + tid * cpg < N) {
+            float a = 0.f, q = 0.f;
+            for (int c = 0; c < cpg; ++c)
+#pragma unroll
+                for (int w = 0; w < C::WM; ++w) { a += red[(w * BN + tid * cpg + c) * 2]; q += red[(w * BN + tid * cpg + c) * 2 + 1]; }
+            float* pp = d.gn_part + ((size_t)mt * G + n0 / cpg + tid) * 2;
+            __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(pp + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int tps = d.gn_hw / BM;                 // M tiles per sample (host: gn_hw % BM == 0)
+        const int sample = mt / tps;
+        unsigned* arrival = reinterpret_cast<unsigned*>(smem) + 2 * C::WM * BN;
+        if (tid == 0) *arrival = __hip_atomic_fetch_add(d.gn_count + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        if (*arrival == (unsigned)(tps * ntiles) - 1u) {
+            if (tid == 0) __hip_atomic_store(d.gn_count + sample, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            // All threads share the walk over the sample's tps tile partials: thread (chunk = tid / G, group = tid % G) adds tiles chunk,
+            // chunk + nch, ... (four loads in flight at a time), then the chunks are added in chunk order: a fixed order for a given shape,
+            // so the statistics stay bitwise reproducible.  (One thread per group walking all tps partials with dependent L2-bypassing
+            // loads kept this workgroup alive for ~50 us at 72 tiles per sample -- most of the launch: r03 autotune, ResNetV2 stage 0.)
+            double* red64 = reinterpret_cast<double*>(smem + ((2 * C::WM * BN + 2) * 4 + 7) / 8 * 8);
+            const int nch = C::THREADS / G > 0 ? C::THREADS / G : 1;
+            const int g = tid % G, ch = tid / G;
+            if (ch < nch && G <= C::THREADS) {
+                double a = 0.0, q = 0.0;
+                const float* base = d.gn_part + ((size_t)sample * tps * G + g) * 2;
+                int t = ch;
+                for (; t + 3 * nch < tps; t += 4 * nch) {
+                    float va[4], vq[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const float* pp = base + (size_t)(t + u * nch) * G * 2;
+                        va[u] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        vq[u] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) { a += (double)va[u]; q += (double)vq[u]; }
+                }
+                for (; t < tps; t += nch) {
+                    const float* pp = base + (size_t)t * G * 2;
+                    a += (double)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    q += (double)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                red64[(ch * G + g) * 2] = a;
+                red64[(ch * G + g) * 2 + 1] = q;
+            }
+            __syncthreads();
+            if (tid < G) {
+                double a = 0.0, q = 0.0;
+                for (int c2 = 0; c2 < nch; ++c2) { a += red64[(c2 * G + tid) * 2]; q += red64[(c2 * G + tid) * 2 + 1]; }
+                const double cnt = (double)d.gn_hw * cpg;
+                const double mean = a / cnt;
+                double var = q / cnt - mean * mean;
+                var = var > 0.0 ? var : 0.0;
+                d.gn_stats[((size_t)sample * G + tid) * 2] = (float)mean;
+                d.gn_stats[((size_t)sample * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+            }
+        }
+    }
+    if (GEN && d.stamps) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) d.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+    }
+    if (MF == 16 && d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
+#pragma unroll
+        for (int j = 0; j < TME; ++j) {
+            float s = dot_part[j];
+            s += __shfl_xor(s, 16);
+            s += __shfl_xor(s, 32);
+            const int m = m_of(j);
+            if ((lane >> 4) == 0 && m < d.M) d.out_dot[m] = fmaxf(s + d.dot_b, 0.f);
+        }
+    }
+    }  // generic epilogue
+}
+
+template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
+__global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // XCD-aware bijective remap: consecutive logical tiles -> same XCD (blocks b, b+8 share one)
+    int bid = blockIdx.x;
+    {
+        const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    }
+    igemm_tile<C, T, LN, SK, ST, GEN>(d, nk, kpt, ntiles, bid, smem);
+}
+
+}  // namespace soccdpt

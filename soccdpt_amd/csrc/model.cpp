@@ -623,8 +623,12 @@ void model_prec_default(Handle& h) {
             x3({"rn.s0", "rn.s1", "rn.s2", "ro1", "oc0", "oc1", "oc2", "oc3", "head.s1"});
             break;
         case SOCCDPT_BACKBONE_SWIN2B24_384:
-            // profiles/r04_precision_map_base384.json (B = 8, budget 5e-4)
-            x3({"s1.*", "s2.*", "s3.b0.attn", "s3.b1.attn", "merge1", "merge2", "lrn2", "lrn3", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            // profiles/r04_precision_map_base384.json (B = 8, budget 5e-4): worst of the seven quantities 4.5e-4 (fp16 everywhere: 1.2e-3 on path_1 --
+            // the 24-block encoder does not meet the north star in plain fp16)
+            x3({"s0.b0.attn", "s0.b0.mlp", "s0.b1.attn", "merge0", "s1.b0.attn", "s1.b0.mlp", "s1.b1.attn", "s1.b1.mlp", "merge1",
+                "s2.b0.attn", "s2.b0.mlp", "s2.b1.attn", "s2.b1.mlp", "s2.b2.attn", "s2.b2.mlp", "s2.b3.attn", "s2.b3.mlp", "s2.b4.attn", "s2.b5.attn", "s2.b5.mlp",
+                "s2.b6.attn", "s2.b7.attn", "s2.b8.attn", "s2.b10.attn", "s2.b15.attn", "merge2", "s3.b0.attn", "s3.b0.mlp", "s3.b1.attn",
+                "lrn2", "lrn3", "ref2", "oc0", "oc1", "oc2", "oc3"});
             break;
         default:
             // profiles/r04_precision_map_tiny256.json (B = 8, budget 5e-4): worst of the seven quantities 4.6e-4 (fp16 everywhere: 9.8e-4).  Stage 0's
