@@ -79,6 +79,14 @@ struct x3_t { uint32_t v; };   // element tag of the x3 instantiations: 4 bytes 
 // of 2^-24 absolute) below |v| ~ 6e-8.  There is no per-tensor exponent shift: callers whose values live below ~1e-4 (gradients under a large
 // batch mean) scale by a power of two first (the training step's loss scale, soccdpt_hip.h).
 __device__ __forceinline__ void x3_split(float v, _Float16& hi, _Float16& lo) {
+    // No contraction across this function's boundary: callers pass products (`acc * inv`), and whether `v - hi` became fma(acc, inv, -hi) -- the
+    // exact product, a different lo -- used to depend on the code around the inlined call: the same attention body gave different lo words as a
+    // stand-alone kernel and inside the persistent stage kernel (round 4; 3 % of the words of one tensor).
+#pragma clang fp contract(off)
+    // ... and no single-rounding shortcut either: with v = a * b in the caller the compiler may emit v_fma_mixlo_f16 (the EXACT product rounded once to
+    // fp16) for the conversion below, which differs from fp16(f32(a * b)) whenever the f32 product sits on an fp16 tie -- observed as hi words one ulp
+    // apart (and lo = +-0.5 ulp) between two instantiations of the same body.  The empty asm pins v to its f32 value first.
+    asm volatile("" : "+v"(v));
     hi = (_Float16)v;                          // round to nearest even; overflow -> +-inf, NaN stays NaN
     const float hf = (float)hi;
     float r = (v - hf) * 2048.f;               // exact in f32 for finite hi

@@ -58,9 +58,10 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // GEN: the generalised addressing (strided / un-haloed / gathered convolution, row groups, second A segment) and the diagnostics stamps.
 // A separate instantiation: carried by every launch they cost the Swin models 1.5 % of the forward (A/B in one GPU call, tools/ab_bench.sh).
 // One output tile `bid` (logical id: n-tile fastest, split fastest of all under SK) of the launch described by d.  `smem`: C::NS * C::STAGE bytes
-// of LDS, free on entry (callers that run several tiles in a row put a workgroup barrier between them).
+// of LDS, free on entry (callers that run several tiles in a row put a workgroup barrier between them).  tid: the thread's index in the workgroup
+// (a parameter so that the persistent kernel can keep the per-thread index arithmetic of one phase from being hoisted over all phases).
 template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
-__device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, int ntiles, int bid, char* smem) {
+__device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, int ntiles, int bid, char* smem, const int tid) {
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
     constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
@@ -75,7 +76,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     constexpr int TNE = MF == 32 ? (BN / C::WN / 32) * 4 : C::TN;
     const T* const Xp = static_cast<const T*>(d.X);
     const T* const Wtp = static_cast<const T*>(d.Wt);
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
     if (GEN && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x] = __builtin_amdgcn_s_memrealtime();
@@ -778,7 +779,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    igemm_tile<C, T, LN, SK, ST, GEN>(d, nk, kpt, ntiles, bid, smem);
+    igemm_tile<C, T, LN, SK, ST, GEN>(d, nk, kpt, ntiles, bid, smem, (int)threadIdx.x);
 }
 
 }  // namespace soccdpt
