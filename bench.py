@@ -134,7 +134,8 @@ def train_step_bench(args):
               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": ("f16x3 (split-fp16 operands, f32 accumulate) in every GEMM, f32 tape" if args.amp == "x3" else f"f32 forward, {args.amp}-operand gradient GEMMs" if args.amp else "f32"), "data": "synthetic",
               "config": {"workload": f"SOccDPT_V3 {args.model_type} patch-wise training step, synthetic 1080x1920 targets", "batch_per_gpu": B, "image": S,
                          "encoder_percentage": args.encoder_percentage, "patchwise_percentage": args.patchwise_percentage,
-                         "trainable_tensors": sum(1 for q in net.parameters() if q.requires_grad)},
+                         "trainable_tensors": sum(1 for q in net.parameters() if q.requires_grad),
+                         "drop_path_rate": float(getattr(net, "drop_path_rate", 0.0)), "seg_head_dropout_p": float(net.seg_head[3].p)},
               "split_ms": {"train_forward": round(ev[0].elapsed_time(ev[1]), 2), "criterion": round(ev[1].elapsed_time(ev[2]), 2),
                            "backward_all_unfrozen": round(ev[2].elapsed_time(ev[3]), 2)},
               "launches_per_step": round(launches, 1),

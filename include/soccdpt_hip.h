@@ -103,9 +103,10 @@ int soccdpt_stage_xcd_timeline(void* handle, int on, unsigned long long* host_ou
 /* ---- precision map (SOCCDPT_PREC_MIXED handles only) ----
  * Groups are named launch sites of the forward (one operand format per group: its GEMMs / convolutions, their weights and the
  * activation buffers they read):
- *   Swin-V2:  "s<stage>.b<block>.attn" (qkv + proj), "s<stage>.b<block>.mlp" (fc1 + fc2), "merge<stage>" (PatchMerging reduction)
- *   hybrid:   "rn.s<stage>.b<block>" (one ResNetV2 bottleneck: conv1-3 + shortcut), "pe" (patch-embedding projection),
- *             "vit.b<i>.attn" (qkv + proj), "vit.b<i>.mlp", "ro<k>" (ProjectReadout + 1x1 of act_postprocess3 / 4), "pp4" (its 3x3 / 2)
+ *   Swin-V2:  "s<stage>.b<block>.qkv" / ".proj" / ".fc1" / ".fc2" (the four Linear layers of a block; the attention core between qkv and proj
+ *             always runs the fp16 kernel and hands proj its operands in proj's format), "merge<stage>" (PatchMerging reduction)
+ *   hybrid:   "rn.s<stage>" (one ResNetV2 stage: its bottlenecks share the zero-halo images of their 3x3 inputs), "pe" (patch-embedding
+ *             projection), "vit.b<i>.qkv" / ".proj" / ".fc1" / ".fc2", "ro<k>" (ProjectReadout + 1x1 of act_postprocess3 / 4), "pp4" (its 3x3 / 2)
  *   decoder:  "lrn<l>" (scratch.layer<l+1>_rn), "ref<l>" (the four RCU convolutions of refinenet<l+1>), "oc<l>" (its out_conv),
  *             "head" (output_conv.0 and seg_head.0: both read path_1), "head.d2" (output_conv.2 + .4), "head.s1" (format in which
  *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32)

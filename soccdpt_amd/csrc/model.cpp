@@ -204,10 +204,10 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         for (int i = 0; i < a.vit_depth; ++i) {
             const std::string b = vitblk(i);
             VitBlockW vb{};
-            vb.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * E * E, GF(gvit(i, "attn")));
-            vb.proj_w = cvt(b + "attn.proj.weight", (size_t)E * E, GF(gvit(i, "attn")));
-            vb.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * E * E, GF(gvit(i, "mlp")));
-            vb.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * E * E, GF(gvit(i, "mlp")));
+            vb.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * E * E, GF(gvit(i, "qkv")));
+            vb.proj_w = cvt(b + "attn.proj.weight", (size_t)E * E, GF(gvit(i, "proj")));
+            vb.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * E * E, GF(gvit(i, "fc1")));
+            vb.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * E * E, GF(gvit(i, "fc2")));
             if (run) {
                 if (!vb.qkv_w || !vb.proj_w || !vb.fc1_w || !vb.fc2_w) return 1;
                 vb.qkv_b = W(b + "attn.qkv.bias"); vb.proj_b = W(b + "attn.proj.bias");
@@ -246,10 +246,10 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
         for (int j = 0; j < a.depths[s]; ++j) {
             const std::string b = blk(s, j);
             BlockW bw{};
-            bw.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * C * C, GF(gblk(s, j, "attn")));
-            bw.proj_w = cvt(b + "attn.proj.weight", (size_t)C * C, GF(gblk(s, j, "attn")));
-            bw.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * C * C, GF(gblk(s, j, "mlp")));
-            bw.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * C * C, GF(gblk(s, j, "mlp")));
+            bw.qkv_w = cvt(b + "attn.qkv.weight", (size_t)3 * C * C, GF(gblk(s, j, "qkv")));
+            bw.proj_w = cvt(b + "attn.proj.weight", (size_t)C * C, GF(gblk(s, j, "proj")));
+            bw.fc1_w = cvt(b + "mlp.fc1.weight", (size_t)4 * C * C, GF(gblk(s, j, "fc1")));
+            bw.fc2_w = cvt(b + "mlp.fc2.weight", (size_t)4 * C * C, GF(gblk(s, j, "fc2")));
             bw.qkv_bias = ar.take<float>(3 * C);
             bw.scale = ar.take<float>(H);
             bw.table = ar.take<float>((size_t)(2 * ws - 1) * (2 * ws - 1) * H);
@@ -613,11 +613,11 @@ std::vector<std::string> model_prec_groups(const Handle& h) {
     if (a.hybrid) {
         for (int s = 0; s < 3; ++s) g.push_back(gname("rn.s", s));
         g.push_back("pe");
-        for (int i = 0; i < a.vit_depth; ++i) { g.push_back(gvit(i, "attn")); g.push_back(gvit(i, "mlp")); }
+        for (int i = 0; i < a.vit_depth; ++i) for (const char* part : {"qkv", "proj", "fc1", "fc2"}) g.push_back(gvit(i, part));
         g.push_back("ro0"); g.push_back("ro1"); g.push_back("pp4");
     } else {
         for (int s = 0; s < 4; ++s) {
-            for (int j = 0; j < a.depths[s]; ++j) { g.push_back(gblk(s, j, "attn")); g.push_back(gblk(s, j, "mlp")); }
+            for (int j = 0; j < a.depths[s]; ++j) for (const char* part : {"qkv", "proj", "fc1", "fc2"}) g.push_back(gblk(s, j, part));
             if (s < 3) g.push_back(gname("merge", s));
         }
     }
@@ -658,16 +658,12 @@ void model_prec_default(Handle& h) {
         case SOCCDPT_BACKBONE_SWIN2B24_384:
             // profiles/r04_precision_map_base384.json (B = 8, budget 5e-4): worst of the seven quantities 4.5e-4 (fp16 everywhere: 1.2e-3 on path_1 --
             // the 24-block encoder does not meet the north star in plain fp16)
-            x3({"s0.b0.attn", "s0.b0.mlp", "s0.b1.attn", "merge0", "s1.b0.attn", "s1.b0.mlp", "s1.b1.attn", "s1.b1.mlp", "merge1",
-                "s2.b0.attn", "s2.b0.mlp", "s2.b1.attn", "s2.b1.mlp", "s2.b2.attn", "s2.b2.mlp", "s2.b3.attn", "s2.b3.mlp", "s2.b4.attn", "s2.b5.attn", "s2.b5.mlp",
-                "s2.b6.attn", "s2.b7.attn", "s2.b8.attn", "s2.b10.attn", "s2.b15.attn", "merge2", "s3.b0.attn", "s3.b0.mlp", "s3.b1.attn",
-                "lrn2", "lrn3", "ref2", "oc0", "oc1", "oc2", "oc3"});
+            x3({"s0.b0.qkv", "s0.b0.proj", "s0.b0.fc1", "s0.b0.fc2", "s0.b1.qkv", "s0.b1.proj", "merge0", "s1.b0.qkv", "s1.b0.proj", "s1.b0.fc1", "s1.b0.fc2", "s1.b1.qkv", "s1.b1.proj", "s1.b1.fc1", "s1.b1.fc2", "merge1", "s2.b0.qkv", "s2.b0.proj", "s2.b0.fc1", "s2.b0.fc2", "s2.b1.qkv", "s2.b1.proj", "s2.b1.fc1", "s2.b1.fc2", "s2.b2.qkv", "s2.b2.proj", "s2.b2.fc1", "s2.b2.fc2", "s2.b3.qkv", "s2.b3.proj", "s2.b3.fc1", "s2.b3.fc2", "s2.b4.qkv", "s2.b4.proj", "s2.b5.qkv", "s2.b5.proj", "s2.b5.fc1", "s2.b5.fc2", "s2.b6.qkv", "s2.b6.proj", "s2.b7.qkv", "s2.b7.proj", "s2.b8.qkv", "s2.b8.proj", "s2.b10.qkv", "s2.b10.proj", "s2.b15.qkv", "s2.b15.proj", "merge2", "s3.b0.qkv", "s3.b0.proj", "s3.b0.fc1", "s3.b0.fc2", "s3.b1.qkv", "s3.b1.proj", "lrn2", "lrn3", "ref2", "oc0", "oc1", "oc2", "oc3"});
             break;
         default:
             // profiles/r04_precision_map_tiny256.json (B = 8, budget 5e-4): worst of the seven quantities 4.6e-4 (fp16 everywhere: 9.8e-4).  Stage 0's
             // second block, its PatchMerging, the big 3x3 convolutions of refinenet1-3 and both heads stay fp16 (they hold 85 % of the FLOPs).
-            x3({"s0.b0.attn", "s0.b0.mlp", "s1.b0.attn", "s1.b0.mlp", "s1.b1.attn", "s1.b1.mlp", "merge1", "s2.b0.attn", "s2.b0.mlp", "s2.b1.attn", "s2.b1.mlp",
-                "s2.b3.attn", "s2.b4.attn", "s2.b5.attn", "merge2", "s3.b0.attn", "s3.b0.mlp", "s3.b1.attn", "lrn2", "lrn3", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            x3({"s0.b0.qkv", "s0.b0.proj", "s0.b0.fc1", "s0.b0.fc2", "s1.b0.qkv", "s1.b0.proj", "s1.b0.fc1", "s1.b0.fc2", "s1.b1.qkv", "s1.b1.proj", "s1.b1.fc1", "s1.b1.fc2", "merge1", "s2.b0.qkv", "s2.b0.proj", "s2.b0.fc1", "s2.b0.fc2", "s2.b1.qkv", "s2.b1.proj", "s2.b1.fc1", "s2.b1.fc2", "s2.b3.qkv", "s2.b3.proj", "s2.b4.qkv", "s2.b4.proj", "s2.b5.qkv", "s2.b5.proj", "merge2", "s3.b0.qkv", "s3.b0.proj", "s3.b0.fc1", "s3.b0.fc2", "s3.b1.qkv", "s3.b1.proj", "lrn2", "lrn3", "oc0", "oc1", "oc2", "oc3", "head.s1"});
             break;
     }
 }
@@ -875,36 +871,37 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             IgemmDesc d;
             d.X = w.hy_xop; d.Wt = Y.pe_w; d.M = Mp; d.N = E; d.Cin = 1024; d.ldx = 1024; d.bias = Y.pe_b; d.out_f32 = w.vt_y;
             RUN(gemm(d, fPe));
-            const int f0 = GF(gvit(0, "attn"));
+            const int f0 = GF(gvit(0, "qkv"));
             PROF("vit_tokens_ln", 0.0, (double)Mt * E * (8.0 + 4.0 + (f0 >= 2 ? 4 : 2)));
             RUN(launch_vit_tokens_ln(w.vt_y, Y.cls, Y.pos, w.vt_xf, Y.blocks[0].n1_g, Y.blocks[0].n1_b, w.vt_xb, f0, B, NT, E, 1e-6f, st, err));
         }
         for (int i = 0; i < a.vit_depth; ++i) {
             const VitBlockW& vb = Y.blocks[i];
-            const int fa = GF(gvit(i, "attn")), fm = GF(gvit(i, "mlp"));
+            // one format per GEMM: fq (qkv), fp (proj), f1 (fc1), f2 (fc2); each producer writes for its reader
+            const int fq = GF(gvit(i, "qkv")), fp = GF(gvit(i, "proj")), f1 = GF(gvit(i, "fc1")), f2 = GF(gvit(i, "fc2"));
             IgemmDesc d;
             d.X = w.vt_xb; d.Wt = vb.qkv_w; d.M = Mt; d.N = 3 * E; d.Cin = E; d.ldx = E; d.bias = vb.qkv_b;
             if (MIX) { d.out_op = w.vt_qkv; d.out_fmt = 1; }   // mixed mode: fp16 q, k, v for the fp16 attention kernel
-            else to_plain(d, w.vt_qkv, fa);
-            RUN(gemm(d, fa));
-            { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * (fa >= 2 && !MIX ? 4 : 2));
+            else to_plain(d, w.vt_qkv, fq);
+            RUN(gemm(d, fq));
+            { PROF("vit_attention", 4.0 * B * (double)NT * NT * E, (double)Mt * E * 4.0 * (fq >= 2 && !MIX ? 4 : 2));
               const int aprec = MIX ? SOCCDPT_PREC_F16 : h.cfg.precision;
-              RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, aprec, B, NT, a.vit_heads, st, err, (MIX && fa == 3) ? 1 : 0)); }
+              RUN(launch_vit_attention(w.vt_qkv, w.vt_attn, aprec, B, NT, a.vit_heads, st, err, (MIX && fp == 3) ? 1 : 0)); }
             d = IgemmDesc();
             d.X = w.vt_attn; d.Wt = vb.proj_w; d.M = Mt; d.N = E; d.Cin = E; d.ldx = E; d.bias = vb.proj_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;   // x += attn (in place)
-            RUN(gemm(d, fa));
-            { PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + (fm >= 2 ? 4 : 2)));
-              RUN(launch_ln_rows(w.vt_xf, vb.n2_g, vb.n2_b, w.vt_xb, fm, Mt, E, 1e-6f, st, err)); }
+            RUN(gemm(d, fp));
+            { PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + (f1 >= 2 ? 4 : 2)));
+              RUN(launch_ln_rows(w.vt_xf, vb.n2_g, vb.n2_b, w.vt_xb, f1, Mt, E, 1e-6f, st, err)); }
             d = IgemmDesc();
-            d.X = w.vt_xb; d.Wt = vb.fc1_w; d.M = Mt; d.N = 4 * E; d.Cin = E; d.ldx = E; d.bias = vb.fc1_b; d.act = ACT_GELU; d.out_op = w.vt_h;
-            RUN(gemm(d, fm));
+            d.X = w.vt_xb; d.Wt = vb.fc1_w; d.M = Mt; d.N = 4 * E; d.Cin = E; d.ldx = E; d.bias = vb.fc1_b; d.act = ACT_GELU; d.out_op = w.vt_h; d.out_fmt = MIX ? f2 : -1;
+            RUN(gemm(d, f1));
             d = IgemmDesc();
             d.X = w.vt_h; d.Wt = vb.fc2_w; d.M = Mt; d.N = E; d.Cin = 4 * E; d.ldx = 4 * E; d.bias = vb.fc2_b; d.res1 = w.vt_xf; d.out_f32 = w.vt_xf;      // x += mlp (in place)
             for (int k = 0; k < 2; ++k)
                 if (i == a.vit_hooks[k]) { d.out_op = w.vt_tok[k]; d.out_fmt = MIX ? GF(gname("ro", k)) : -1; }   // hooks on blocks[8], blocks[11] (vit.py:168-171): operand copy for the readout GEMM
-            RUN(gemm(d, fm));
+            RUN(gemm(d, f2));
             if (i + 1 < a.vit_depth) {
-                const int fn = GF(gvit(i + 1, "attn"));
+                const int fn = GF(gvit(i + 1, "qkv"));
                 PROF("ln_rows", 0.0, (double)Mt * E * (4.0 + (fn >= 2 ? 4 : 2)));
                 RUN(launch_ln_rows(w.vt_xf, Y.blocks[i + 1].n1_g, Y.blocks[i + 1].n1_b, w.vt_xb, fn, Mt, E, 1e-6f, st, err));
             }
@@ -932,13 +929,13 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
     // Every launch-site group carries its own operand format (uniform modes: the same one everywhere).  A producer writes each operand
     // copy in the format of the group that READS it: fa / fm = this block's attention / MLP group, fnext = the group that reads the
     // block's output (the next block's attention, or the PatchMerging reduction), fhook = the decoder's layer_rn conv of this stage.
-    { const int f0 = GF(gblk(0, 0, "attn"));
+    { const int f0 = GF(gblk(0, 0, "qkv"));
       PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
                            W(ENC + "patch_embed.norm.bias"), w.xf, f0 == 2 ? nullptr : static_cast<bf16_t*>(w.xb), f0 == 2 ? 0 : f0, B, a.img, a.embed, st, err)); }
     // ---- XCD-local persistent form of stages 2-3 (stage_xcd.hip): the same launches recorded as phases of ONE launch, every (block, tensor) in a
     // buffer of its own (Workspace::xblk); everything else of the forward is unchanged ----
-    const bool xcd = xcd_eligible(h, B) && (MIX || GF(gblk(2, 0, "attn")) <= 1) && !w.xblk[0].empty();
+    const bool xcd = xcd_eligible(h, B) && (MIX || GF(gblk(2, 0, "qkv")) <= 1) && !w.xblk[0].empty();
     std::vector<XPhase> xph;
     double xflops = 0.0;
     auto xgemm = [&](IgemmDesc d, int fmt, int rows) -> int {   // one GEMM launch of the chain as a phase (rows = tokens per frame)
@@ -969,8 +966,9 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
             const bool last = j == a.depths[s] - 1;
-            const int fa = GF(gblk(s, j, "attn")), fm = GF(gblk(s, j, "mlp"));
-            const int fnext = !last ? GF(gblk(s, j + 1, "attn")) : (s < 3 ? GF(gname("merge", s)) : fm);
+            // one format per GEMM: fa (qkv), fp (proj), fm (fc1), f2 (fc2); each producer writes its operand copy for the launch that reads it
+            const int fa = GF(gblk(s, j, "qkv")), fp = GF(gblk(s, j, "proj")), fm = GF(gblk(s, j, "fc1")), f2 = GF(gblk(s, j, "fc2"));
+            const int fnext = !last ? GF(gblk(s, j + 1, "qkv")) : (s < 3 ? GF(gname("merge", s)) : f2);
             // the operand copy goes straight into the PatchMerging layout where the reduction GEMM reads 16-bit (or, mixed mode, x3) operands
             const bool to_merge = s < 3 && last && (fnext <= 1 || (MIX && fnext == 3));
             const bool hook = (j == a.hooks[s]);
@@ -995,7 +993,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 ph.kind = XP_ATTN; ph.fmt = MIX ? 1 : fa; ph.rows_per_frame = res * res; ph.ws = wsz; ph.res = res; ph.heads = H;
                 ph.items_per_frame = wsz == 16 ? 2 * H : (H + 3) / 4;
                 ph.qkv = static_cast<const bf16_t*>(b_qkv); ph.bias_acc = bw.bias_acc; ph.scale = bw.scale; ph.attn_out = static_cast<bf16_t*>(b_attn);
-                ph.out_x3 = (MIX && fa == 3) ? 1 : 0;
+                ph.out_x3 = (MIX && fp == 3) ? 1 : 0;
                 xph.push_back(ph);
                 xflops += 4.0 * M * (double)(wsz * wsz) * C;
             } else
@@ -1003,24 +1001,24 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
               if (!MIX && fa >= 2) RUN(launch_window_attention_f32(static_cast<const float*>(b_qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(b_attn), B, res, wsz,
                                                        a.shift(s, j), H, st, err, fa == 3 ? 1 : 0));
               else RUN(launch_window_attention(static_cast<const bf16_t*>(b_qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(b_attn), MIX ? 1 : fa, B, res, wsz,
-                                               a.shift(s, j), H, st, err, (MIX && fa == 3) ? 1 : 0)); }
+                                               a.shift(s, j), H, st, err, (MIX && fp == 3) ? 1 : 0)); }
             const bool fuse_ln = C <= 128;  // whole rows fit one igemm tile; measured: a win for C = 96, a wash at 192, a loss beyond
             d = IgemmDesc();
             d.X = b_attn; d.Wt = bw.proj_w; d.M = M; d.N = C; d.Cin = C; d.ldx = C; d.bias = bw.proj_b;
             if (fuse_ln) {
                 d.ln_g = bw.n1_g; d.ln_b = bw.n1_b; d.ln_xf = w.xf; d.out_op = fm == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fm : -1;
-                RUN(gemm(d, fa));
+                RUN(gemm(d, fp));
             } else if (xs) {
                 d.out_f32 = b_y1;
-                if (xgemm(d, fa, res * res)) return 1;
+                if (xgemm(d, fp, res * res)) return 1;
                 xln(b_y1, bw.n1_g, bw.n1_b, b_xf, b_x1, nullptr, fm, -1, M, C, 1, res, 0);
             } else {
                 d.out_f32 = b_y1;
-                RUN(gemm(d, fa));
+                RUN(gemm(d, fp));
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
                   RUN(launch_ln_residual(b_y1, bw.n1_g, bw.n1_b, b_xf, fm == 2 ? nullptr : static_cast<bf16_t*>(b_x1), nullptr, nullptr, fm == 2 ? 0 : fm, M, C, 1, res, 0, st, err)); }
             }
-            if (fm <= 1 && fnext == fm && (!hook || fhook == fm) && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
+            if (fm <= 1 && f2 == fm && fnext == fm && (!hook || fhook == fm) && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
                 PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
                 RUN(launch_mlp_ln(static_cast<const bf16_t*>(b_x1), b_xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
                                   bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(b_x2), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, fm,
@@ -1029,14 +1027,14 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 continue;
             }
             d = IgemmDesc();
-            d.X = b_x1; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = b_hbuf;
+            d.X = b_x1; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = b_hbuf; d.out_fmt = MIX ? f2 : -1;
             if (xs) { if (xgemm(d, fm, res * res)) return 1; }
             else RUN(gemm(d, fm));
             d = IgemmDesc();
             d.X = b_hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b;
             if (xs) {
                 d.out_f32 = b_y2;
-                if (xgemm(d, fm, res * res)) return 1;
+                if (xgemm(d, f2, res * res)) return 1;
                 xln(b_y2, bw.n2_g, bw.n2_b, b_xf, b_x2, hook ? w.feat[s] : nullptr, fnext, fhook, M, C, 1, res, to_merge ? 1 : 0);
                 merged = to_merge;
                 continue;
@@ -1044,10 +1042,10 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             if (fuse_ln) {
                 d.ln_g = bw.n2_g; d.ln_b = bw.n2_b; d.ln_xf = w.xf; d.out_op = fnext == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fnext : -1;   // C <= 128: never a persistent-path stage; the LayerNorm epilogue writes plain rows (merge_gather follows)
                 if (hook) { d.ln_halo = w.feat[s]; d.H = res; d.W = res; d.halo_fmt = MIX ? fhook : -1; }
-                RUN(gemm(d, fm));
+                RUN(gemm(d, f2));
             } else {
             d.out_f32 = b_y2;
-            RUN(gemm(d, fm));
+            RUN(gemm(d, f2));
             { PROF("ln_residual", 0.0, (double)M * C * 14.0);
               RUN(launch_ln_residual(b_y2, bw.n2_g, bw.n2_b, b_xf, fnext == 2 ? nullptr : static_cast<bf16_t*>(b_x2),
                                      (hook && fhook != 2) ? static_cast<bf16_t*>(w.feat[s]) : nullptr, (hook && fhook == 2) ? static_cast<float*>(w.feat[s]) : nullptr,
@@ -1056,13 +1054,13 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             }
         }
         if (s < 3 && xs) {   // stage 2 -> 3 inside the persistent launch: reduction GEMM on the merged operand layout, LayerNorm without residual
-            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "attn"));
+            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "qkv"));
             IgemmDesc d;
             d.X = w.x_hbm; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.x_ym;
             if (xgemm(d, fg, res * res / 4)) return 1;
             xln(w.x_ym, P.merge[s].g, P.merge[s].b, w.x_xf3, w.x_xbm, nullptr, fn, -1, M / 4, 2 * C, 0, res / 2, 0);
         } else if (s < 3) {
-            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "attn"));
+            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "qkv"));
             if (!merged) { PROF("merge_gather", 0.0, (double)M * C * 4.0);
               RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, fg >= 2 ? 4 : 2, st, err)); }
             IgemmDesc d;

@@ -45,15 +45,32 @@ def gather_occ_bits(bits: torch.Tensor, group=None, out: Optional[torch.Tensor] 
     return flat.reshape(world, bits.numel())
 
 
-def all_reduce_mean_scalar(value: float, group=None) -> float:
-    """Mean of a host scalar over the ranks (the training loop's loss for ReduceLROnPlateau / logging): identical on every rank."""
+def all_reduce_mean_scalar(value, group=None) -> float:
+    """Mean of a scalar over the ranks (the training loop's loss for ReduceLROnPlateau / logging): identical on every rank.  `value` may be a
+    device tensor (the step's loss as the library left it): it is reduced where it lives -- no host-to-device copy, one .item() -- or a host float."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
-        return float(value)
-    t = torch.tensor([float(value)], dtype=torch.float64)
-    if dist.get_backend(group) == "nccl":
-        t = t.cuda()
+        return float(value.item()) if torch.is_tensor(value) else float(value)
+    world = dist.get_world_size(group)
+    if torch.is_tensor(value):
+        t = value.detach().reshape(1).to(torch.float64)
+        if t.is_cuda and dist.get_backend(group) == "gloo":   # rehearsal only: gloo moves host memory
+            t = t.cpu()
+    else:
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        if dist.get_backend(group) == "nccl":
+            t = t.to(torch.device("cuda", torch.cuda.current_device()))
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
-    return float(t.item()) / dist.get_world_size(group)
+    return float(t.item()) / world
+
+
+def barrier(group=None):
+    """dist.barrier on the device this rank owns (RCCL wants the device named; gloo takes none)."""
+    if not dist.is_initialized():
+        return
+    if dist.get_backend(group) == "nccl":
+        dist.barrier(group=group, device_ids=[torch.cuda.current_device()])
+    else:
+        dist.barrier(group=group)
 
 
 class OccExchange:
@@ -179,11 +196,13 @@ def init_from_env(backend: str = "nccl"):
             with socket.socket() as s:   # single forced rank: any free port (a fixed default collides between concurrent jobs)
                 s.bind(("127.0.0.1", 0))
                 os.environ["MASTER_PORT"] = str(s.getsockname()[1])
+        import datetime
+        timeout = datetime.timedelta(minutes=60)   # a validation pass on rank 0 may hold the other ranks at a barrier for a long time (train_SOccDPT.py)
         if backend == "nccl":
             torch.cuda.set_device(local)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, device_id=torch.device("cuda", local), timeout=timeout)
         else:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, timeout=timeout)
     return rank, local, world
 
 

@@ -338,6 +338,11 @@ class SOccDPT_V3(SOccDPT):
         seg = torch.empty((B, self.num_classes, img, img), device=x.device)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            # data-parallel replicas seed torch identically (train_net: manual_seed(0)); the Dropout / DropPath masks hash (seed, block, LOCAL sample
+            # index), so without the rank in the seed every rank would drop the same pattern on its shard (masks correlated over the global batch: ADVICE r3)
+            import torch.distributed as _dist
+            if _dist.is_available() and _dist.is_initialized() and _dist.get_world_size() > 1:
+                seed = (seed + 0x9E3779B1 * (_dist.get_rank() + 1)) & 0x7FFFFFFF
         eng.train_forward(xin, inv, seg, dropout_p=float(self.seg_head[3].p), seed=seed)
         # BatchNorm bookkeeping that lives on the host side of nn.BatchNorm2d
         bn = self.seg_head[1]

@@ -221,10 +221,10 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
                     net_patch.backward(*grad_scaler.scale(out["d_inv"], out["d_seg"]))
                     grad_scaler.step(optimizer, net_patch)
                     grad_scaler.update()
-            loss = float(out["loss"].item())
-            if world > 1:   # the GLOBAL-batch loss on every rank: ReduceLROnPlateau must see the same number everywhere, or the ranks cut the
-                            # learning rate at different steps and the replicas diverge silently
-                loss = sdist.all_reduce_mean_scalar(loss)
+            # the GLOBAL-batch loss on every rank (ReduceLROnPlateau must see the same number everywhere, or the ranks cut the learning rate at different
+            # steps and the replicas diverge silently: ADVICE r2): the device scalar is all-reduced in place and read back once -- one collective and
+            # one host sync per step instead of a host round trip + a second blocking collective
+            loss = sdist.all_reduce_mean_scalar(out["loss"]) if world > 1 else float(out["loss"].item())
             epoch_loss += loss
             history.append(loss)
             if rank == 0:
@@ -233,14 +233,18 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
             if global_step % division_step == 0:
                 # evaluation round (train_SOccDPT.py:406-430 -> utils/__init__.py:598-768): the 7 depth metrics and the IoU over the validation
                 # split, computed on the GPU (csrc/metrics.hip); the wandb histograms / images of the reference are not produced
-                val_batches = [val_set[i] for i in range(len(val_set))]      # items carry their batch dimension (datasets' layout)
-                if rank == 0:      # the replicas are identical: one rank evaluates and prints
+                if rank == 0:      # the replicas are identical: one rank builds the validation batches, evaluates and prints
+                    val_batches = [val_set[i] for i in range(len(val_set))]      # items carry their batch dimension (datasets' layout)
                     abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3 = evaluate_depth(DepthNet(net), val_batches, device, amp=p["amp"])
                     print("abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3", abs_rel, sq_rel, rmse, rmse_log, a1, a2, a3)
                     iou = evaluate_seg(SegNet(net), val_batches, device, amp=p["amp"])
                     print("iou", iou)
                     evals.append(dict(step=global_step, abs_rel=abs_rel, rmse=rmse, a1=a1, iou=iou))
                     net.train()
+                if world > 1:
+                    # the other ranks wait HERE, not inside the next step's gradient all-reduce, where a long validation pass would run into the
+                    # collective watchdog (init_from_env gives the process group a generous timeout as well): ADVICE r3
+                    sdist.barrier()
                 scheduler.step(loss)   # `loss` is the all-reduced global-batch loss: every rank takes the same decision
             global_step += 1
             if max_steps and global_step >= max_steps:

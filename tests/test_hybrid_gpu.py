@@ -145,7 +145,9 @@ def _model(gpu_device, precision, sigmoid=False):
 #   bf16  feat 1.1e-2 / 4.0e-2 / 1.5e-1 / 1.4e-1, path_1 7.2e-2, inv 3.4e-2, logits 1.1e-1     -> does NOT meet 1e-3
 # The random-weight hybrid network amplifies any perturbation ~17x between its first and its last hooked map (visible in f32 too:
 # 2.2e-6 -> 4.1e-5): 16 weight-standardised (zero-mean filter) bottlenecks + 12 ViT blocks.  16-bit operand rounding is therefore not
-# parity-grade on this model; SOCCDPT_PREC_F32 is the mode that carries the parity claim for configs[2].
+# parity-grade on this model.  The parity claim for configs[2] is carried by SOCCDPT_PREC_MIXED (x3 on the ResNetV2 stages, the 1x1 out_convs and
+# one read-out projection, fp16 elsewhere: all seven quantities <= 1e-3 at 820 frames/s, tests/test_mixed_gpu.py), by SOCCDPT_PREC_F16X3 (1e-5, 520
+# frames/s) and by the exact-f32 mode (DESIGN.md sections 2 and 10).
 TOL = {
     "f32": dict(feat0=1e-4, feat1=1e-4, feat2=1e-4, feat3=1e-4, path1=1e-4, inv=1e-4, logits=1e-4),
     # split-operand fp16 (three fp16 MFMAs per product, ~22 significand bits): the fast parity-grade mode, same bounds as f32

@@ -122,7 +122,7 @@ def test_prec_map_errors(gpu_device):
     m, _ = _build(PREC_MIXED)
     eng = m._engine(gpu_device)
     with pytest.raises(RuntimeError, match="no such group"):
-        eng.prec_map_set("s9.b0.attn", PREC_F16X3)
+        eng.prec_map_set("s9.b0.qkv", PREC_F16X3)
     with pytest.raises(RuntimeError, match="fmt must be"):
         eng.prec_map_set("*", PREC_BF16)
     m16, _ = _build(PREC_F16)
