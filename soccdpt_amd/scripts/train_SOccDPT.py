@@ -179,7 +179,7 @@ def train_net(SOccDPT_version=3, device="cuda:0", model_type="dpt_swin2_tiny_256
     # gradients scaled, parameter gradients unscaled and inf-checked before the step.  SOCCDPT_AMP=bf16 selects bf16 operands instead (no scaling needed).
     amp_mode = (os.environ.get("SOCCDPT_AMP", "f16") if p["amp"] else False)
     net.train_amp = amp_mode
-    grad_scaler = GradScaler(enabled=(amp_mode == "f16"))
+    grad_scaler = GradScaler(enabled=(amp_mode in ("f16", "x3")))   # x3 operands are fp16 pairs: the same exponent range, so the same power-of-two loss scale (unscaled in f32)
     if world > 1:
         # equal shards: the gradient exchange averages with a flat 1 / world, which is the global-batch gradient only when every rank holds
         # batch_size / world frames

@@ -341,6 +341,74 @@ def test_training_step_gradients_with_criterion(gpu_device, patchwise_percentage
     assert not bad, bad[:10]
 
 
+def test_x3_amp_small_gradients_and_overflow(gpu_device):
+    """the x3 operand pair keeps 22 significand bits only while both halves are normal fp16 numbers.  (1) Output gradients 1e-4 of the
+    criterion's (a large-batch mean, a small loss weight) push the activations' gradients towards fp16's subnormals: WITHOUT a loss scale the
+    parameter gradients lose accuracy, WITH the power-of-two GradScaler (the training script enables it for amp = "x3" as well) they are as good as
+    at full magnitude.  (2) An overflowing gradient is not clipped to 65504 any more: it reaches the flat gradient buffer as a non-finite value,
+    GradScaler.step sees it, skips the optimizer step and backs the scale off."""
+    from oracle import loss_ref
+    from soccdpt_amd.scripts.train_SOccDPT import SyntheticDepthSegDataset, get_batch
+    from soccdpt_amd.utils.loss import training_loss
+    from soccdpt_amd.utils.optim import Adam, GradScaler
+    from soccdpt_amd.utils.synth import synth_input
+    m, sd = _make(gpu_device, sigmoid=True)
+    m.train()
+    m.seg_head[3].p = 0.0
+    for p in m.parameters():
+        p.requires_grad_(True)
+    B = 2
+    x = synth_input(B, seed0=3)
+    _, _, mask_disp, y_disp, mask_seg, y_seg = get_batch(SyntheticDepthSegDataset(B, 256), B, B)
+    y_disp, y_seg = y_disp.float(), y_seg.float()
+    sd_o = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running_" not in k else v.clone()) for k, v in sd.items()}
+    o_inv, o_seg, _ = R.soccdpt_v3_network(sd_o, x, sigmoid=True, training=True)
+    loss_ref.training_loss(o_inv, o_seg, y_disp, mask_disp, y_seg, mask_seg, 0.5, 0.5, True)[0].backward()
+    dev = gpu_device
+    m.train_amp = "x3"
+    small = 1e-4
+
+    def run(scaler):
+        for p in m.parameters():
+            p.grad = None
+        inv, seg = m.train_forward(x.to(dev))
+        r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
+        d_inv, d_seg = r["d_inv"] * small, r["d_seg"] * small
+        if scaler is not None:
+            d_inv, d_seg = scaler.scale(d_inv, d_seg)
+        m.backward(d_inv, d_seg)
+        unscale = 1.0 / scaler.get_scale() if scaler is not None else 1.0
+        torch.cuda.synchronize()
+        errs = []
+        for k, p in m.named_parameters():
+            ref = sd_o[k].grad
+            if ref is None or float(ref.norm()) < 1e-5:
+                continue
+            errs.append(_rel(p.grad.cpu() * (unscale / small), ref))
+        errs.sort()
+        return errs[len(errs) // 2], errs[-1]
+
+    med_raw, worst_raw = run(None)
+    med_sc, worst_sc = run(GradScaler(init_scale=65536.0))
+    print(f"x3 amp, output gradients x {small:g}: without loss scale median {med_raw:.2e} worst {worst_raw:.2e}; with GradScaler(65536) median {med_sc:.2e} worst {worst_sc:.2e}")
+    assert med_sc < 4e-4 and worst_sc < 2e-3
+    assert med_raw >= med_sc            # the scale can only help; how much depends on how deep into the subnormals the smallest gradients reach
+    # (2) overflow: a scale that takes dY past fp16's range must surface as a skipped step, not as a silently clipped gradient
+    big = GradScaler(init_scale=2.0 ** 40)
+    opt = Adam([p for p in m.parameters() if p.requires_grad], lr=1e-5)
+    for p in m.parameters():
+        p.grad = None
+    inv, seg = m.train_forward(x.to(dev))
+    r = training_loss(inv, seg, y_disp.to(dev), mask_disp.to(dev), y_seg.to(dev), mask_seg.to(dev), 0.5, 0.5, compute_scale_and_shift=True)
+    m.backward(*big.scale(r["d_inv"], r["d_seg"]))
+    w0 = m.seg_head[4].weight.detach().clone()
+    big.step(opt, m)
+    big.update()
+    torch.cuda.synchronize()
+    assert big.skipped_steps == 1 and big.get_scale() == 2.0 ** 39
+    assert torch.equal(m.seg_head[4].weight.detach(), w0)
+
+
 def test_amp_gradients_with_criterion(gpu_device):
     """net.train_amp = True (the reference's `amp` sweep parameter -> soccdpt_train_set_amp): the gradient GEMMs run with bf16 MFMA operands
     (f32 accumulate; forward, saved activations, weights and gradients stay f32).  Same whole-step comparison as above at B = 3; the bound is
