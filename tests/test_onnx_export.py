@@ -1,0 +1,168 @@
+"""CPU: the ONNX export (/root/reference/SOccDPT/scripts/export_SOccDPT.py:122-141).
+
+The image has neither `onnx` nor `onnxruntime`, so three things are pinned separately:
+  1. the WIRE FORMAT of soccdpt_amd.utils.onnx_proto against a real producer: torch's own C++ ONNX serialiser (reachable through torch.onnx internals
+     without the `onnx` package) writes small graphs, the codec decodes / re-encodes them;
+  2. the OPERATOR SEMANTICS of soccdpt_amd.utils.onnx_eval against torch: those torch-exported graphs (Conv, MatMul, LayerNorm decomposition, Erf-GELU,
+     L2 normalisation, Softmax, roll = Slice + Concat, the three Resize flavours the SOccDPT graph uses) evaluate to what the torch modules return;
+  3. the EXPORTED SOccDPT_V3 GRAPH, run by that evaluator: against the fp32 oracle end to end (dynamic batch: B = 1 and 2), and its decoder + heads
+     against the fixture recorded from the REFERENCE's own modules (tests/golden/decoder_B1_*.npz)."""
+import contextlib
+import importlib
+import io
+import os
+import tempfile
+import warnings
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from oracle import soccdpt_ref as R
+from soccdpt_amd.utils import onnx_eval as E
+from soccdpt_amd.utils import onnx_proto as P
+
+
+def _torch_export(module, x):
+    """ONNX bytes of a small torch module from torch's own exporter internals (TorchScript tracer + C++ serialiser; no `onnx` package needed)."""
+    warnings.filterwarnings("ignore")
+    from torch.onnx._internal.torchscript_exporter import utils as TU
+    from torch.onnx._internal.torchscript_exporter._globals import GLOBALS
+    for v in range(9, 14):
+        importlib.import_module(f"torch.onnx._internal.torchscript_exporter.symbolic_opset{v}")
+    GLOBALS.export_onnx_opset_version = 13
+    da = {"input": {0: "batch_size"}, "output": {0: "batch_size"}}
+    with torch.no_grad():
+        graph, params, _ = TU._model_to_graph(module.eval(), (x,), input_names=["input"], output_names=["output"], dynamic_axes=da)
+    return graph._export_onnx(params, 13, da, False, torch._C._onnx.OperatorExportTypes.ONNX, True, False, {}, True, "", {})[0]
+
+
+class _Interp(nn.Module):
+    def __init__(self, mode, ac, size):
+        super().__init__()
+        self.mode, self.ac, self.size = mode, ac, size
+
+    def forward(self, x):
+        return F.interpolate(x, size=self.size, mode=self.mode, align_corners=self.ac)
+
+
+class _Block(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.l, self.n = nn.Linear(8, 16), nn.LayerNorm(16)
+
+    def forward(self, x):
+        y = self.n(F.gelu(self.l(x)))
+        q = F.normalize(y, dim=-1)
+        a = torch.softmax(q @ q.transpose(-2, -1), dim=-1)
+        return torch.roll(a @ y, shifts=(1,), dims=(1,))
+
+
+_CASES = {
+    "conv": (lambda: nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 2, 4, stride=4)), (2, 3, 8, 8)),
+    "block": (_Block, (2, 5, 8)),
+    "bicubic": (lambda: _Interp("bicubic", False, (9, 13)), (2, 3, 4, 5)),
+    "bilinear_align_corners": (lambda: _Interp("bilinear", True, (8, 10)), (2, 3, 4, 5)),
+    "nearest": (lambda: _Interp("nearest", None, (9, 13)), (2, 3, 4, 5)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(_CASES))
+def test_codec_and_evaluator_against_torchs_own_exporter(case):
+    try:
+        import torch.onnx._internal.torchscript_exporter.utils  # noqa: F401
+    except Exception:
+        pytest.skip("this torch build has no TorchScript ONNX exporter internals")
+    torch.manual_seed(0)
+    make, shape = _CASES[case]
+    m, x = make(), torch.randn(*shape)
+    pb = _torch_export(m, x)
+    model = P.Model.decode(pb)
+    assert model.ir_version == 7 and model.opset == 13
+    assert model.graph.inputs[0].name == "input" and model.graph.inputs[0].shape[0] == "batch_size"
+    assert model.graph.outputs[0].name == "output" and model.graph.outputs[0].shape[0] == "batch_size"
+    y = E.run(model, {"input": x})[0]
+    assert float((y - m(x)).abs().max()) < 1e-5
+    # what the codec writes is what it read: decode(encode(decode(bytes))) evaluates identically, node for node
+    again = P.Model.decode(model.encode())
+    assert [(n.op_type, n.inputs, n.outputs, sorted(n.attrs)) for n in again.graph.nodes] == [(n.op_type, n.inputs, n.outputs, sorted(n.attrs)) for n in model.graph.nodes]
+    assert torch.equal(E.run(again, {"input": x})[0], y)
+    if "Resize" in [n.op_type for n in model.graph.nodes]:   # the attribute values the SOccDPT exporter writes are the ones torch writes
+        from soccdpt_amd.scripts.export_SOccDPT import GraphBuilder
+        b = GraphBuilder()
+        b.resize("x", 2.0, 2.0, {"bicubic": "bicubic", "bilinear_align_corners": "bilinear_ac", "nearest": "nearest"}[case])
+        mine = b.g.nodes[-1].attrs
+        theirs = [n for n in model.graph.nodes if n.op_type == "Resize"][0].attrs
+        for k, v in mine.items():
+            assert theirs[k] == pytest.approx(v) if isinstance(v, float) else theirs[k] == v, (k, theirs[k], v)
+
+
+@pytest.fixture(scope="module")
+def exported():
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.scripts.export_SOccDPT import export
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    tmp = tempfile.mkdtemp()
+    calib = write_synth_calib(os.path.join(tmp, "calib.yaml"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False)
+    sd = synth_state_dict(alias_pretrained=True)
+    net.load_state_dict(sd, strict=False)
+    path = os.path.join(tmp, "onnx", "SOccDPT.onnx")
+    built = export(net.eval(), path)
+    return path, built, sd
+
+
+def test_exported_file_structure(exported):
+    path, built, _ = exported
+    model = P.load(path)                       # what a consumer reads back from disk
+    g = model.graph
+    assert model.opset == 13 and model.ir_version == 7
+    assert [(v.name, v.shape) for v in g.inputs] == [("input", ["batch_size", 3, 256, 256])]
+    assert [(v.name, v.shape) for v in g.outputs] == [("output", ["batch_size", 1080, 1920]), ("segmentation", ["batch_size", 3, 1080, 1920]),
+                                                     ("points", ["batch_size", 1080, 1920, 3])]
+    ops = {n.op_type for n in g.nodes}
+    standard = {"Conv", "MatMul", "Add", "Sub", "Mul", "Div", "Sqrt", "Erf", "Tanh", "Relu", "Reciprocal", "Max", "Less", "Or", "IsInf", "IsNaN", "Where",
+                "ReduceMean", "ReduceL2", "Softmax", "Reshape", "Transpose", "Concat", "Slice", "Unsqueeze", "Resize", "BatchNormalization", "Identity"}
+    assert ops <= standard, ops - standard      # opset-13 operators of the default domain only
+    produced = {o for n in g.nodes for o in n.outputs} | {t.name for t in g.initializers} | {"input", ""}
+    assert all(x in produced for n in g.nodes for x in n.inputs)       # no dangling edges
+    n_weights = sum(t.array.size for t in g.initializers)
+    assert 38e6 < n_weights < 50e6                                      # the 42 M parameters + folded bias tables / masks
+    src = open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "soccdpt_amd", "scripts", "export_SOccDPT.py")).read()
+    assert "oracle" not in src.replace("fp32 oracle", "")              # the writer does not route through the test oracle
+
+
+@pytest.mark.parametrize("B", [1, 2])
+def test_exported_graph_matches_the_fp32_oracle(exported, B):
+    from soccdpt_amd.utils.synth import synth_input
+    path, _, sd = exported
+    model = P.load(path)
+    x = synth_input(B, seed0=4)
+    torch.set_num_threads(8)
+    inv, seg, pts = E.run(model, {"input": x})
+    o_inv, o_seg, o_pts, _ = R.soccdpt_v3_forward(sd, x, sigmoid=False, compute_occ=False)
+    if B == 1:      # the reference squeezes the batch dimension of the segmentation away at B = 1 (model/SOccDPT.py:276-285); the graph keeps it (dynamic batch)
+        o_seg = o_seg.reshape(1, 3, 1080, 1920)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    assert tuple(inv.shape) == (B, 1080, 1920) and tuple(seg.shape) == (B, 3, 1080, 1920) and tuple(pts.shape) == (B, 1080, 1920, 3)
+    assert rel(inv, o_inv) < 1e-5 and rel(seg, o_seg) < 1e-4
+    fin = torch.isfinite(o_pts)
+    assert torch.equal(torch.isfinite(pts), fin) and rel(pts[fin], o_pts[fin]) < 1e-5
+    assert torch.allclose(pts[:, 0, :3], o_pts[:, 0, :3], rtol=1e-5)        # the three pc_scale / pc_shift pixels of the reference's quirk
+
+
+@pytest.mark.parametrize("name", ["tanh"])
+def test_exported_decoder_and_heads_match_the_reference_golden(exported, golden_dir, name):
+    """Feed the hooked feature maps the fixture was recorded with (tests/golden_inputs.decoder_features) into the exported graph: inverse depth and
+    class probabilities at network resolution equal what the REFERENCE's own DPT decoder / depth head / seg head returned (oracle/make_golden.py)."""
+    from tests.golden_inputs import decoder_features
+    _, built, _ = exported
+    g = np.load(os.path.join(golden_dir, f"decoder_B1_{name}.npz"))
+    feats = decoder_features()
+    names = built.tensor_names
+    inv, seg = E.run(built, {names[f"feat{i}"]: feats[i] for i in range(4)}, outputs=[names["inv256"], names["seg256"]])
+    assert float((inv[:, 0] - torch.from_numpy(g["inv256"])).abs().max()) < 1e-4 * float(np.abs(g["inv256"]).max())
+    assert float((seg - torch.from_numpy(g["seg256"])).abs().max()) < 1e-5
