@@ -447,6 +447,7 @@ def test_fused_mlp_matches_unfused_path(gpu_device, model_type, backbone, img, m
     """The stage-0 MLP half-blocks run as one fused launch (csrc/mlp_fused.hip); SOCCDPT_MLP_FUSE_MAX=0 at handle creation keeps
     the three-launch path.  Same operand rounding and the same k order in both, only the LayerNorm reduction tree differs:
     the stage features, depth and logits agree to float round-off."""
+    from soccdpt_amd.lib import PREC_BF16
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
@@ -458,7 +459,7 @@ def test_fused_mlp_matches_unfused_path(gpu_device, model_type, backbone, img, m
             monkeypatch.delenv("SOCCDPT_MLP_FUSE_MAX", raising=False)
         else:
             monkeypatch.setenv("SOCCDPT_MLP_FUSE_MAX", fuse)
-        m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type=model_type)
+        m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, model_type=model_type, precision=PREC_BF16)   # a uniform 16-bit mode: every stage-0 MLP is eligible
         m.load_state_dict(sd, strict=False)
         m = m.eval().to(gpu_device)
         inv, _ = m.network(x)             # the class probabilities saturate (ScaledTanh of logits of magnitude 10-100): compare the logits
