@@ -474,6 +474,35 @@ __global__ __launch_bounds__(256) void seg_up_act_kernel(const float* __restrict
     }
 }
 
+// Finish of the classifier fused into the seg head's convolution (igemm D3 epilogue): logits[m][c] = bias[c] + sum over the n-tiles (in tile order) of
+// part[t][m][c]; then the same up-sampling + activation as below.
+__global__ __launch_bounds__(256) void seg_logits_finish_kernel(const float* __restrict__ part /*[T][M][4]*/, const float* __restrict__ bias, float* __restrict__ out /*[M][3]*/,
+                                                                 size_t M, int T) {
+    for (size_t m = (size_t)blockIdx.x * blockDim.x + threadIdx.x; m < M; m += (size_t)gridDim.x * blockDim.x) {
+        float4 a = *reinterpret_cast<const float4*>(part + m * 4);
+        for (int t = 1; t < T; ++t) {
+            const float4 v = *reinterpret_cast<const float4*>(part + ((size_t)t * M + m) * 4);
+            a.x += v.x; a.y += v.y; a.z += v.z;
+        }
+        out[m * 3 + 0] = a.x + bias[0];
+        out[m * 3 + 1] = a.y + bias[1];
+        out[m * 3 + 2] = a.z + bias[2];
+    }
+}
+
+int launch_seg_tail_parts(const float* part, int ntiles, const float* bias, float* tmp, float* seg, int B, int h, int wd, int sigmoid, hipStream_t st, std::string& err) {
+    const size_t M = (size_t)B * h * wd;
+    size_t blocks = (M + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    SOCCDPT_LAUNCH(seg_logits_finish_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, bias, tmp, M, ntiles);
+    if (check_launch("seg_logits_finish", err)) return 1;
+    const size_t total = (size_t)B * 4 * h * wd;
+    blocks = (total + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    SOCCDPT_LAUNCH(seg_up_act_kernel, dim3((unsigned)blocks), dim3(256), 0, st, tmp, seg, B, h, wd, sigmoid);
+    return check_launch("seg_up_act", err);
+}
+
 int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
                     int sigmoid, hipStream_t st, std::string& err) {
     const int M = B * h * wd;

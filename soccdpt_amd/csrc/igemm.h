@@ -90,6 +90,9 @@ struct IgemmDesc {
     const float* dot_w = nullptr;
     float dot_b = 0.f;
     float* out_dot = nullptr;
+    // fused THREE-class 1x1 tail (the seg head's classifier): dot3 != 0: out_dot[(n_tile * M + m) * 4 + c] = sum over the n-tile's channels of
+    // act(v)[n] * dot_w[c * N + n] (c < 3; n-tiles of 128 channels); nothing else is stored.  16-bit operand launches only (igemm.hip)
+    int dot3 = 0;
     // fused Swin-V2 residual post-norm (N <= tile width, one n-tile): xf[m][:] = (residual ? xf[m][:] : 0) + LN(v[m][:]) * g + b;
     // also writes the operand-typed copy to out_op (plain) and, when ln_halo != nullptr, to a zero-halo image (hooked stage)
     const float* ln_g = nullptr;

@@ -39,8 +39,9 @@ __global__ __launch_bounds__(256) void sk_reduce_kernel(const float* __restrict_
     }
 }
 
-template <class C, typename T, bool LN = false, bool SK = false, bool ST = false, bool GEN = false>
+template <class C, typename T, bool LN = false, bool SK = false, bool ST = false, bool GEN = false, bool D3 = false>
 static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err) {
+    if (D3 != (d.dot3 != 0)) { err = "igemm: this configuration has no three-class classifier epilogue"; return 1; }
     if (!GEN && need_gen(d)) { err = "igemm: this configuration has no generalised-addressing instantiation (use 2, 20 or a GroupNorm-statistics launch)"; return 1; }
     if (LN != (d.ln_g != nullptr)) { err = "igemm: this configuration has no fused-LayerNorm instantiation"; return 1; }
     if (SK != (d.splitk > 1)) { err = "igemm: this configuration has no split-K instantiation"; return 1; }
@@ -60,7 +61,7 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     }
     static PerDeviceOnce attr_done;
     if (attr_done.need()) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK, ST, GEN>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&igemm_kernel<C, T, LN, SK, ST, GEN, D3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) { err = std::string("igemm: hipFuncSetAttribute: ") + hipGetErrorString(e); return 1; }
         attr_done.done();
     }
@@ -68,7 +69,7 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     if (SK && (!d.sk_part || !d.sk_count || splits > nk || (size_t)splits * d.M * d.N > d.sk_part_floats ||
                (size_t)mtiles * ntiles > d.sk_count_words)) { err = "igemm: bad split-K descriptor (scratch too small?)"; return 1; }
     if (SK && d.sk_defer && (!d.out_f32 || d.out_op || d.bias || d.res1 || d.res2 || d.act || (d.N & 3))) { err = "igemm: deferred split-K writes out_f32 only"; return 1; }
-    SOCCDPT_LAUNCH((igemm_kernel<C, T, LN, SK, ST, GEN>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
+    SOCCDPT_LAUNCH((igemm_kernel<C, T, LN, SK, ST, GEN, D3>), dim3((unsigned)(mtiles * ntiles * splits)), dim3(C::THREADS), lds, stream, d, nk, kpt, ntiles);
     if (SK && d.sk_defer) {
         const size_t n4 = (size_t)d.M * d.N / 4;
         size_t blocks = (n4 + 255) / 256;
@@ -266,6 +267,7 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
 int igemm_config_id(const IgemmDesc& d) { return d.x3 ? pick_cfg_f32(d) : (d.f32 ? -1 : pick_cfg(d)); }
 
 const char* igemm_family(const IgemmDesc& d) {
+    if (d.dot3 && !d.x3 && !d.f32) return d.f16 ? "igemm_f16_128x128x64_s2_w8_dot3" : "igemm_bf16_128x128x64_s2_w8_dot3";
     if (d.x3) return d.splitk > 1 ? (d.tune == 3 || d.tune == 8 ? "igemm_x3_128x128_w8_splitk" : "igemm_x3_64x64x32_s4_splitk") : kCfgNamesX3[pick_cfg_f32(d)];
     if (d.f32) return d.splitk > 1 ? (d.tune == 3 ? "igemm_f32_128x128x32_s2_w8_splitk" : "igemm_f32_64x64x32_s4_splitk") : kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
@@ -296,7 +298,8 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.wt_grp_rows && (d.taps != 1 || d.gather1 || d.wt_grp_rows % 64 != 0 || d.N > 9 * d.wt_grp_rows || d.N % d.wt_grp_rows != 0 ||
                           (!d.wt_kx && d.wt_base - d.wt_rp - 1 + (d.wt_odd < 0 ? d.wt_odd : 0) < 0))) { err = "igemm: bad weight row-group descriptor"; return 1; }
     if ((d.out_halo || d.res2_h) && (d.H <= 0 || d.W <= 0)) { err = "igemm: halo output / sampled residual need H, W"; return 1; }
-    if (d.out_dot && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    if (d.out_dot && !d.dot3 && d.N > 32) { err = "igemm: fused dot tail needs N <= 32"; return 1; }
+    if (d.dot3 && (d.x3 || d.f32)) { err = "igemm: the fused three-class classifier exists for 16-bit operands only"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32 && !d.x3) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.x3) {   // split-fp16 operands (SOCCDPT_PREC_F16X3): the f32 tile set with T = x3_t
@@ -358,6 +361,14 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             case 3: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, float>(d, stream, err);   // 8 waves, 64 x 32 per wave
             default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, float>(d, stream, err);
         }
+    }
+    if (d.dot3) {   // Conv3x3 + (folded BN) + ReLU + Conv1x1(N -> 3) of the seg head as one launch: the 8-wave 128 x 128 x 64 tile with the D3 epilogue
+        if (d.taps != 9 || d.Cin % 64 || d.N % 128 || !d.dot_w || !d.out_dot || d.out_op || d.out_f32 || d.splitk > 1 || d.ln_g || d.gn_stats || need_gen(d)) {
+            err = "igemm: bad three-class classifier descriptor (3x3 convolution, N a multiple of 128, no other outputs)";
+            return 1;
+        }
+        return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, false, false, false, true>(d, stream, err)
+                     : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, false, false, false, true>(d, stream, err);
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);

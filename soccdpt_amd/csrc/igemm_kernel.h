@@ -60,7 +60,10 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // One output tile `bid` (logical id: n-tile fastest, split fastest of all under SK) of the launch described by d.  `smem`: C::NS * C::STAGE bytes
 // of LDS, free on entry (callers that run several tiles in a row put a workgroup barrier between them).  tid: the thread's index in the workgroup
 // (a parameter so that the persistent kernel can keep the per-thread index arithmetic of one phase from being hoisted over all phases).
-template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
+// D3: three-class classifier tail fused into the epilogue (the seg head: Conv3x3 + BN + ReLU -> Conv1x1(N -> 3), model/SOccDPT.py:660-671): every
+// workgroup reduces act(v) . dot_w[c][n0 .. n0 + BN) over its n-tile for its BM pixels and writes the three partial logits to
+// out_dot[(n_tile * M + m) * 4 + c]; a finishing pass adds the n-tiles' partials in tile order and the bias.  The N-channel feature map is never stored.
+template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false, bool D3 = false>
 __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, int ntiles, int bid, char* smem, const int tid) {
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
@@ -552,6 +555,11 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     float dot_part[TME];
 #pragma unroll
     for (int j = 0; j < TME; ++j) dot_part[j] = 0.f;
+    float d3[D3 ? TME : 1][3];   // D3: this lane's part of the three class logits of its pixels (its 4 x TNE channels)
+    if constexpr (D3) {
+#pragma unroll
+        for (int j = 0; j < TME; ++j) d3[j][0] = d3[j][1] = d3[j][2] = 0.f;
+    }
     float gsum[ST ? TNE : 1][4], gsq[ST ? TNE : 1][4];   // ST: per-lane sums over this wave's pixel rows of its 4 channels per n-tile
     if constexpr (ST) {
 #pragma unroll
@@ -656,7 +664,13 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
                     *reinterpret_cast<float4*>(static_cast<float*>(d.out_op) + (d.out_halo ? hrow : orow) + n) = make_float4(a[0], a[1], a[2], a[3]);
                 }
             }
-            if (d.out_dot) {
+            if constexpr (D3) {
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + (size_t)c * N + n);
+                    d3[j][c] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+                }
+            } else if (d.out_dot) {
                 const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
                 dot_part[j] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
             }
@@ -757,7 +771,35 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         __syncthreads();
         if (tid == 0) d.stamps[4 * (size_t)blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
     }
-    if (MF == 16 && d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
+    if constexpr (D3) {
+        // lanes (lane & 15) + 16 q hold 4-channel groups q of the same pixel: two shuffles; the WN waves of a wave row hold the tile's other
+        // channels: they meet in LDS (the staging ring is free once every wave has left the main loop), summed in wave order
+        float* red = reinterpret_cast<float*>(smem);   // [BM][WN][4]
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TME; ++j) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float v3 = d3[j][c];
+                v3 += __shfl_xor(v3, 16);
+                v3 += __shfl_xor(v3, 32);
+                d3[j][c] = v3;
+            }
+            if ((lane >> 4) == 0) {
+                float* q = red + ((size_t)(wm * TME * 16 + j * 16 + (lane & 15)) * C::WN + wn) * 4;
+                q[0] = d3[j][0]; q[1] = d3[j][1]; q[2] = d3[j][2];
+            }
+        }
+        __syncthreads();
+        for (int r = tid; r < BM; r += C::THREADS) {
+            const int m = m0 + r;
+            if (m >= d.M) continue;
+            float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < C::WN; ++w) { const float* q = red + ((size_t)r * C::WN + w) * 4; s0 += q[0]; s1 += q[1]; s2 += q[2]; }
+            *reinterpret_cast<float4*>(d.out_dot + ((size_t)nt * d.M + m) * 4) = make_float4(s0, s1, s2, 0.f);
+        }
+    } else if (MF == 16 && d.out_dot) {  // host guarantees WN == 1 and N <= BN: the whole channel range is in this wave
 #pragma unroll
         for (int j = 0; j < TME; ++j) {
             float s = dot_part[j];
@@ -770,7 +812,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     }  // generic epilogue
 }
 
-template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false>
+template <class C, typename T, bool LN, bool SK = false, bool ST = false, bool GEN = false, bool D3 = false>
 __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, int kpt, int ntiles) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     // XCD-aware bijective remap: consecutive logical tiles -> same XCD (blocks b, b+8 share one)
@@ -779,7 +821,7 @@ __global__ __launch_bounds__(C::THREADS) void igemm_kernel(IgemmDesc d, int nk, 
         const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     }
-    igemm_tile<C, T, LN, SK, ST, GEN>(d, nk, kpt, ntiles, bid, smem, (int)threadIdx.x);
+    igemm_tile<C, T, LN, SK, ST, GEN, D3>(d, nk, kpt, ntiles, bid, smem, (int)threadIdx.x);
 }
 
 }  // namespace soccdpt

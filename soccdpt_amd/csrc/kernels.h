@@ -34,6 +34,8 @@ int launch_bilinear(const void* in, int in_is_bf16, float* out_f32, bf16_t* out_
                     int w, int H, int W, int C, hipStream_t st, std::string& err);
 int launch_seg_tail(const void* feat, int feat_is_f32, int hf, const float* w, const float* bias, float* tmp, float* seg, int B, int h, int wd,
                     int sigmoid, hipStream_t st, std::string& err);
+// the classifier was fused into the seg head's convolution (IgemmDesc::dot3): add the n-tiles' partial logits [ntiles][M][4] + bias -> tmp [M][3], then up-sample + activate
+int launch_seg_tail_parts(const float* part, int ntiles, const float* bias, float* tmp, float* seg, int B, int h, int wd, int sigmoid, hipStream_t st, std::string& err);
 int launch_patch_w(const float* w, float* out, int C0, hipStream_t st, std::string& err);
 int launch_cvt_bf16(const float* in, bf16_t* out, size_t n, int hf, hipStream_t st, std::string& err);
 int launch_conv_w(const float* in, const float* scale, void* out, int out_is_f32, int hf, int Cout, int Cin, hipStream_t st, std::string& err);

@@ -8,6 +8,7 @@
 // with a one-pixel zero halo that no kernel ever writes (the workspace is zero-filled once by the
 // host), which removes all bounds checks from the convolution main loop.
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "internal.h"
@@ -1163,10 +1164,20 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         const bool s1_f32 = fS1 >= 2;
         d = conv(w.path1, F, P.s0_w, F, r1);
         d.bias = P.bn_shift; d.act = ACT_RELU;
+        static const bool no_dot3 = getenv("SOCCDPT_SEG_DOT3_OFF") != nullptr;   // A/B switch: the unfused classifier of rounds 1-3
+        if (fH <= 1 && F % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3) {
+            // the 1x1 classifier rides in the convolution's epilogue (igemm D3): the 256-channel feature map -- 67 MB written and read back per
+            // forward at B = 8, rounded to 16 bits on the way -- is never stored; the logits come from the f32 accumulators
+            d.dot3 = 1; d.dot_w = P.s4_w; d.out_dot = static_cast<float*>(w.s1);   // [F / 128][M][4] partial logits in the feature map's buffer
+            RUN(gemm(d, fH));
+            PROF("seg_tail", 0.0, (double)B * r1 * r1 * ((F / 128) * 16.0 + 12.0 + 12.0 + 48.0));
+            RUN(launch_seg_tail_parts(static_cast<const float*>(w.s1), F / 128, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err));
+        } else {
         if (s1_f32) to_plain(d, w.s1, fH); else { d.out_op = w.s1; d.out_fmt = MIX ? 1 : -1; }
         RUN(gemm(d, fH));
         { PROF("seg_tail", 0.0, (double)B * r1 * r1 * (F * 2.0 + 12.0 + 48.0));
           RUN(launch_seg_tail(w.s1, s1_f32 ? 1 : 0, fS1 == 1, P.s4_w, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err)); }
+        }
         ++launches;
     }
 #undef RUN

@@ -53,6 +53,12 @@ def test_pmc_family_names_follow_the_kernel_templates():
     assert m.family(sig % ("128, 128, 64, 2, 2, 2, 16", "float", "false")) == "igemm_f32_128x128x32_s2"
     assert m.family(sig % ("128, 128, 128, 2, 4, 2, 16", "soccdpt::x3_t", "false")) == "igemm_x3_128x128x64_s2_w8"
     assert m.family(sig % ("128, 128, 64, 2, 4, 2, 32", "unsigned short", "false")) == "igemm_bf16_128x128x64_s2_m32"
+    assert m.family(sig % ("64, 64, 64, 2, 4, 4, 16", "soccdpt::x3_t", "false")) == "igemm_x3_64x64x32_s4_w8"              # the x3 tiles of the mixed-precision forward
+    assert m.family(sig % ("32, 64, 128, 2, 4, 3, 16", "soccdpt::x3_t", "false")) == "igemm_x3_32x64x64_s3_w8"
+    assert m.family(sig % ("64, 64, 64, 2, 4, 4, 16", "soccdpt::f16_t", "false")) == "igemm_f16_64x64x64_s4_w8"
+    sig7 = "void soccdpt::igemm_kernel<soccdpt::Cfg<128, 128, 64, 2, 4, 2, 16>, soccdpt::f16_t, false, false, false, false, %s>(soccdpt::IgemmDesc, int, int, int)"
+    assert m.family(sig7 % "true") == "igemm_f16_128x128x64_s2_w8_dot3"           # the seg head's convolution with the classifier in its epilogue
+    assert m.family(sig7 % "false") == "igemm_f16_128x128x64_s2_w8"
     assert m.family("soccdpt::occ_expand_kernel(unsigned int const*, float*, unsigned long, int)") == "occ_expand"
     assert m.family("void soccdpt::project_rowsR_kernel<3, 256, 4, 7>(soccdpt::ProjParams, int, int)") == "project_voxelise"
 
@@ -68,3 +74,36 @@ def test_newest_bench_line_carries_traffic(suffix):
     assert isinstance(d["roofline"]["traffic"], (int, float)) and d["roofline"]["traffic"] > 0, d["roofline"].get("traffic_note")
     assert d["roofline"].get("traffic_source") == os.path.basename(f)
     assert d["roofline_hbm"]["traffic"] > 0
+
+
+def _r04_lines():
+    out = []
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", "r04*_bench*.json"))):
+        txt = open(f).read().strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            out.append((os.path.basename(f), json.loads(txt.splitlines()[-1])))
+    return out
+
+
+def test_round4_bench_lines_carry_the_required_objects():
+    """every committed bench line of this round has its roofline; forward lines at N = 1 name the arithmetic of `value`, carry the live
+    tolerance measurement and (the full runs) the B = 1 latency the paper's 47 Hz is compared with; every training-step line -- the amp ones too --
+    has roofline AND cpu_baseline."""
+    lines = _r04_lines()
+    assert lines, "no profiles/r04*_bench*.json"
+    for name, d in lines:
+        if "under_rocprof" in name:
+            continue
+        assert d.get("roofline") and d["roofline"].get("frac") is not None, name
+        if "training step" in d["metric"]:
+            assert d.get("cpu_baseline") and d["cpu_baseline"]["value"] > 0, name
+            assert "drop_path_rate" in d["config"], name
+        else:
+            assert d["tolerance"]["dtype_of_value"] in d["dtype"] or d["dtype"].startswith(d["tolerance"]["dtype_of_value"]), name
+            if d["n_gpus"] == 1 and "latency_b1" in d:
+                assert d["latency_b1"]["forwards"] == 50 and abs(d["x_paper_hz"] - d["latency_b1"]["hz"] / 47.0) < 0.02, name
+    main = dict(lines).get("r04_bench.json")
+    assert main is not None
+    assert main["dtype"].startswith("mixed") and main["tolerance"]["value_meets_tolerance"] is True
+    assert main["tolerance"]["worst_measured"]["mixed"] <= main["tolerance"]["bar_for_value"] == 5e-4
+    assert "latency_b1" in main and "f16_operands" in main and "bf16_operands" in main and main["f16_operands"]["roofline"]["frac"] > 0

@@ -22,14 +22,14 @@ python3 bench.py --config 3 --precision f16x3 --no-cpu-baseline > $OUT/bench_bas
 echo "modes done"
 fi
 python3 bench.py --train-step > $OUT/bench_train_step.json 2>> $OUT/bench.err
-python3 bench.py --train-step --amp x3 --no-cpu-baseline > $OUT/bench_train_step_x3.json 2>> $OUT/bench.err
-python3 bench.py --train-step --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err
-python3 bench.py --train-step --amp f16 --no-cpu-baseline > $OUT/bench_train_step_amp_f16.json 2>> $OUT/bench.err
-python3 bench.py --train-step --batch 3 --encoder-percentage 0.5 --patchwise-percentage 0.5 --no-cpu-baseline > $OUT/bench_train_step_B3_enc50_patch50.json 2>> $OUT/bench.err
-python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --no-cpu-baseline > $OUT/bench_train_step_base384.json 2>> $OUT/bench.err
-python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp_base384.json 2>> $OUT/bench.err
-python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 --no-cpu-baseline > $OUT/bench_train_step_hybrid384.json 2>> $OUT/bench.err
-python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 --amp bf16 --no-cpu-baseline > $OUT/bench_train_step_amp_hybrid384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp x3 > $OUT/bench_train_step_x3.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp bf16 > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp f16 > $OUT/bench_train_step_amp_f16.json 2>> $OUT/bench.err
+python3 bench.py --train-step --batch 3 --encoder-percentage 0.5 --patchwise-percentage 0.5 > $OUT/bench_train_step_B3_enc50_patch50.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 > $OUT/bench_train_step_base384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --amp bf16 > $OUT/bench_train_step_amp_base384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 > $OUT/bench_train_step_hybrid384.json 2>> $OUT/bench.err
+python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 --amp bf16 > $OUT/bench_train_step_amp_hybrid384.json 2>> $OUT/bench.err
 echo "train lines done"
 for a in 0 x3 bf16; do
   TRAIN_AMP=$a rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/train_$a -o t -- python3 tools/train_bench.py 8 6 > $OUT/train_$a.json 2>> $OUT/bench.err

@@ -13,18 +13,19 @@ def family(kernel_name: str) -> str:
         m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)
         t = m.group(7)
         if t == "float" or "x3_t" in t:   # 4 bytes per element: the k-tile holds BK / 2 elements (igemm.hip kCfgNamesF32 / kCfgNamesX3)
-            w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("64", "64"))
+            w8 = int(m.group(4)) * int(m.group(5)) == 8 and ((m.group(1), m.group(2)) in (("128", "128"), ("64", "64")) or ((m.group(1), m.group(2)) == ("32", "64") and "x3_t" in t))
             return (f"igemm_{'f32' if t == 'float' else 'x3'}_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(6)}" + ("_w8" if w8 else "") +
                     ("_splitk" if m.group(9) == "true" else ""))
         if mf32:
             return f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}_m32"
         # 8-wave forms of tiles that also exist with 4 waves carry a _w8 suffix in igemm.hip's kCfgNames
         w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("32", "64"), ("64", "64"))
+        flags = re.findall(r"true|false", n[n.index(">,") :])   # LN, SK[, ST, GEN[, D3]]
         return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") +
-                ("_splitk" if m.group(9) == "true" else ""))
+                ("_splitk" if m.group(9) == "true" else "") + ("_dot3" if len(flags) >= 5 and flags[4] == "true" else ""))
     for prefix, fam in (("window_attention", "window_attention"), ("mlp_ln_kernel", "mlp_ln_fused"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
                         ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
-                        ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail")):
+                        ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail"), ("seg_logits_finish", "seg_tail")):
         if n.startswith(prefix):
             return fam
     return n
@@ -58,7 +59,8 @@ if __name__ == "__main__":
     import os
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from soccdpt_amd.lib import csrc_sha  # noqa: E402
-    json.dump(dict(csrc_sha=csrc_sha(), note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --headline-only --steps 3 --warmup 1`; KiB->bytes; "
+    json.dump(dict(csrc_sha=csrc_sha(), precision=os.environ.get("SOCCDPT_PROFILE_PRECISION", "mixed"),   # the arithmetic of the profiled headline leg (bench.py's default)
+                   note="rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes over `bench.py --headline-only --steps 3 --warmup 1`; KiB->bytes; "
                         "FETCH_SIZE doubled per MI355X_MICROARCH.md §HBM (gfx950 reports half of wide coalesced reads)", kernels=out),
               open(sys.argv[3], "w"), indent=1)
     print("wrote", sys.argv[3], len(out), "kernels")
