@@ -8,11 +8,17 @@ TAG=${1:-rXX}
 OUT=gpurun_out/${TAG}_extra
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-if [ -z "$TRAIN_ONLY" ]; then   # TRAIN_ONLY=1: only the training-step lines and kernel tables (the forward's sources did not change)
+# PART=1: tiny_256 + base_384 forward profiles; PART=2: hybrid_384 + the other arithmetic modes; PART=3 (or TRAIN_ONLY=1): the training-step lines and tables.
+# Unset: everything (does not fit one 1200 s gpurun call any more: run the three parts as three calls).
+PART=${PART:-all}
+if [ -n "$TRAIN_ONLY" ]; then PART=3; fi
+if [ "$PART" = "all" ] || [ "$PART" = "1" ]; then
 bash tools/collect_profiles.sh ${TAG} > $OUT/collect_tiny.log 2>&1
 echo "tiny done"
 bash tools/collect_profiles.sh ${TAG}_base384 --config 3 > $OUT/collect_base.log 2>&1
 echo "base done"
+fi
+if [ "$PART" = "all" ] || [ "$PART" = "2" ]; then
 bash tools/collect_profiles.sh ${TAG}_hybrid384 --config 2 > $OUT/collect_hybrid.log 2>&1
 echo "hybrid done"
 for p in f16 f16x3 f32; do python3 bench.py --precision $p --no-cpu-baseline > $OUT/bench_$p.json 2>> $OUT/bench.err; done
@@ -21,6 +27,7 @@ python3 bench.py --config 2 --precision f32 --no-cpu-baseline > $OUT/bench_hybri
 python3 bench.py --config 3 --precision f16x3 --no-cpu-baseline > $OUT/bench_base384_f16x3.json 2>> $OUT/bench.err
 echo "modes done"
 fi
+if [ "$PART" = "1" ] || [ "$PART" = "2" ]; then exit 0; fi
 python3 bench.py --train-step > $OUT/bench_train_step.json 2>> $OUT/bench.err
 python3 bench.py --train-step --amp x3 > $OUT/bench_train_step_x3.json 2>> $OUT/bench.err
 python3 bench.py --train-step --amp bf16 > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err

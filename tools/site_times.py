@@ -1,7 +1,7 @@
 """Per-site device time of every GEMM / conv launch shape of one forward, for one precision mode, plus the non-GEMM families:
 the cost side of the precision map (tools/precision_map.py).
 
-    python tools/site_times.py [model_type] [batch] [precision] > gpurun_out/site_times_<model>_<precision>.json
+    python tools/site_times.py [model_type] [batch] [precision] [x3 groups: "empty" | "a,b,c"] > gpurun_out/site_times_<model>_<precision>.json
 """
 import os, sys, tempfile, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -23,6 +23,10 @@ net.load_state_dict(synth_state_dict(backbone, alias_pretrained=True), strict=Fa
 net = net.eval().to(dev)
 x = synth_input(B, size=img, seed0=0).to(dev)
 eng = net._engine(dev)
+if len(sys.argv) > 4 and prec == 4:   # override the shipped precision map
+    eng.prec_map_set("*", 2)
+    for g in ([] if sys.argv[4] == "empty" else sys.argv[4].split(",")):
+        eng.prec_map_set(g, 3)
 REPS = 20
 for _ in range(5):
     net(x)
@@ -33,7 +37,9 @@ for _ in range(REPS):
 torch.cuda.synchronize()
 st = eng.profile_collect()
 eng.profile_enable(False)
-sites = {s["site"]: s for s in eng.sites()}
+sites = {}
+for s in eng.sites():   # the x3 launches of a shape in the mixed mode are their own site, named "siteNNNx"
+    sites[s["site"]] = sites[s["site"] + "x"] = s
 rows = []
 for k, v in st.items():
     r = {"name": k, "us_per_forward": v["ms"] / REPS * 1e3, "launches": v.get("launches", 0) / REPS}
