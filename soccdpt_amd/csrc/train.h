@@ -5,6 +5,8 @@
 
 namespace soccdpt {
 
+constexpr size_t kTrainColCountWords = 256;   // arrival counters of the single-launch column sums (tr_colsum): one per 64-column group
+
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err);
 int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err);
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
@@ -19,8 +21,8 @@ int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStrea
 int tr_to_halo_full(const float* in, void* out, int B, int H, int W, int C, int fmt, hipStream_t st, std::string& err);   // whole image incl. a zero border
 int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err);
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
-int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
-int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, size_t M, int N, hipStream_t st, std::string& err);   // sum a*b and sum a in one pass
+int tr_colsum(const float* a, const float* b, float* out, float* scratch, unsigned* count, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
+int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, unsigned* count, size_t M, int N, hipStream_t st, std::string& err);   // sum a*b and sum a in one pass
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);
 int tr_relu_bwd(const float* dy, const float* ref, const float* add, float* dx, size_t n, hipStream_t st, std::string& err);
 int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, float* dx, int B, int H, int W, int C, hipStream_t st, std::string& err);

@@ -86,6 +86,7 @@ struct Tape {
     float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb, *attn_part;
     float* sk_part;
     unsigned* sk_count;
+    unsigned* col_count;   // arrival counters of tr_colsum (kTrainColCountWords), zero at rest like sk_count
     size_t maxAct = 0;
     float dropout_p = 0.f;
 };

@@ -41,6 +41,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.path1 = halo(r1, F);
     T.d1u = halo(r0, F / 2);
     T.sk_count = reinterpret_cast<unsigned*>(ar.f(kTrainSkCountWords));   // split-K arrival counters: zero at rest (zeroed with the halos)
+    T.col_count = reinterpret_cast<unsigned*>(ar.f(kTrainColCountWords));
     if (a.hybrid) hy_carve_halo(h, B, ar, T);
     ar.f(0);
     T.halo_hi = (ar.off + 255) & ~size_t(255);
@@ -275,7 +276,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
             TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
             return 0;
         } else if (x3) {
             const int Mp = (int)((M + 31) / 32 * 32);
@@ -298,7 +299,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
             TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
             return 0;
         } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
@@ -315,7 +316,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
         }
         TRY(gemm_wgrad(c, d, amp, x3));
     }
-    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
     return 0;
 }
 
@@ -464,16 +465,16 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         }
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }
-    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
     return 0;
 }
 
 // out = LN(y) g + b backward: d y -> dy; gamma / beta gradients
 int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps) {
     TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, eps, c.st, c.err));
-    if (dg && dbeta) return tr_colsum2(dout, xhat, dg, dbeta, c.T.S_col, M, C, c.st, c.err);   // one pass over dout for both (same addition order as the single forms)
-    if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, M, C, 0, c.st, c.err));
-    if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, M, C, 0, c.st, c.err));
+    if (dg && dbeta) return tr_colsum2(dout, xhat, dg, dbeta, c.T.S_col, c.T.col_count, M, C, c.st, c.err);   // one pass over dout for both (same addition order as the single forms)
+    if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, c.T.col_count, M, C, 0, c.st, c.err));
+    if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, c.T.col_count, M, C, 0, c.st, c.err));
     return 0;
 }
 
@@ -859,7 +860,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         float* dw4 = c.Gd(SCR + "output_conv.4.weight");
         float* db4 = c.Gd(SCR + "output_conv.4.bias");
         if (dw4 || db4) {
-            TRY(tr_colsum(G[1], nullptr, T.S_vec, T.S_col, M0p, 33, 0, st, err));
+            TRY(tr_colsum(G[1], nullptr, T.S_vec, T.S_col, T.col_count, M0p, 33, 0, st, err));
             if (dw4) TRY(copy_d2d(c, dw4, T.S_vec, 32 * 4, "train_backward"));
             if (db4) TRY(copy_d2d(c, db4, T.S_vec + 32, 4, "train_backward"));
         }
@@ -875,15 +876,15 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         if (float* dw = c.Gd("seg_head.4.weight")) TRY(tr_smallk_wgrad(G[1], T.r, dw, T.S_col, M1, F, 3, st, err));
         if (float* db = c.Gd("seg_head.4.bias")) {
             // colsum needs N >= 1: three columns
-            TRY(tr_colsum(G[1], nullptr, db, T.S_col, M1, 3, 0, st, err));
+            TRY(tr_colsum(G[1], nullptr, db, T.S_col, T.col_count, M1, 3, 0, st, err));
         }
         TRY(tr_smallk_dgrad(G[1], c.W("seg_head.4.weight"), G[2], M1, F, 3, st, err));
         TRY(tr_bn_relu_dropout_bwd_pre(G[2], T.r, T.keep, G[0], M1 * F, T.dropout_p, st, err));
         TRY(tr_bn_xhat(T.c_raw, T.bn_stats, G[3], M1, F, st, err));
         float* dbeta = T.S_vec;
         float* dgamma = T.S_vec + F;
-        TRY(tr_colsum(G[0], nullptr, dbeta, T.S_col, M1, F, 0, st, err));
-        TRY(tr_colsum(G[0], G[3], dgamma, T.S_col, M1, F, 0, st, err));
+        TRY(tr_colsum(G[0], nullptr, dbeta, T.S_col, T.col_count, M1, F, 0, st, err));
+        TRY(tr_colsum(G[0], G[3], dgamma, T.S_col, T.col_count, M1, F, 0, st, err));
         if (float* p = c.Gd("seg_head.1.bias")) TRY(copy_d2d(c, p, dbeta, F * 4, "train_backward"));
         if (float* p = c.Gd("seg_head.1.weight")) TRY(copy_d2d(c, p, dgamma, F * 4, "train_backward"));
         TRY(tr_bn_bwd(G[0], T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), dbeta, dgamma, G[2], M1, F, st, err));

@@ -22,7 +22,7 @@ WHAT = {
     "project_voxelise": "`get_semantic_occupancy` + `rotate_points` + voxel index pass (`projection.hip`, 4 camera rows per workgroup)",
     "depth_tail_fused": "Interpolate x2 + Conv3x3(128->32) + ReLU + Conv1x1 + ReLU (`depth_tail.hip`)",
     "occ_expand": "packed bits -> B dense f32 rows",
-    "seg_tail": "seg head Conv1x1(256->3) + bilinear x2 + ScaledTanh / Sigmoid",
+    "seg_tail": "seg head: n-tile partial logits + bias, bilinear x2, ScaledTanh / Sigmoid (the Conv1x1(256->3) itself rides in the `_dot3` launch)",
     "bilinear_resize": "`F.interpolate(bilinear, align_corners=True)` of path_1 into the zero-halo operand image",
     "mlp_ln_fused": "fc1 + GELU + fc2 + LayerNorm + residual in one launch (C <= 128, `mlp_fused.hip`)",
     "patch_embed_ln": "PatchEmbed conv 4x4 / 4 + LayerNorm",
@@ -32,6 +32,8 @@ rows = ["| kernel family | replaces | bound | launches | us / forward | achieved
 for k in d["kernels"]:
     name = k["name"]
     what = next((v for p, v in WHAT.items() if name.startswith(p)), "")
+    if name.endswith("_dot3"):
+        what = "seg head Conv3x3(256->256) + BN + ReLU with the Conv1x1(256->3) classifier in its epilogue (section 10.3)"
     if "tflops" in k:
         peak = 2500.0 / 3 if name.startswith("igemm_x3") else 2500.0
         ach, frac, bound = f"{k['tflops']:.0f} TFLOP/s", f"{k['tflops'] / peak:.3f}", "MFMA" if k["tflops"] > 300 else "MFMA nominally; launch / L2->LDS fill latency in practice"
