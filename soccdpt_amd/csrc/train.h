@@ -5,8 +5,20 @@
 
 namespace soccdpt {
 
-constexpr size_t kTrainColCountWords = 256;   // arrival counters of the single-launch column sums (tr_colsum): one per 64-column group
-
+// Every dgrad weight operand of one backward pass staged by a handful of launches instead of one per layer (round 4: 81 launches, 0.7 ms per bf16-amp step).
+// kind 0: [R][C] -> [C][R] (tr_transpose / tr_transpose16 with Rp = R); kind 1: conv weight [R = N][C][3][3] -> tr_conv_w_dgrad's layout.  Same
+// element conversions as the single forms (fmt: -1 f32, 0 bf16, 1 / 2 fp16, 3 x3), so the staged copies are bit-identical to theirs.
+struct TrBatchEntry {
+    const float* src;
+    void* dst;
+    int R, C, kind, tile0;   // tile0: first block of this entry in the launch's grid
+};
+constexpr int kTrBatchMax = 64;
+struct TrBatchTable {
+    TrBatchEntry e[kTrBatchMax];
+    int n;
+};
+int tr_weight_batch(const TrBatchTable& t, int total_tiles, int fmt, hipStream_t st, std::string& err);
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err);
 int tr_transpose16(const float* in, uint16_t* out, int R, int C, int Rp, int f16, hipStream_t st, std::string& err);
 int tr_im2colT(const float* halo, float* out, int B, int H, int W, int C, size_t Mp, hipStream_t st, std::string& err);
@@ -21,8 +33,8 @@ int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStrea
 int tr_to_halo_full(const float* in, void* out, int B, int H, int W, int C, int fmt, hipStream_t st, std::string& err);   // whole image incl. a zero border
 int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err);
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
-int tr_colsum(const float* a, const float* b, float* out, float* scratch, unsigned* count, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
-int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, unsigned* count, size_t M, int N, hipStream_t st, std::string& err);   // sum a*b and sum a in one pass
+int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
+int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, size_t M, int N, hipStream_t st, std::string& err);   // sum a*b and sum a in one pass
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);
 int tr_relu_bwd(const float* dy, const float* ref, const float* add, float* dx, size_t n, hipStream_t st, std::string& err);
 int tr_relu_bwd_halo(const float* dy, const float* ref_halo, const float* add, float* dx, int B, int H, int W, int C, hipStream_t st, std::string& err);

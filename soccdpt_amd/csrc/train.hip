@@ -147,6 +147,40 @@ __global__ void conv_w_dgrad_kernel(const float* __restrict__ w, OT* __restrict_
     }
 }
 
+// many weights, one launch (TrBatchTable): block -> entry by the entries' first-block numbers, then the body of transpose_kernel (Rp = R) or
+// conv_w_dgrad_kernel (1024 elements per block)
+template <typename OT>
+__global__ __launch_bounds__(256) void weight_batch_kernel(const TrBatchTable t) {
+    __shared__ float tl[32][33];
+    int i = 0;
+    while (i + 1 < t.n && (int)blockIdx.x >= t.e[i + 1].tile0) ++i;
+    const float* __restrict__ in = t.e[i].src;
+    OT* __restrict__ out = static_cast<OT*>(t.e[i].dst);
+    const int R = t.e[i].R, C = t.e[i].C, local = (int)blockIdx.x - t.e[i].tile0;
+    if (t.e[i].kind == 0) {
+        const int tiles_x = (C + 31) / 32;
+        const int bx = (local % tiles_x) * 32, by = (local / tiles_x) * 32;
+        const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+        for (int k = ty; k < 32; k += 8) {
+            const int r = by + k, c = bx + tx;
+            tl[k][tx] = (r < R && c < C) ? in[(size_t)r * C + c] : 0.f;
+        }
+        __syncthreads();
+        for (int k = ty; k < 32; k += 8) {
+            const int c = bx + k, r = by + tx;
+            if (c < C && r < R) store_out<OT>(out, (size_t)c * R + r, tl[tx][k]);
+        }
+    } else {
+        const size_t n = (size_t)R * C * 9;
+        for (size_t q = (size_t)local * 1024 + threadIdx.x; q < n && q < (size_t)(local + 1) * 1024; q += 256) {
+            const int nn = (int)(q % R);
+            const size_t r = q / R;
+            const int tap = (int)(r % 9), c = (int)(r / 9);
+            store_out<OT>(out, q, in[((size_t)nn * C + c) * 9 + (8 - tap)]);
+        }
+    }
+}
+
 // dW tap-major [N][9][C] -> parameter layout [N][C][3][3]
 __global__ void wgrad_permute_kernel(const float* __restrict__ in, float* __restrict__ out, int N, int C) {
     const size_t n = (size_t)N * C * 9;
@@ -267,70 +301,6 @@ __global__ __launch_bounds__(1024) void colsum_final_kernel(const float* __restr
         for (int i = 0; i < 16; i += 4) v += (red[i][tx] + red[i + 1][tx]) + (red[i + 2][tx] + red[i + 3][tx]);
         float* o = n < N ? out + n : out2 + (n - N);
         *o = accumulate ? *o + v : v;
-    }
-}
-// Both stages in ONE launch (round 4: the two-launch form cost ~200 launches and 1.06 ms per bf16-amp step): every block publishes its chunk's partial sums at
-// device scope, then the LAST block to arrive at its 64-column group (one arrival counter per group, zero at rest and left zero) adds the chunks in chunk
-// order -- four phases of every fourth chunk, combined as (p0 + p1) + (p2 + p3) -- so the result does not depend on which block was last.  chunks == 1:
-// the block's sum is the result.
-template <bool TWO>
-__global__ __launch_bounds__(256) void colsum_fused_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part, unsigned* __restrict__ count,
-                                                           float* __restrict__ out, float* __restrict__ out2, size_t M, int N, int chunks, int accumulate) {
-    __shared__ float red[TWO ? 2 : 1][4][64];
-    __shared__ unsigned arrival;
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-    const int n = blockIdx.x * 64 + tx;
-    const int ch = blockIdx.y;
-    const int NN = TWO ? 2 * N : N;
-    const size_t per = (M + chunks - 1) / chunks, lo = (size_t)ch * per, hi = lo + per < M ? lo + per : M;
-    float s[4] = {0.f, 0.f, 0.f, 0.f}, t[4] = {0.f, 0.f, 0.f, 0.f};
-    if (n < N) {
-        size_t m = lo + ty;
-        for (; m + 12 < hi; m += 16) {
-            float av[4], bv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = a[(m + 4 * u) * N + n]; bv[u] = b ? b[(m + 4 * u) * N + n] : 1.f; }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { s[u] += b ? av[u] * bv[u] : av[u]; if (TWO) t[u] += av[u]; }
-        }
-        for (; m < hi; m += 4) { const float av = a[m * N + n]; s[0] += b ? av * b[m * N + n] : av; if (TWO) t[0] += av; }
-    }
-    red[0][ty][tx] = (s[0] + s[1]) + (s[2] + s[3]);
-    if (TWO) red[TWO ? 1 : 0][ty][tx] = (t[0] + t[1]) + (t[2] + t[3]);
-    __syncthreads();
-    float v0 = 0.f, v1 = 0.f;
-    if (ty == 0) {
-        v0 = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
-        if (TWO) v1 = (red[TWO ? 1 : 0][0][tx] + red[TWO ? 1 : 0][1][tx]) + (red[TWO ? 1 : 0][2][tx] + red[TWO ? 1 : 0][3][tx]);
-    }
-    if (chunks > 1) {
-        if (ty == 0 && n < N) {
-            __hip_atomic_store(part + (size_t)ch * NN + n, v0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (TWO) __hip_atomic_store(part + (size_t)ch * NN + N + n, v1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this block's partials are acknowledged at device scope ...
-        __syncthreads();                                   // ... all of them, and red[] is free again
-        if (threadIdx.x == 0) arrival = __hip_atomic_fetch_add(count + blockIdx.x, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (arrival != (unsigned)chunks - 1) return;       // not the last chunk of this column group: done, nobody waits
-        if (threadIdx.x == 0) __hip_atomic_store(count + blockIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // zero at rest again
-        float p0 = 0.f, p1 = 0.f;
-        if (n < N)
-            for (int c = ty; c < chunks; c += 4) {
-                p0 += __hip_atomic_load(part + (size_t)c * NN + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (TWO) p1 += __hip_atomic_load(part + (size_t)c * NN + N + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        red[0][ty][tx] = p0;
-        if (TWO) red[TWO ? 1 : 0][ty][tx] = p1;
-        __syncthreads();
-        if (ty == 0) {
-            v0 = (red[0][0][tx] + red[0][1][tx]) + (red[0][2][tx] + red[0][3][tx]);
-            if (TWO) v1 = (red[TWO ? 1 : 0][0][tx] + red[TWO ? 1 : 0][1][tx]) + (red[TWO ? 1 : 0][2][tx] + red[TWO ? 1 : 0][3][tx]);
-        }
-    }
-    if (ty == 0 && n < N) {
-        out[n] = accumulate ? out[n] + v0 : v0;
-        if (TWO) out2[n] = v1;
     }
 }
 // sum over the leading axis of [R][n] with n large (attention logit gradients summed over windows): one thread per column
@@ -1227,6 +1197,14 @@ inline unsigned gs_blocks(size_t n) {
 
 #define TK(name) return check_launch(name, err)
 
+int tr_weight_batch(const TrBatchTable& t, int total_tiles, int fmt, hipStream_t st, std::string& err) {
+    if (t.n < 1 || t.n > kTrBatchMax || total_tiles < 1) { err = "weight_batch: bad table"; return 1; }
+    if (fmt == 3) SOCCDPT_LAUNCH(weight_batch_kernel<x3raw>, dim3(total_tiles), dim3(256), 0, st, t);
+    else if (fmt == 1 || fmt == 2) SOCCDPT_LAUNCH(weight_batch_kernel<f16raw>, dim3(total_tiles), dim3(256), 0, st, t);
+    else if (fmt == 0) SOCCDPT_LAUNCH(weight_batch_kernel<uint16_t>, dim3(total_tiles), dim3(256), 0, st, t);
+    else SOCCDPT_LAUNCH(weight_batch_kernel<float>, dim3(total_tiles), dim3(256), 0, st, t);
+    TK("weight_batch");
+}
 int tr_transpose(const float* in, float* out, int R, int C, int Rp, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(transpose_kernel<float>, dim3((C + 31) / 32, (Rp + 31) / 32), dim3(256), 0, st, in, out, R, C, Rp);
     TK("transpose");
@@ -1304,24 +1282,24 @@ int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int 
     SOCCDPT_LAUNCH(from_halo_kernel, dim3(gs_blocks((size_t)B * H * W * C)), dim3(256), 0, st, halo, out, B, H, W, C, accumulate);
     TK("from_halo");
 }
-// scratch: up to 65536 + N floats; count: kTrainColCountWords arrival counters, zero at rest (Tape::col_count)
-int tr_colsum(const float* a, const float* b, float* out, float* scratch, unsigned* count, size_t M, int N, int accumulate, hipStream_t st, std::string& err) {
+// scratch: up to 65536 + N floats
+int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err) {
     const int cb = (N + 63) / 64;
     int chunks = 512 / cb;
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
-    if (chunks > 1 && (size_t)cb > kTrainColCountWords) { err = "colsum: more column groups than arrival counters"; return 1; }
-    SOCCDPT_LAUNCH(colsum_fused_kernel<false>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, count, out, static_cast<float*>(nullptr), M, N, chunks, accumulate);
+    SOCCDPT_LAUNCH(colsum_part_kernel<false>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3(cb), dim3(1024), 0, st, scratch, out, static_cast<float*>(nullptr), N, N, chunks, accumulate);
     TK("colsum");
 }
 // out_ab[n] = sum_m a b, out_a[n] = sum_m a from ONE pass over a (LayerNorm gamma / beta gradients).  scratch: up to 131072 + 2N floats
-int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, unsigned* count, size_t M, int N, hipStream_t st, std::string& err) {
+int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, size_t M, int N, hipStream_t st, std::string& err) {
     const int cb = (N + 63) / 64;
     int chunks = 512 / cb;
     if ((size_t)chunks > (M + 15) / 16) chunks = (int)((M + 15) / 16);
     if (chunks < 1) chunks = 1;
-    if (chunks > 1 && (size_t)cb > kTrainColCountWords) { err = "colsum2: more column groups than arrival counters"; return 1; }
-    SOCCDPT_LAUNCH(colsum_fused_kernel<true>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, count, out_ab, out_a, M, N, chunks, 0);
+    SOCCDPT_LAUNCH(colsum_part_kernel<true>, dim3(cb, chunks), dim3(256), 0, st, a, b, scratch, M, N, chunks);
+    SOCCDPT_LAUNCH(colsum_final_kernel, dim3((2 * N + 63) / 64), dim3(1024), 0, st, scratch, out_ab, out_a, N, 2 * N, chunks, 0);
     TK("colsum2");
 }
 int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, void* out1, size_t n1, hipStream_t st, std::string& err) {

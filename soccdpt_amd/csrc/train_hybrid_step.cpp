@@ -92,7 +92,7 @@ int conv_gen_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* Wtap,
                 c.T.xt_tn_src = nullptr;   // S_T2 no longer holds conv3_bwd's staged image
                 TRY(tr_wgrad_tn(h16, N, xb + mrg * C, C, Kp, N, C, 9, rp, F16, T.sk_part, kTrainSkPartFloats, dWtap_out, c.st, c.err));
             }
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, Mo, N, 0, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, Mo, N, 0, c.st, c.err));
             return 0;
         }
     }
@@ -122,7 +122,7 @@ int conv_gen_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* Wtap,
         d.X = T.S_T1; d.Wt = T.S_T2; d.M = N; d.N = 9 * C; d.Cin = Mp; d.ldx = Mp; d.out_f32 = dWtap_out;
         TRY(gemm_wgrad(c, d, false));   // f32 staging (the strided / weight-standardised convolutions do not take the amp path)
     }
-    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, Mo, N, 0, c.st, c.err));
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, Mo, N, 0, c.st, c.err));
     return 0;
 }
 
@@ -408,7 +408,7 @@ int hy_backward(Ctx& c) {
         if (dpos || dcls) {
             // sum over the batch of the token-stream gradient: [B][NT*E] -> [NT*E]  (tr_colsum: rows = samples)
             float* tmp = dpos ? dpos : G[3];
-            TRY(tr_colsum(Y.GT, nullptr, tmp, T.S_col, T.col_count, (size_t)B, NT * E, 0, st, err));
+            TRY(tr_colsum(Y.GT, nullptr, tmp, T.S_col, (size_t)B, NT * E, 0, st, err));
             if (dcls) TRY(copy_d2d(c, dcls, tmp, (size_t)E * 4, "hy_backward"));
         }
         TRY(th_tokens_to_patches(Y.GT, G[0], B, NT, E, st, err));

@@ -3,6 +3,7 @@
 #pragma once
 #include <algorithm>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "train.h"
@@ -86,7 +87,10 @@ struct Tape {
     float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb, *attn_part;
     float* sk_part;
     unsigned* sk_count;
-    unsigned* col_count;   // arrival counters of tr_colsum (kTrainColCountWords), zero at rest like sk_count
+    // dgrad weight operands of the whole backward pass, staged by stage_weights() in a few batched launches (4 bytes per element reserved per weight)
+    float* WT = nullptr;
+    std::vector<long long> wt_off;                        // per Handle::weights index: element offset of its slot in WT, -1 = not staged (odd shapes)
+    std::unordered_map<const float*, long long> wt_by_ptr;   // bound weight pointer -> slot offset, filled by stage_weights()
     size_t maxAct = 0;
     float dropout_p = 0.f;
 };
@@ -111,6 +115,11 @@ int gemm_fwd(Ctx& c, IgemmDesc d, size_t x_elems, size_t w_elems);
 int gemm16(Ctx& c, IgemmDesc d);   // 16-bit operands of the amp mode (bf16 / fp16), f32 outputs
 int gemm_wgrad(Ctx& c, IgemmDesc d, bool bf16_operands, bool x3 = false);   // operands as written by the caller's staging kernels
 int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what);
+// Transposed (Linear / 1x1) or rotated tap-major (3x3) copies of every regularly shaped bound weight in the amp mode's operand format, for the dgrad GEMMs of
+// this backward pass: two or three launches instead of one per layer.  linear_bwd / conv3_bwd use a staged copy when they find one (staged_wt) and stage their
+// own otherwise (derived weights: padded patch embedding, standardised ResNetV2 kernels).
+int stage_weights(Ctx& c);
+const void* staged_wt(const Ctx& c, const float* W);
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db);
 int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r, int N, int C, float* dX_out, const float* dX_res, float* dW, float* db,

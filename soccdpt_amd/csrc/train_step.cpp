@@ -41,7 +41,6 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.path1 = halo(r1, F);
     T.d1u = halo(r0, F / 2);
     T.sk_count = reinterpret_cast<unsigned*>(ar.f(kTrainSkCountWords));   // split-K arrival counters: zero at rest (zeroed with the halos)
-    T.col_count = reinterpret_cast<unsigned*>(ar.f(kTrainColCountWords));
     if (a.hybrid) hy_carve_halo(h, B, ar, T);
     ar.f(0);
     T.halo_hi = (ar.off + 255) & ~size_t(255);
@@ -130,6 +129,19 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     T.S_wt = ar.f(wmax);
     T.S_dw = ar.f(wmax);
     T.S_col = ar.f((size_t)1 << 20);
+    {   // slots of the staged dgrad weight operands (stage_weights): Linear [N][K] and 1x1 conv weights with N, K multiples of 32 and K > 32, 3x3 conv weights with N, C multiples of 32
+        T.wt_off.assign(h.weights.size(), -1);
+        size_t tot = 0;
+        for (size_t i = 0; i < h.weights.size(); ++i) {
+            const auto& sh = h.weights[i].shape;
+            const bool lin = (sh.size() == 2 || (sh.size() == 4 && sh[2] == 1 && sh[3] == 1)) && sh[0] % 32 == 0 && sh[1] % 32 == 0 && sh[1] > 32;
+            const bool c3 = sh.size() == 4 && sh[2] == 3 && sh[3] == 3 && sh[0] % 32 == 0 && sh[1] % 32 == 0;
+            if (!lin && !c3) continue;
+            T.wt_off[i] = (long long)tot;
+            tot += (h.weights[i].numel() + 63) & ~size_t(63);
+        }
+        T.WT = ar.f(tot);
+    }
     T.sk_part = ar.f(kTrainSkPartFloats);
     T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
     T.dS = ar.f(maxDS);
@@ -231,6 +243,44 @@ static bool wgrad_tn_on() {
     return !off;
 }
 
+int stage_weights(Ctx& c) {
+    static const bool off = getenv("SOCCDPT_NO_WEIGHT_BATCH") != nullptr;   // A/B switch: one staging launch per layer, as in rounds 2-3
+    Tape& T = c.T;
+    T.wt_by_ptr.clear();
+    if (off || !T.WT) return 0;
+    const int amp = c.h.train_amp;
+    const int fmt = amp == 3 ? 3 : amp == 2 ? 1 : amp == 1 ? 0 : -1;
+    TrBatchTable t;
+    t.n = 0;
+    int tiles = 0;
+    auto flush = [&]() -> int {
+        if (t.n) TRY(tr_weight_batch(t, tiles, fmt, c.st, c.err));
+        t.n = 0;
+        tiles = 0;
+        return 0;
+    };
+    for (size_t i = 0; i < c.h.weights.size(); ++i) {
+        if (T.wt_off[i] < 0 || !c.h.weights[i].ptr) continue;
+        const auto& w = c.h.weights[i];
+        TrBatchEntry& e = t.e[t.n++];
+        e.src = w.ptr;
+        e.dst = T.WT + T.wt_off[i];
+        e.R = (int)w.shape[0];
+        e.C = (int)w.shape[1];
+        e.kind = (w.shape.size() == 4 && w.shape[2] == 3) ? 1 : 0;
+        e.tile0 = tiles;
+        tiles += e.kind ? (int)(((size_t)e.R * e.C * 9 + 1023) / 1024) : ((e.C + 31) / 32) * ((e.R + 31) / 32);
+        T.wt_by_ptr[w.ptr] = T.wt_off[i];
+        if (t.n == kTrBatchMax) TRY(flush());
+    }
+    return flush();
+}
+
+const void* staged_wt(const Ctx& c, const float* W) {
+    const auto it = c.T.wt_by_ptr.find(W);
+    return it == c.T.wt_by_ptr.end() ? nullptr : static_cast<const void*>(c.T.WT + it->second);
+}
+
 // y = x W^T + b backward.  dY [M][N], X [M][K], W [N][K].  dX_out = dY W (+ dX_res); dW = dY^T X; db = colsum(dY).
 int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M, int N, int K, float* dX_out, const float* dX_res, float* dW, float* db) {
     Tape& T = c.T;
@@ -241,22 +291,23 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
         IgemmDesc d;
         d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
         if (x3) {
-            uint16_t* w3 = reinterpret_cast<uint16_t*>(T.S_wt);
+            const void* w3 = staged_wt(c, W);
             uint16_t* a3 = reinterpret_cast<uint16_t*>(T.S_T1);
-            TRY(tr_transpose16(W, w3, N, K, N, 3, c.st, c.err));
+            if (!w3) { TRY(tr_transpose16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, K, N, 3, c.st, c.err)); w3 = T.S_wt; }
             TRY(launch_cvt_bf16(dY, a3, M * N, 3, c.st, c.err));
             d.X = a3; d.Wt = w3;
             TRY(gemm(c, d, true));
         } else if (amp) {
-            uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
+            const void* w16 = staged_wt(c, W);
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
-            TRY(tr_transpose16(W, w16, N, K, N, F16, c.st, c.err));
+            if (!w16) { TRY(tr_transpose16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, K, N, F16, c.st, c.err)); w16 = T.S_wt; }
             TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));   // fp16: IEEE conversion, an overflow of the scaled gradient becomes inf
             d.X = a16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
-            TRY(tr_transpose(W, T.S_wt, N, K, N, c.st, c.err));   // [K][N]
-            d.X = dY; d.Wt = T.S_wt;
+            const void* wt = staged_wt(c, W);
+            if (!wt) { TRY(tr_transpose(W, T.S_wt, N, K, N, c.st, c.err)); wt = T.S_wt; }   // [K][N]
+            d.X = dY; d.Wt = wt;
             TRY(gemm(c, d));
         }
     }
@@ -276,7 +327,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
             TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (x3) {
             const int Mp = (int)((M + 31) / 32 * 32);
@@ -299,7 +350,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
             TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
+            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
@@ -316,7 +367,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
         }
         TRY(gemm_wgrad(c, d, amp, x3));
     }
-    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
     return 0;
 }
 
@@ -340,23 +391,24 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         d.M = (int)M; d.N = C; d.Cin = N; d.taps = 9; d.H = r; d.W = r; d.res1 = dX_res; d.out_f32 = dX_out;
         if (x3) {
             uint16_t* h3 = reinterpret_cast<uint16_t*>(T.S_halo);
-            uint16_t* w3 = reinterpret_cast<uint16_t*>(T.S_wt);
+            const void* w3 = staged_wt(c, W);
             TRY(tr_to_halo_full(dY, h3, B, r, r, N, 3, c.st, c.err));
-            TRY(tr_conv_w_dgrad16(W, w3, N, C, 3, c.st, c.err));
+            if (!w3) { TRY(tr_conv_w_dgrad16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, C, 3, c.st, c.err)); w3 = T.S_wt; }
             d.X = h3; d.Wt = w3;
             TRY(gemm(c, d, true));
         } else if (amp) {
             uint16_t* h16 = reinterpret_cast<uint16_t*>(T.S_halo);
-            uint16_t* w16 = reinterpret_cast<uint16_t*>(T.S_wt);
+            const void* w16 = staged_wt(c, W);
             TRY(tr_to_halo_full(dY, h16, B, r, r, N, 1 + F16, c.st, c.err));
-            TRY(tr_conv_w_dgrad16(W, w16, N, C, F16, c.st, c.err));
+            if (!w16) { TRY(tr_conv_w_dgrad16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, C, F16, c.st, c.err)); w16 = T.S_wt; }
             d.X = h16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
             if (full) TRY(tr_to_halo_full(dY, T.S_halo, B, r, r, N, 0, c.st, c.err));
             else TRY(tr_to_halo(dY, T.S_halo, B, r, r, N, c.st, c.err));
-            TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err));   // [C][9][N], rotated
-            d.X = T.S_halo; d.Wt = T.S_wt;
+            const void* wt = staged_wt(c, W);
+            if (!wt) { TRY(tr_conv_w_dgrad(W, T.S_wt, N, C, c.st, c.err)); wt = T.S_wt; }   // [C][9][N], rotated
+            d.X = T.S_halo; d.Wt = wt;
             TRY(gemm(c, d));
         }
     }
@@ -465,16 +517,16 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         }
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
     }
-    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, T.col_count, M, N, 0, c.st, c.err));
+    if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
     return 0;
 }
 
 // out = LN(y) g + b backward: d y -> dy; gamma / beta gradients
 int ln_bwd(Ctx& c, const float* y, const float* g, const float* dout, float* dy, float* xhat, size_t M, int C, float* dg, float* dbeta, float eps) {
     TRY(tr_ln_bwd(y, g, dout, dy, xhat, (int)M, C, eps, c.st, c.err));
-    if (dg && dbeta) return tr_colsum2(dout, xhat, dg, dbeta, c.T.S_col, c.T.col_count, M, C, c.st, c.err);   // one pass over dout for both (same addition order as the single forms)
-    if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, c.T.col_count, M, C, 0, c.st, c.err));
-    if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, c.T.col_count, M, C, 0, c.st, c.err));
+    if (dg && dbeta) return tr_colsum2(dout, xhat, dg, dbeta, c.T.S_col, M, C, c.st, c.err);   // one pass over dout for both (same addition order as the single forms)
+    if (dg) TRY(tr_colsum(dout, xhat, dg, c.T.S_col, M, C, 0, c.st, c.err));
+    if (dbeta) TRY(tr_colsum(dout, nullptr, dbeta, c.T.S_col, M, C, 0, c.st, c.err));
     return 0;
 }
 
@@ -827,6 +879,7 @@ int train_backward_encoder(Handle& h, int B, const float* const* d_feat, void* w
         const size_t n = (size_t)B * h.arch.fres(l) * h.arch.fres(l) * h.arch.fdim(l);
         TRY(copy_d2d(c, T.DF[l], d_feat[l], n * 4, "train_backward_encoder"));
     }
+    TRY(stage_weights(c));
     return encoder_backward(c);
 }
 
@@ -839,6 +892,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     carve(h, B, ar, T);
     T.dropout_p = h.train_key.dropout_p;
     Ctx c{h, T, B, st, err};
+    TRY(stage_weights(c));
     const int F = h.cfg.features;
     float** G = T.G;
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
@@ -860,7 +914,7 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         float* dw4 = c.Gd(SCR + "output_conv.4.weight");
         float* db4 = c.Gd(SCR + "output_conv.4.bias");
         if (dw4 || db4) {
-            TRY(tr_colsum(G[1], nullptr, T.S_vec, T.S_col, T.col_count, M0p, 33, 0, st, err));
+            TRY(tr_colsum(G[1], nullptr, T.S_vec, T.S_col, M0p, 33, 0, st, err));
             if (dw4) TRY(copy_d2d(c, dw4, T.S_vec, 32 * 4, "train_backward"));
             if (db4) TRY(copy_d2d(c, db4, T.S_vec + 32, 4, "train_backward"));
         }
@@ -876,15 +930,15 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
         if (float* dw = c.Gd("seg_head.4.weight")) TRY(tr_smallk_wgrad(G[1], T.r, dw, T.S_col, M1, F, 3, st, err));
         if (float* db = c.Gd("seg_head.4.bias")) {
             // colsum needs N >= 1: three columns
-            TRY(tr_colsum(G[1], nullptr, db, T.S_col, T.col_count, M1, 3, 0, st, err));
+            TRY(tr_colsum(G[1], nullptr, db, T.S_col, M1, 3, 0, st, err));
         }
         TRY(tr_smallk_dgrad(G[1], c.W("seg_head.4.weight"), G[2], M1, F, 3, st, err));
         TRY(tr_bn_relu_dropout_bwd_pre(G[2], T.r, T.keep, G[0], M1 * F, T.dropout_p, st, err));
         TRY(tr_bn_xhat(T.c_raw, T.bn_stats, G[3], M1, F, st, err));
         float* dbeta = T.S_vec;
         float* dgamma = T.S_vec + F;
-        TRY(tr_colsum(G[0], nullptr, dbeta, T.S_col, T.col_count, M1, F, 0, st, err));
-        TRY(tr_colsum(G[0], G[3], dgamma, T.S_col, T.col_count, M1, F, 0, st, err));
+        TRY(tr_colsum(G[0], nullptr, dbeta, T.S_col, M1, F, 0, st, err));
+        TRY(tr_colsum(G[0], G[3], dgamma, T.S_col, M1, F, 0, st, err));
         if (float* p = c.Gd("seg_head.1.bias")) TRY(copy_d2d(c, p, dbeta, F * 4, "train_backward"));
         if (float* p = c.Gd("seg_head.1.weight")) TRY(copy_d2d(c, p, dgamma, F * 4, "train_backward"));
         TRY(tr_bn_bwd(G[0], T.c_raw, T.bn_stats, c.W("seg_head.1.weight"), dbeta, dgamma, G[2], M1, F, st, err));
