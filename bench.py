@@ -118,6 +118,14 @@ def train_step_bench(args):
                 "peak_note": ("exact-f32 MFMA" if not args.amp else "x3: a third of the 16-bit MFMA peak" if args.amp == "x3" else
                               "x3 forward (1/3 of the FLOPs at 833.3) + 16-bit dgrad / wgrad (2/3 at 2500): FLOP-weighted harmonic mean"),
                 "flops_per_sample_gflop": round(3.0 * FWD_GFLOP_PER_FRAME[args.model_type], 1)}
+    else:
+        # partly frozen schedule (encoder_percentage / patchwise_percentage < 1): frozen tensors skip their wgrad GEMM and the dgrad stops where nothing
+        # upstream trains, so the executed FLOPs vary per patch.  What always runs in full is the train-mode forward: a LOWER BOUND of the achieved rate.
+        peak = PEAK_F32_TFLOPS if not args.amp else round(PEAK_BF16_TFLOPS / 3.0, 1)
+        ach = FWD_GFLOP_PER_FRAME[args.model_type] * sps / 1e3
+        roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None, "lower_bound": True,
+                "kernel": "whole step; only the train-mode forward's FLOPs are counted (the backward's share depends on the frozen set of each patch)",
+                "flops_per_sample_gflop": round(FWD_GFLOP_PER_FRAME[args.model_type], 1)}
     cpu = None
     if not args.no_cpu_baseline and not args.headline_only:
         from oracle import soccdpt_ref as R
