@@ -10,8 +10,8 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 for model_type, backbone, img, n in (("dpt_swin2_tiny_256", "swin2t16_256", 256, N), ("dpt_swin2_base_384", "swin2b24_384", 384, N // 4)):
     sd = synth_state_dict(backbone, alias_pretrained=True)
-    for prec, name in ((0, "bf16"), (2, "f16"), (1, "f32")):
-        reps = n if prec != 1 else n // 4
+    for prec, name in ((4, "mixed"), (0, "bf16"), (2, "f16"), (3, "f16x3"), (1, "f32")):
+        reps = n if prec not in (1, 3) else n // 4
         m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, precision=prec, model_type=model_type)
         m.load_state_dict(sd, strict=False)
         m = m.eval().to(dev)
