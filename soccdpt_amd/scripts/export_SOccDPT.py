@@ -2,10 +2,12 @@
 torch.onnx.export(net, x, export_path, opset_version=13, input_names=["input"], output_names=["output"], dynamic batch)).
 
 The reference traces the torch forward.  This build's forward is a launch sequence of HIP kernels behind a C ABI, so there is nothing to trace:
-the graph of `SOccDPT_V3.forward` with compute_occ=False -- Swin-V2 encoder, DPT decoder, depth + seg heads, bicubic / nearest up-sampling and
+the graph of `SOccDPT_V3.forward` with compute_occ=False -- Swin-V2 (tiny_256, base_384) or ViT-hybrid (dpt_hybrid_384) encoder, DPT decoder, depth + seg
+heads, bicubic / nearest up-sampling and
 the back-projection to camera-frame points (model/SOccDPT.py:264-372, 681-685) -- is written node by node in standard opset-13 operators from
 the model's own weights (`soccdpt_amd.utils.onnx_proto`, a protobuf writer; the `onnx` package is not in the image).  What the reference's
-constant folding would fold is folded here too: the continuous-position-bias MLP, the logit scales and the shift masks become initializers.
+constant folding would fold is folded here too: the continuous-position-bias MLP, the logit scales and the shift masks become initializers, and so do
+the standardised StdConv2dSame filters of the hybrid's ResNetV2.
 
 Outputs (the 3-output graph run_SOccDPT_onnx.py:165-176 consumes): "output" = inverse depth [B, Hc, Wc], "segmentation" [B, C, Hc, Wc], "points"
 [B, Hc, Wc, 3] (incl. the reference's 3-pixel pc_scale quirk); input "input" [B, 3, S, S]; batch is dynamic.  `soccdpt_amd.utils.onnx_eval`
@@ -96,10 +98,19 @@ class GraphBuilder:
         e = self.op("Erf", [self.div(x, self.f32(math.sqrt(2.0)))])
         return self.mul(self.mul(x, self.add(e, self.f32(1.0))), self.f32(0.5))
 
-    def conv(self, x, w: torch.Tensor, b: Optional[torch.Tensor], hint: str, stride: int = 1, pad: int = 0):
+    def conv(self, x, w: torch.Tensor, b: Optional[torch.Tensor], hint: str, stride: int = 1, pad: int = 0, pads: Optional[Sequence[int]] = None):
         k = int(w.shape[-1])
         ins = [x, self.weight(w, hint + "_w")] + ([self.weight(b, hint + "_b")] if b is not None else [])
-        return self.op("Conv", ins, kernel_shape=[k, k], strides=[stride, stride], pads=[pad] * 4, dilations=[1, 1], group=1)
+        return self.op("Conv", ins, kernel_shape=[k, k], strides=[stride, stride], pads=list(pads) if pads is not None else [pad] * 4, dilations=[1, 1], group=1)
+
+    def group_norm(self, x, C: int, H: int, W: int, g: torch.Tensor, b: torch.Tensor, groups: int, eps: float, hint: str):
+        """nn.GroupNorm on [B, C, H, W] (opset 13 has no GroupNormalization): per (sample, group) statistics over a [B, groups, -1] view."""
+        v = self.reshape(x, [0, groups, -1])
+        mean = self.op("ReduceMean", [v], axes=[-1], keepdims=1)
+        d = self.sub(v, mean)
+        var = self.op("ReduceMean", [self.mul(d, d)], axes=[-1], keepdims=1)
+        y = self.reshape(self.div(d, self.op("Sqrt", [self.add(var, self.f32(eps))])), [0, C, H, W])
+        return self.add(self.mul(y, self.weight(g.reshape(1, C, 1, 1), hint + "_g")), self.weight(b.reshape(1, C, 1, 1), hint + "_b"))
 
     def resize(self, x, sh: float, sw: float, mode: str):
         attrs = {"bilinear_ac": dict(mode="linear", coordinate_transformation_mode="align_corners"),
@@ -148,19 +159,10 @@ SWIN = {   # model/dpt.py:51-89 (hooks), backbones/swin2.py:15-30 (timm model na
 }
 
 
-def build_graph(net, opset: int = 13) -> P.Model:
-    """The ONNX model of `net` (a soccdpt_amd SOccDPT_V3 with a Swin-V2 backbone), weights taken from its state dict."""
-    backbone = net._engine_backbone()
-    if backbone not in SWIN:
-        raise NotImplementedError(f"ONNX export is written for the Swin-V2 backbones ({list(SWIN)}); got {backbone}")
-    A = SWIN[backbone]
-    sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
-    ENC, SCR = "depth_net.pretrained.model.", "depth_net.scratch."
-    b = GraphBuilder()
+def _swin_encoder(b: GraphBuilder, sd, A) -> List[str]:
+    """timm SwinTransformerV2 (backbones/swin2.py:15-30) with the forward hooks + act_postprocess of backbones/swin_common.py:12-54: the four NCHW maps."""
+    ENC = "depth_net.pretrained.model."
     S, C0 = A["img"], A["embed"]
-    b.g.inputs.append(P.ValueInfo("input", P.FLOAT, ["batch_size", 3, S, S]))
-
-    # ---------------- encoder ----------------
     t = b.conv("input", sd[ENC + "patch_embed.proj.weight"], sd[ENC + "patch_embed.proj.bias"], "patch_embed", stride=A["patch"])
     t = b.transpose(b.reshape(t, [0, C0, -1]), [0, 2, 1])
     t = b.layer_norm(t, sd[ENC + "patch_embed.norm.weight"], sd[ENC + "patch_embed.norm.bias"], 1e-5, "patch_norm")
@@ -208,6 +210,119 @@ def build_graph(net, opset: int = 13) -> P.Model:
             h = b.reshape(b.concat(parts, 3), [-1, res * res // 4, 4 * C])
             t = b.layer_norm(b.linear(h, sd[pfx + "reduction.weight"], None, f"merge{s}"), sd[pfx + "norm.weight"], sd[pfx + "norm.bias"], 1e-5, f"merge{s}_n")
             res //= 2
+
+    return feats
+
+
+HYBRID = dict(img=384, patch=16, embed=768, depth=12, heads=12, layers=(3, 4, 9), hooks=(0, 1, 8, 11), features=(256, 512, 768, 768))   # model/dpt.py:86, model/blocks.py:103-112
+
+
+def _same_pads(i: int, k: int, s: int) -> List[int]:
+    """timm pad_same / TF 'SAME': total = max((ceil(i / s) - 1) s + k - i, 0), the odd pixel goes bottom / right.  ONNX order [top, left, bottom, right]."""
+    t = max((math.ceil(i / s) - 1) * s + k - i, 0)
+    return [t // 2, t // 2, t - t // 2, t - t // 2]
+
+
+def _std_weight(w: torch.Tensor, eps: float = 1e-8) -> torch.Tensor:
+    """timm StdConv2dSame: per-output-channel weight standardisation (biased variance, evaluated through F.batch_norm like timm does).  A function of
+    the weights alone: folded into the initializer, like do_constant_folding would."""
+    return torch.nn.functional.batch_norm(w.reshape(1, w.shape[0], -1), None, None, training=True, momentum=0.0, eps=eps).reshape_as(w)
+
+
+def _hybrid_encoder(b: GraphBuilder, sd, A) -> List[str]:
+    """timm vit_base_resnet50_384 as backbones/vit.py:147-258 wires it: ResNetV2 (3, 4, 9) stem / stages (StdConv2dSame + GroupNormAct(32) + MaxPool2dSame),
+    1x1 projection, class token + position embedding, 12 pre-norm ViT-B blocks; hooks on stages 0 / 1 and blocks 8 / 11; act_postprocess3 / 4 =
+    ProjectReadout + Transpose + Unflatten + Conv1x1 (+ Conv3x3 stride 2) (backbones/utils.py:27-40,84-133).  Returns the four NCHW maps."""
+    M = "depth_net.pretrained.model."
+    BB = M + "patch_embed.backbone."
+    S, E, heads = A["img"], A["embed"], A["heads"]
+
+    def std_conv(x, key, hint, size, stride=1):
+        w = _std_weight(sd[key])
+        k = int(w.shape[-1])
+        pads = [(k - 1) // 2] * 4 if stride == 1 else _same_pads(size, k, stride)     # static symmetric padding at stride 1, dynamic SAME padding otherwise
+        return b.conv(x, w, None, hint, stride=stride, pads=pads)
+
+    def gn(x, C, size, key, hint, relu=True):
+        y = b.group_norm(x, C, size, size, sd[key + ".weight"], sd[key + ".bias"], 32, 1e-5, hint)
+        return b.relu(y) if relu else y
+
+    size = S // 2
+    y = gn(std_conv("input", BB + "stem.conv.weight", "stem", S, 2), 64, size, BB + "stem.norm", "stem_gn")
+    y = b.op("MaxPool", [y], kernel_shape=[3, 3], strides=[2, 2], pads=_same_pads(size, 3, 2))    # MaxPool2dSame: the padding is -inf, as in ONNX's MaxPool
+    size //= 2
+    stages = []
+    cin = 64
+    for s, depth in enumerate(A["layers"]):
+        cout, mid = 256 << s, 64 << s
+        for j in range(depth):
+            p, hint = f"{BB}stages.{s}.blocks.{j}.", f"rn{s}b{j}"
+            stride = 2 if (s > 0 and j == 0) else 1
+            osz = size // stride
+            sc = y
+            if p + "downsample.conv.weight" in sd:
+                sc = gn(std_conv(y, p + "downsample.conv.weight", hint + "_ds", size, stride), cout, osz, p + "downsample.norm", hint + "_dsn", relu=False)
+            t = gn(std_conv(y, p + "conv1.weight", hint + "_c1", size), mid, size, p + "norm1", hint + "_n1")
+            t = gn(std_conv(t, p + "conv2.weight", hint + "_c2", size, stride), mid, osz, p + "norm2", hint + "_n2")
+            t = gn(std_conv(t, p + "conv3.weight", hint + "_c3", osz), cout, osz, p + "norm3", hint + "_n3", relu=False)
+            y = b.relu(b.add(t, sc))
+            size, cin = osz, cout
+        stages.append(y)
+    g = S // A["patch"]
+    assert size == g, (size, g)
+    # tokens: 1x1 projection, flatten(2).transpose(1, 2), class token in front, position embedding (resized like backbones/vit.py:23-41 when the grid differs)
+    t = b.conv(stages[-1], sd[M + "patch_embed.proj.weight"], sd[M + "patch_embed.proj.bias"], "pe")
+    t = b.transpose(b.reshape(t, [0, E, -1]), [0, 2, 1])
+    pos = sd[M + "pos_embed"]
+    g_old = int(math.sqrt(pos.shape[1] - 1))
+    if g_old != g:
+        grid = torch.nn.functional.interpolate(pos[0, 1:].reshape(1, g_old, g_old, -1).permute(0, 3, 1, 2), size=(g, g), mode="bilinear")
+        pos = torch.cat([pos[:, :1], grid.permute(0, 2, 3, 1).reshape(1, g * g, -1)], dim=1)
+    batch = b.op("Gather", [b.op("Shape", [t]), b.i64([0])], axis=0)
+    cls = b.op("Expand", [b.weight(sd[M + "cls_token"], "cls"), b.concat([batch, b.i64([1, E])], 0)])
+    t = b.add(b.concat([cls, t], 1), b.weight(pos, "pos_embed"))
+    N, d = g * g + 1, E // heads
+    hooked = {}
+    for i in range(A["depth"]):
+        p, hint = f"{M}blocks.{i}.", f"vit{i}"
+        h = b.layer_norm(t, sd[p + "norm1.weight"], sd[p + "norm1.bias"], 1e-6, hint + "_n1")
+        qkv = b.linear(h, sd[p + "attn.qkv.weight"], sd[p + "attn.qkv.bias"], hint + "_qkv")
+        q, k, v = [b.transpose(b.reshape(b.slice(qkv, [c * E], [(c + 1) * E], [2]), [0, N, heads, d]), [0, 2, 1, 3]) for c in range(3)]
+        a = b.op("Softmax", [b.mul(b.matmul(q, b.transpose(k, [0, 1, 3, 2])), b.f32(d ** -0.5))], axis=-1)
+        o = b.reshape(b.transpose(b.matmul(a, v), [0, 2, 1, 3]), [0, N, E])
+        t = b.add(t, b.linear(o, sd[p + "attn.proj.weight"], sd[p + "attn.proj.bias"], hint + "_proj"))
+        h = b.layer_norm(t, sd[p + "norm2.weight"], sd[p + "norm2.bias"], 1e-6, hint + "_n2")
+        h = b.gelu(b.linear(h, sd[p + "mlp.fc1.weight"], sd[p + "mlp.fc1.bias"], hint + "_fc1"))
+        t = b.add(t, b.linear(h, sd[p + "mlp.fc2.weight"], sd[p + "mlp.fc2.bias"], hint + "_fc2"))
+        if i in A["hooks"][2:]:
+            hooked[i] = t           # (the final model.norm is dead on this path: both hooks fire before it)
+    feats = [stages[0], stages[1]]  # act_postprocess1 / 2 are identities (backbones/vit.py:179-182)
+    for n, hk in ((3, A["hooks"][2]), (4, A["hooks"][3])):
+        ap = f"depth_net.pretrained.act_postprocess{n}."
+        x = hooked[hk]
+        tok = b.slice(x, [1], [N], [1])
+        readout = b.op("Expand", [b.slice(x, [0], [1], [1]), b.op("Shape", [tok])])
+        f = b.gelu(b.linear(b.concat([tok, readout], 2), sd[ap + "0.project.0.weight"], sd[ap + "0.project.0.bias"], f"ro{n}"))
+        f = b.reshape(b.transpose(f, [0, 2, 1]), [0, E, g, g])
+        f = b.conv(f, sd[ap + "3.weight"], sd[ap + "3.bias"], f"pp{n}_c1")
+        if n == 4:
+            f = b.conv(f, sd[ap + "4.weight"], sd[ap + "4.bias"], "pp4_c3", stride=2, pad=1)
+        feats.append(f)
+    return feats
+
+
+def build_graph(net, opset: int = 13) -> P.Model:
+    """The ONNX model of `net` (a soccdpt_amd SOccDPT_V3 with a Swin-V2 or the ViT-hybrid backbone), weights taken from its state dict."""
+    backbone = net._engine_backbone()
+    if backbone not in SWIN and backbone != "vitb_rn50_384":
+        raise NotImplementedError(f"ONNX export is written for {list(SWIN) + ['vitb_rn50_384']}; got {backbone}")
+    A = SWIN.get(backbone, HYBRID)
+    sd = {k: v.detach().cpu().float() for k, v in net.state_dict().items()}
+    SCR = "depth_net.scratch."
+    b = GraphBuilder()
+    S = A["img"]
+    b.g.inputs.append(P.ValueInfo("input", P.FLOAT, ["batch_size", 3, S, S]))
+    feats = _hybrid_encoder(b, sd, A) if backbone == "vitb_rn50_384" else _swin_encoder(b, sd, A)
 
     # ---------------- decoder (model/dpt.py:152-182, model/blocks.py:391-497) ----------------
     def rcu(x, pfx, hint):

@@ -92,6 +92,15 @@ def run(model: P.Model, feeds: Dict[str, torch.Tensor], outputs: Optional[List[s
             else:
                 x, pad = i[0], list(pads[:nd])
             o = F.conv2d(x, i[1], get(2), stride=a.get("strides", [1] * nd), padding=pad, dilation=a.get("dilations", [1] * nd), groups=int(a.get("group", 1)))
+        elif op == "MaxPool":   # padding cells never win: -inf, as the operator specification says
+            nd = i[0].dim() - 2
+            pads = list(a.get("pads", [0] * (2 * nd)))
+            x = i[0]
+            if any(pads):
+                x = F.pad(x, [p for d in reversed(range(nd)) for p in (pads[d], pads[nd + d])], value=float("-inf"))
+            if any(int(v) != 1 for v in a.get("dilations", [1] * nd)):
+                raise NotImplementedError("MaxPool with dilations")
+            o = F.max_pool2d(x, list(a["kernel_shape"]), list(a.get("strides", [1] * nd)), 0, 1, bool(a.get("ceil_mode", 0)))
         elif op == "BatchNormalization":   # inference form: (x - mean) / sqrt(var + eps) * scale + B
             o = F.batch_norm(i[0], i[3], i[4], i[1], i[2], False, 0.0, float(a.get("epsilon", 1e-5)))
         elif op == "MatMul":
@@ -158,14 +167,20 @@ def run(model: P.Model, feeds: Dict[str, torch.Tensor], outputs: Optional[List[s
             axes = _ints(i[3]) if get(3) is not None else list(range(len(st)))
             steps = _ints(i[4]) if get(4) is not None else [1] * len(st)
             idx = [slice(None)] * i[0].dim()
+            back = []   # axes walked backwards (negative step): an index_select after the forward slices
             for s0, e0, ax, sp in zip(st, en, axes, steps):
-                if sp < 0:
-                    raise NotImplementedError("Slice with a negative step")
                 dim = i[0].shape[ax]
+                if sp < 0:      # starts clamp to [0, dim - 1], ends to [-1, dim - 1] (operator specification)
+                    s0 = max(0, min(dim - 1, s0 + dim if s0 < 0 else s0))
+                    e0 = max(-1, min(dim - 1, e0 + dim if e0 < 0 else e0))
+                    back.append((ax, torch.arange(s0, e0, sp)))
+                    continue
                 s0 = max(0, min(dim, s0 + dim if s0 < 0 else s0))
                 e0 = max(0, min(dim, e0 + dim if e0 < 0 else e0))
                 idx[ax] = slice(s0, e0, sp)
             o = i[0][tuple(idx)]
+            for ax, sel in back:
+                o = torch.index_select(o, ax, sel)
         elif op == "Gather":
             ax = int(a.get("axis", 0))
             ind = i[1].long()
@@ -197,6 +212,13 @@ def run(model: P.Model, feeds: Dict[str, torch.Tensor], outputs: Optional[List[s
             for name, t in zip(n.outputs, torch.split(i[0], parts, dim=ax)):
                 env[name] = t
             continue
+        elif op == "Pad":        # opset 13: pads (begin of every axis, then end of every axis) and the constant are inputs
+            if a.get("mode", "constant") != "constant":
+                raise NotImplementedError(f"Pad mode {a.get('mode')}")
+            pads = _ints(i[1])
+            nd = i[0].dim()
+            value = float(i[2].reshape(-1)[0]) if get(2) is not None and i[2].numel() else 0.0
+            o = F.pad(i[0], [p for d in reversed(range(nd)) for p in (pads[d], pads[nd + d])], value=value)
         elif op == "Resize":
             o = _resize(i[0], get(2), get(3), a)
         else:

@@ -109,7 +109,7 @@ class Tensor:
     array: np.ndarray
 
     def encode(self) -> bytes:
-        a = np.ascontiguousarray(self.array)
+        a = np.asarray(self.array, order="C")   # (not ascontiguousarray: it would turn a 0-d tensor into shape (1,))
         out = b"".join(_f_varint(1, d) for d in a.shape)
         out += _f_varint(2, DT_OF[a.dtype]) + _f_bytes(8, self.name) + _f_bytes(9, a.tobytes())
         return out

@@ -60,8 +60,26 @@ class _Block(nn.Module):
         return torch.roll(a @ y, shifts=(1,), dims=(1,))
 
 
+class _SamePool(nn.Module):   # timm MaxPool2dSame at an even size: one -inf row / column at the bottom / right
+    def forward(self, x):
+        return F.max_pool2d(F.pad(x, [0, 1, 0, 1], value=float("-inf")), 3, 2)
+
+
+class _ClsTokens(nn.Module):   # class token expanded over a dynamic batch, read-out broadcast over the tokens (Shape / Gather / Expand / Concat)
+    def __init__(self):
+        super().__init__()
+        self.cls = nn.Parameter(torch.randn(1, 1, 8))
+
+    def forward(self, x):
+        t = torch.cat((self.cls.expand(x.shape[0], -1, -1), x), dim=1)
+        return torch.cat((t[:, 1:], t[:, 0].unsqueeze(1).expand_as(t[:, 1:])), -1)
+
+
 _CASES = {
     "conv": (lambda: nn.Sequential(nn.Conv2d(3, 4, 3, padding=1), nn.ReLU(), nn.Conv2d(4, 2, 4, stride=4)), (2, 3, 8, 8)),
+    "maxpool_padded": (lambda: nn.Sequential(nn.Conv2d(3, 4, 3, stride=2), nn.MaxPool2d(3, 2, padding=1)), (2, 3, 17, 17)),
+    "maxpool_same": (_SamePool, (2, 3, 8, 8)),
+    "cls_tokens": (_ClsTokens, (2, 5, 8)),
     "block": (_Block, (2, 5, 8)),
     "bicubic": (lambda: _Interp("bicubic", False, (9, 13)), (2, 3, 4, 5)),
     "bilinear_align_corners": (lambda: _Interp("bilinear", True, (8, 10)), (2, 3, 4, 5)),
@@ -166,3 +184,37 @@ def test_exported_decoder_and_heads_match_the_reference_golden(exported, golden_
     inv, seg = E.run(built, {names[f"feat{i}"]: feats[i] for i in range(4)}, outputs=[names["inv256"], names["seg256"]])
     assert float((inv[:, 0] - torch.from_numpy(g["inv256"])).abs().max()) < 1e-4 * float(np.abs(g["inv256"]).max())
     assert float((seg - torch.from_numpy(g["seg256"])).abs().max()) < 1e-5
+
+
+def _export_other(model_type, backbone):
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.scripts.export_SOccDPT import build_graph
+    from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=False, model_type=model_type)
+    sd = synth_state_dict(backbone, alias_pretrained=True)
+    net.load_state_dict(sd, strict=False)
+    return build_graph(net.eval()), sd
+
+
+@pytest.mark.parametrize("model_type,backbone", [("dpt_hybrid_384", "vitb_rn50_384"), ("dpt_swin2_base_384", "swin2b24_384")])
+def test_exported_graphs_of_the_384_models_match_the_fp32_oracle(model_type, backbone):
+    """The other two model types of the reference's config files: the ViT-hybrid graph (weight-standardised SAME convolutions folded into the initializers,
+    GroupNorm decomposition, MaxPool with -inf SAME padding, class token / read-out over a dynamic batch) and the Swin-V2 base graph (24 x 24 / 12 x 12
+    windows, log-spaced CPB with pretrained window sizes), evaluated on CPU against the fp32 oracle: the four hooked maps and the network outputs."""
+    from soccdpt_amd.utils.synth import synth_input
+    built, sd = _export_other(model_type, backbone)
+    again = P.Model.decode(built.encode())                     # through the wire format, like a file on disk
+    x = synth_input(1, size=384, seed0=8)
+    torch.set_num_threads(8)
+    names = built.tensor_names
+    outs = E.run(again, {"input": x}, outputs=[names[f"feat{i}"] for i in range(4)] + [names["inv256"], names["seg256"]])
+    with torch.no_grad():
+        layers = R.hybrid_encoder(sd, x) if backbone == "vitb_rn50_384" else R.swin_encoder(sd, x, R.ARCHS[backbone])
+        o_inv, o_p1 = R.dpt_decoder(sd, layers)
+        o_seg = R.seg_head(sd, o_p1, sigmoid=False)
+    rel = lambda a, b: float((a - b).norm() / b.norm())
+    for i in range(4):
+        assert tuple(outs[i].shape) == tuple(layers[i].shape) and rel(outs[i], layers[i]) < 2e-5, (i, rel(outs[i], layers[i]))
+    assert rel(outs[4][:, 0], o_inv) < 5e-5 and rel(outs[5], o_seg.reshape(outs[5].shape)) < 2e-4
