@@ -218,3 +218,21 @@ def test_exported_graphs_of_the_384_models_match_the_fp32_oracle(model_type, bac
     for i in range(4):
         assert tuple(outs[i].shape) == tuple(layers[i].shape) and rel(outs[i], layers[i]) < 2e-5, (i, rel(outs[i], layers[i]))
     assert rel(outs[4][:, 0], o_inv) < 5e-5 and rel(outs[5], o_seg.reshape(outs[5].shape)) < 2e-4
+
+
+def test_export_script_takes_the_reference_flags(tmp_path):
+    """`python -m soccdpt_amd.scripts.export_SOccDPT -v 3 -dt bdd -t <model_type> -e <path>` (scripts/export_SOccDPT.py of the reference: same flags) writes a
+    file the codec reads back; versions 1 / 2 are refused like everywhere else in this build."""
+    from soccdpt_amd.scripts.export_SOccDPT import build_parser, main
+    from soccdpt_amd.utils.synth import write_synth_calib
+    calib = write_synth_calib(str(tmp_path / "calib.yaml"))
+    out = str(tmp_path / "onnx" / "m.onnx")
+    with contextlib.redirect_stdout(io.StringIO()) as log:
+        assert main(build_parser().parse_args(["-v", "3", "-dt", "bdd", "-t", "dpt_swin2_tiny_256", "-e", out, "--camera_intrinsics_yaml", calib])) == 0
+    assert "nodes" in log.getvalue()
+    m = P.load(out)
+    assert [v.name for v in m.graph.outputs] == ["output", "segmentation", "points"] and m.opset == 13
+    with pytest.raises(AssertionError):
+        main(build_parser().parse_args(["-v", "2", "-dt", "bdd", "-t", "dpt_swin2_tiny_256", "-e", out, "--camera_intrinsics_yaml", calib]))
+    with pytest.raises(SystemExit):
+        build_parser().parse_args(["-v", "3", "-dt", "bdd", "-t", "dpt_swin2_tiny_256"])       # -e is required, as in the reference
