@@ -29,8 +29,10 @@ extern "C" {
 /* Bumped whenever a public struct or signature changes (a binding built against another version is refused by soccdpt_create):
  *   1 rounds 1-2; 2 round 3 (soccdpt_igemm_args gained stamps / sk_defer, soccdpt_train_forward changed arity);
  *   3 round 4 (SOCCDPT_PREC_MIXED + the precision map entry points, soccdpt_sizeof, soccdpt_occ_zero / soccdpt_occ_set,
- *     soccdpt_set_stage_xcd / soccdpt_stage_xcd_status). */
-#define SOCCDPT_ABI_VERSION 3
+ *     soccdpt_set_stage_xcd / soccdpt_stage_xcd_status);
+ *   4 round 5 (the opt-in XCD-local persistent stage kernel and its three entry points are gone: measured 13-15 % slower than the launch
+ *     chain in round 4; soccdpt_prec_calibrate and the precision-map source query are new). */
+#define SOCCDPT_ABI_VERSION 4
 
 /* backbone ids: model/loader.py:65-77 (model_type switch), model/blocks.py:59-78 */
 #define SOCCDPT_BACKBONE_SWIN2T16_256 0 /* dpt_swin2_tiny_256 */
@@ -86,19 +88,6 @@ int soccdpt_abi_version(void);
 /* sizeof of the public structs as the LIBRARY was compiled (a binding checks its own layout against these): which = 0 soccdpt_config,
  * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat; unknown -> 0 */
 size_t soccdpt_sizeof(int which);
-
-/* ---- XCD-local persistent stage kernel (csrc/stage_xcd.hip) ----
- * on != 0: Swin-V2 stages 2-3 of dpt_swin2_tiny_256 (58 launches of the chain) run as ONE launch whenever the batch is a multiple of 8 (one frame per
- * XCD: its 32 CUs and private L2 hold every inter-phase tensor; phase barriers on a per-XCD counter).  Bit-identical outputs; other shapes, other
- * backbones, the f32 / f16x3 modes and multi-stream handles keep the launch chain.  Changes the workspace size (query soccdpt_workspace_bytes again).
- * Also switched by the environment variable SOCCDPT_STAGE_XCD at soccdpt_create.  soccdpt_stage_xcd_status: 0 = every bounded spin of the
- * persistent launches so far completed, > 0 = one gave up (outputs invalid), -1 = the kernel has not run on this handle.  Synchronises the device. */
-int soccdpt_set_stage_xcd(void* handle, int on);
-int soccdpt_stage_xcd_status(void* handle);
-/* Diagnostics: phase timeline of the persistent launch.  on = 1 / 0 switches the recording for the following launches (-1: leave as is); out (host
- * memory, n <= 288 words) receives s_memrealtime stamps (100 MHz) of XCD 0's rank-0 workgroup: [3p] phase start, [3p+1] its last item done,
- * [3p+2] phase barrier passed.  Synchronises the device.  -1 before the kernel's first launch. */
-int soccdpt_stage_xcd_timeline(void* handle, int on, unsigned long long* host_out, int n);
 
 /* ---- precision map (SOCCDPT_PREC_MIXED handles only) ----
  * Groups are named launch sites of the forward (one operand format per group: its GEMMs / convolutions, their weights and the

@@ -1,4 +1,4 @@
-// Device bodies of the 16-bit window-attention kernels (attention.hip), shared with the XCD-local persistent stage kernel (stage_xcd.hip).
+// Device bodies of the 16-bit window-attention kernels (attention.hip), kept as device functions so that a caller can pass its own block / thread ids and LDS base.
 // Design notes: attention.hip.
 #pragma once
 #include <stdlib.h>
@@ -28,7 +28,7 @@ struct AttnCfg {
 // query blocks: stages 1-2 of the B = 8 forward have only 192 / 96 (window, head) pairs for 256 CUs (0.258 -> 0.216 ms per
 // forward; a 4-way split with two staging-only waves measured slower again).
 // The body takes the block index, the thread index within the cooperating group of A::THREADS threads and that group's LDS region explicitly:
-// the stand-alone kernel below passes blockIdx.x / threadIdx.x / the dynamic LDS base; the XCD-local persistent stage kernel (stage_xcd.hip) runs
+// the stand-alone kernel below passes blockIdx.x / threadIdx.x / the dynamic LDS base; a persistent caller (round 4 built one: DESIGN.md section 10.2) runs
 // one (window, head) item per wave of a larger workgroup for the single-wave 8 x 8 form.  __syncthreads() inside is workgroup-wide in both uses.
 template <int WS, bool F16, int QS>
 __device__ __forceinline__ void window_attention_body(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,

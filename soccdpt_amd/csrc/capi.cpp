@@ -48,21 +48,6 @@ size_t soccdpt_sizeof(int which) {
     }
 }
 
-int soccdpt_set_stage_xcd(void* handle, int on) {
-    Handle* h = static_cast<Handle*>(handle);
-    if (!h) return 1;
-    h->stage_xcd = on != 0;
-    h->stage_xcd_mode = on == 2 ? 2 : 1;
-    h->ws_key = Handle::WsKey();   // the workspace layout gains / loses the per-block buffers
-    h->xcd_key = Handle::XcdKey();
-    model_drop_graph(*h);
-    return 0;
-}
-int soccdpt_stage_xcd_timeline(void* handle, int on, unsigned long long* out, int n) {
-    return handle ? model_stage_xcd_timeline(*static_cast<Handle*>(handle), on, out, n) : -2;
-}
-int soccdpt_stage_xcd_status(void* handle) { return handle ? model_stage_xcd_status(*static_cast<Handle*>(handle)) : -2; }
-
 int soccdpt_prec_map_set(void* handle, const char* group, int fmt) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !group) return -1;
@@ -73,7 +58,6 @@ int soccdpt_prec_map_set(void* handle, const char* group, int fmt) {
     // formats decide where the zero borders of the 3x3 inputs lie and which weight copies exist: both caches are void
     h->ws_key = Handle::WsKey();
     h->is_prepared = false;
-    h->xcd_gen++;
     model_drop_graph(*h);
     return n;
 }
@@ -109,7 +93,6 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
         return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
     Handle* h = new Handle();
     if (const char* e = getenv("SOCCDPT_MLP_FUSE_MAX")) h->mlp_fuse_max = atoi(e);   // measurement switch (0 = unfused everywhere)
-    if (const char* e = getenv("SOCCDPT_STAGE_XCD")) { h->stage_xcd = atoi(e) != 0; h->stage_xcd_mode = atoi(e) == 2 ? 2 : 1; }   // XCD-local persistent stage kernel (soccdpt_set_stage_xcd)
     h->cfg = *cfg;
     (void)hipGetDevice(&h->device);
     std::string err;

@@ -1,5 +1,5 @@
-// The implicit-GEMM tile of igemm.hip as a device function, shared by the stand-alone kernel (igemm.hip: one workgroup = one tile) and the
-// XCD-local persistent stage kernel (stage_xcd.hip: a workgroup walks the tiles of one phase after another).  Design notes: igemm.hip.
+// The implicit-GEMM tile of igemm.hip as a device function (igemm.hip: one workgroup = one tile; round 4 also drove it from a persistent
+// kernel that walked the tiles of one phase after another: DESIGN.md section 10.2, removed in round 5).  Design notes: igemm.hip.
 #pragma once
 #include <type_traits>
 

@@ -110,19 +110,6 @@ struct Handle {
     std::vector<SiteRec> sites;                           // shapes seen while prof_sites was on, in first-launch order
     std::unordered_map<long long, int> tune_by_shape;     // shape key -> forced tile configuration (in-network tuning)
     int mlp_fuse_max = 128;                               // widest stage whose MLP half-block runs as one fused launch (mlp_fused.hip; wider ones lose)
-    // XCD-local persistent stage kernel (stage_xcd.hip): Swin-V2 stages 2-3 of dpt_swin2_tiny_256 as ONE launch when the batch is a multiple of 8
-    // (one frame per XCD).  soccdpt_set_stage_xcd / SOCCDPT_STAGE_XCD; the launch chain stays the fallback for every other shape.
-    bool stage_xcd = false;
-    int stage_xcd_mode = 1;           // 1: phases of the persistent launch; 2: the launch chain on the per-block buffers (debugging aid: the two can be diffed buffer by buffer)
-    void* xcd_phases_dev = nullptr;   // device copy of the phase table (XPhase[kXcdMaxPhases])
-    void* xcd_sync_dev = nullptr;     // XSync
-    struct XcdKey {
-        const void *ws = nullptr, *prep = nullptr;
-        int B = 0, n = 0;
-        unsigned long long gen = 0;
-        bool operator==(const XcdKey& o) const { return ws == o.ws && prep == o.prep && B == o.B && n == o.n && gen == o.gen; }
-    } xcd_key;                        // what the device copy of the phase table was built for
-    unsigned long long xcd_gen = 0;   // bumped by whatever changes the table's contents besides its key pointers (prepare, precision map)
     // SOCCDPT_PREC_MIXED: operand format of every launch-site group (model.cpp: prec_groups), 1 = fp16, 3 = x3; groups absent from the map are fp16
     std::unordered_map<std::string, int> prec_map;
     std::vector<WeightSlot> weights;
@@ -179,8 +166,6 @@ std::vector<std::string> model_prec_groups(const Handle& h);   // every group na
 void model_prec_default(Handle& h);                            // the shipped map of the backbone
 int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err);   // -> groups changed, < 0 on error
 int model_set_streams(Handle& h, int n, std::string& err);
-int model_stage_xcd_status(Handle& h);
-int model_stage_xcd_timeline(Handle& h, int on, unsigned long long* out, int n);   // XSync::err of the last persistent launches (synchronises; 0 = fine, -1 = not in use)
 void model_drop_graph(Handle& h);
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C);
 

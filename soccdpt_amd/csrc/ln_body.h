@@ -1,5 +1,5 @@
-// One row of the Swin-V2 post-norm residual LayerNorm (elementwise.hip: ln_residual_kernel) as a device function: one wave = one row.  Shared by
-// the stand-alone kernels and the XCD-local persistent stage kernel (stage_xcd.hip).
+// One row of the Swin-V2 post-norm residual LayerNorm (elementwise.hip: ln_residual_kernel) as a device function: one wave = one row.  A device
+// function so that a caller can pass its own row index and lane.
 #pragma once
 #include <type_traits>
 

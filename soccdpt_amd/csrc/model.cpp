@@ -13,7 +13,6 @@
 
 #include "internal.h"
 #include "kernels.h"
-#include "stage_xcd.h"
 
 namespace soccdpt {
 
@@ -77,8 +76,6 @@ Handle::~Handle() {
     delete prep;
     for (auto s : sub_streams) (void)hipStreamDestroy(s);
     for (auto e : join_events) (void)hipEventDestroy(e);
-    if (xcd_phases_dev) (void)hipFree(xcd_phases_dev);
-    if (xcd_sync_dev) (void)hipFree(xcd_sync_dev);
 }
 
 namespace {
@@ -339,21 +336,7 @@ struct Workspace {
     void *vt_xb = nullptr, *vt_qkv = nullptr, *vt_attn = nullptr, *vt_h = nullptr, *vt_tok[2] = {nullptr, nullptr}, *vt_ro = nullptr, *vt_pp4 = nullptr;
     float* sk_part;      // split-K partial tiles (igemm.h): kSplitKPartFloats floats
     unsigned* sk_count;  // split-K arrival counters: zero from workspace init, left zero by every launch
-    // XCD-local persistent stage kernel (stage_xcd.hip): every (block, tensor) of stages 2-3 gets a region of its own -- a buffer is written by one
-    // phase and read by the next one only, which is what makes the hand-over between CUs of an XCD safe without cache maintenance
-    struct XBlk { void *qkv, *attn, *xb1, *xb2, *hbuf; float *y1, *y2; };
-    std::vector<XBlk> xblk[2];   // [stage - 2][block]
-    float* x_xf3 = nullptr;      // stage 3's residual stream
-    void *x_hbm = nullptr, *x_xbm = nullptr;   // PatchMerging operand (merged layout), stage 3's first operand copy
-    float* x_ym = nullptr;
 };
-constexpr int kXcdMaxPhases = 96;
-
-// the persistent path is built for dpt_swin2_tiny_256's stages 2-3 (one 16 x 16 / 8 x 8 window per frame, 8 waves per attention item)
-bool xcd_eligible(const Handle& h, int B) {
-    return h.stage_xcd && h.cfg.backbone == SOCCDPT_BACKBONE_SWIN2T16_256 && B > 0 && B % 8 == 0 && h.n_streams == 1 &&
-           h.cfg.precision != SOCCDPT_PREC_F32 && h.cfg.precision != SOCCDPT_PREC_F16X3;
-}
 
 void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     const Arch& a = h.arch;
@@ -423,21 +406,6 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
     w.s2 = ar.take<float>((size_t)B * r1 * r1 * 4);
     w.sk_part = ar.take<float>(kSplitKPartFloats);
     w.sk_count = ar.take<unsigned>(kSplitKCountWords);
-    if (xcd_eligible(h, B)) {
-        for (int s = 2; s < 4; ++s) {
-            const size_t M = (size_t)B * a.res(s) * a.res(s), C = a.dim(s);
-            w.xblk[s - 2].resize(a.depths[s]);
-            for (auto& xb : w.xblk[s - 2]) {
-                xb.qkv = op(M * 3 * C); xb.attn = op(M * C); xb.xb1 = op(M * C); xb.xb2 = op(M * C); xb.hbuf = op(M * 4 * C);
-                xb.y1 = ar.take<float>(M * C); xb.y2 = ar.take<float>(M * C);
-            }
-        }
-        const size_t M3 = (size_t)B * a.res(3) * a.res(3), C3 = a.dim(3);
-        w.x_xf3 = ar.take<float>(M3 * C3);
-        w.x_hbm = op(M3 * 4 * a.dim(2));
-        w.x_xbm = op(M3 * C3);
-        w.x_ym = ar.take<float>(M3 * C3);
-    }
 }
 
 }  // namespace
@@ -699,23 +667,7 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
         return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, fs >= 2 ? 0 : (fs == 1 ? 4 : 1), r1, r1, h.cfg.features);
     }
     if (n == "seg_logits") return set(w.s2, (size_t)B * r1 * r1 * 3, 0, r1, r1, 3);  // Conv2d(256,3,1) output before up-sampling / activation
-    if (n.compare(0, 5, "xblk.") == 0 && !a.hybrid && !w.xblk[0].empty()) {   // "xblk.<stage>.<block>.<field>": a per-block buffer of the persistent stage path, raw 4-byte words
-        int st = 0, bj = 0; char field[16] = {0};
-        if (sscanf(n.c_str(), "xblk.%d.%d.%15s", &st, &bj, field) == 3 && st >= 2 && st <= 3 && bj >= 0 && bj < (int)w.xblk[st - 2].size()) {
-            const Workspace::XBlk& X = w.xblk[st - 2][bj];
-            const size_t M = (size_t)B * a.res(st) * a.res(st), C = a.dim(st);
-            const std::string f(field);
-            if (f == "qkv") return set(X.qkv, M * 3 * C, 0, 1, (int)(M / B), 3 * (int)C);
-            if (f == "attn") return set(X.attn, M * C, 0, 1, (int)(M / B), (int)C);
-            if (f == "xb1") return set(X.xb1, M * C, 0, 1, (int)(M / B), (int)C);
-            if (f == "xb2") return set(X.xb2, M * C, 0, 1, (int)(M / B), (int)C);
-            if (f == "hbuf") return set(X.hbuf, M * 4 * C, 0, 1, (int)(M / B), 4 * (int)C);
-            if (f == "y1") return set(X.y1, M * C, 0, 1, (int)(M / B), (int)C);
-            if (f == "y2") return set(X.y2, M * C, 0, 1, (int)(M / B), (int)C);
-        }
-        return 1;
-    }
-    if (n == "xf" && !a.hybrid) return set(w.x_xf3 ? w.x_xf3 : w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));   // stage 3's residual stream
+    if (n == "xf" && !a.hybrid) return set(w.xf, (size_t)B * a.res(3) * a.res(3) * a.dim(3), 0, a.res(3), a.res(3), a.dim(3));   // stage 3's residual stream
     if (n == "vit_tokens" && a.hybrid) return set(w.vt_xf, (size_t)B * (a.grid() * a.grid() + 1) * a.vit_dim, 0, 1, a.grid() * a.grid() + 1, a.vit_dim);  // residual stream after the last block
     if (n == "rn_stage2" && a.hybrid) return set(w.hy_xf, (size_t)B * a.grid() * a.grid() * 1024, 0, a.grid(), a.grid(), 1024);                     // ResNetV2 output (stage 2)
     return 1;
@@ -734,7 +686,6 @@ int model_prepare(Handle& h, void* prepared, size_t bytes, hipStream_t st, std::
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { err = std::string("soccdpt_prepare: ") + hipGetErrorString(e); return 1; }
     h.is_prepared = true;
-    h.xcd_gen++;          // the persistent stage kernel's phase table holds pointers into the prepared arena
     model_drop_graph(h);  // the captured kernel arguments point into the old prepared arena
     return 0;
 }
@@ -934,36 +885,10 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
       PROF("patch_embed_ln", 0.0, (double)B * a.img * a.img * 12.0 + (double)B * a.grid() * a.grid() * a.embed * 6.0);
     RUN(launch_patch_embed(x, P.patch_wT, W(ENC + "patch_embed.proj.bias"), W(ENC + "patch_embed.norm.weight"),
                            W(ENC + "patch_embed.norm.bias"), w.xf, f0 == 2 ? nullptr : static_cast<bf16_t*>(w.xb), f0 == 2 ? 0 : f0, B, a.img, a.embed, st, err)); }
-    // ---- XCD-local persistent form of stages 2-3 (stage_xcd.hip): the same launches recorded as phases of ONE launch, every (block, tensor) in a
-    // buffer of its own (Workspace::xblk); everything else of the forward is unchanged ----
-    const bool xcd = xcd_eligible(h, B) && (MIX || GF(gblk(2, 0, "qkv")) <= 1) && !w.xblk[0].empty();
-    std::vector<XPhase> xph;
-    double xflops = 0.0;
-    auto xgemm = [&](IgemmDesc d, int fmt, int rows) -> int {   // one GEMM launch of the chain as a phase (rows = tokens per frame)
-        d.f32 = 0; d.f16 = fmt == 1; d.x3 = fmt == 3; d.splitk = 1;
-        XPhase ph;
-        int cfg = 0;
-        if (!stage_xcd_gemm_supported(d, fmt, rows, &cfg)) { err = "soccdpt_network: a stage-2/3 launch does not fit the persistent stage kernel"; return 1; }
-        ph.kind = XP_GEMM; ph.fmt = fmt; ph.cfg = cfg; ph.g = d; ph.rows_per_frame = rows;
-        const int BM = cfg == 0 ? 64 : 32, BKe = (cfg == 0 ? 128 : 256) / (fmt == 3 ? 4 : 2);
-        ph.nk = d.Cin / BKe; ph.kpt = ph.nk; ph.ntn = (d.N + 63) / 64; ph.mt_per_frame = rows / BM; ph.items_per_frame = ph.mt_per_frame * ph.ntn;
-        xph.push_back(ph);
-        xflops += igemm_flops(d);
-        return 0;
-    };
-    auto xln = [&](const float* y, const float* g, const float* be, float* xf, void* xb, void* halo, int hf, int hf_halo, int M, int C, int residual, int res, int merge) {
-        XPhase ph;
-        ph.kind = XP_LN; ph.fmt = (hf == 0 && (hf_halo <= 0)) ? 0 : 1; ph.rows_per_frame = M / B; ph.items_per_frame = (M / B + 7) / 8; ph.rows_total = M;
-        ph.y = y; ph.ln_g = g; ph.ln_b = be; ph.xf = xf; ph.xb = static_cast<bf16_t*>(xb); ph.halo = static_cast<bf16_t*>(halo);
-        ph.C = C; ph.residual = residual; ph.ln_res = res; ph.merge = merge; ph.x3 = hf == 3; ph.x3h = (hf_halo < 0 ? hf : hf_halo) == 3;
-        xph.push_back(ph);
-    };
     for (int s = 0; s < 4; ++s) {
         const int C = a.dim(s), res = a.res(s), M = B * res * res, wsz = a.ws(s), H = a.heads[s];
         bool merged = false;   // the stage's last block wrote its operand copy straight into the PatchMerging layout (w.hbuf)
         const int fhook = GF(gname("lrn", s));
-        const bool xbuf = xcd && s >= 2;              // the stage's blocks use their own buffers (Workspace::xblk)
-        const bool xs = xbuf && h.stage_xcd_mode == 1;   // ... and are recorded as phases (mode 2: the launch chain on those buffers, a debugging aid)
         for (int j = 0; j < a.depths[s]; ++j) {
             const BlockW& bw = P.blocks[s][j];
             const bool last = j == a.depths[s] - 1;
@@ -973,31 +898,13 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             // the operand copy goes straight into the PatchMerging layout where the reduction GEMM reads 16-bit (or, mixed mode, x3) operands
             const bool to_merge = s < 3 && last && (fnext <= 1 || (MIX && fnext == 3));
             const bool hook = (j == a.hooks[s]);
-            // buffers of this block: the shared ones of the launch chain, or the block's own under the persistent kernel
             void *b_qkv = w.qkv, *b_attn = w.attn, *b_hbuf = w.hbuf, *b_xin = w.xb, *b_x1 = w.xb, *b_x2 = to_merge ? w.hbuf : w.xb;
             float *b_y1 = w.y, *b_y2 = w.y, *b_xf = w.xf;
-            if (xbuf) {
-                const Workspace::XBlk& X = w.xblk[s - 2][j];
-                b_qkv = X.qkv; b_attn = X.attn; b_hbuf = X.hbuf; b_x1 = X.xb1; b_y1 = X.y1; b_y2 = X.y2;
-                b_xin = j == 0 ? (s == 2 ? w.xb : w.x_xbm) : w.xblk[s - 2][j - 1].xb2;
-                b_x2 = to_merge ? w.x_hbm : ((s == 3 && last) ? nullptr : X.xb2);   // the last block of the encoder has no reader of its operand copy
-                b_xf = s == 3 ? w.x_xf3 : w.xf;
-            }
             IgemmDesc d;
             d.X = b_xin; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias;
             if (MIX) { d.out_op = b_qkv; d.out_fmt = 1; }   // mixed mode: fp16 q, k, v for the fp16 attention kernel whatever the GEMM ran in
             else to_plain(d, b_qkv, fa);
-            if (xs) { if (xgemm(d, fa, res * res)) return 1; }
-            else RUN(gemm(d, fa));
-            if (xs) {
-                XPhase ph;
-                ph.kind = XP_ATTN; ph.fmt = MIX ? 1 : fa; ph.rows_per_frame = res * res; ph.ws = wsz; ph.res = res; ph.heads = H;
-                ph.items_per_frame = wsz == 16 ? 2 * H : (H + 3) / 4;
-                ph.qkv = static_cast<const bf16_t*>(b_qkv); ph.bias_acc = bw.bias_acc; ph.scale = bw.scale; ph.attn_out = static_cast<bf16_t*>(b_attn);
-                ph.out_x3 = (MIX && fp == 3) ? 1 : 0;
-                xph.push_back(ph);
-                xflops += 4.0 * M * (double)(wsz * wsz) * C;
-            } else
+            RUN(gemm(d, fa));
             { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
               if (!MIX && fa >= 2) RUN(launch_window_attention_f32(static_cast<const float*>(b_qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(b_attn), B, res, wsz,
                                                        a.shift(s, j), H, st, err, fa == 3 ? 1 : 0));
@@ -1009,10 +916,6 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             if (fuse_ln) {
                 d.ln_g = bw.n1_g; d.ln_b = bw.n1_b; d.ln_xf = w.xf; d.out_op = fm == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fm : -1;
                 RUN(gemm(d, fp));
-            } else if (xs) {
-                d.out_f32 = b_y1;
-                if (xgemm(d, fp, res * res)) return 1;
-                xln(b_y1, bw.n1_g, bw.n1_b, b_xf, b_x1, nullptr, fm, -1, M, C, 1, res, 0);
             } else {
                 d.out_f32 = b_y1;
                 RUN(gemm(d, fp));
@@ -1029,17 +932,9 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             }
             d = IgemmDesc();
             d.X = b_x1; d.Wt = bw.fc1_w; d.M = M; d.N = 4 * C; d.Cin = C; d.ldx = C; d.bias = bw.fc1_b; d.act = ACT_GELU; d.out_op = b_hbuf; d.out_fmt = MIX ? f2 : -1;
-            if (xs) { if (xgemm(d, fm, res * res)) return 1; }
-            else RUN(gemm(d, fm));
+            RUN(gemm(d, fm));
             d = IgemmDesc();
             d.X = b_hbuf; d.Wt = bw.fc2_w; d.M = M; d.N = C; d.Cin = 4 * C; d.ldx = 4 * C; d.bias = bw.fc2_b;
-            if (xs) {
-                d.out_f32 = b_y2;
-                if (xgemm(d, f2, res * res)) return 1;
-                xln(b_y2, bw.n2_g, bw.n2_b, b_xf, b_x2, hook ? w.feat[s] : nullptr, fnext, fhook, M, C, 1, res, to_merge ? 1 : 0);
-                merged = to_merge;
-                continue;
-            }
             if (fuse_ln) {
                 d.ln_g = bw.n2_g; d.ln_b = bw.n2_b; d.ln_xf = w.xf; d.out_op = fnext == 2 ? nullptr : w.xb; d.out_fmt = MIX ? fnext : -1;   // C <= 128: never a persistent-path stage; the LayerNorm epilogue writes plain rows (merge_gather follows)
                 if (hook) { d.ln_halo = w.feat[s]; d.H = res; d.W = res; d.halo_fmt = MIX ? fhook : -1; }
@@ -1054,38 +949,17 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
               merged = to_merge; }
             }
         }
-        if (s < 3 && xs) {   // stage 2 -> 3 inside the persistent launch: reduction GEMM on the merged operand layout, LayerNorm without residual
-            const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "qkv"));
-            IgemmDesc d;
-            d.X = w.x_hbm; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.x_ym;
-            if (xgemm(d, fg, res * res / 4)) return 1;
-            xln(w.x_ym, P.merge[s].g, P.merge[s].b, w.x_xf3, w.x_xbm, nullptr, fn, -1, M / 4, 2 * C, 0, res / 2, 0);
-        } else if (s < 3) {
+        if (s < 3) {
             const int fg = GF(gname("merge", s)), fn = GF(gblk(s + 1, 0, "qkv"));
             if (!merged) { PROF("merge_gather", 0.0, (double)M * C * 4.0);
               RUN(launch_merge_gather(w.xb, w.hbuf, B, res, C, fg >= 2 ? 4 : 2, st, err)); }
             IgemmDesc d;
-            d.X = xbuf ? w.x_hbm : w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = xbuf ? w.x_ym : w.y;
+            d.X = w.hbuf; d.Wt = P.merge[s].red_w; d.M = M / 4; d.N = 2 * C; d.Cin = 4 * C; d.ldx = 4 * C; d.out_f32 = w.y;
             RUN(gemm(d, fg));
             { PROF("ln_residual", 0.0, (double)(M / 4) * 2 * C * 10.0);
-              RUN(launch_ln_residual(xbuf ? w.x_ym : w.y, P.merge[s].g, P.merge[s].b, xbuf ? w.x_xf3 : w.xf, fn == 2 ? nullptr : static_cast<bf16_t*>(xbuf ? w.x_xbm : w.xb), nullptr, nullptr,
+              RUN(launch_ln_residual(w.y, P.merge[s].g, P.merge[s].b, w.xf, fn == 2 ? nullptr : static_cast<bf16_t*>(w.xb), nullptr, nullptr,
                                      fn == 2 ? 0 : fn, M / 4, 2 * C, 0, res / 2, 0, st, err)); }
         }
-    }
-    if (xcd && h.stage_xcd_mode == 1) {   // upload the phase table when it changed, one launch for stages 2-3
-        if ((int)xph.size() > kXcdMaxPhases) { err = "soccdpt_network: too many phases for the persistent stage kernel"; return 1; }
-        if (!h.xcd_phases_dev) {
-            if (hipMalloc(&h.xcd_phases_dev, sizeof(XPhase) * kXcdMaxPhases) != hipSuccess || hipMalloc(&h.xcd_sync_dev, sizeof(XSync)) != hipSuccess ||
-                hipMemsetAsync(h.xcd_sync_dev, 0, sizeof(XSync), st) != hipSuccess) { err = "soccdpt_network: allocating the persistent kernel's tables failed"; return 1; }
-        }
-        const Handle::XcdKey key{static_cast<const void*>(w.xblk[0][0].qkv), static_cast<const void*>(h.prep), B, (int)xph.size(), h.xcd_gen};
-        if (!(key == h.xcd_key)) {
-            if (hipMemcpyAsync(h.xcd_phases_dev, xph.data(), sizeof(XPhase) * xph.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
-                hipStreamSynchronize(st) != hipSuccess) { err = "soccdpt_network: uploading the phase table failed"; return 1; }   // xph is a local: the copy must have left it
-            h.xcd_key = key;
-        }
-        PROF("stage_xcd", xflops, 0.0);
-        RUN(launch_stage_xcd(static_cast<const XPhase*>(h.xcd_phases_dev), (int)xph.size(), static_cast<XSync*>(h.xcd_sync_dev), B, st, err));
     }
     }   // Swin-V2 encoder
     // ---------------- decoder: reassemble + RefineNet fusion (coarse -> fine) ----------------
@@ -1271,30 +1145,6 @@ static int network_eager(Handle& h, const float* x, int B, float* inv256, float*
     }
     h.launches = launches;
     return 0;
-}
-
-// diagnostics: switch the phase timeline of the persistent kernel on / off (on < 0: leave), copy the 3 x 96 stamps of the last launch out
-int model_stage_xcd_timeline(Handle& h, int on, unsigned long long* out, int n) {
-    if (!h.xcd_sync_dev) return -1;
-    XSync* sy = static_cast<XSync*>(h.xcd_sync_dev);
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (out && n > 0) {
-        const size_t cnt = (size_t)(n < 3 * 96 ? n : 3 * 96);
-        if (hipMemcpy(out, sy->t, cnt * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    }
-    if (on >= 0) {
-        const unsigned v = on ? 1u : 0u;
-        if (hipMemcpy(&sy->stamp_on, &v, sizeof(v), hipMemcpyHostToDevice) != hipSuccess) return -2;
-    }
-    return 0;
-}
-
-int model_stage_xcd_status(Handle& h) {
-    if (!h.xcd_sync_dev) return -1;
-    unsigned e = 0;
-    if (hipDeviceSynchronize() != hipSuccess) return -2;
-    if (hipMemcpy(&e, &static_cast<XSync*>(h.xcd_sync_dev)->err, sizeof(e), hipMemcpyDeviceToHost) != hipSuccess) return -2;
-    return (int)e;
 }
 
 void model_drop_graph(Handle& h) {

@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SOCCDPT_LIB_PATH") or os.path.join(_HERE, "libsoccdpt_hip.so")   # override: A/B of two builds in one GPU call (tools/ab_bench.sh)
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -79,7 +79,7 @@ _lib = None
 # nothing inside soccdpt_forward, so editing them does not invalidate PMC counters collected for the forward's kernels.
 FORWARD_SOURCES = ("Makefile", "attention.hip", "attention_body.h", "conv8p.hip", "depth_tail.hip", "elementwise.hip", "gelu.h", "half16.h", "hybrid.hip", "igemm.h",
                    "igemm.hip", "igemm_kernel.h", "kernels.h", "launch.h", "ln_body.h", "mlp_fused.hip", "model.cpp", "projection.hip", "resample.h",
-                   "stage_xcd.h", "stage_xcd.hip", "vit_attention.hip")
+                   "vit_attention.hip")
 
 
 def csrc_sha() -> str:
@@ -207,12 +207,6 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_occ_zero.restype = ci
     L.soccdpt_occ_set.argtypes = [vp, vp, ci, vp, vp]
     L.soccdpt_occ_set.restype = ci
-    L.soccdpt_set_stage_xcd.argtypes = [vp, ci]
-    L.soccdpt_set_stage_xcd.restype = ci
-    L.soccdpt_stage_xcd_timeline.argtypes = [vp, ci, ctypes.POINTER(ctypes.c_ulonglong), ci]
-    L.soccdpt_stage_xcd_timeline.restype = ci
-    L.soccdpt_stage_xcd_status.argtypes = [vp]
-    L.soccdpt_stage_xcd_status.restype = ci
     L.soccdpt_sizeof.argtypes = [ci]
     L.soccdpt_sizeof.restype = cs
     L.soccdpt_prec_map_set.argtypes = [vp, ctypes.c_char_p, ci]
@@ -357,22 +351,6 @@ class Engine:
             self._check(self.L.soccdpt_prepare(self._h, self._prepared.data_ptr(), nbytes, _stream_ptr(self.device)),
                         "soccdpt_prepare")
 
-    # ---- XCD-local persistent stage kernel (csrc/stage_xcd.hip) ----
-    def set_stage_xcd(self, on):
-        """True / 1: stages 2-3 as one persistent launch; 2: the launch chain on the persistent path's per-block buffers (debugging aid)."""
-        self._check(self.L.soccdpt_set_stage_xcd(self._h, int(on)), "soccdpt_set_stage_xcd")
-        self._workspace = None   # the layout changes
-
-    def stage_xcd_timeline(self, on: int = -1, n: int = 0):
-        """Switch the persistent kernel's phase timeline on / off (on = -1: leave) and return the first n stamps (100 MHz ticks) of the last launch."""
-        buf = (ctypes.c_ulonglong * max(n, 1))()
-        rc = self.L.soccdpt_stage_xcd_timeline(self._h, int(on), buf, int(n))
-        if rc != 0:
-            raise RuntimeError(f"soccdpt_stage_xcd_timeline: {rc}")
-        return list(buf)[:n]
-
-    def stage_xcd_status(self) -> int:
-        return int(self.L.soccdpt_stage_xcd_status(self._h))
 
     # ---- precision map (PREC_MIXED handles) ----
     def prec_map(self) -> dict:

@@ -1,10 +1,12 @@
 """GPU: the whole network (encoder + decoder + heads) and the full forward through the C ABI against
 the CPU oracle on the same synthetic weights/inputs.
 
-Tolerance (bf16 MFMA operands, fp32 accumulation, f32 residual streams): the north star asks for 1e-3
-relative against the fp32 CPU forward; a bf16-operand pipeline of ~30 layers cannot reach that
-(SURVEY.md §7 "Hard parts").  This file pins what IS achieved — relative L2 error per tensor — and the
-downstream metrics (IoU / RMSE within 0.5 %); DESIGN.md reports the measured numbers."""
+One section per arithmetic mode.  The first tests pin SOCCDPT_PREC_BF16 EXPLICITLY (the `net` fixture; BASELINE configs[1] says
+"bf16"): bf16 MFMA operands with fp32 accumulation and f32 residual streams cannot reach the north star's 1e-3 relative over ~30
+layers (SURVEY.md section 7 "Hard parts"), so their bounds are 2x the measured bf16 errors and serve as regression pins, not as the parity
+claim.  The parity claim is carried by the f32 / f16 / f16x3 sections below and by tests/test_mixed_gpu.py for the default
+arithmetic (SOCCDPT_PREC_MIXED) at the BASELINE batch sizes; the B = 8 sigmoid / plug-in test here runs the default arithmetic at its
+own (mixed) bounds.  DESIGN.md section 2 reports the measured numbers."""
 import os
 import tempfile
 
@@ -23,10 +25,12 @@ def _rel_l2(a, b):
 
 @pytest.fixture(scope="module")
 def net(gpu_device):
+    """SOCCDPT_PREC_BF16, pinned explicitly: the class default is SOCCDPT_PREC_MIXED since round 4 and the bounds below are bf16's."""
+    from soccdpt_amd.lib import PREC_BF16
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
     from soccdpt_amd.utils.synth import synth_state_dict, write_synth_calib
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
-    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True)
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, precision=PREC_BF16)
     sd = synth_state_dict(alias_pretrained=True)
     m.load_state_dict(sd, strict=False)
     return m.eval().to(gpu_device), sd
@@ -108,7 +112,8 @@ def test_multi_stream_sub_batches_match_single_stream(net, gpu_device):
     inv1, seg1 = m.network(x)
     out1 = m(x)
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
-    m4 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=4)
+    from soccdpt_amd.lib import PREC_BF16
+    m4 = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=4, precision=PREC_BF16)
     m4.load_state_dict(sd, strict=False)
     m4 = m4.eval().to(gpu_device)
     inv4, seg4 = m4.network(x)
@@ -258,8 +263,10 @@ def test_full_batch_8_sigmoid_and_plugin_pattern(gpu_device):
     with torch.no_grad():
         o_inv, o_seg, _ = R.soccdpt_v3_network(sd, x, sigmoid=True)
     e_inv, e_seg = _rel_l2(inv.cpu(), o_inv), _rel_l2(seg.cpu(), o_seg)
-    print(f"B=8 sigmoid bf16: rel L2 inv {e_inv:.2e} seg {e_seg:.2e}")
-    assert e_inv < 7e-3 and e_seg < 4e-2   # seg: x12 synthetic logit gain
+    print(f"B=8 sigmoid, default arithmetic (mixed): rel L2 inv {e_inv:.2e} seg {e_seg:.2e}")
+    from soccdpt_amd.lib import PREC_MIXED
+    assert m.precision == PREC_MIXED
+    assert e_inv < 5e-4 and e_seg < 3e-3   # the shipped map's bar on inverse depth; probabilities: x12 synthetic logit gain on ~4.5e-4 logits
     assert tuple(out[3].shape) == (8, 256, 256, 32, 3)
     for b in range(1, 8):
         assert torch.equal(out[3][0], out[3][b])          # the union grid in every batch row
@@ -380,11 +387,10 @@ def test_hip_graph_replay_matches_eager(net, gpu_device, streams):
     mg = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=streams, graph=True)
     mg.load_state_dict(sd, strict=False)
     mg = mg.eval().to(gpu_device)
-    ms = m
-    if streams != 1:   # the eager twin with the same sub-batch split (tile shapes depend on the per-chunk M)
-        ms = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=streams)
-        ms.load_state_dict(sd, strict=False)
-        ms = ms.eval().to(gpu_device)
+    # the eager twin: same (default) arithmetic and the same sub-batch split (tile shapes depend on the per-chunk M)
+    ms = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=streams)
+    ms.load_state_dict(sd, strict=False)
+    ms = ms.eval().to(gpu_device)
     for seed in (60, 61, 62):          # first call captures, the next ones replay with new inputs
         x = synth_input(4, seed0=seed).to(gpu_device)
         inv_g, seg_g = mg.network(x)
@@ -402,14 +408,14 @@ def test_back_to_back_modes_without_host_sync(net, gpu_device):
     kernels of different launches are co-resident.  Every mode must give the single-stream result."""
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
     from soccdpt_amd.utils.synth import synth_input, write_synth_calib
-    m1, sd = net
+    _, sd = net
     calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
 
-    def mk(**kw):
+    def mk(**kw):   # the default arithmetic (SOCCDPT_PREC_MIXED) in all three
         m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, **kw)
         m.load_state_dict(sd, strict=False)
         return m.eval().to(gpu_device)
-    mg, ms = mk(streams=2, graph=True), mk(streams=2)
+    mg, ms, m1 = mk(streams=2, graph=True), mk(streams=2), mk()
     bad = 0
     for seed in range(200, 240):
         x = synth_input(4, seed0=seed).to(gpu_device)
@@ -425,8 +431,12 @@ def test_repeated_forward_is_bitwise_reproducible(net, gpu_device):
     """300 repeats of the B = 8 forward reproduce the first result bit for bit (network outputs and packed occupancy): every
     kernel is deterministic (no float atomics; split-K sums partials in a fixed order), and a schedule race would show up as a
     sporadic mismatch (tools/soak_determinism.py runs the long version over all modes and both models)."""
-    from soccdpt_amd.utils.synth import synth_input
-    m, sd = net
+    from soccdpt_amd.model.SOccDPT import SOccDPT_V3
+    from soccdpt_amd.utils.synth import synth_input, write_synth_calib
+    _, sd = net
+    m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml")), compute_occ=True)
+    m.load_state_dict(sd, strict=False)   # the default arithmetic (SOCCDPT_PREC_MIXED): the one bench.py times
+    m = m.eval().to(gpu_device)
     x = synth_input(8, seed0=7).to(gpu_device)
     inv0, seg0 = m.network(x)
     out0 = m(x)

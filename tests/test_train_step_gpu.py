@@ -193,9 +193,15 @@ def test_partial_freeze_matches_full_backward(gpu_device):
 
 
 def test_depth_head_gradients_exact(gpu_device):
-    """B = 1, gradient through the depth output only: the two ReLUs of the depth head (after output_conv.2 and after output_conv.4) take
-    the same masks in the HIP forward and in the float64 oracle (checked here), so nothing but kernel arithmetic separates the gradients
-    of output_conv.{0,2,4}: 3x3 conv dgrad + wgrad at 128^2 and 256^2, bilinear x2 backward, column sums, the fused 1x1 tail.  2e-5."""
+    """B = 1, gradient through the depth output only: with the two ReLUs of the depth head (after output_conv.2 and after output_conv.4) taking
+    the same masks in the HIP forward and in the float64 oracle, nothing but kernel arithmetic separates the gradients of output_conv.{0,2,4}:
+    3x3 conv dgrad + wgrad at 128^2 and 256^2, bilinear x2 backward, column sums, the fused 1x1 tail.  2e-5.
+
+    A pre-activation within f32 rounding of zero can take the other mask in an f32 forward (round 4's -ffp-contract / x3_split changes moved one
+    by an ulp and this test went silent behind a skip).  Such pixels are found first and the upstream gradient is zeroed THERE, in both the HIP
+    backward and the oracle: every gradient path of the head passes through the pixel's own 1x1 tail, so a zero upstream value removes the
+    pixel from both sides and the comparison stays exact on the rest.  More than 64 such pixels of 65536 would mean the forward is off, not
+    rounding: that FAILS."""
     import torch.nn.functional as F
     from soccdpt_amd.utils.synth import synth_input
     m, sd = _make(gpu_device)
@@ -206,9 +212,7 @@ def test_depth_head_gradients_exact(gpu_device):
     x = synth_input(1, seed0=3)
     g = torch.Generator().manual_seed(11)
     a = torch.randn((1, 256, 256), generator=g)
-    sd_64, o_inv, _ = _oracle_grads(sd, x, a, torch.zeros(1, 3, 256, 256), False, torch.float64)
     inv, seg = m.train_forward(x.to(gpu_device))
-    m.backward(a.to(gpu_device), torch.zeros(1, 3, 256, 256, device=gpu_device))
     torch.cuda.synchronize()
     eng = m._engine(gpu_device)
     with torch.no_grad():
@@ -218,14 +222,25 @@ def test_depth_head_gradients_exact(gpu_device):
         h = F.conv2d(p1, s64["depth_net.scratch.output_conv.0.weight"], s64["depth_net.scratch.output_conv.0.bias"], padding=1)
         h = F.interpolate(h, scale_factor=2, mode="bilinear", align_corners=True)
         e = F.conv2d(h, s64["depth_net.scratch.output_conv.2.weight"], s64["depth_net.scratch.output_conv.2.bias"], padding=1)
+        z = F.conv2d(F.relu(e), s64["depth_net.scratch.output_conv.4.weight"], s64["depth_net.scratch.output_conv.4.bias"])
     e_hip = eng.train_tensor(1, "depth_conv2", 32).cpu()
-    flips = int(((e_hip > 0) != (e.permute(0, 2, 3, 1).reshape(-1, 32) > 0)).sum()) + int(((inv.cpu() > 0) != (o_inv > 0)).sum())
-    if flips:
-        pytest.skip(f"{flips} ReLU masks of the depth head differ from the float64 oracle on this input: the exactness premise does not hold")
+    flip_mid = ((e_hip > 0) != (e.permute(0, 2, 3, 1).reshape(-1, 32) > 0)).any(dim=1).view(1, 256, 256)
+    flip_out = (inv.cpu() > 0) != (z[:, 0] > 0)
+    flip = flip_mid | flip_out
+    nflip = int(flip.sum())
+    print(f"depth head: {int(flip_mid.sum())} pixels with a flipped mid ReLU mask, {int(flip_out.sum())} with a flipped output mask (of 65536); upstream gradient zeroed there")
+    assert nflip <= 64, f"{nflip} pixels of the depth head take another ReLU mask than the float64 oracle: more than rounding explains"
+    a = a * (~flip).to(a.dtype)
+    sd_64, o_inv, _ = _oracle_grads(sd, x, a, torch.zeros(1, 3, 256, 256), False, torch.float64)
+    m.backward(a.to(gpu_device), torch.zeros(1, 3, 256, 256, device=gpu_device))
+    torch.cuda.synchronize()
+    worst = 0.0
     for k, p in m.named_parameters():
         if "output_conv" in k:
             e_k = _rel(p.grad.cpu().double(), sd_64[k].grad)
+            worst = max(worst, e_k)
             assert e_k < 2e-5, (k, e_k)
+    print(f"depth-head gradients vs float64 autograd: worst relative L2 {worst:.2e}")
 
 
 def test_hybrid_backward_matches_autograd(gpu_device):
