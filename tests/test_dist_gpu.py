@@ -53,7 +53,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(gpu_device, tmp_path):
     assert d["config"]["global_batch"] == 4 and d["scaling"] == "weak" and d["config"]["dist_backend"] == "gloo"
     assert abs(d["value"] - 4 * 5 / (d["ms_per_step"] * 5e-3)) / d["value"] < 1e-3      # whole-job frames / max-over-ranks time
     assert d["repeats"]["count"] * d["repeats"]["steps_each"] >= 25 and len(d["repeats"]["ms_per_step"]) == d["repeats"]["count"]
-    assert "cpu_baseline" not in d                                                         # N = 1 only
+    assert d["cpu_baseline"] is None and "N = 1" in d["cpu_baseline_note"]                  # the key is always there; the CPU leg runs at N = 1 only
 
 
 def test_bench_config3_four_rank_rehearsal_on_one_gpu(gpu_device):

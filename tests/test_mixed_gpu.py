@@ -71,7 +71,7 @@ def test_mixed_default_map_within_half_the_tolerance(gpu_device, tiny_oracle):
           f"inv per pixel: p99.9 {p999:.2e} max {float(pix.max()):.2e}; x3 groups: {sorted(g for g, v in pm.items() if v == PREC_F16X3)}")
     for k, v in errs.items():
         assert v <= 5e-4, (k, errs)
-    assert p999 < 1e-3 and float(pix.max()) < 3e-3
+    assert p999 < 1e-3 and float(pix.max()) < 2e-3   # measured 8.3e-4 / 1.15e-3
 
 
 def test_mixed_all_fp16_is_the_f16_mode_bit_for_bit(gpu_device):
@@ -210,14 +210,14 @@ def _batch_case(gpu_device, model_type, backbone, B, size, bar, pix_p999, pix_ma
 
 def test_mixed_tiny_256_B8_baseline_batch(gpu_device):
     """BASELINE configs[1]: B = 8 dpt_swin2_tiny_256, the batch bench.py's `value` is timed at."""
-    _batch_case(gpu_device, "dpt_swin2_tiny_256", "swin2t16_256", 8, 256, 5e-4, 1e-3, 3e-3, 4e-4, 4e-3)
+    _batch_case(gpu_device, "dpt_swin2_tiny_256", "swin2t16_256", 8, 256, 5e-4, 1e-3, 2e-3, 4e-4, 4e-3)   # measured: worst 4.65e-4; p99.9 8.6e-4, max 1.07e-3; B=2: 1.5e-4 / 1.7e-3
 
 
 def test_mixed_hybrid_384_B4_baseline_batch(gpu_device):
     """BASELINE configs[2]: B = 4 dpt_hybrid_384 (bar: the north star's 1e-3)."""
-    _batch_case(gpu_device, "dpt_hybrid_384", "vitb_rn50_384", 4, 384, 1e-3, 3e-3, 2e-2, 8e-4, 8e-3)
+    _batch_case(gpu_device, "dpt_hybrid_384", "vitb_rn50_384", 4, 384, 1e-3, 2.5e-3, 4e-3, 5e-4, 5e-3)   # measured: worst 7.3e-4; p99.9 1.5e-3, max 1.85e-3; B=2: 2.4e-4 / 2.5e-3
 
 
 def test_mixed_base_384_B8_baseline_batch(gpu_device):
     """BASELINE configs[3]: 8 frames of dpt_swin2_base_384 per GPU."""
-    _batch_case(gpu_device, "dpt_swin2_base_384", "swin2b24_384", 8, 384, 5e-4, 1e-3, 3e-3, 4e-4, 4e-3)
+    _batch_case(gpu_device, "dpt_swin2_base_384", "swin2b24_384", 8, 384, 5e-4, 1e-3, 2e-3, 4e-4, 1e-3)   # measured: worst 4.6e-4; p99.9 4.7e-4, max 8.1e-4; B=2: 1.0e-4 / 2.9e-4
