@@ -249,6 +249,9 @@ def main():
                          "north star's 1e-3; bf16: bf16 operands (what BASELINE configs[1] names; 3e-3, fails the tolerance); f16: IEEE fp16 operands, "
                          "same kernels and MFMA rate, meets 1e-3 on the Swin-V2 models without margin; f32: exact-f32 parity mode (1/16 MFMA rate); "
                          "f16x3: split-operand fp16 everywhere (three fp16 MFMAs per product, ~22 significand bits at 1/3 of the 16-bit rate)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="--precision mixed: derive the precision map on the bound weights with soccdpt_prec_calibrate (sample = the first two frames of the "
+                         "benchmark batch, budget = the bar of `tolerance`) before timing; config.precision_map_source says which map `value` ran")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 / fp16 side legs and the live error measurement")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: slower than eager)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
@@ -321,6 +324,9 @@ def main():
 
     B = args.batch
     x = synth_input(B, size=img, seed0=rank * B).to(dev)   # different frames per rank
+    calib_report = None
+    if args.calibrate and args.precision == "mixed":
+        calib_report = net.calibrate_precision(x[:2].contiguous(), budget=1e-3 if args.model_type == "dpt_hybrid_384" else 5e-4)
 
     def barrier():
         if dist.is_initialized():
@@ -452,7 +458,10 @@ def main():
                        "batch_per_gpu": B, "global_batch": B * world, "image": img, "streams_per_gpu": args.streams, "hip_graph": args.graph,
                        "parallelism": f"dp{world}" if world > 1 else "single", "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none",
-                       "precision_map_x3_groups": (sorted(g for g, f in eng.prec_map().items() if f == 3) if args.precision == "mixed" else None)},
+                       "precision_map_x3_groups": (sorted(g for g, f in eng.prec_map().items() if f == 3) if args.precision == "mixed" else None),
+                       # shipped = the compiled-in map on the synthetic weights it was derived from; calibrated = soccdpt_prec_calibrate ran (--calibrate)
+                       "precision_map_source": (net.precision_map_source(dev) if args.precision == "mixed" else None),
+                       "precision_map_calibration": ({k: v for k, v in calib_report.items() if k != "x3_groups"} if calib_report else None)},
             "roofline": roofline,
             "roofline_hbm": roofline_hbm,
             "rccl_ranks": rccl_ranks, "per_rank_ms_per_step": per_rank_ms,

@@ -86,7 +86,7 @@ void soccdpt_destroy(void* handle);
 const char* soccdpt_last_error(void* handle); /* handle may be NULL: last create error */
 int soccdpt_abi_version(void);
 /* sizeof of the public structs as the LIBRARY was compiled (a binding checks its own layout against these): which = 0 soccdpt_config,
- * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat; unknown -> 0 */
+ * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat, 3 soccdpt_calib_report; unknown -> 0 */
 size_t soccdpt_sizeof(int which);
 
 /* ---- precision map (SOCCDPT_PREC_MIXED handles only) ----
@@ -104,6 +104,42 @@ size_t soccdpt_sizeof(int which);
 int soccdpt_prec_map_set(void* handle, const char* group, int fmt);
 /* Writes "name=fmt name=fmt ..." (fmt 2 / 3, launch order) into buf; returns the length needed (excluding the terminator). */
 int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes);
+
+/* ---- calibration of the precision map on the weights bound to the handle (round 5) ----
+ * The shipped maps were derived on one synthetic weight draw.  The reference runs whatever checkpoint load_net binds, in fp32
+ * (model/SOccDPT.py:29-57,634-636, model/base_model.py:5-37): for any other weights the map is re-derived HERE, inside the library, against the
+ * library's own exact-f32 arithmetic on the same weights and the caller's sample frames:
+ *   1. an f32 twin of the handle (same bound weight pointers) runs the sample: the reference for the seven checked quantities (hooked feature
+ *      maps 0-3, path_1, inverse depth, class logits; relative L2);
+ *   2. all groups x3 but ONE in fp16 -> the variance that group adds to each quantity;
+ *   3. greedy selection by variance removed per microsecond (compiled-in per-group device-time costs, csrc/prec_cost_table.h) until every
+ *      quantity's predicted error is under `budget`, checked by a measured run (tightened and repeated if the additive model was optimistic);
+ *   4. measured prune: demote x3 groups one at a time, most expensive first, while the measured worst error stays under the budget.
+ * The handle's map is replaced by the result (soccdpt_prec_map_source() == 1) and its weights are prepared for it.  Synchronises; runs about
+ * (groups + x3 groups + 10) forwards of the sample.  All device memory comes from the caller: dev_prepared / dev_workspace as for
+ * soccdpt_prepare / soccdpt_network at batch B, dev_scratch of soccdpt_prec_calibrate_scratch_bytes(handle, B) bytes.
+ * report (host memory, may be NULL): what was measured. */
+typedef struct soccdpt_calib_report {
+    int32_t n_groups;          /* launch-site groups of this backbone */
+    int32_t n_x3;              /* groups the calibrated map promotes to x3 */
+    int32_t n_x3_shipped;      /* ... and the shipped map */
+    int32_t forwards;          /* network forwards the calibration ran */
+    int32_t met_budget;        /* 1: the calibrated map's measured worst error <= budget */
+    int32_t shipped_met_budget;/* 1: the SHIPPED map met the budget on these weights and frames */
+    float budget;
+    float worst_calibrated, worst_shipped, worst_all_fp16, worst_all_x3;
+    float err_calibrated[7], err_shipped[7]; /* feat0, feat1, feat2, feat3, path1, inv, seg_logits */
+    float cost_us_calibrated, cost_us_shipped; /* sums of the compiled-in promotion costs of the x3 groups */
+} soccdpt_calib_report;
+size_t soccdpt_prec_calibrate_scratch_bytes(void* handle, int B);
+int soccdpt_prec_calibrate(void* handle, const float* dev_x, int B, float budget, void* dev_prepared, size_t prepared_bytes, void* dev_workspace,
+                           size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream);
+/* Where the handle's current map comes from: 0 = the shipped map, bound weights = the synthetic draw it was derived from (checked by a
+ * fingerprint of a few tensors at soccdpt_prepare); 1 = soccdpt_prec_calibrate ran on the bound weights; 2 = edited through
+ * soccdpt_prec_map_set; 3 = the shipped map on OTHER weights and no calibration has run: its "within tolerance" claim is unverified for them
+ * (the Python mirror warns; soccdpt_prec_map_set("*", SOCCDPT_PREC_F16X3) is the safe setting).  -1: not a SOCCDPT_PREC_MIXED handle, or not
+ * prepared yet. */
+int soccdpt_prec_map_source(void* handle);
 
 /* ---- weights: replaces BaseModel.load_net -> load_state_dict (model/base_model.py:5-37) ----
  * `key` is the reference's state-dict key, e.g.

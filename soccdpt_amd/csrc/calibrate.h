@@ -1,4 +1,4 @@
-// In-product calibration of the SOCCDPT_PREC_MIXED precision map (soccdpt_prec_calibrate): kernels (calibrate.hip) and the procedure
+// In-product calibration of the SOCCDPT_PREC_MIXED precision map (soccdpt_prec_calibrate): kernels (calibrate_kernels.hip) and the procedure
 // (calibrate.cpp).  Replaces the out-of-tree tools/precision_map.py of round 4 for everything but the per-group cost measurement, whose
 // results ship as a compiled-in table (prec_cost_table.h).
 #pragma once

@@ -6,6 +6,7 @@
 #include <string>
 
 #include "internal.h"
+#include "calibrate.h"
 #include "train.h"
 #include "kernels.h"
 
@@ -44,6 +45,7 @@ size_t soccdpt_sizeof(int which) {
         case 0: return sizeof(soccdpt_config);
         case 1: return sizeof(soccdpt_igemm_args);
         case 2: return sizeof(soccdpt_kernel_stat);
+        case 3: return sizeof(soccdpt_calib_report);
         default: return 0;
     }
 }
@@ -58,6 +60,7 @@ int soccdpt_prec_map_set(void* handle, const char* group, int fmt) {
     // formats decide where the zero borders of the 3x3 inputs lie and which weight copies exist: both caches are void
     h->ws_key = Handle::WsKey();
     h->is_prepared = false;
+    h->prec_source = 2;   // edited by the caller
     model_drop_graph(*h);
     return n;
 }
@@ -138,7 +141,27 @@ int soccdpt_workspace_zero_fills(void* handle) { return handle ? static_cast<Han
 int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
-    return model_prepare(*h, dev_prepared, prepared_bytes, (hipStream_t)stream, h->err);
+    if (model_prepare(*h, dev_prepared, prepared_bytes, (hipStream_t)stream, h->err)) return 1;
+    if (h->cfg.precision == SOCCDPT_PREC_MIXED && h->prec_source != 1 && h->prec_source != 2) {
+        // is the shipped map running on the weights it was derived from?  (a fingerprint of four tensors; the arena's 256-byte tail is free)
+        unsigned long long* tmp = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(dev_prepared) + h->prepared_bytes - 8) & ~uintptr_t(7));
+        const int same = calib_weights_are_the_shipped_draw(*h, tmp, (hipStream_t)stream, h->err);
+        if (same < 0) return 1;
+        h->prec_source = same ? 0 : 3;
+    }
+    return 0;
+}
+
+size_t soccdpt_prec_calibrate_scratch_bytes(void* handle, int B) { return handle ? calib_scratch_bytes(*static_cast<Handle*>(handle), B) : 0; }
+int soccdpt_prec_calibrate(void* handle, const float* dev_x, int B, float budget, void* dev_prepared, size_t prepared_bytes, void* dev_workspace,
+                           size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    return calib_run(*h, dev_x, B, budget, dev_prepared, prepared_bytes, dev_workspace, workspace_bytes, dev_scratch, scratch_bytes, report, (hipStream_t)stream, h->err);
+}
+int soccdpt_prec_map_source(void* handle) {
+    Handle* h = static_cast<Handle*>(handle);
+    return (h && h->cfg.precision == SOCCDPT_PREC_MIXED) ? h->prec_source : -1;
 }
 
 int soccdpt_network(void* handle, const float* dev_x, int B, float* dev_inv256, float* dev_seg256, void* dev_workspace,

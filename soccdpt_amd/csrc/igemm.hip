@@ -130,7 +130,8 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "conv8p_var37", "conv8p_var38", "conv8p_var39",
                                         "igemm_bf16_128x128x64_s2_m32", "igemm_bf16_128x128x64_s2_w8_m32", "igemm_bf16_256x128x64_s2_m32", "igemm_bf16_128x256x64_s2_m32",
                                         "igemm_bf16_256x256x64_s2_m32", "igemm_bf16_128x128x64_s3_m32",
-                                        "igemm_bf16_128x128x64_s2_w8_splitk"};
+                                        "igemm_bf16_128x128x64_s2_w8_splitk",
+                                        "igemm_bf16_256x256x64_s2_w16", "igemm_bf16_256x256x32_s4_w16", "igemm_bf16_512x128x64_s2_w16"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
@@ -373,7 +374,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if (id >= 30 && id <= 39) return launch_conv8p(d, id - 30, stream, err);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 46)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 47) || id == 49) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
@@ -415,6 +416,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, true, false, true>(d, stream, err)
                                           : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, true, false, true>(d, stream, err);
             return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, true>(d, stream, err) : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, true>(d, stream, err);
+        // 16-wave tiles (round 5; 1024 threads = 4 waves per SIMD from ONE workgroup: the resident waves of two 8-wave workgroups with the operand
+        // bytes per FLOP of a 256 x 256 tile; tools/fill_probe.hip: the L2 -> LDS fill of the 128 x 128 tile is what holds its MFMAs at 0.3-0.4)
+        case 47: return launch_cfg<Cfg<256, 256, 64, 4, 4, 2>>(d, stream, err);   // 64 x 64 per wave, 128 KB LDS
+        case 48: return launch_cfg<Cfg<256, 256, 32, 4, 4, 4>>(d, stream, err);   // 32-deep k-tiles, three tiles in flight, 128 KB LDS
+        case 49: return launch_cfg<Cfg<512, 128, 64, 8, 2, 2>>(d, stream, err);   // N = 128 (depth head): 64 x 64 per wave, all 160 KB of LDS
         case 20:
             if (d.gn_stats || (need_gen(d) && d.splitk <= 1)) return launch_cfg_gen<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, f16_t, false, true, false, true>(d, stream, err)

@@ -112,6 +112,7 @@ struct Handle {
     int mlp_fuse_max = 128;                               // widest stage whose MLP half-block runs as one fused launch (mlp_fused.hip; wider ones lose)
     // SOCCDPT_PREC_MIXED: operand format of every launch-site group (model.cpp: prec_groups), 1 = fp16, 3 = x3; groups absent from the map are fp16
     std::unordered_map<std::string, int> prec_map;
+    int prec_source = -1;   // soccdpt_prec_map_source: -1 unknown (not prepared), 0 shipped map on its own weights, 1 calibrated, 2 edited, 3 shipped map on other weights
     std::vector<WeightSlot> weights;
     std::unordered_map<std::string, int> index;
     size_t prepared_bytes = 0;

@@ -49,6 +49,19 @@ class KernelStat(ctypes.Structure):
                 ("flops", ctypes.c_double), ("bytes", ctypes.c_double)]
 
 
+class CalibReport(ctypes.Structure):
+    """soccdpt_calib_report (include/soccdpt_hip.h): what soccdpt_prec_calibrate measured."""
+    _fields_ = [("n_groups", ctypes.c_int32), ("n_x3", ctypes.c_int32), ("n_x3_shipped", ctypes.c_int32), ("forwards", ctypes.c_int32),
+                ("met_budget", ctypes.c_int32), ("shipped_met_budget", ctypes.c_int32), ("budget", ctypes.c_float),
+                ("worst_calibrated", ctypes.c_float), ("worst_shipped", ctypes.c_float), ("worst_all_fp16", ctypes.c_float), ("worst_all_x3", ctypes.c_float),
+                ("err_calibrated", ctypes.c_float * 7), ("err_shipped", ctypes.c_float * 7),
+                ("cost_us_calibrated", ctypes.c_float), ("cost_us_shipped", ctypes.c_float)]
+
+
+CALIB_QUANTITIES = ("feat0", "feat1", "feat2", "feat3", "path1", "inv", "seg_logits")
+PREC_SOURCE_NAMES = {0: "shipped", 1: "calibrated", 2: "edited", 3: "shipped-on-other-weights", -1: "n/a"}
+
+
 class IgemmArgs(ctypes.Structure):
     _fields_ = [
         ("x", ctypes.c_void_p), ("wt", ctypes.c_void_p),
@@ -213,10 +226,16 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_prec_map_set.restype = ci
     L.soccdpt_prec_map_get.argtypes = [vp, ctypes.c_char_p, ci]
     L.soccdpt_prec_map_get.restype = ci
+    L.soccdpt_prec_calibrate_scratch_bytes.argtypes = [vp, ci]
+    L.soccdpt_prec_calibrate_scratch_bytes.restype = cs
+    L.soccdpt_prec_calibrate.argtypes = [vp, vp, ci, ctypes.c_float, vp, cs, vp, cs, vp, cs, ctypes.POINTER(CalibReport), vp]
+    L.soccdpt_prec_calibrate.restype = ci
+    L.soccdpt_prec_map_source.argtypes = [vp]
+    L.soccdpt_prec_map_source.restype = ci
     if L.soccdpt_abi_version() != ABI_VERSION:
         raise RuntimeError("libsoccdpt_hip.so ABI version mismatch; rebuild the library")
     # the ctypes mirrors of the public structs must have the layout the library was compiled with (include/soccdpt_hip.h)
-    for which, cls in ((0, SoccdptConfig), (1, IgemmArgs), (2, KernelStat)):
+    for which, cls in ((0, SoccdptConfig), (1, IgemmArgs), (2, KernelStat), (3, CalibReport)):
         if L.soccdpt_sizeof(which) != ctypes.sizeof(cls):
             raise RuntimeError(f"libsoccdpt_hip.so: sizeof mismatch for {cls.__name__}: library {L.soccdpt_sizeof(which)}, binding {ctypes.sizeof(cls)}")
     _lib = L
@@ -368,6 +387,34 @@ class Engine:
         if self._bound:
             self.prepare()
         return n
+
+    def prec_map_source(self) -> int:
+        """0 shipped map on the weights it was derived from, 1 calibrated on the bound weights, 2 edited, 3 shipped map on OTHER weights (unverified),
+        -1 not a PREC_MIXED handle / not prepared (soccdpt_prec_map_source)."""
+        return int(self.L.soccdpt_prec_map_source(self._h))
+
+    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4) -> dict:
+        """soccdpt_prec_calibrate: derive the precision map on the BOUND weights from the sample frames x [B,3,S,S] (against the library's exact-f32
+        arithmetic on the same weights); the handle keeps the calibrated map, prepared.  Returns the report as a dict."""
+        assert x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
+        B = x.shape[0]
+        nb = self.L.soccdpt_prec_calibrate_scratch_bytes(self._h, B)
+        if nb == 0:
+            raise RuntimeError("soccdpt_prec_calibrate: only SOCCDPT_PREC_MIXED handles have a precision map to calibrate")
+        scratch = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        npre = self.L.soccdpt_prepared_bytes(self._h)
+        if self._prepared is None or self._prepared.numel() < npre:
+            self._prepared = torch.zeros(max(npre, 16), dtype=torch.uint8, device=self.device)
+        ws = self.workspace(B)
+        rep = CalibReport()
+        with torch.cuda.device(self.device):
+            self._check(self.L.soccdpt_prec_calibrate(self._h, x.data_ptr(), B, float(budget), self._prepared.data_ptr(), self._prepared.numel(), ws.data_ptr(), ws.numel(),
+                                                      scratch.data_ptr(), nb, ctypes.byref(rep), _stream_ptr(self.device)), "soccdpt_prec_calibrate")
+        out = {k: getattr(rep, k) for k, _ in CalibReport._fields_ if not k.startswith("err_")}
+        out["err_calibrated"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_calibrated)))
+        out["err_shipped"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_shipped)))
+        out["x3_groups"] = sorted(g for g, f in self.prec_map().items() if f == PREC_F16X3)
+        return out
 
     def workspace(self, B: int) -> torch.Tensor:
         """Per-forward scratch.  The library zero-fills it itself whenever (buffer, B, streams) changes (include/soccdpt_hip.h,

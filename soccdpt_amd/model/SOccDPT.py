@@ -233,6 +233,12 @@ class SOccDPT_V3(SOccDPT):
         eng.prepare()
         self._weight_refs[id(eng)] = refs
         self._bound_versions[id(eng)] = version
+        if self.precision == PREC_MIXED and eng.prec_map_source() == 3 and not self.__dict__.get("_warned_uncalibrated"):
+            # printed, not raised: the reference's convention for checkpoint mismatches (model/base_model.py:30-34)
+            self.__dict__["_warned_uncalibrated"] = True
+            print("soccdpt_amd: the default arithmetic (SOCCDPT_PREC_MIXED) is running its SHIPPED precision map on weights it was not derived from; "
+                  "its within-tolerance claim is unverified for them.  Call net.calibrate_precision(sample_frames, budget=5e-4) once after loading "
+                  "the checkpoint (or construct with precision=PREC_F16X3 for f32-grade results everywhere).")
 
     def forward(self, x: torch.Tensor):
         """x [B,3,S,S] f32 on cuda -> (inv_depth, segmentation, points, occupancy | None); see SOccDPT_V3.forward
@@ -402,6 +408,27 @@ class SOccDPT_V3(SOccDPT):
             else:
                 p.grad.add_(g)
         self._train_x = None
+
+    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4) -> dict:
+        """Derive the precision map of the default arithmetic (SOCCDPT_PREC_MIXED) on the weights this model holds NOW, from sample frames
+        x [B,3,S,S] on the model's device: per launch-site group fp16 or x3 operands such that every hooked feature map, path_1, inverse depth and
+        the class logits stay within `budget` (relative L2) of the library's exact-f32 arithmetic on the same weights -- what the reference computes
+        in (model/loader.py:126-139; model/base_model.py:5-37 loads whatever checkpoint it is given).  Call it once after load_net / load_state_dict
+        of a real checkpoint; the shipped map was derived on the synthetic weights of the tests.  Returns the measured report (soccdpt_calib_report)."""
+        assert self.precision == PREC_MIXED, "only the mixed arithmetic has a precision map"
+        eng = self._engine(x.device)
+        self._sync_weights(eng)
+        rep = eng.calibrate_precision(x.detach().to(torch.float32).contiguous(), budget)
+        self.__dict__["_warned_uncalibrated"] = True
+        return rep
+
+    def precision_map_source(self, device=None) -> str:
+        """'shipped' | 'calibrated' | 'edited' | 'shipped-on-other-weights' | 'n/a' for the engine of `device` (default: the parameters' device)."""
+        from ..lib import PREC_SOURCE_NAMES
+        dev = torch.device(device) if device is not None else next(self.parameters()).device
+        eng = self._engine(dev)
+        self._sync_weights(eng)
+        return PREC_SOURCE_NAMES.get(eng.prec_map_source(), "n/a")
 
     def network(self, x: torch.Tensor):
         """Stage-level: encoder + decoder + heads only -> (inv_depth [B,S,S], segmentation [B,C,S,S])."""
