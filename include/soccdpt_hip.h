@@ -136,9 +136,10 @@ int soccdpt_prec_calibrate(void* handle, const float* dev_x, int B, float budget
                            size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream);
 /* Where the handle's current map comes from: 0 = the shipped map, bound weights = the synthetic draw it was derived from (checked by a
  * fingerprint of a few tensors at soccdpt_prepare); 1 = soccdpt_prec_calibrate ran on the bound weights; 2 = edited through
- * soccdpt_prec_map_set; 3 = the shipped map on OTHER weights and no calibration has run: its "within tolerance" claim is unverified for them
- * (the Python mirror warns; soccdpt_prec_map_set("*", SOCCDPT_PREC_F16X3) is the safe setting).  -1: not a SOCCDPT_PREC_MIXED handle, or not
- * prepared yet. */
+ * soccdpt_prec_map_set; 3 = OTHER weights are bound and no calibration has run: the shipped map's "within tolerance" claim does not carry over
+ * (measured: a second synthetic draw leaves the class logits at 1.4e-3 under it), so soccdpt_prepare has put EVERY group on x3 operands -- f32-grade
+ * results at about 1.7x the step -- until soccdpt_prec_calibrate (or soccdpt_prec_map_set) says otherwise; the Python mirror prints a notice.
+ * -1: not a SOCCDPT_PREC_MIXED handle, or not prepared yet. */
 int soccdpt_prec_map_source(void* handle);
 
 /* ---- weights: replaces BaseModel.load_net -> load_state_dict (model/base_model.py:5-37) ----

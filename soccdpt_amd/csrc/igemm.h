@@ -136,6 +136,7 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
 constexpr size_t kSplitKPartFloats = 2u << 20;  // 8 MB of f32 partials per workspace: splitk * M * N <= this
 constexpr size_t kSplitKCountWords = 4096;
 const char* igemm_family(const IgemmDesc& d);
+int igemm_dot3_bn(const IgemmDesc& d);      // channel tile (128 / 256) of a dot3 launch = N / (number of partial-logit planes it writes)
 int igemm_config_id(const IgemmDesc& d);    // tile configuration id launch_igemm picks (bf16 / fp16 path; -1 for f32)  // name of the kernel configuration launch_igemm picks
 inline double igemm_flops(const IgemmDesc& d) { return 2.0 * d.M * d.N * (double)d.taps * d.Cin; }
 

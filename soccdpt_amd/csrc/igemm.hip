@@ -131,7 +131,8 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
                                         "igemm_bf16_128x128x64_s2_m32", "igemm_bf16_128x128x64_s2_w8_m32", "igemm_bf16_256x128x64_s2_m32", "igemm_bf16_128x256x64_s2_m32",
                                         "igemm_bf16_256x256x64_s2_m32", "igemm_bf16_128x128x64_s3_m32",
                                         "igemm_bf16_128x128x64_s2_w8_splitk",
-                                        "igemm_bf16_256x256x64_s2_w16", "igemm_bf16_256x256x32_s4_w16", "igemm_bf16_512x128x64_s2_w16"};
+                                        "igemm_bf16_256x256x64_s2_w16", "igemm_bf16_256x256x32_s4_w16", "igemm_bf16_512x128x64_s2_w16",
+                                        "igemm_bf16_256x128x64_s2_w16", "igemm_bf16_128x256x64_s2_w16", "igemm_bf16_128x256x64_s2_w16b"};
 
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
@@ -265,10 +266,26 @@ int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words
     return (int)S;
 }
 
+// channel tile of the fused three-class classifier launch (dot3): 256 when the 16-wave 256 x 256 tile runs it -- M a multiple of 256 whose
+// 256-row tiles fill the 256 CUs in whole rounds or at least four of them (fill_probe / conv_tiles A/B of round 5: 928 vs 765 TFLOP/s on the
+// seg-head convolution of tiny_256; 4.5 rounds on base_384's), N == 256 -- else 128.  d.tune == 21 / 47 force one or the other.
+int igemm_dot3_bn(const IgemmDesc& d) {
+    if (d.tune == 21) return 128;
+    if (d.N != 256 || d.M % 256 != 0) return 128;
+    if (d.tune == 47) return 256;
+    static const int mode = getenv("SOCCDPT_CONV16W") ? atoi(getenv("SOCCDPT_CONV16W")) : 1;
+    if (!mode) return 128;
+    const long tiles = d.M / 256;
+    return (tiles % 256 == 0 || tiles >= 1024) ? 256 : 128;
+}
+
 int igemm_config_id(const IgemmDesc& d) { return d.x3 ? pick_cfg_f32(d) : (d.f32 ? -1 : pick_cfg(d)); }
 
 const char* igemm_family(const IgemmDesc& d) {
-    if (d.dot3 && !d.x3 && !d.f32) return d.f16 ? "igemm_f16_128x128x64_s2_w8_dot3" : "igemm_bf16_128x128x64_s2_w8_dot3";
+    if (d.dot3 && !d.x3 && !d.f32) {
+        if (igemm_dot3_bn(d) == 256) return d.f16 ? "igemm_f16_256x256x64_s2_w16_dot3" : "igemm_bf16_256x256x64_s2_w16_dot3";
+        return d.f16 ? "igemm_f16_128x128x64_s2_w8_dot3" : "igemm_bf16_128x128x64_s2_w8_dot3";
+    }
     if (d.x3) return d.splitk > 1 ? (d.tune == 3 || d.tune == 8 ? "igemm_x3_128x128_w8_splitk" : "igemm_x3_64x64x32_s4_splitk") : kCfgNamesX3[pick_cfg_f32(d)];
     if (d.f32) return d.splitk > 1 ? (d.tune == 3 ? "igemm_f32_128x128x32_s2_w8_splitk" : "igemm_f32_64x64x32_s4_splitk") : kCfgNamesF32[pick_cfg_f32(d)];
     const int id = pick_cfg(d);
@@ -368,13 +385,16 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             err = "igemm: bad three-class classifier descriptor (3x3 convolution, N a multiple of 128, no other outputs)";
             return 1;
         }
+        if (igemm_dot3_bn(d) == 256)   // the 16-wave 256 x 256 tile: one n-tile holds all 256 channels, the partial logits need no finishing sum
+            return d.f16 ? launch_cfg_t<Cfg<256, 256, 64, 4, 4, 2>, f16_t, false, false, false, false, true>(d, stream, err)
+                         : launch_cfg_t<Cfg<256, 256, 64, 4, 4, 2>, bf16_t, false, false, false, false, true>(d, stream, err);
         return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, false, false, false, true>(d, stream, err)
                      : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, false, false, false, true>(d, stream, err);
     }
     const int id = pick_cfg(d);
     const bool k64 = (d.Cin % 64 == 0);
     if (id >= 30 && id <= 39) return launch_conv8p(d, id - 30, stream, err);
-    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 47) || id == 49) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
+    if ((id == 0 || id == 1 || id == 2 || id == 5 || id == 6 || id == 7 || id == 8 || (id >= 10 && id <= 14) || (id >= 21 && id <= 23) || (id >= 40 && id <= 47) || (id >= 49 && id <= 52)) && !k64) { err = "igemm: this configuration needs Cin % 64 == 0"; return 1; }
     if ((id == 20 || id == 22) && d.Cin % 128 != 0) { err = "igemm: this configuration needs Cin % 128 == 0"; return 1; }
     if (d.out_dot && id != 5) { err = "igemm: fused dot tail needs the 128x32 configuration"; return 1; }
     switch (id) {
@@ -421,6 +441,9 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 47: return launch_cfg<Cfg<256, 256, 64, 4, 4, 2>>(d, stream, err);   // 64 x 64 per wave, 128 KB LDS
         case 48: return launch_cfg<Cfg<256, 256, 32, 4, 4, 4>>(d, stream, err);   // 32-deep k-tiles, three tiles in flight, 128 KB LDS
         case 49: return launch_cfg<Cfg<512, 128, 64, 8, 2, 2>>(d, stream, err);   // N = 128 (depth head): 64 x 64 per wave, all 160 KB of LDS
+        case 50: return launch_cfg<Cfg<256, 128, 64, 4, 4, 2>>(d, stream, err);   // N = 128: 64 x 32 per wave, 96 KB
+        case 51: return launch_cfg<Cfg<128, 256, 64, 2, 8, 2>>(d, stream, err);   // M = 32768 (64^2 RCU convolutions: 256 tiles): 64 x 32 per wave, 96 KB
+        case 52: return launch_cfg<Cfg<128, 256, 64, 4, 4, 2>>(d, stream, err);   // same tile, 32 x 64 per wave
         case 20:
             if (d.gn_stats || (need_gen(d) && d.splitk <= 1)) return launch_cfg_gen<Cfg<32, 64, 128, 2, 2, 3>>(d, stream, err);
             if (need_gen(d)) return d.f16 ? launch_cfg_t<Cfg<32, 64, 128, 2, 2, 3>, f16_t, false, true, false, true>(d, stream, err)

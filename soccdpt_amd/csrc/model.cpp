@@ -1042,10 +1042,12 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         if (fH <= 1 && F % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3) {
             // the 1x1 classifier rides in the convolution's epilogue (igemm D3): the 256-channel feature map -- 67 MB written and read back per
             // forward at B = 8, rounded to 16 bits on the way -- is never stored; the logits come from the f32 accumulators
-            d.dot3 = 1; d.dot_w = P.s4_w; d.out_dot = static_cast<float*>(w.s1);   // [F / 128][M][4] partial logits in the feature map's buffer
+            d.dot3 = 1; d.dot_w = P.s4_w; d.out_dot = static_cast<float*>(w.s1);   // [F / BN][M][4] partial logits in the feature map's buffer
+            d.f16 = fH == 1;
+            const int parts = F / igemm_dot3_bn(d);   // one plane per channel tile of the launch (128-wide tiles: 2; the 16-wave 256 x 256 tile: 1)
             RUN(gemm(d, fH));
-            PROF("seg_tail", 0.0, (double)B * r1 * r1 * ((F / 128) * 16.0 + 12.0 + 12.0 + 48.0));
-            RUN(launch_seg_tail_parts(static_cast<const float*>(w.s1), F / 128, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err));
+            PROF("seg_tail", 0.0, (double)B * r1 * r1 * (parts * 16.0 + 12.0 + 12.0 + 48.0));
+            RUN(launch_seg_tail_parts(static_cast<const float*>(w.s1), parts, P.s4_b, w.s2, seg256, B, r1, r1, h.cfg.sigmoid, st, err));
         } else {
         if (s1_f32) to_plain(d, w.s1, fH); else { d.out_op = w.s1; d.out_fmt = MIX ? 1 : -1; }
         RUN(gemm(d, fH));

@@ -59,7 +59,7 @@ class CalibReport(ctypes.Structure):
 
 
 CALIB_QUANTITIES = ("feat0", "feat1", "feat2", "feat3", "path1", "inv", "seg_logits")
-PREC_SOURCE_NAMES = {0: "shipped", 1: "calibrated", 2: "edited", 3: "shipped-on-other-weights", -1: "n/a"}
+PREC_SOURCE_NAMES = {0: "shipped", 1: "calibrated", 2: "edited", 3: "uncalibrated-all-x3", -1: "n/a"}
 
 
 class IgemmArgs(ctypes.Structure):
@@ -389,8 +389,8 @@ class Engine:
         return n
 
     def prec_map_source(self) -> int:
-        """0 shipped map on the weights it was derived from, 1 calibrated on the bound weights, 2 edited, 3 shipped map on OTHER weights (unverified),
-        -1 not a PREC_MIXED handle / not prepared (soccdpt_prec_map_source)."""
+        """0 shipped map on the weights it was derived from, 1 calibrated on the bound weights, 2 edited, 3 other weights and no calibration yet (the
+        library runs every group in x3 until one has run), -1 not a PREC_MIXED handle / not prepared (soccdpt_prec_map_source)."""
         return int(self.L.soccdpt_prec_map_source(self._h))
 
     def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4) -> dict:

@@ -236,9 +236,9 @@ class SOccDPT_V3(SOccDPT):
         if self.precision == PREC_MIXED and eng.prec_map_source() == 3 and not self.__dict__.get("_warned_uncalibrated"):
             # printed, not raised: the reference's convention for checkpoint mismatches (model/base_model.py:30-34)
             self.__dict__["_warned_uncalibrated"] = True
-            print("soccdpt_amd: the default arithmetic (SOCCDPT_PREC_MIXED) is running its SHIPPED precision map on weights it was not derived from; "
-                  "its within-tolerance claim is unverified for them.  Call net.calibrate_precision(sample_frames, budget=5e-4) once after loading "
-                  "the checkpoint (or construct with precision=PREC_F16X3 for f32-grade results everywhere).")
+            print("soccdpt_amd: these are not the weights the shipped precision map of the default arithmetic (SOCCDPT_PREC_MIXED) was derived on, so its "
+                  "within-tolerance claim does not carry over: every GEMM / convolution runs x3 split-fp16 operands (f32-grade, about 1.7x the step) "
+                  "until net.calibrate_precision(sample_frames, budget=5e-4) has derived a map for THIS checkpoint.")
 
     def forward(self, x: torch.Tensor):
         """x [B,3,S,S] f32 on cuda -> (inv_depth, segmentation, points, occupancy | None); see SOccDPT_V3.forward
@@ -423,7 +423,7 @@ class SOccDPT_V3(SOccDPT):
         return rep
 
     def precision_map_source(self, device=None) -> str:
-        """'shipped' | 'calibrated' | 'edited' | 'shipped-on-other-weights' | 'n/a' for the engine of `device` (default: the parameters' device)."""
+        """'shipped' | 'calibrated' | 'edited' | 'uncalibrated-all-x3' | 'n/a' for the engine of `device` (default: the parameters' device)."""
         from ..lib import PREC_SOURCE_NAMES
         dev = torch.device(device) if device is not None else next(self.parameters()).device
         eng = self._engine(dev)

@@ -4,8 +4,10 @@ The reference computes in fp32 whatever checkpoint BaseModel.load_net binds (/ro
 model/SOccDPT.py:29-57,634-636).  The shipped maps of SOCCDPT_PREC_MIXED were fitted to ONE synthetic weight draw (salt 0); these tests bind
 OTHER weights -- two more synthetic draws and a draw with trained-like statistics (LayerNorm gains spread over U(0.2, 3), a few 10x outlier
 channels) -- and check, against the fp32 CPU oracle on frames the calibration never saw:
-  * the library says so: soccdpt_prec_map_source() == 3 (shipped map on other weights), the Python mirror prints the warning once;
-  * how the SHIPPED map generalises: its worst-of-seven on those weights is reported and must stay inside the north star's 1e-3;
+  * the library notices: soccdpt_prec_map_source() == 3, every group runs x3 operands (f32-grade) until a calibration has run, and the Python
+    mirror prints the notice once;
+  * how the SHIPPED map would have generalised is measured and reported by the calibration (round 5: on the second synthetic draw it leaves the
+    class logits at 1.4e-3 -- outside the north star -- which is why the uncalibrated default is all-x3 and not the shipped map);
   * the CALIBRATED map keeps all seven quantities within the budget (5e-4) -- measured by the library against its own f32 mode on the
     calibration frames, and re-measured here against the CPU oracle on held-out frames (10 % head-room for the change of frames)."""
 import os
@@ -100,21 +102,22 @@ def test_other_weights_shipped_map_reported_calibrated_map_within_budget(gpu_dev
     x_cal = synth_input(2, seed0=4)          # what the calibration sees
     x_test = synth_input(2, seed0=90)        # what it never saw
     ora = _oracle(sd, x_test, "swin2t16_256")
-    e_ship = _errors_vs_oracle(m, x_test, gpu_device, ora)
-    assert m.precision_map_source() == "shipped-on-other-weights"
-    assert "SHIPPED precision map on weights it was not derived from" in capsys.readouterr().out
+    e_safe = _errors_vs_oracle(m, x_test, gpu_device, ora)
+    assert m.precision_map_source() == "uncalibrated-all-x3"
+    assert "not the weights the shipped precision map" in capsys.readouterr().out
+    pm = m._engine(gpu_device).prec_map()
+    assert all(v == 3 for v in pm.values())
     rep = m.calibrate_precision(x_cal.to(gpu_device), budget=5e-4)
     assert m.precision_map_source() == "calibrated"
     e_cal = _errors_vs_oracle(m, x_test, gpu_device, ora)
-    print(f"[{case}] shipped map on these weights, held-out frames vs fp32 CPU oracle: worst {max(e_ship.values()):.2e}", {k: f"{v:.2e}" for k, v in e_ship.items()})
+    print(f"[{case}] before calibration (all groups x3), held-out frames vs fp32 CPU oracle: worst {max(e_safe.values()):.2e}", {k: f"{v:.2e}" for k, v in e_safe.items()})
     print(f"[{case}] calibrated map ({rep['n_x3']} of {rep['n_groups']} groups x3, shipped {rep['n_x3_shipped']}; {rep['forwards']} forwards; library-measured worst "
           f"{rep['worst_calibrated']:.2e}, shipped {rep['worst_shipped']:.2e}, all-fp16 {rep['worst_all_fp16']:.2e}): held-out worst {max(e_cal.values()):.2e}",
           {k: f"{v:.2e}" for k, v in e_cal.items()})
     assert rep["met_budget"] == 1 and rep["worst_calibrated"] <= 5e-4
-    assert max(e_ship.values()) <= 1e-3, "the shipped map leaves the north star's tolerance on these weights"
+    assert max(e_safe.values()) <= 2e-4          # the uncalibrated default is parity-grade
     assert max(e_cal.values()) <= 5.5e-4
-    # the library's own measurement of the shipped map (vs its f32 mode, calibration frames) agrees with the oracle's view (held-out frames) to ~20 %
-    assert abs(rep["worst_shipped"] - max(e_ship.values())) <= 0.25 * max(e_ship.values())
+    assert rep["worst_all_x3"] < 2e-4 < rep["worst_all_fp16"] and rep["worst_shipped"] > 0     # reported, not bounded: the shipped map is not claimed for these weights
 
 
 def test_calibrate_hybrid_384(gpu_device):
@@ -124,10 +127,12 @@ def test_calibrate_hybrid_384(gpu_device):
     m = _build(sd, "dpt_hybrid_384")
     x_cal, x_test = synth_input(1, size=384, seed0=4), synth_input(1, size=384, seed0=90)
     ora = _oracle(sd, x_test, "vitb_rn50_384")
-    e_ship = _errors_vs_oracle(m, x_test, gpu_device, ora)
+    e_safe = _errors_vs_oracle(m, x_test, gpu_device, ora)
+    print("[hybrid salt1] before calibration (all groups x3; the attention core stays fp16):", {k: f"{v:.2e}" for k, v in e_safe.items()})
+    assert max(e_safe.values()) <= 4e-4
     rep = m.calibrate_precision(x_cal.to(gpu_device), budget=1e-3)
     e_cal = _errors_vs_oracle(m, x_test, gpu_device, ora)
-    print(f"[hybrid salt1] shipped worst {max(e_ship.values()):.2e}; calibrated {rep['n_x3']} of {rep['n_groups']} x3: library {rep['worst_calibrated']:.2e}, held-out vs oracle {max(e_cal.values()):.2e}",
+    print(f"[hybrid salt1] shipped map would give {rep['worst_shipped']:.2e} (library-measured); calibrated {rep['n_x3']} of {rep['n_groups']} x3: library {rep['worst_calibrated']:.2e}, held-out vs oracle {max(e_cal.values()):.2e}",
           {k: f"{v:.2e}" for k, v in e_cal.items()})
     assert rep["met_budget"] == 1 and max(e_cal.values()) <= 1.15e-3
 

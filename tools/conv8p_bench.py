@@ -22,7 +22,7 @@ for name, B, H, Cin, Cout in shapes:
     bias = torch.randn(Cout, generator=g).to(dev)
     outh = torch.zeros(B, H + 2, H + 2, Cout, dtype=torch.bfloat16, device=dev)
     M = B * H * H
-    cands = [21, 1, 16, 6, 30, 47, 48] if Cout % 256 == 0 else [21, 1, 16, 32, 49]   # 47-49: the 16-wave tiles of round 5
+    cands = [21, 16, 47, 51, 52] if Cout % 256 == 0 else [21, 1, 16, 49, 50]   # 47-49: the 16-wave tiles of round 5
     if os.environ.get("CONV_BENCH_M32") == "1":   # the v_mfma_f32_32x32x16 forms (40-45) against the 16x16x32 tiles of the same shape
         cands = [21, 41, 1, 40, 45, 42] + ([43, 44, 30] if Cout % 256 == 0 else [])
     if ABL:
