@@ -94,7 +94,8 @@ size_t soccdpt_sizeof(int which);
  * activation buffers they read):
  *   Swin-V2:  "s<stage>.b<block>.qkv" / ".proj" / ".fc1" / ".fc2" (the four Linear layers of a block; the attention core between qkv and proj
  *             always runs the fp16 kernel and hands proj its operands in proj's format), "merge<stage>" (PatchMerging reduction)
- *   hybrid:   "rn.s<stage>" (one ResNetV2 stage: its bottlenecks share the zero-halo images of their 3x3 inputs), "pe" (patch-embedding
+ *   hybrid:   "rn.s<stage>.c1" / ".c2" / ".c3" (per ResNetV2 stage: the 1x1 reduce convolutions + the shortcut projection -- both read the block
+ *             input --, the 3x3 convolutions, the 1x1 expand convolutions; one group per stage until round 4), "pe" (patch-embedding
  *             projection), "vit.b<i>.qkv" / ".proj" / ".fc1" / ".fc2", "ro<k>" (ProjectReadout + 1x1 of act_postprocess3 / 4), "pp4" (its 3x3 / 2)
  *   decoder:  "lrn<l>" (scratch.layer<l+1>_rn), "ref<l>" (the four RCU convolutions of refinenet<l+1>), "oc<l>" (its out_conv),
  *             "head" (output_conv.0 and seg_head.0: both read path_1), "head.d2" (output_conv.2 + .4), "head.s1" (format in which

@@ -95,6 +95,8 @@ int group_fmt(const Handle& h, const std::string& g) {
 inline std::string gname(const char* a, int i) { return std::string(a) + std::to_string(i); }
 inline std::string gblk(int s, int j, const char* part) { return "s" + std::to_string(s) + ".b" + std::to_string(j) + "." + part; }
 inline std::string gvit(int i, const char* part) { return "vit.b" + std::to_string(i) + "." + part; }
+// ResNetV2 stage s of the hybrid: c = 1 the 1x1 reduce convolutions and the shortcut projection (both read the block input), 2 the 3x3, 3 the 1x1 expand
+inline std::string grn(int s, int c) { return "rn.s" + std::to_string(s) + ".c" + std::to_string(c); }
 
 
 struct Arena {
@@ -172,12 +174,12 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
             for (int j = 0; j < a.rn_layers[s3]; ++j) {
                 const std::string b = rnblk(s3, j);
                 RnBlockW bw;
-                const int fb = GF(gname("rn.s", s3));
+                const int f1 = GF(grn(s3, 1)), f2 = GF(grn(s3, 2)), f3 = GF(grn(s3, 3));
                 bw.cin = prev; bw.cout = cout; bw.mid = mid; bw.proj = (j == 0); bw.stride = (j == 0 && s3 > 0) ? 2 : 1;
-                if (bw.proj) bw.ds_w = wsw(b + "downsample.conv.weight", cout, prev, 1, prev, fb);
-                bw.c1_w = wsw(b + "conv1.weight", mid, prev, 1, prev, fb);
-                bw.c2_w = wsw(b + "conv2.weight", mid, mid, 3, 9 * mid, fb);
-                bw.c3_w = wsw(b + "conv3.weight", cout, mid, 1, mid, fb);
+                if (bw.proj) bw.ds_w = wsw(b + "downsample.conv.weight", cout, prev, 1, prev, f1);   // reads the block input like conv1: same group
+                bw.c1_w = wsw(b + "conv1.weight", mid, prev, 1, prev, f1);
+                bw.c2_w = wsw(b + "conv2.weight", mid, mid, 3, 9 * mid, f2);
+                bw.c3_w = wsw(b + "conv3.weight", cout, mid, 1, mid, f3);
                 if (run) {
                     if ((bw.proj && !bw.ds_w) || !bw.c1_w || !bw.c2_w || !bw.c3_w) return 1;
                     if (bw.proj) { bw.ds_g = W(b + "downsample.norm.weight"); bw.ds_b = W(b + "downsample.norm.bias"); }
@@ -580,7 +582,7 @@ std::vector<std::string> model_prec_groups(const Handle& h) {
     const Arch& a = h.arch;
     std::vector<std::string> g;
     if (a.hybrid) {
-        for (int s = 0; s < 3; ++s) g.push_back(gname("rn.s", s));
+        for (int s = 0; s < 3; ++s) for (int c = 1; c <= 3; ++c) g.push_back(grn(s, c));
         g.push_back("pe");
         for (int i = 0; i < a.vit_depth; ++i) for (const char* part : {"qkv", "proj", "fc1", "fc2"}) g.push_back(gvit(i, part));
         g.push_back("ro0"); g.push_back("ro1"); g.push_back("pp4");
@@ -622,7 +624,7 @@ void model_prec_default(Handle& h) {
             // profiles/r04_precision_map_hybrid384.json (B = 4, budget 1e-3): worst of the seven quantities 7.1e-4 (fp16 everywhere: 2.5e-2).  The
             // weight-standardised ResNetV2 stages amplify operand rounding and take x3; the ViT blocks and the 3x3 convolutions
             // of the decoder stay fp16; the 1x1 out_convs, the last read-out projection and the seg-head feature map are the cheap rest of the budget.
-            x3({"rn.s0", "rn.s1", "rn.s2", "ro1", "oc0", "oc1", "oc2", "oc3", "head.s1"});
+            x3({"rn.s0.*", "rn.s1.*", "rn.s2.*", "ro1", "oc0", "oc1", "oc2", "oc3", "head.s1"});
             break;
         case SOCCDPT_BACKBONE_SWIN2B24_384:
             // profiles/r04_precision_map_base384.json (B = 8, budget 5e-4): worst of the seven quantities 4.5e-4 (fp16 everywhere: 1.2e-3 on path_1 --
@@ -736,9 +738,12 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         // launch for launch what oracle/soccdpt_ref.py hybrid_encoder() states.
         const HybridW& Y = P.hy;
         const int S = a.img, H1 = S / 2, H2 = S / 4;
-        // Per-group operand formats (uniform modes: one code everywhere): a ResNetV2 stage "rn.s<k>" (its bottlenecks share the zero-halo images
-        // of their 3x3 inputs, so the stage is the unit), "pe", the ViT blocks' "vit.b<i>.attn" / ".mlp", "ro<k>", "pp4".
-        const int fRn[3] = {GF("rn.s0"), GF("rn.s1"), GF("rn.s2")}, fPe = GF("pe");
+        // Per-group operand formats (uniform modes: one code everywhere): "rn.s<k>.c<1|2|3>" (a ResNetV2 stage's bottlenecks share the zero-halo images
+        // of their 3x3 inputs, so a convolution TYPE of a stage is the unit), "pe", the ViT blocks' "vit.b<i>.qkv" / ".proj" / ".fc1" / ".fc2", "ro<k>", "pp4".
+        // per convolution type of a ResNetV2 stage (round 5; round 4 had one group per stage): [stage][0] 1x1 reduce + shortcut, [1] 3x3, [2] 1x1 expand
+        int fRn[3][3];
+        for (int s3 = 0; s3 < 3; ++s3) for (int c = 0; c < 3; ++c) fRn[s3][c] = GF(grn(s3, c + 1));
+        const int fPe = GF("pe");
         // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
         auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
             d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part; d.gn_count = w.hy_count; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
@@ -757,18 +762,18 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             d.X = w.hy_a0; d.Wt = Y.stem_w; d.M = B * H1 * H1; d.N = a.stem_ch; d.Cin = 160; d.ldx = 160; d.out_f32 = w.hy_r[0];
             with_stats(d, 0, a.stem_ch, H1 * H1);
             RUN(gemm(d, 2));
-            { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * (fRn[0] >= 2 ? 4 : 2));
-              RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, fRn[0], B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
+            { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * (fRn[0][0] >= 2 ? 4 : 2));
+              RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, fRn[0][0], B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
         }
         int rcur = H2;
         for (int s3 = 0; s3 < 3; ++s3) {
             const int nb = (int)Y.stages[s3].size();
-            const int fb = fRn[s3];
+            const int f1 = fRn[s3][0], f2 = fRn[s3][1], f3 = fRn[s3][2];
             for (int j = 0; j < nb; ++j) {
                 const RnBlockW& bw = Y.stages[s3][j];
                 const int rin = rcur, rout = rin / bw.stride;
                 const int Min = B * rin * rin, Mout = B * rout * rout;
-                const int fnext = j + 1 < nb ? fb : (s3 < 2 ? fRn[s3 + 1] : fPe);   // who reads this bottleneck's output
+                const int fnext = j + 1 < nb ? f1 : (s3 < 2 ? fRn[s3 + 1][0] : fPe);   // who reads this bottleneck's output
                 // zero-halo image for this (resolution, width): see carve()
                 const int ti = s3 == 0 ? 0 : (s3 == 1 ? (j == 0 ? 1 : 2) : (j == 0 ? 3 : 4));
                 if (bw.proj) {   // shortcut: GN(1x1 stride-s conv)
@@ -777,34 +782,34 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                     if (bw.stride == 1) { d.ldx = bw.cin; }
                     else { d.gather1 = 1; d.stride = bw.stride; d.pad = 0; d.in_halo = 0; d.Hi = rin; d.Wi = rin; d.H = rout; d.W = rout; }
                     with_stats(d, 3, bw.cout, rout * rout);
-                    RUN(gemm(d, fb));
+                    RUN(gemm(d, f1));
                 }
                 {   // conv1 1x1 -> GN + ReLU -> halo image
                     IgemmDesc d;
                     d.X = w.hy_xop; d.Wt = bw.c1_w; d.M = Min; d.N = bw.mid; d.Cin = bw.cin; d.ldx = bw.cin; d.out_f32 = w.hy_r[0];
                     with_stats(d, 0, bw.mid, rin * rin);
-                    RUN(gemm(d, fb));
+                    RUN(gemm(d, f1));
                     GnApplyArgs g;
                     g.raw = w.hy_r[0]; g.stats = w.hy_stats[0]; g.gamma = bw.n1_g; g.beta = bw.n1_b; g.out_halo = w.hy_t1[ti];
                     g.M = (size_t)Min; g.HW = rin * rin; g.W = rin; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g, fb));
+                    RUN(gn(g, f2));   // written in the format of its reader, the 3x3
                 }
                 {   // conv2 3x3 (stride on this conv; 'SAME': pad 1 at stride 1, the extra pixel right / bottom at stride 2) -> GN + ReLU
                     IgemmDesc d;
                     d.X = w.hy_t1[ti]; d.Wt = bw.c2_w; d.M = Mout; d.N = bw.mid; d.Cin = bw.mid; d.taps = 9; d.H = rout; d.W = rout; d.Hi = rin; d.Wi = rin;
                     d.stride = bw.stride; d.pad = bw.stride == 1 ? 1 : 0; d.in_halo = 1; d.out_f32 = w.hy_r[1];
                     with_stats(d, 1, bw.mid, rout * rout);
-                    RUN(gemm(d, fb));
+                    RUN(gemm(d, f2));
                     GnApplyArgs g;
                     g.raw = w.hy_r[1]; g.stats = w.hy_stats[1]; g.gamma = bw.n2_g; g.beta = bw.n2_b; g.out_op = w.hy_t2;
                     g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g, fb));
+                    RUN(gn(g, f3));
                 }
                 {   // conv3 1x1 -> GN, + shortcut, ReLU: the new residual stream (f32) and its operand copy; hooked stages also as a halo image
                     IgemmDesc d;
                     d.X = w.hy_t2; d.Wt = bw.c3_w; d.M = Mout; d.N = bw.cout; d.Cin = bw.mid; d.ldx = bw.mid; d.out_f32 = w.hy_r[2];
                     with_stats(d, 2, bw.cout, rout * rout);
-                    RUN(gemm(d, fb));
+                    RUN(gemm(d, f3));
                     GnApplyArgs g;
                     g.raw = w.hy_r[2]; g.stats = w.hy_stats[2]; g.gamma = bw.n3_g; g.beta = bw.n3_b;
                     if (bw.proj) { g.raw2 = w.hy_r[3]; g.stats2 = w.hy_stats[3]; g.gamma2 = bw.ds_g; g.beta2 = bw.ds_b; }
