@@ -60,6 +60,11 @@ extern "C" {
                                tools/precision_map.py that keeps depth, logits, path_1 and every hooked feature map within HALF the north
                                star's 1e-3 of the fp32 reference (model/loader.py:126-139 computes in fp32); soccdpt_prec_map_set edits it. */
 
+#define SOCCDPT_PREC_F16X2W 5 /* a precision-MAP value (and a soccdpt_op_igemm operand mode), not a handle mode: one-sided split -- fp16 activations, the
+                               group's weights as x3 pairs, two fp16 MFMAs per product.  Removes the WEIGHT rounding of a launch site (a median 72 % of
+                               its fp16 rounding variance on the synthetic weights, profiles/r05_x2_variance_tiny256.json) at 1.5x the operand bytes of an
+                               fp16 launch; the producers of the site's activations keep writing 2-byte operands. */
+
 /* Constructor constants of SOccDPT / SOccDPT_V3 (model/SOccDPT.py:134-245,626-679). */
 typedef struct soccdpt_config {
     int32_t abi_version;  /* SOCCDPT_ABI_VERSION */
@@ -100,10 +105,10 @@ size_t soccdpt_sizeof(int which);
  *   decoder:  "lrn<l>" (scratch.layer<l+1>_rn), "ref<l>" (the four RCU convolutions of refinenet<l+1>), "oc<l>" (its out_conv),
  *             "head" (output_conv.0 and seg_head.0: both read path_1), "head.d2" (output_conv.2 + .4), "head.s1" (format in which
  *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32)
- * `group` may end in '*' (prefix match) or be "*".  fmt = SOCCDPT_PREC_F16 or SOCCDPT_PREC_F16X3.  Returns the number of groups
+ * `group` may end in '*' (prefix match) or be "*".  fmt = SOCCDPT_PREC_F16, SOCCDPT_PREC_F16X2W or SOCCDPT_PREC_F16X3.  Returns the number of groups
  * changed (>= 0) or a negative value on error.  Invalidates the prepared weights and the workspace (call soccdpt_prepare again). */
 int soccdpt_prec_map_set(void* handle, const char* group, int fmt);
-/* Writes "name=fmt name=fmt ..." (fmt 2 / 3, launch order) into buf; returns the length needed (excluding the terminator). */
+/* Writes "name=fmt name=fmt ..." (fmt 2 / 5 / 3, launch order) into buf; returns the length needed (excluding the terminator). */
 int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes);
 
 /* ---- calibration of the precision map on the weights bound to the handle (round 5) ----

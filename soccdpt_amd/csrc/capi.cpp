@@ -54,8 +54,8 @@ int soccdpt_prec_map_set(void* handle, const char* group, int fmt) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h || !group) return -1;
     if (h->cfg.precision != SOCCDPT_PREC_MIXED) { fail(h, "soccdpt_prec_map_set: the handle was not created with SOCCDPT_PREC_MIXED"); return -1; }
-    if (fmt != SOCCDPT_PREC_F16 && fmt != SOCCDPT_PREC_F16X3) { fail(h, "soccdpt_prec_map_set: fmt must be SOCCDPT_PREC_F16 or SOCCDPT_PREC_F16X3"); return -1; }
-    const int n = model_prec_set(*h, group, fmt == SOCCDPT_PREC_F16X3 ? 3 : 1, h->err);
+    if (fmt != SOCCDPT_PREC_F16 && fmt != SOCCDPT_PREC_F16X3 && fmt != SOCCDPT_PREC_F16X2W) { fail(h, "soccdpt_prec_map_set: fmt must be SOCCDPT_PREC_F16, SOCCDPT_PREC_F16X2W or SOCCDPT_PREC_F16X3"); return -1; }
+    const int n = model_prec_set(*h, group, fmt == SOCCDPT_PREC_F16X3 ? 3 : (fmt == SOCCDPT_PREC_F16X2W ? 4 : 1), h->err);
     if (n < 0) return n;
     // formats decide where the zero borders of the 3x3 inputs lie and which weight copies exist: both caches are void
     h->ws_key = Handle::WsKey();
@@ -70,7 +70,8 @@ int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes) {
     std::string out;
     for (const auto& g : model_prec_groups(*h)) {
         auto it = h->prec_map.find(g);
-        const int f = h->cfg.precision == SOCCDPT_PREC_MIXED ? (it != h->prec_map.end() && it->second == 3 ? SOCCDPT_PREC_F16X3 : SOCCDPT_PREC_F16) : h->cfg.precision;
+        const int f = h->cfg.precision == SOCCDPT_PREC_MIXED ? (it == h->prec_map.end() ? SOCCDPT_PREC_F16 : it->second == 3 ? SOCCDPT_PREC_F16X3 : it->second == 4 ? SOCCDPT_PREC_F16X2W : SOCCDPT_PREC_F16)
+                                                             : h->cfg.precision;
         if (!out.empty()) out += ' ';
         out += g + "=" + std::to_string(f);
     }
@@ -528,7 +529,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.X = a->x; d.Wt = a->wt;
     d.M = a->M; d.N = a->N; d.Cin = a->Cin; d.taps = a->taps; d.ldx = a->ldx; d.H = a->H; d.W = a->W;
     d.bias = a->bias; d.res1 = a->res1; d.res2 = a->res2; d.act = a->act; d.out_f32 = a->out_f32; d.act_on_f32 = a->act_on_f32;
-    d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.x3 = a->precision == SOCCDPT_PREC_F16X3; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
+    d.out_op = a->out_bf16; d.f32 = a->precision == SOCCDPT_PREC_F32; d.f16 = a->precision == SOCCDPT_PREC_F16; d.x3 = a->precision == SOCCDPT_PREC_F16X3; d.x2w = a->precision == SOCCDPT_PREC_F16X2W; if (d.x2w) d.f16 = 1; d.out_halo = a->out_halo; d.dot_w = a->dot_w; d.dot_b = a->dot_b; d.out_dot = a->out_dot; d.tune = a->tune;
     d.splitk = a->splitk > 1 ? a->splitk : 1; d.sk_part = a->sk_part; d.sk_count = a->sk_count;
     d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words; d.sk_defer = a->sk_defer;
     if (a->conv_general) { d.stride = a->stride; d.pad = a->pad; d.in_halo = a->in_halo; d.Hi = a->Hi; d.Wi = a->Wi; d.gather1 = a->gather1; }

@@ -40,6 +40,7 @@ struct IgemmDesc {
     int f32 = 0;               // exact-f32 operands and f32 MFMA (SOCCDPT_PREC_F32)
     int f16 = 0;               // 16-bit operands are IEEE fp16 instead of bf16 (SOCCDPT_PREC_F16); ignored when f32 != 0
     int x3 = 0;                // split-fp16 operands in the x3 layout (half16.h), three fp16 MFMAs per product (SOCCDPT_PREC_F16X3); wins over f32 / f16
+    int x2w = 0;               // one-sided split (round 5): X is plain fp16, Wt holds x3 pairs (4 bytes per element), two fp16 MFMAs per product; wins over f16
     int M = 0, N = 0;
     int Cin = 0;      // channels per tap (K of a plain GEMM)
     int taps = 1;     // 1 (GEMM / 1x1) or 9 (3x3, pad 1)

@@ -49,7 +49,7 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     constexpr int BK = C::ROWB / (int)sizeof(T);
     const int nk = d.taps * d.Cin / BK, kpt = d.Cin / BK;
     const int mtiles = (d.M + C::BM - 1) / C::BM, ntiles = (d.N + C::BN - 1) / C::BN;
-    const size_t lds = (size_t)C::NS * C::STAGE;
+    const size_t lds = (size_t)C::NS * igemm_stage_bytes<C, T>();
     if constexpr (ST) {
         const int G = d.gn_cpg > 0 ? d.N / d.gn_cpg : 0;
         if (!d.gn_part || !d.gn_count || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
@@ -235,7 +235,25 @@ static int pick_cfg(const IgemmDesc& d) {
     return 23;  // 64x64 (8 waves; the 4-wave form is configuration 2): 4x the blocks of 128x128
 }
 
+// x2w launches (fp16 activations, x3 weight pairs, two MFMAs per product): the tile ids of the x2w family
+//   0 64x64x64_s3_w8   1 32x64x64_s4 (small grids, long K)   2 128x128x64_s2_w8 (big grids)   3 64x128x32_s3 (fused LayerNorm, N <= 128)   4 64x64x32_s4 (C = 96)
+static const char* const kCfgNamesX2W[] = {"igemm_x2w_64x64x64_s3_w8", "igemm_x2w_32x64x64_s4", "igemm_x2w_128x128x64_s2_w8", "igemm_x2w_64x128x32_s3_ln", "igemm_x2w_64x64x32_s4"};
+static int pick_cfg_x2w(const IgemmDesc& d) {
+    if (d.ln_g) return 3;
+    const bool k64 = d.Cin % 64 == 0;
+    if (!k64) return 4;
+    if (d.tune >= 0 && d.tune <= 2) return d.tune;
+    auto cdiv = [](long a, long b) { return (a + b - 1) / b; };
+    const long b64 = cdiv(d.M, 64) * cdiv(d.N, 64), b128 = cdiv(d.M, 128) * cdiv(d.N, 128);
+    if (d.gn_stats) return (d.gn_hw % 128 == 0 && 128 % d.gn_cpg == 0 && b128 >= 256) ? 2 : 0;
+    if (need_gen(d)) return 0;
+    if (b128 >= 384) return 2;          // the rule of the x3 family (7 / 8): big grids take the 128 x 128 tile
+    if (b64 <= 256) return 1;           // the rule of x3 configuration 10
+    return 0;
+}
+
 int igemm_pick_splitk(const IgemmDesc& d, size_t part_floats, size_t count_words) {
+    if (d.x2w) return 1;
     // Measured (tools/igemm_tune.py, rocprofv3 durations): the partial-tile exchange costs ~5 us per split (L2-bypassing stores
     // and loads: the 8 XCD L2s are not coherent with each other inside a kernel), about one kernel floor.  It only pays for the
     // longest K on the smallest grid: layer4_rn (M=512, N=256, K=6912) 30.9 -> 18.3 us at 4 splits; K=2304..3456 on 64..256
@@ -282,6 +300,7 @@ int igemm_dot3_bn(const IgemmDesc& d) {
 int igemm_config_id(const IgemmDesc& d) { return d.x3 ? pick_cfg_f32(d) : (d.f32 ? -1 : pick_cfg(d)); }
 
 const char* igemm_family(const IgemmDesc& d) {
+    if (d.x2w) return kCfgNamesX2W[pick_cfg_x2w(d)];
     if (d.dot3 && !d.x3 && !d.f32) {
         if (igemm_dot3_bn(d) == 256) return d.f16 ? "igemm_f16_256x256x64_s2_w16_dot3" : "igemm_bf16_256x256x64_s2_w16_dot3";
         return d.f16 ? "igemm_f16_128x128x64_s2_w8_dot3" : "igemm_bf16_128x128x64_s2_w8_dot3";
@@ -320,6 +339,26 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.dot3 && (d.x3 || d.f32)) { err = "igemm: the fused three-class classifier exists for 16-bit operands only"; return 1; }
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32 && !d.x3) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
+    if (d.x2w) {   // one-sided split (round 5): fp16 activations, x3 weight pairs
+        if (d.f32 || d.x3 || d.dot3 || d.out_dot || d.splitk > 1 || d.wt_grp_rows || d.seg2_k || d.grp_rows) { err = "igemm: x2w launches are plain / LayerNorm / GroupNorm-statistics launches"; return 1; }
+        if (d.ln_g && d.Cin % 32) { err = "igemm: x2w needs Cin % 32 == 0"; return 1; }
+        const bool gen = need_gen(d);
+        switch (pick_cfg_x2w(d)) {
+            case 1: if (gen || d.gn_stats) break;
+                    return launch_cfg_t<Cfg<32, 64, 64, 2, 2, 4>, x2w_t>(d, stream, err);
+            case 2: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x2w_t, false, false, true, true>(d, stream, err)
+                         : gen ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x2w_t, false, false, false, true>(d, stream, err)
+                               : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x2w_t>(d, stream, err);
+            case 3: if (gen || d.gn_stats) break;
+                    return launch_cfg_t<Cfg<64, 128, 32, 2, 2, 3>, x2w_t, true>(d, stream, err);
+            case 4: if (gen || d.gn_stats) break;
+                    return launch_cfg_t<Cfg<64, 64, 32, 2, 2, 4>, x2w_t>(d, stream, err);
+            default: break;
+        }
+        return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 3>, x2w_t, false, false, true, true>(d, stream, err)
+                   : gen ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 3>, x2w_t, false, false, false, true>(d, stream, err)
+                         : launch_cfg_t<Cfg<64, 64, 64, 2, 4, 3>, x2w_t>(d, stream, err);
+    }
     if (d.x3) {   // split-fp16 operands (SOCCDPT_PREC_F16X3): the f32 tile set with T = x3_t
         if (d.wt_grp_rows && (!d.wt_kx || d.wt_kx % 16 || d.wt_base % 16 || d.wt_rp % 16 || d.wt_base - d.wt_rp < 0)) {
             err = "igemm: x3 weight-row views must start at multiples of 16 elements (wt_kx copies)";

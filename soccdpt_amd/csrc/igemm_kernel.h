@@ -11,6 +11,12 @@ namespace soccdpt {
 
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 struct f16_t { uint16_t v; };  // element tag of the fp16 instantiations (SOCCDPT_PREC_F16); bf16_t tags bf16, float exact f32
+// x2w (round 5): ONE-SIDED split.  Activations are plain fp16 (2 bytes per element, staged and read exactly like an fp16 launch's), the WEIGHTS are x3
+// pairs (hi, lo * 2^11; 4 bytes per element, prepared once), and a product is TWO fp16 MFMAs, hi x + 2^-11 lo x: the weight rounding -- a median 72 % of
+// a launch site's fp16 rounding variance (tools/x2_variance_probe.py, profiles/r05_x2_variance_tiny256.json) -- is gone at 1.5x the operand bytes of an
+// fp16 launch instead of x3's 2x, and the producers of the site's activations keep writing 2-byte operands.  The element tag is 2 bytes wide: every
+// `sizeof(T) == 2` branch (activation addressing, 16-bit epilogue stores) is the fp16 one; the weight tile has its own geometry (rows of 2 * ROWB bytes).
+struct x2w_t { uint16_t v; };
 
 // BK_ is the k-tile depth in bf16 elements; a tile row is ROWB = 2*BK_ bytes (128 or 64).  With f32 operands
 // (SOCCDPT_PREC_F32) the same byte geometry holds BK_/2 elements per row.
@@ -32,6 +38,10 @@ struct Cfg {
     static_assert(X_LOADS * THREADS * 16 == X_BYTES && W_LOADS * THREADS * 16 == W_BYTES, "tile/threads mismatch");
     static_assert(NS >= 2 && (NS - 2) * LOADS <= 63, "vmcnt immediate is 6 bits");
 };
+
+// bytes of one ring slot: X tile + W tile (the x2w weight tile holds 4-byte x3 pairs beside 2-byte activations)
+template <class C, typename T>
+constexpr int igemm_stage_bytes() { return C::X_BYTES + C::W_BYTES * (std::is_same<T, x2w_t>::value ? 2 : 1); }
 
 template <int BK, int MF = 16>
 __device__ __forceinline__ int swz_of_row(int row) {
@@ -68,9 +78,17 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     constexpr int BM = C::BM, BN = C::BN;
     constexpr int BK = C::ROWB / (int)sizeof(T);   // k-tile depth in elements of T
     constexpr int EPC = 16 / (int)sizeof(T);       // elements per 16-byte chunk
-    constexpr bool F16 = std::is_same<T, f16_t>::value;
+    constexpr bool X2W = std::is_same<T, x2w_t>::value;
+    constexpr bool F16 = std::is_same<T, f16_t>::value || X2W;
     constexpr bool X3 = std::is_same<T, x3_t>::value;
     static_assert(!X3 || C::ROWB >= 128, "an x3 k-step (32 elements) is 128 bytes of a tile row");
+    static_assert(!X2W || ((C::BK == 32 || C::BK == 64) && C::MF == 16), "x2w tiles: 32- or 64-deep k-tiles (64- / 128-byte activation rows, 128- / 256-byte weight rows)");
+    // weight-tile geometry: that of the activations except under x2w (4-byte x3 pairs: rows, chunks per row and LDS-DMA pieces double)
+    typedef typename std::conditional<X2W, x3_t, T>::type WT;
+    constexpr int WMUL = X2W ? 2 : 1;
+    constexpr int W_ROWB = C::ROWB * WMUL, W_CPR = C::CPR * WMUL, W_LOADS = C::W_LOADS * WMUL, W_EPC = 16 / (int)sizeof(WT);
+    constexpr int STAGE = C::X_BYTES + C::W_BYTES * WMUL, LOADS = C::X_LOADS + W_LOADS;
+    static_assert((C::NS - 2) * LOADS <= 63, "vmcnt immediate is 6 bits");
     constexpr int MF = C::MF;
     static_assert(MF == 16 || (MF == 32 && sizeof(T) == 2 && C::BK == 64 && !LN && !SK && !ST), "32x32x16 tiles: 16-bit operands, 64-deep k-tiles, plain epilogue");
     // epilogue view of a wave's accumulators, common to both MFMA shapes: TME m-tiles x TNE groups of 4 consecutive channels per lane;
@@ -78,7 +96,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     constexpr int TME = MF == 32 ? BM / C::WM / 32 : C::TM;
     constexpr int TNE = MF == 32 ? (BN / C::WN / 32) * 4 : C::TN;
     const T* const Xp = static_cast<const T*>(d.X);
-    const T* const Wtp = static_cast<const T*>(d.Wt);
+    const WT* const Wtp = static_cast<const WT*>(d.Wt);
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WN, wn = wave % C::WN;
@@ -103,7 +121,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     const int Hpi = GEN ? (d.Hi ? d.Hi : d.H) + 2 * d.in_halo : d.H + 2;
 
     // ---- per-thread staging sources (element offsets) ----
-    uint32_t x_off[C::X_LOADS], x_off2[C::X_LOADS], w_off[C::W_LOADS];
+    uint32_t x_off[C::X_LOADS], x_off2[C::X_LOADS], w_off[W_LOADS];
 #pragma unroll
     for (int i = 0; i < C::X_LOADS; ++i) {
         const int cid = i * C::THREADS + tid;
@@ -130,11 +148,14 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         x_off2[i] = base2 - base;   // delta to the second-segment row (mod 2^32), added when the k-tile lies in the second segment
     }
 #pragma unroll
-    for (int i = 0; i < C::W_LOADS; ++i) {
+    for (int i = 0; i < W_LOADS; ++i) {
         const int cid = i * C::THREADS + tid;
-        const int row = cid / C::CPR, c = cid % C::CPR;
+        const int row = cid / W_CPR, c = cid % W_CPR;
         int n = n0 + row;
         n = n < d.N ? n : d.N - 1;
+        if constexpr (X2W) {   // x3 pairs in rows of W_ROWB bytes: the swizzle of the x3 tiles of that row length
+            w_off[i] = (uint32_t)n * (uint32_t)Ktot + (uint32_t)((c ^ swz_of_row<C::BK * 2, 16>(row)) * W_EPC);
+        } else
         if (GEN && d.wt_grp_rows) {   // weight row groups: the tile's rows belong to ONE group (wt_grp_rows % BN == 0): a shifted view of the same matrix
             const int g = n0 / d.wt_grp_rows, ky = g / 3, kx = g - ky * 3;
             const uint32_t shift = d.wt_kx ? (uint32_t)(d.wt_base + (ky - 1) * d.wt_rp + kx * d.wt_kx)
@@ -158,7 +179,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         } else {
             xk = wk;
         }
-        char* sb = smem + buf * C::STAGE;
+        char* sb = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < C::X_LOADS; ++i) {
             const T* g = Xp + (x_off[i] + ((GEN && seg2) ? x_off2[i] : 0u)) + xk;   // a VALUE select: selecting between the two arrays demotes them (and d) to scratch
@@ -167,8 +188,8 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
         }
 #pragma unroll
-        for (int i = 0; i < C::W_LOADS; ++i) {
-            const T* g = Wtp + w_off[i] + wk;
+        for (int i = 0; i < W_LOADS; ++i) {
+            const WT* g = Wtp + w_off[i] + wk;
             char* l = sb + C::X_BYTES + (i * C::THREADS + wave * 64) * 16;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                              (__attribute__((address_space(3))) void*)l, 16, 0, 0);
@@ -180,8 +201,8 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     for (int i = 0; i < TNE; ++i)
 #pragma unroll
         for (int j = 0; j < TME; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    f32x4 accx[X3 ? TNE : 1][X3 ? TME : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11)
-    if constexpr (X3) {
+    f32x4 accx[(X3 || X2W) ? TNE : 1][(X3 || X2W) ? TME : 1];   // x3: the cross terms hi*lo + lo*hi (scaled by 2^11); x2w: lo_w * x
+    if constexpr (X3 || X2W) {
 #pragma unroll
         for (int i = 0; i < TNE; ++i)
 #pragma unroll
@@ -245,7 +266,19 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
             x3l_off[ks] = ((2 * u + 1 - (u & 1)) ^ fswz) * 16;
         }
     }
-    const int x_row0 = (wm * C::TM * 16 + frow) * C::ROWB, w_row0 = C::X_BYTES + (wn * C::TN * 16 + frow) * C::ROWB;
+    const int x_row0 = (wm * C::TM * 16 + frow) * C::ROWB, w_row0 = C::X_BYTES + (wn * C::TN * 16 + frow) * W_ROWB;
+    // x2w: weight fragments of k-step ks = unit 4 ks + fq of the 2 * ROWB-byte x3 row (hi / lo chunk as in the x3 tiles); the activation fragments
+    // are the fp16 ones (xr_off)
+    int w2h_off[X2W ? C::KS : 1], w2l_off[X2W ? C::KS : 1];
+    if constexpr (X2W) {
+        const int wswz = swz_of_row<C::BK * 2, 16>(frow);
+#pragma unroll
+        for (int ks = 0; ks < C::KS; ++ks) {
+            const int u = ks * 4 + fq;
+            w2h_off[ks] = ((2 * u + (u & 1)) ^ wswz) * 16;
+            w2l_off[ks] = ((2 * u + 1 - (u & 1)) ^ wswz) * 16;
+        }
+    }
     // 32 x 32 x 16 fragments: lane (row r32, half h2) reads chunk 2 ks + h2 of k-step ks (16 elements per step)
     constexpr int KS32 = MF == 32 ? C::BK / 16 : 1;
     int x32_off[KS32], w32_off[KS32];
@@ -264,7 +297,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     // both publishes it to the other waves and retires everybody's reads of ring slot (kt-1)%NS, which the
     // next LDS-DMA group overwrites.  (__syncthreads() would drain vmcnt(0): cdna_hip_programming.md §5.)
     auto wait_tile = [&](int kt) {
-        if (kt + C::NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::NS - 2) * C::LOADS) : "memory");
+        if (kt + C::NS - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((C::NS - 2) * LOADS) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     };
 #pragma unroll
@@ -281,8 +314,27 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         __builtin_amdgcn_s_barrier();
         if (GEN && kt == 0 && d.stamps && tid == 0) d.stamps[4 * (size_t)blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
         if (kt + C::NS - 1 < nk) stage(kt + C::NS - 1, (kt + C::NS - 1) % C::NS);
-        const char* sb = smem + (kt % C::NS) * C::STAGE;
-        if constexpr (X3) {
+        const char* sb = smem + (kt % C::NS) * STAGE;
+        if constexpr (X2W) {
+#pragma unroll
+            for (int ks = 0; ks < C::KS; ++ks) {
+                h16x8 wh[C::TN], wl[C::TN], xf[C::TM];
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i) {
+                    wh[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + w2h_off[ks] + i * 16 * W_ROWB);
+                    wl[i] = *reinterpret_cast<const h16x8*>(sb + w_row0 + w2l_off[ks] + i * 16 * W_ROWB);
+                }
+#pragma unroll
+                for (int j = 0; j < C::TM; ++j) xf[j] = *reinterpret_cast<const h16x8*>(sb + xr_off[ks] + j * 16 * C::ROWB);
+#pragma unroll
+                for (int i = 0; i < C::TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < C::TM; ++j) {
+                        acc[i][j] = mfma_16x16x32<true>(wh[i], xf[j], acc[i][j]);
+                        accx[i][j] = mfma_16x16x32<true>(wl[i], xf[j], accx[i][j]);
+                    }
+            }
+        } else if constexpr (X3) {
 #pragma unroll
             for (int ks = 0; ks < KSX; ++ks) {
                 h16x8 wh[C::TN], wl[C::TN], xh[C::TM], xl[C::TM];
@@ -362,7 +414,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
 #pragma unroll
                     for (int r = 0; r < 4; ++r) acc[i * 4 + g][j][r] = acc32[i][j][4 * g + r];
     }
-    if constexpr (X3) {   // fold the cross terms in: a b = hi hi + 2^-11 (hi lo + lo hi)
+    if constexpr (X3 || X2W) {   // fold the cross terms in: a b = hi hi + 2^-11 (hi lo + lo hi)   (x2w: w x = hi x + 2^-11 lo x)
 #pragma unroll
         for (int i = 0; i < TNE; ++i)
 #pragma unroll

@@ -11,6 +11,8 @@
 #include <cstdlib>
 #include <cstring>
 
+#include <unordered_set>
+
 #include "internal.h"
 #include "kernels.h"
 
@@ -66,6 +68,7 @@ struct Prepared {
     float *bn_scale, *bn_shift;
     const float *s4_w, *s4_b;
     float* patch_wT = nullptr;  // [48][128]
+    std::unordered_set<const void*> x2w;   // prepared weights of x2w groups (x3 pairs read beside fp16 activations): gemm() picks the x2w tiles for them
 };
 
 Handle::~Handle() {
@@ -88,9 +91,16 @@ int group_fmt(const Handle& h, const std::string& g) {
         case SOCCDPT_PREC_F32: return 2;
         case SOCCDPT_PREC_F16: return 1;
         case SOCCDPT_PREC_F16X3: return 3;
-        case SOCCDPT_PREC_MIXED: { auto it = h.prec_map.find(g); return (it != h.prec_map.end() && it->second == 3) ? 3 : 1; }
+        case SOCCDPT_PREC_MIXED: { auto it = h.prec_map.find(g); return (it != h.prec_map.end() && it->second == 3) ? 3 : 1; }   // an x2w group (4) reads fp16 activations
         default: return 0;
     }
+}
+// x2w (round 5): the group's ACTIVATIONS stay fp16 -- group_fmt() says 1, every producer / consumer of its operand buffers treats it as an fp16 group --
+// and only its WEIGHTS are prepared as x3 pairs; the launch runs the two-MFMA x2w tiles (igemm_kernel.h)
+bool group_x2w(const Handle& h, const std::string& g) {
+    if (h.cfg.precision != SOCCDPT_PREC_MIXED) return false;
+    auto it = h.prec_map.find(g);
+    return it != h.prec_map.end() && it->second == 4;
 }
 inline std::string gname(const char* a, int i) { return std::string(a) + std::to_string(i); }
 inline std::string gblk(int s, int j, const char* part) { return "s" + std::to_string(s) + ".b" + std::to_string(j) + "." + part; }
@@ -134,25 +144,33 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     // SOCCDPT_PREC_MIXED: every weight copy gets 4 bytes per element whatever its group's format, so the arena layout (and
     // soccdpt_prepared_bytes) does not depend on the precision map
     const bool MIX = h.cfg.precision == SOCCDPT_PREC_MIXED;
-    auto GF = [&](const std::string& g) { return group_fmt(h, g); };   // operand format code of a group: 0 bf16, 1 fp16, 2 f32, 3 x3 (half16.h)
+    // WEIGHT format code of a group: 0 bf16, 1 fp16, 2 f32, 3 x3 (half16.h); + 0x100 when the group is x2w (x3 weights beside fp16 activations)
+    auto GF = [&](const std::string& g) { return group_x2w(h, g) ? (3 | 0x100) : group_fmt(h, g); };
+    auto reg = [&](int& fmt, const void* p) { if ((fmt & 0x100) && run && P && p) P->x2w.insert(p); };
     static const char kNoCopy = 0;  // non-null placeholder while measuring
-    auto cvt = [&](const std::string& key, size_t n, int fmt) -> const void* {
+    auto cvt = [&](const std::string& key, size_t n, int fmt_) -> const void* {
+        const int fmt = fmt_ & 0xff;
         if (fmt == 2) return run ? static_cast<const void*>(W(key)) : static_cast<const void*>(&kNoCopy);  // [N][K] f32 as bound
         bf16_t* p = (fmt == 3 || MIX) ? reinterpret_cast<bf16_t*>(ar.take<float>(n)) : ar.take<bf16_t>(n);
         if (run && launch_cvt_bf16(W(key), p, n, fmt, st, err)) return nullptr;
+        reg(fmt_, p);
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
-    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale, int fmt) -> const void* {
+    auto convw = [&](const std::string& key, int Cout, int Cin, const float* scale, int fmt_) -> const void* {
+        const int fmt = fmt_ & 0xff;
         const size_t n = (size_t)Cout * Cin * 9;
         void* p = (fmt >= 2 || MIX) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
         if (run && launch_conv_w(W(key), scale, p, fmt == 2 ? 1 : 0, fmt == 2 ? 0 : fmt, Cout, Cin, st, err)) return nullptr;
+        reg(fmt_, p);
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     // weight-standardised convolution weight (timm StdConv2dSame, eps 1e-8), tap-major [Cout][Kpad]; fmt = operand format code of hybrid.hip
-    auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad, int fmt) -> const void* {
+    auto wsw = [&](const std::string& key, int Cout, int Cin, int k, int Kpad, int fmt_) -> const void* {
+        const int fmt = fmt_ & 0xff;
         const size_t n = (size_t)Cout * Kpad;
         void* p = (fmt >= 2 || MIX) ? static_cast<void*>(ar.take<float>(n)) : static_cast<void*>(ar.take<bf16_t>(n));
         if (run && launch_ws_conv_w(W(key), p, fmt, Cout, Cin, k, Kpad, 1e-8f, st, err)) return nullptr;
+        reg(fmt_, p);
         return run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
     };
     if (a.hybrid) {
@@ -708,7 +726,8 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d, int fmt) {   // fmt: operand format code of the launch's group
         if (!d.f32) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
-        const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps + ((MIX && fmt == 3) ? 16 : 0));   // mixed mode: the x3 launches of a shape are their own site
+        if (MIX && fmt == 1 && !P.x2w.empty() && P.x2w.count(d.Wt)) d.x2w = 1;   // the group's weights were prepared as x3 pairs: the two-MFMA x2w tiles
+        const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps + ((MIX && fmt == 3) ? 16 : 0) + (d.x2w ? 32 : 0));   // mixed mode: the x3 / x2w launches of a shape are their own sites
         if (!MIX && !h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g) {   // in-network tuning override (tools/autotune_network.py; uniform modes: tile ids are per format)
             auto it = h.tune_by_shape.find(key);
             if (it != h.tune_by_shape.end()) d.tune = it->second;
@@ -719,11 +738,11 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         if (h.prof_sites && h.prof.on) {
             size_t i = 0;
             for (; i < h.sites.size(); ++i)
-                if (shape_key(h.sites[i].M, h.sites[i].N, h.sites[i].K, h.sites[i].taps + (h.sites[i].name[7] == 'x' ? 16 : 0)) == key) break;
+                if (shape_key(h.sites[i].M, h.sites[i].N, h.sites[i].K, h.sites[i].taps + (h.sites[i].name[7] == 'x' ? 16 : 0) + (h.sites[i].name[7] == 'w' ? 32 : 0)) == key) break;
             if (i == h.sites.size() && h.sites.size() >= 1024) { err = "soccdpt: too many distinct igemm shapes for site profiling"; return 1; }
             if (i == h.sites.size()) {
                 SiteRec r{d.M, d.N, d.taps * d.Cin, d.taps, igemm_config_id(d), 0, {0}};
-                snprintf(r.name, sizeof(r.name), (MIX && fmt == 3) ? "site%03zux" : "site%03zu", i);
+                snprintf(r.name, sizeof(r.name), (MIX && fmt == 3) ? "site%03zux" : (d.x2w ? "site%03zuw" : "site%03zu"), i);
                 h.sites.push_back(r);
             }
             h.sites[i].count++;
@@ -927,7 +946,8 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                 { PROF("ln_residual", 0.0, (double)M * C * 14.0);
                   RUN(launch_ln_residual(b_y1, bw.n1_g, bw.n1_b, b_xf, fm == 2 ? nullptr : static_cast<bf16_t*>(b_x1), nullptr, nullptr, fm == 2 ? 0 : fm, M, C, 1, res, 0, st, err)); }
             }
-            if (fm <= 1 && f2 == fm && fnext == fm && (!hook || fhook == fm) && C <= h.mlp_fuse_max && mlp_ln_supported(C)) {   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
+            if (fm <= 1 && f2 == fm && fnext == fm && (!hook || fhook == fm) && C <= h.mlp_fuse_max && mlp_ln_supported(C) &&
+                !group_x2w(h, gblk(s, j, "fc1")) && !group_x2w(h, gblk(s, j, "fc2"))) {   // (the fused kernel reads plain fp16 weights)   // fc1 + GELU + fc2 + LayerNorm + residual as one launch
                 PROF("mlp_ln_fused", 16.0 * M * (double)C * C, 0.0);
                 RUN(launch_mlp_ln(static_cast<const bf16_t*>(b_x1), b_xf, static_cast<const bf16_t*>(bw.fc1_w), bw.fc1_b, static_cast<const bf16_t*>(bw.fc2_w),
                                   bw.fc2_b, bw.n2_g, bw.n2_b, static_cast<bf16_t*>(b_x2), hook ? static_cast<bf16_t*>(w.feat[s]) : nullptr, fm,
@@ -1044,7 +1064,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         d = conv(w.path1, F, P.s0_w, F, r1);
         d.bias = P.bn_shift; d.act = ACT_RELU;
         static const bool no_dot3 = getenv("SOCCDPT_SEG_DOT3_OFF") != nullptr;   // A/B switch: the unfused classifier of rounds 1-3
-        if (fH <= 1 && F % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3) {
+        if (fH <= 1 && F % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3 && !group_x2w(h, "head")) {
             // the 1x1 classifier rides in the convolution's epilogue (igemm D3): the 256-channel feature map -- 67 MB written and read back per
             // forward at B = 8, rounded to 16 bits on the way -- is never stored; the logits come from the f32 accumulators
             d.dot3 = 1; d.dot_w = P.s4_w; d.out_dot = static_cast<float*>(w.s1);   // [F / BN][M][4] partial logits in the feature map's buffer

@@ -22,6 +22,7 @@ PREC_F32 = 1
 PREC_F16 = 2
 PREC_F16X3 = 3
 PREC_MIXED = 4   # fp16 operands, x3 where the precision map says so (include/soccdpt_hip.h)
+PREC_F16X2W = 5  # a precision-map value: fp16 activations, x3 weight pairs (two MFMAs per product)
 
 
 class SoccdptConfig(ctypes.Structure):
