@@ -117,18 +117,21 @@ int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes);
  * library's own exact-f32 arithmetic on the same weights and the caller's sample frames:
  *   1. an f32 twin of the handle (same bound weight pointers) runs the sample: the reference for the seven checked quantities (hooked feature
  *      maps 0-3, path_1, inverse depth, class logits; relative L2);
- *   2. all groups x3 but ONE in fp16 -> the variance that group adds to each quantity;
- *   3. greedy selection by variance removed per microsecond (compiled-in per-group device-time costs, csrc/prec_cost_table.h) until every
- *      quantity's predicted error is under `budget`, checked by a measured run (tightened and repeated if the additive model was optimistic);
- *   4. measured prune: demote x3 groups one at a time, most expensive first, while the measured worst error stays under the budget.
+ *   2. all groups x3 but ONE in fp16, then that one in x2w -> the variance the group adds to each quantity in either format;
+ *   3. greedy selection over single-group upgrades (fp16 -> x2w -> x3) by variance removed per microsecond (compiled-in per-group device-time
+ *      costs, csrc/prec_cost_table.h) until every quantity's predicted error is under `budget`, checked by a measured run (tightened and
+ *      repeated if the additive model was optimistic);
+ *   4. measured prune: demote groups one level at a time, largest saving first, while the measured worst error stays under the budget.
  * The handle's map is replaced by the result (soccdpt_prec_map_source() == 1) and its weights are prepared for it.  Synchronises; runs about
- * (groups + x3 groups + 10) forwards of the sample.  All device memory comes from the caller: dev_prepared / dev_workspace as for
+ * (2 x groups + promoted groups + 10) forwards of the sample.  All device memory comes from the caller: dev_prepared / dev_workspace as for
  * soccdpt_prepare / soccdpt_network at batch B, dev_scratch of soccdpt_prec_calibrate_scratch_bytes(handle, B) bytes.
  * report (host memory, may be NULL): what was measured. */
 typedef struct soccdpt_calib_report {
     int32_t n_groups;          /* launch-site groups of this backbone */
     int32_t n_x3;              /* groups the calibrated map promotes to x3 */
-    int32_t n_x3_shipped;      /* ... and the shipped map */
+    int32_t n_x2w;             /* ... and to x2w (fp16 activations, x3 weight pairs) */
+    int32_t n_x3_shipped;      /* the shipped map's */
+    int32_t n_x2w_shipped;
     int32_t forwards;          /* network forwards the calibration ran */
     int32_t met_budget;        /* 1: the calibrated map's measured worst error <= budget */
     int32_t shipped_met_budget;/* 1: the SHIPPED map met the budget on these weights and frames */

@@ -8,8 +8,8 @@
 #include "calibrate.h"
 
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
-#include <set>
 
 #include "prec_cost_table.h"
 
@@ -132,6 +132,7 @@ int calib_weights_are_the_shipped_draw(Handle& h, unsigned long long* tmp, hipSt
 
 int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes, void* scratch, size_t scratch_bytes,
               soccdpt_calib_report* rep, hipStream_t st, std::string& err) {
+    static const bool flags_no_x2w = getenv("SOCCDPT_CALIB_NO_X2W") != nullptr;   // measurement switch: the two-format (fp16 / x3) selection of round 4
     if (h.cfg.precision != SOCCDPT_PREC_MIXED) { err = "soccdpt_prec_calibrate: the handle was not created with SOCCDPT_PREC_MIXED"; return 1; }
     if (!x || B <= 0 || !(budget > 0.f) || !prepared || !ws || !scratch) { err = "soccdpt_prec_calibrate: bad argument"; return 1; }
     if (h.n_streams != 1 || h.use_graph) { err = "soccdpt_prec_calibrate: calibrate on one stream without graph replay (soccdpt_set_streams(1), soccdpt_set_graph(0))"; return 1; }
@@ -157,12 +158,14 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
 
     const std::vector<std::string> groups = model_prec_groups(h);
     const int G = (int)groups.size();
-    typedef std::set<std::string> Set;
+    // a map = one state per group: 0 fp16, 1 x2w (fp16 activations, x3 weight pairs), 2 x3
+    typedef std::vector<int> Map;
     struct Err { double e[kCalibQuantities]; double worst() const { double w = 0; for (double v : e) w = std::max(w, v); return w; } };
 
-    auto measure = [&](const Set& x3, Err& out) -> int {   // the forward under the map {x3 groups}, its seven relative L2 errors against the reference
+    auto measure = [&](const Map& m, Err& out) -> int {   // the forward under the map, its seven relative L2 errors against the reference
         h.prec_map.clear();
-        for (const auto& gname : x3) h.prec_map[gname] = 3;
+        for (int i = 0; i < G; ++i)
+            if (m[i]) h.prec_map[groups[i]] = m[i] == 2 ? 3 : 4;
         h.ws_key = Handle::WsKey();
         h.is_prepared = false;
         if (model_prepare(h, prepared, prepared_bytes, st, err)) return 1;
@@ -180,101 +183,130 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
         ++forwards;
         return 0;
     };
-    auto cost = [&](const std::string& gname) { return (double)prec_cost_us(h.cfg.backbone, gname.c_str()); };
-    auto cost_of = [&](const Set& x3) { double c = 0; for (const auto& gname : x3) c += cost(gname); return c; };
+    // device-time cost of a group's state over fp16 (compiled-in table, prec_cost_table.h)
+    auto cost = [&](int i, int state) -> double {
+        if (state == 0) return 0.0;
+        return state == 2 ? (double)prec_cost_us(h.cfg.backbone, groups[i].c_str()) : (double)prec_cost_x2w_us(h.cfg.backbone, groups[i].c_str());
+    };
+    auto cost_of = [&](const Map& m) { double c = 0; for (int i = 0; i < G; ++i) c += cost(i, m[i]); return c; };
+    auto count_state = [&](const Map& m, int st_) { int n = 0; for (int v : m) n += v == st_; return n; };
+    auto fill_report = [&](const Map& chosen, const Err& e_final, const Map& shipped, const Err& e_ship, const Err& e_f16, const Err& e_x3) {
+        if (!rep) return;
+        memset(rep, 0, sizeof(*rep));
+        rep->n_groups = G; rep->n_x3 = count_state(chosen, 2); rep->n_x2w = count_state(chosen, 1); rep->n_x3_shipped = count_state(shipped, 2); rep->n_x2w_shipped = count_state(shipped, 1);
+        rep->forwards = forwards;
+        rep->met_budget = e_final.worst() <= budget ? 1 : 0; rep->shipped_met_budget = e_ship.worst() <= budget ? 1 : 0; rep->budget = budget;
+        rep->worst_calibrated = (float)e_final.worst(); rep->worst_shipped = (float)e_ship.worst(); rep->worst_all_fp16 = (float)e_f16.worst(); rep->worst_all_x3 = (float)e_x3.worst();
+        for (int q = 0; q < kCalibQuantities; ++q) { rep->err_calibrated[q] = (float)e_final.e[q]; rep->err_shipped[q] = (float)e_ship.e[q]; }
+        rep->cost_us_calibrated = (float)cost_of(chosen); rep->cost_us_shipped = (float)cost_of(shipped);
+    };
 
     // ---- 2. the corner cases and the shipped map on these weights ----
-    const Set all(groups.begin(), groups.end());
+    const Map all3(G, 2), all16(G, 0);
     Err e_x3, e_f16, e_ship;
-    if (measure(all, e_x3) || measure(Set(), e_f16)) return 1;
+    if (measure(all3, e_x3) || measure(all16, e_f16)) return 1;
     model_prec_default(h);
-    Set shipped;
-    for (const auto& kv : h.prec_map) if (kv.second == 3) shipped.insert(kv.first);
+    Map shipped(G, 0);
+    for (int i = 0; i < G; ++i) {
+        auto it = h.prec_map.find(groups[i]);
+        if (it != h.prec_map.end()) shipped[i] = it->second == 3 ? 2 : (it->second == 4 ? 1 : 0);
+    }
     if (measure(shipped, e_ship)) return 1;
     if (e_x3.worst() > budget) {   // even every group in x3 misses the budget (the fp16 attention core, or a budget under the f32 noise floor): nothing to select
         Err tmp;
-        if (measure(all, tmp)) return 1;
+        if (measure(all3, tmp)) return 1;
         h.prec_source = 1;
-        if (rep) {
-            memset(rep, 0, sizeof(*rep));
-            rep->n_groups = G; rep->n_x3 = G; rep->n_x3_shipped = (int)shipped.size(); rep->forwards = forwards; rep->met_budget = 0; rep->budget = budget;
-            rep->shipped_met_budget = 0;
-            rep->worst_calibrated = (float)tmp.worst(); rep->worst_shipped = (float)e_ship.worst(); rep->worst_all_fp16 = (float)e_f16.worst(); rep->worst_all_x3 = (float)e_x3.worst();
-            for (int q = 0; q < kCalibQuantities; ++q) { rep->err_calibrated[q] = (float)tmp.e[q]; rep->err_shipped[q] = (float)e_ship.e[q]; }
-            rep->cost_us_calibrated = (float)cost_of(all); rep->cost_us_shipped = (float)cost_of(shipped);
-        }
+        fill_report(all3, tmp, shipped, e_ship, e_f16, e_x3);
         return 0;
     }
 
-    // ---- 3. one-group-out variances ----
-    std::vector<Err> var(G);
+    // ---- 3. one-group-out variances: T = what the group adds in fp16, A = what it still adds as x2w (its activation rounding) ----
+    const bool use_x2w = !(flags_no_x2w);
+    std::vector<Err> T(G), A(G);
     for (int i = 0; i < G; ++i) {
-        Set m = all;
-        m.erase(groups[i]);
+        Map m = all3;
         Err e;
+        m[i] = 0;
         if (measure(m, e)) return 1;
-        for (int q = 0; q < kCalibQuantities; ++q) var[i].e[q] = std::max(e.e[q] * e.e[q] - e_x3.e[q] * e_x3.e[q], 0.0);
+        for (int q = 0; q < kCalibQuantities; ++q) T[i].e[q] = std::max(e.e[q] * e.e[q] - e_x3.e[q] * e_x3.e[q], 0.0);
+        A[i] = T[i];
+        if (use_x2w) {
+            m[i] = 1;
+            if (measure(m, e)) return 1;
+            for (int q = 0; q < kCalibQuantities; ++q) A[i].e[q] = std::min(T[i].e[q], std::max(e.e[q] * e.e[q] - e_x3.e[q] * e_x3.e[q], 0.0));
+        }
     }
-    auto predict = [&](const Set& x3, Err& out) {
+    auto rem = [&](int i, int state, int q) { return state == 2 ? 0.0 : (state == 1 ? A[i].e[q] : T[i].e[q]); };
+    auto predict = [&](const Map& m, Err& out) {
         for (int q = 0; q < kCalibQuantities; ++q) {
             double v = e_x3.e[q] * e_x3.e[q];
-            for (int i = 0; i < G; ++i) if (!x3.count(groups[i])) v += var[i].e[q];
+            for (int i = 0; i < G; ++i) v += rem(i, m[i], q);
             out.e[q] = std::sqrt(v);
         }
     };
     auto solve = [&](double target) {
-        Set prom;
-        for (;;) {
+        Map m(G, 0);
+        for (;;) {   // greedy over single-group upgrades (fp16 -> x2w, fp16 -> x3, x2w -> x3) by violated variance removed per microsecond
             Err e;
-            predict(prom, e);
+            predict(m, e);
             bool viol = false;
             for (double v : e.e) viol |= v > target;
             if (!viol) break;
-            int best = -1;
+            int best = -1, best_to = 0;
             double best_rate = 0;
-            for (int i = 0; i < G; ++i) {
-                if (prom.count(groups[i])) continue;
-                double gain = 0;
-                for (int q = 0; q < kCalibQuantities; ++q)
-                    if (e.e[q] > target) gain += std::min(var[i].e[q], std::max(0.0, e.e[q] * e.e[q] - target * target));
-                const double rate = gain / cost(groups[i]);
-                if (gain > 0 && (best < 0 || rate > best_rate)) { best = i; best_rate = rate; }
-            }
+            for (int i = 0; i < G; ++i)
+                for (int to = m[i] + 1; to <= 2; ++to) {
+                    if (to == 1 && !use_x2w) continue;
+                    double gain = 0;
+                    for (int q = 0; q < kCalibQuantities; ++q)
+                        if (e.e[q] > target) gain += std::min(rem(i, m[i], q) - rem(i, to, q), std::max(0.0, e.e[q] * e.e[q] - target * target));
+                    const double dc = std::max(cost(i, to) - cost(i, m[i]), 0.25);
+                    if (gain > 0 && (best < 0 || gain / dc > best_rate)) { best = i; best_to = to; best_rate = gain / dc; }
+                }
             if (best < 0) break;
-            prom.insert(groups[best]);
+            m[best] = best_to;
         }
-        // drop what later picks made redundant (predicted), most expensive first
-        std::vector<std::string> order(prom.begin(), prom.end());
-        std::sort(order.begin(), order.end(), [&](const std::string& a, const std::string& b) { return cost(a) > cost(b); });
-        for (const auto& gname : order) {
-            Set t = prom;
-            t.erase(gname);
-            Err e;
-            predict(t, e);
-            if (e.worst() <= target) prom = t;
+        // predicted prune: single-level demotions, largest saving first, while the prediction stays under the target
+        for (bool changed = true; changed;) {
+            changed = false;
+            int bi = -1;
+            double bsave = 0;
+            for (int i = 0; i < G; ++i) {
+                if (!m[i] || (m[i] == 2 && !use_x2w && false)) continue;
+                const int to = (m[i] == 2 && use_x2w) ? 1 : 0;
+                Map t = m;
+                t[i] = to;
+                Err e;
+                predict(t, e);
+                const double save = cost(i, m[i]) - cost(i, to);
+                if (e.worst() <= target && save > bsave) { bi = i; bsave = save; }
+            }
+            if (bi >= 0) { m[bi] = (m[bi] == 2 && use_x2w) ? 1 : 0; changed = true; }
         }
-        return prom;
+        return m;
     };
 
     // ---- 4. greedy selection, checked by a measured run; the additive model is within a few per cent, so tighten and repeat when it was optimistic ----
-    Set chosen = all;
+    Map chosen = all3;
     Err e_chosen = e_x3;
     double target = (double)budget * 0.96;
     for (int attempt = 0; attempt < 5; ++attempt) {
-        Set cand = solve(target);
+        Map cand = solve(target);
         Err e;
         if (measure(cand, e)) return 1;
         if (e.worst() <= budget) { chosen = cand; e_chosen = e; break; }
         target *= 0.9;
     }
-    // ---- 5. measured prune: demote one group at a time, most expensive first, keeping every demotion that stays under 0.97 x budget ----
+    // ---- 5. measured prune: demote one group by one level at a time, largest saving first, keeping every demotion that stays under 0.97 x budget ----
     {
-        std::vector<std::string> order(chosen.begin(), chosen.end());
-        std::sort(order.begin(), order.end(), [&](const std::string& a, const std::string& b) { return cost(a) > cost(b); });
-        for (const auto& gname : order) {
-            if (cost(gname) < 1.0) continue;   // nothing to win
-            Set t = chosen;
-            t.erase(gname);
+        std::vector<int> order;
+        for (int i = 0; i < G; ++i) if (chosen[i]) order.push_back(i);
+        auto saving = [&](int i) { const int to = (chosen[i] == 2 && use_x2w) ? 1 : 0; return cost(i, chosen[i]) - cost(i, to); };
+        std::sort(order.begin(), order.end(), [&](int a, int b) { return saving(a) > saving(b); });
+        for (int i : order) {
+            if (saving(i) < 1.0) continue;   // nothing to win
+            Map t = chosen;
+            t[i] = (chosen[i] == 2 && use_x2w) ? 1 : 0;
             Err e;
             if (measure(t, e)) return 1;
             if (e.worst() <= (double)budget * 0.97) { chosen = t; e_chosen = e; }
@@ -286,14 +318,7 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
     if (measure(chosen, e_final)) return 1;   // leaves the handle prepared for the chosen map
     h.prec_source = 1;
     model_drop_graph(h);
-    if (rep) {
-        memset(rep, 0, sizeof(*rep));
-        rep->n_groups = G; rep->n_x3 = (int)chosen.size(); rep->n_x3_shipped = (int)shipped.size(); rep->forwards = forwards;
-        rep->met_budget = e_final.worst() <= budget ? 1 : 0; rep->shipped_met_budget = e_ship.worst() <= budget ? 1 : 0; rep->budget = budget;
-        rep->worst_calibrated = (float)e_final.worst(); rep->worst_shipped = (float)e_ship.worst(); rep->worst_all_fp16 = (float)e_f16.worst(); rep->worst_all_x3 = (float)e_x3.worst();
-        for (int q = 0; q < kCalibQuantities; ++q) { rep->err_calibrated[q] = (float)e_final.e[q]; rep->err_shipped[q] = (float)e_ship.e[q]; }
-        rep->cost_us_calibrated = (float)cost_of(chosen); rep->cost_us_shipped = (float)cost_of(shipped);
-    }
+    fill_report(chosen, e_final, shipped, e_ship, e_f16, e_x3);
     return 0;
 }
 

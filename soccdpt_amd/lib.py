@@ -52,7 +52,7 @@ class KernelStat(ctypes.Structure):
 
 class CalibReport(ctypes.Structure):
     """soccdpt_calib_report (include/soccdpt_hip.h): what soccdpt_prec_calibrate measured."""
-    _fields_ = [("n_groups", ctypes.c_int32), ("n_x3", ctypes.c_int32), ("n_x3_shipped", ctypes.c_int32), ("forwards", ctypes.c_int32),
+    _fields_ = [("n_groups", ctypes.c_int32), ("n_x3", ctypes.c_int32), ("n_x2w", ctypes.c_int32), ("n_x3_shipped", ctypes.c_int32), ("n_x2w_shipped", ctypes.c_int32), ("forwards", ctypes.c_int32),
                 ("met_budget", ctypes.c_int32), ("shipped_met_budget", ctypes.c_int32), ("budget", ctypes.c_float),
                 ("worst_calibrated", ctypes.c_float), ("worst_shipped", ctypes.c_float), ("worst_all_fp16", ctypes.c_float), ("worst_all_x3", ctypes.c_float),
                 ("err_calibrated", ctypes.c_float * 7), ("err_shipped", ctypes.c_float * 7),
@@ -415,6 +415,7 @@ class Engine:
         out["err_calibrated"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_calibrated)))
         out["err_shipped"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_shipped)))
         out["x3_groups"] = sorted(g for g, f in self.prec_map().items() if f == PREC_F16X3)
+        out["x2w_groups"] = sorted(g for g, f in self.prec_map().items() if f == PREC_F16X2W)
         return out
 
     def workspace(self, B: int) -> torch.Tensor:
