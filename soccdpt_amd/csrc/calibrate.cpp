@@ -230,7 +230,7 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
         if (measure(m, e)) return 1;
         for (int q = 0; q < kCalibQuantities; ++q) T[i].e[q] = std::max(e.e[q] * e.e[q] - e_x3.e[q] * e_x3.e[q], 0.0);
         A[i] = T[i];
-        if (use_x2w) {
+        if (use_x2w && model_prec_x2w_ok(groups[i])) {
             m[i] = 1;
             if (measure(m, e)) return 1;
             for (int q = 0; q < kCalibQuantities; ++q) A[i].e[q] = std::min(T[i].e[q], std::max(e.e[q] * e.e[q] - e_x3.e[q] * e_x3.e[q], 0.0));
@@ -256,7 +256,7 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
             double best_rate = 0;
             for (int i = 0; i < G; ++i)
                 for (int to = m[i] + 1; to <= 2; ++to) {
-                    if (to == 1 && !use_x2w) continue;
+                    if (to == 1 && !(use_x2w && model_prec_x2w_ok(groups[i]))) continue;
                     double gain = 0;
                     for (int q = 0; q < kCalibQuantities; ++q)
                         if (e.e[q] > target) gain += std::min(rem(i, m[i], q) - rem(i, to, q), std::max(0.0, e.e[q] * e.e[q] - target * target));
@@ -272,8 +272,8 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
             int bi = -1;
             double bsave = 0;
             for (int i = 0; i < G; ++i) {
-                if (!m[i] || (m[i] == 2 && !use_x2w && false)) continue;
-                const int to = (m[i] == 2 && use_x2w) ? 1 : 0;
+                if (!m[i]) continue;
+                const int to = (m[i] == 2 && use_x2w && model_prec_x2w_ok(groups[i])) ? 1 : 0;
                 Map t = m;
                 t[i] = to;
                 Err e;
@@ -281,7 +281,7 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
                 const double save = cost(i, m[i]) - cost(i, to);
                 if (e.worst() <= target && save > bsave) { bi = i; bsave = save; }
             }
-            if (bi >= 0) { m[bi] = (m[bi] == 2 && use_x2w) ? 1 : 0; changed = true; }
+            if (bi >= 0) { m[bi] = (m[bi] == 2 && use_x2w && model_prec_x2w_ok(groups[bi])) ? 1 : 0; changed = true; }
         }
         return m;
     };
@@ -301,12 +301,13 @@ int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, si
     {
         std::vector<int> order;
         for (int i = 0; i < G; ++i) if (chosen[i]) order.push_back(i);
-        auto saving = [&](int i) { const int to = (chosen[i] == 2 && use_x2w) ? 1 : 0; return cost(i, chosen[i]) - cost(i, to); };
+        auto down = [&](int i) { return (chosen[i] == 2 && use_x2w && model_prec_x2w_ok(groups[i])) ? 1 : 0; };
+        auto saving = [&](int i) { return cost(i, chosen[i]) - cost(i, down(i)); };
         std::sort(order.begin(), order.end(), [&](int a, int b) { return saving(a) > saving(b); });
         for (int i : order) {
             if (saving(i) < 1.0) continue;   // nothing to win
             Map t = chosen;
-            t[i] = (chosen[i] == 2 && use_x2w) ? 1 : 0;
+            t[i] = down(i);
             Err e;
             if (measure(t, e)) return 1;
             if (e.worst() <= (double)budget * 0.97) { chosen = t; e_chosen = e; }

@@ -166,6 +166,7 @@ int model_network(Handle& h, const float* x, int B, float* inv256, float* seg256
 std::vector<std::string> model_prec_groups(const Handle& h);   // every group name of this backbone, in launch order
 void model_prec_default(Handle& h);                            // the shipped map of the backbone
 int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err);   // -> groups changed, < 0 on error
+bool model_prec_x2w_ok(const std::string& group);                                // may the group take x2w (fmt 4)?
 int model_set_streams(Handle& h, int n, std::string& err);
 void model_drop_graph(Handle& h);
 int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W, int* C);

@@ -615,6 +615,11 @@ std::vector<std::string> model_prec_groups(const Handle& h) {
     return g;
 }
 
+// Groups whose weights are read by something else than an igemm launch in the 16-bit formats cannot take x2w (x3 weight pairs beside fp16 activations):
+// "head.d2" (the fused depth tail keeps the 32 x 1152 filter in registers, depth_tail.hip), "head" (the seg head's convolution carries the classifier
+// in its epilogue, a 16-bit-operand instantiation), "head.s1" (a storage format, not a launch).
+bool model_prec_x2w_ok(const std::string& g) { return g != "head" && g != "head.d2" && g != "head.s1"; }
+
 int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err) {
     std::string p(pattern);
     const bool prefix = !p.empty() && p.back() == '*';
@@ -622,6 +627,12 @@ int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err) {
     int n = 0;
     for (const auto& g : model_prec_groups(h)) {
         if (prefix ? g.compare(0, p.size(), p) != 0 : g != p) continue;
+        if (fmt == 4 && !model_prec_x2w_ok(g)) {
+            if (!prefix) { err = std::string("soccdpt_prec_map_set: this group cannot run x2w (its weights are read by a fused 16-bit kernel): ") + g; return -1; }
+            h.prec_map[g] = 1;   // a pattern: the group keeps plain fp16
+            ++n;
+            continue;
+        }
         h.prec_map[g] = fmt;
         ++n;
     }
