@@ -340,7 +340,7 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (d.ln_g && (!d.ln_b || !d.ln_xf || d.N > 128 || (d.ln_halo && (d.H <= 0 || d.W <= 0)))) { err = "igemm: bad fused-LayerNorm descriptor"; return 1; }
     if (d.N <= 32 && d.Cin % 64 != 0 && !d.f32 && !d.x3) { err = "igemm: N <= 32 needs Cin % 64 == 0"; return 1; }
     if (d.x2w) {   // one-sided split (round 5): fp16 activations, x3 weight pairs
-        if (d.f32 || d.x3 || d.dot3 || d.out_dot || d.splitk > 1 || d.wt_grp_rows || d.seg2_k || d.grp_rows) { err = "igemm: x2w launches are plain / LayerNorm / GroupNorm-statistics launches"; return 1; }
+        if (d.f32 || d.x3 || d.dot3 || d.out_dot || d.splitk > 1 || d.wt_grp_rows) { err = "igemm: x2w launches have no fused dot tail, split-K or weight row groups"; return 1; }
         if (d.ln_g && d.Cin % 32) { err = "igemm: x2w needs Cin % 32 == 0"; return 1; }
         const bool gen = need_gen(d);
         switch (pick_cfg_x2w(d)) {
