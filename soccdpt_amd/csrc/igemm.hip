@@ -457,7 +457,11 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
         case 17: return launch_cfg<Cfg<128, 256, 32, 2, 4, 4>>(d, stream, err);
         case 18: return launch_cfg<Cfg<256, 256, 32, 2, 4, 3>>(d, stream, err);
         case 19: return launch_cfg_ln<Cfg<64, 128, 32, 2, 2, 4>>(d, stream, err);
-        case 21: return launch_cfg_st<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
+        case 21:   // 8 waves, 64x32 per wave: twice the resident waves of configuration 1
+            if (d.stamps && !d.gn_stats)   // diagnostics only (tools/conv_stamps.py): the generalised-addressing instantiation carries the four per-workgroup stamps
+                return d.f16 ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, f16_t, false, false, false, true>(d, stream, err)
+                             : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, bf16_t, false, false, false, true>(d, stream, err);
+            return launch_cfg_st<Cfg<128, 128, 64, 2, 4, 2>>(d, stream, err);
         case 22: return launch_cfg<Cfg<32, 64, 128, 2, 4, 3>>(d, stream, err);   // 8 waves, 16x16 per wave: the small-grid long-K launches are latency chains,
         case 23: return launch_cfg_st<Cfg<64, 64, 64, 2, 4, 4>>(d, stream, err);    // 8 waves, 32x16 per wave:   twice the waves halve each wave's dependent MFMA chain
         case 24: return launch_cfg<Cfg<128, 128, 32, 2, 4, 3>>(d, stream, err);  // 8 waves, 64x32 per wave, 32-deep k-tiles (C = 96: layer1_rn 43 -> 34 us)
