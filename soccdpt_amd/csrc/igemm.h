@@ -126,6 +126,7 @@ struct IgemmDesc {
     // diagnostics (tools/igemm_stamps.py): when non-null every workgroup writes 4 s_memrealtime stamps (100 MHz) -- entry, first k-tile
     // landed, main loop done, epilogue done -- to stamps[4 * blockIdx.x ..]; the values are never read by the kernel
     unsigned long long* stamps = nullptr;
+    int dbg_skip_out_op = 0;   // timing-only ablation (SOCCDPT_DBG_SKIP_OUT_OP, WRONG results): the generic epilogue does not store the operand copy -- bounds what a coalesced store path could return
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);
