@@ -223,7 +223,9 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     // Small tiles are latency chains (a handful of k-tiles, then the epilogue): what the epilogue reads -- bias and the f32 residual
     // rows -- is requested here, BEFORE the first LDS-DMA group, so it is older than every counted vmcnt wait and costs no wait of
     // its own.  Big tiles prefetch only the bias (their residual rows would cost 64 registers).
-    constexpr bool PRE = !SK && (TNE * TME <= 8);
+    // (round 5: not for the 128 x 128 tiles either -- 64 KB of f32 residual per workgroup queued ahead of the first LDS-DMA group held the first k-tile
+    //  back by 6 us on the residual convolutions of the decoder, tools/conv_stamps.py: entry -> first tile 8.2 us against 2.0 us)
+    constexpr bool PRE = !SK && (TNE * TME <= 8) && (BM * BN < 128 * 128);
     constexpr bool PREB = !SK;   // the bias alone is cheap enough (TN x 4 registers) for every tile size: 128x128 convs 338 -> 323 us
     float4 bias_pre[PREB ? TNE : 1];
     float4 res1_pre[PRE ? TNE : 1][PRE ? TME : 1];
@@ -604,6 +606,14 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         return;
     } else {
     // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
+    // CO (round 5): the 16-bit operand copy leaves through LDS.  Straight from the accumulators a wave-instruction stores 16 pixels x 32 bytes -- sixteen
+    // half-used 64-byte segments: 4.5 us of a 128 x 128 workgroup's 38 us (tools/conv_stamps.py; the T21 store tail of cdna_hip_programming.md) -- so the
+    // activated tile is packed into the (free) staging ring as [pixel][channel] rows padded by 16 bytes and written out 16 bytes per lane, a pixel's BN
+    // channels contiguous.
+    constexpr int CO_ROWP = BN * 2 + 16;
+    constexpr bool CO_OK = sizeof(T) == 2 && !SK && !ST && !D3 && MF == 16 && (BM * CO_ROWP <= C::NS * STAGE) && ((BM * BN / 8) % C::THREADS == 0);
+    const bool co = CO_OK && d.out_op && d.out_fmt != 3 && (N % 8 == 0) && !d.dbg_skip_out_op;
+    if (CO_OK && co) __syncthreads();   // every wave has left the main loop: the ring is free (all LDS-DMA landed before the last k-tile's barrier)
     float dot_part[TME];
 #pragma unroll
     for (int j = 0; j < TME; ++j) dot_part[j] = 0.f;
@@ -695,10 +705,15 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
                 const float* s = d.act_on_f32 ? a : v;
                 *reinterpret_cast<float4*>(d.out_f32 + orow + n) = make_float4(s[0], s[1], s[2], s[3]);
             }
-            if (d.out_op && !d.dbg_skip_out_op) {
+            if (d.out_op && d.dbg_skip_out_op != 1) {
                 if constexpr (sizeof(T) == 2) {
                     if (F16 && d.out_fmt == 3) x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);   // the next launch reads x3 operands
-                    else {
+                    else if (CO_OK && co) {
+                        uint2 p;
+                        p.x = pack_h2<F16>(a[0], a[1]);
+                        p.y = pack_h2<F16>(a[2], a[3]);
+                        *reinterpret_cast<uint2*>(smem + (m - m0) * CO_ROWP + (n - n0) * 2) = p;
+                    } else {
                         uint2 p;
                         p.x = pack_h2<F16>(a[0], a[1]);
                         p.y = pack_h2<F16>(a[2], a[3]);
@@ -725,6 +740,28 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
             } else if (d.out_dot) {
                 const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
                 dot_part[j] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
+            }
+        }
+    }
+    if constexpr (CO_OK) {
+        if (co) {   // rows of the packed tile -> global, 16 bytes per lane, BN / 8 lanes per pixel
+            __syncthreads();
+            constexpr int CPP = BN / 8;   // 16-byte chunks per pixel row
+#pragma unroll
+            for (int it = 0; it < BM * CPP / C::THREADS; ++it) {
+                const int c = it * C::THREADS + tid;
+                const int row = c / CPP, col = (c % CPP) * 8;
+                const int m = m0 + row, n = n0 + col;
+                if (m < d.M && n < N) {
+                    size_t at = (size_t)m * N;
+                    if (d.out_halo) {
+                        const int hw = d.H * d.W;
+                        const int b = m / hw, rem = m - b * hw;
+                        const int y = rem / d.W, x = rem - y * d.W;
+                        at = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
+                    }
+                    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(d.out_op) + at + n) = *reinterpret_cast<const uint4*>(smem + row * CO_ROWP + col * 2);
+                }
             }
         }
     }
