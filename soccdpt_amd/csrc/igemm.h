@@ -126,8 +126,7 @@ struct IgemmDesc {
     // diagnostics (tools/igemm_stamps.py): when non-null every workgroup writes 4 s_memrealtime stamps (100 MHz) -- entry, first k-tile
     // landed, main loop done, epilogue done -- to stamps[4 * blockIdx.x ..]; the values are never read by the kernel
     unsigned long long* stamps = nullptr;
-    int dbg_skip_out_op = 0;   // SOCCDPT_DBG_SKIP_OUT_OP: 1 = timing-only ablation (WRONG results): the generic epilogue does not store the operand copy (bounded what the
-                               // coalesced store path could return: 133 us of 2005 per forward); 2 = A/B switch: store straight from the accumulators as in round 4
+    int dbg_skip_out_op = 0;   // SOCCDPT_DBG_SKIP_OUT_OP=1: timing-only ablation (WRONG results): the generic epilogue does not store the operand copy (133 us of 2005 per forward)
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);

@@ -606,14 +606,10 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
         return;
     } else {
     // ---- epilogue: lane owns channels n..n+3 of pixel m for each (i, j) ----
-    // CO (round 5): the 16-bit operand copy leaves through LDS.  Straight from the accumulators a wave-instruction stores 16 pixels x 32 bytes -- sixteen
-    // half-used 64-byte segments: 4.5 us of a 128 x 128 workgroup's 38 us (tools/conv_stamps.py; the T21 store tail of cdna_hip_programming.md) -- so the
-    // activated tile is packed into the (free) staging ring as [pixel][channel] rows padded by 16 bytes and written out 16 bytes per lane, a pixel's BN
-    // channels contiguous.
-    constexpr int CO_ROWP = BN * 2 + 16;
-    constexpr bool CO_OK = sizeof(T) == 2 && !SK && !ST && !D3 && MF == 16 && (BM * CO_ROWP <= C::NS * STAGE) && ((BM * BN / 8) % C::THREADS == 0);
-    const bool co = CO_OK && d.out_op && d.out_fmt != 3 && (N % 8 == 0) && !d.dbg_skip_out_op;
-    if (CO_OK && co) __syncthreads();   // every wave has left the main loop: the ring is free (all LDS-DMA landed before the last k-tile's barrier)
+    // (Round 5, built and removed: the 16-bit operand copy staged through LDS and written 16 bytes per lane, a pixel's BN channels contiguous, instead of
+    //  16 pixels x 32 bytes per wave-instruction straight from the accumulators.  The stamps showed a 4.5 us store tail per 128 x 128 workgroup and skipping
+    //  the stores altogether is worth 133 us of a 2005 us forward, but the coalesced path measured 3982-3987 against 3991-4001 frames/s for the direct one,
+    //  alternated in one GPU call (profiles/r05_ab_coalesced_epilogue.txt): what the stores cost is their bytes, not their shape.)
     float dot_part[TME];
 #pragma unroll
     for (int j = 0; j < TME; ++j) dot_part[j] = 0.f;
@@ -708,12 +704,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
             if (d.out_op && d.dbg_skip_out_op != 1) {
                 if constexpr (sizeof(T) == 2) {
                     if (F16 && d.out_fmt == 3) x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);   // the next launch reads x3 operands
-                    else if (CO_OK && co) {
-                        uint2 p;
-                        p.x = pack_h2<F16>(a[0], a[1]);
-                        p.y = pack_h2<F16>(a[2], a[3]);
-                        *reinterpret_cast<uint2*>(smem + (m - m0) * CO_ROWP + (n - n0) * 2) = p;
-                    } else {
+                    else {
                         uint2 p;
                         p.x = pack_h2<F16>(a[0], a[1]);
                         p.y = pack_h2<F16>(a[2], a[3]);
@@ -740,28 +731,6 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
             } else if (d.out_dot) {
                 const float4 w4 = *reinterpret_cast<const float4*>(d.dot_w + n);
                 dot_part[j] += a[0] * w4.x + a[1] * w4.y + a[2] * w4.z + a[3] * w4.w;
-            }
-        }
-    }
-    if constexpr (CO_OK) {
-        if (co) {   // rows of the packed tile -> global, 16 bytes per lane, BN / 8 lanes per pixel
-            __syncthreads();
-            constexpr int CPP = BN / 8;   // 16-byte chunks per pixel row
-#pragma unroll
-            for (int it = 0; it < BM * CPP / C::THREADS; ++it) {
-                const int c = it * C::THREADS + tid;
-                const int row = c / CPP, col = (c % CPP) * 8;
-                const int m = m0 + row, n = n0 + col;
-                if (m < d.M && n < N) {
-                    size_t at = (size_t)m * N;
-                    if (d.out_halo) {
-                        const int hw = d.H * d.W;
-                        const int b = m / hw, rem = m - b * hw;
-                        const int y = rem / d.W, x = rem - y * d.W;
-                        at = ((size_t)(b * (d.H + 2) + y + 1) * Wp + x + 1) * N;
-                    }
-                    *reinterpret_cast<uint4*>(static_cast<uint16_t*>(d.out_op) + at + n) = *reinterpret_cast<const uint4*>(smem + row * CO_ROWP + col * 2);
-                }
             }
         }
     }
