@@ -33,6 +33,7 @@ int tr_to_halo(const float* in, float* out, int B, int H, int W, int C, hipStrea
 int tr_to_halo_full(const float* in, void* out, int B, int H, int W, int C, int fmt, hipStream_t st, std::string& err);   // whole image incl. a zero border
 int tr_to_halo16(const float* in, uint16_t* out, int B, int H, int W, int C, int f16, hipStream_t st, std::string& err);
 int tr_from_halo(const float* halo, float* out, int B, int H, int W, int C, int accumulate, hipStream_t st, std::string& err);
+int tr_cvt16_pair(const float* in0, uint16_t* out0, size_t n0, const float* in1, uint16_t* out1, size_t n1, int f16, hipStream_t st, std::string& err);   // f32 -> bf16 / IEEE fp16 of two tensors, one launch
 int tr_colsum(const float* a, const float* b, float* out, float* scratch, size_t M, int N, int accumulate, hipStream_t st, std::string& err);
 int tr_colsum2(const float* a, const float* b, float* out_ab, float* out_a, float* scratch, size_t M, int N, hipStream_t st, std::string& err);   // sum a*b and sum a in one pass
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err);
@@ -64,7 +65,7 @@ int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, vo
 // Weight gradient from operands as stored (train_wgrad_tn.hip): out[Nout][taps * C] = sum_k A[k][n] B[k + shift(tap)][c], 16-bit operands
 bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps);
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
-                float* out, hipStream_t st, std::string& err);
+                float* out, hipStream_t st, std::string& err, float* bias_out = nullptr);
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err, int dscale_slots = 0);
 int tr_drop_path_fill(float* out, int B, float p, unsigned seed, unsigned stream_id, hipStream_t st, std::string& err);
 int tr_scale_rows(const float* in, float* out, const float* scale, size_t M, int C, int rows_per_scale, hipStream_t st, std::string& err);

@@ -329,6 +329,29 @@ __global__ void cvt_x3_pair_kernel(const float* __restrict__ in0, void* __restri
     }
 }
 
+// f32 -> 16 bit (bf16, or IEEE fp16 without saturation: the scaled operands of the fp16 amp mode) of TWO tensors in one launch, four elements per thread:
+// the dY and X operands of a Linear layer's two gradient GEMMs (train_step.cpp linear_bwd).  Round 4 converted them with two launches of a one-element-per-
+// thread kernel (129 launches, 0.81 ms per bf16-amp step).
+template <bool F16>
+__global__ void cvt16_pair_kernel(const float* __restrict__ in0, uint16_t* __restrict__ out0, size_t n0, const float* __restrict__ in1, uint16_t* __restrict__ out1,
+                                  size_t n1) {   // n0, n1 % 4 == 0
+    const size_t total = n0 + n1;
+    for (size_t i = ((size_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < total; i += (size_t)gridDim.x * blockDim.x * 4) {
+        const bool first = i < n0;
+        const size_t j = first ? i : i - n0;
+        const float4 v = *reinterpret_cast<const float4*>((first ? in0 : in1) + j);
+        uint2 p;
+        if constexpr (F16) {
+            p.x = (uint32_t)f2h_ieee(v.x) | ((uint32_t)f2h_ieee(v.y) << 16);
+            p.y = (uint32_t)f2h_ieee(v.z) | ((uint32_t)f2h_ieee(v.w) << 16);
+        } else {
+            p.x = pack_h2<false>(v.x, v.y);
+            p.y = pack_h2<false>(v.z, v.w);
+        }
+        *reinterpret_cast<uint2*>((first ? out0 : out1) + j) = p;
+    }
+}
+
 // ---------------- elementwise ----------------
 __global__ void axpy_kernel(float* __restrict__ y, const float* __restrict__ x, size_t n) {   // y += x
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] += x[i];
@@ -1308,6 +1331,15 @@ int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, vo
     if (blocks > 2048) blocks = 2048;
     SOCCDPT_LAUNCH(cvt_x3_pair_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in0, out0, n0, in1, out1, n1);
     TK("cvt_x3_pair");
+}
+// mode: 0 bf16, 1 fp16 (IEEE, no clamp); in1 may be null (n1 = 0)
+int tr_cvt16_pair(const float* in0, uint16_t* out0, size_t n0, const float* in1, uint16_t* out1, size_t n1, int f16, hipStream_t st, std::string& err) {
+    if ((n0 | n1) % 4) { err = "cvt16_pair: element counts must be multiples of 4"; return 1; }
+    size_t blocks = ((n0 + n1) / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (f16) SOCCDPT_LAUNCH(cvt16_pair_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, in0, out0, n0, in1, out1, n1);
+    else SOCCDPT_LAUNCH(cvt16_pair_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, in0, out0, n0, in1, out1, n1);
+    TK("cvt16_pair");
 }
 int tr_axpy(float* y, const float* x, size_t n, hipStream_t st, std::string& err) {
     SOCCDPT_LAUNCH(axpy_kernel, dim3(gs_blocks(n)), dim3(256), 0, st, y, x, n);

@@ -237,6 +237,12 @@ int copy_d2d(Ctx& c, void* dst, const void* src, size_t bytes, const char* what)
     return 0;
 }
 
+// A/B switch: SOCCDPT_BIAS_COLSUM=1 keeps the separate column-sum launches for the bias gradients of the layers whose weight gradient runs on wgrad_tn
+static bool bias_in_wgrad() {
+    static const bool off = getenv("SOCCDPT_BIAS_COLSUM") != nullptr;
+    return !off;
+}
+
 // A/B switch: SOCCDPT_WGRAD_TRANSPOSE=1 keeps the transposing weight-gradient path of round 2 in the 16-bit amp modes
 static bool wgrad_tn_on() {
     static const bool off = getenv("SOCCDPT_WGRAD_TRANSPOSE") != nullptr;
@@ -287,6 +293,13 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
     const bool x3 = c.h.train_amp == 3 && N % 32 == 0 && K % 32 == 0 && K > 32;              // x3 split-fp16 operands (f32-grade, 4 bytes per element)
     const bool amp = (c.h.train_amp == 1 || c.h.train_amp == 2) && N % 32 == 0 && K % 4 == 0 && K > 32;   // mixed precision: 16-bit operands for the two gradient GEMMs
     const int F16 = c.h.train_amp == 2 ? 1 : 0;
+    // Both operand conversions of the layer in ONE launch when the weight gradient takes its operands as stored (wgrad_tn): dY for the two gradient
+    // GEMMs, X for the weight gradient (round 5; two launches of a scalar kernel per layer before)
+    const bool tn16 = amp && dW && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1) && (M * N) % 4 == 0 && (M * K) % 4 == 0;
+    const bool tn3 = x3 && dW && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1);
+    bool staged = false;   // S_T1 holds dY and S_T2 holds X in the launch format
+    if (tn16) { TRY(tr_cvt16_pair(dY, reinterpret_cast<uint16_t*>(T.S_T1), M * N, X, reinterpret_cast<uint16_t*>(T.S_T2), M * K, F16, c.st, c.err)); staged = true; }
+    else if (tn3) { TRY(tr_cvt_x3_pair(dY, T.S_T1, M * N, X, T.S_T2, M * K, c.st, c.err)); staged = true; }
     if (dX_out) {
         IgemmDesc d;
         d.M = (int)M; d.N = K; d.Cin = N; d.ldx = N; d.res1 = dX_res; d.out_f32 = dX_out;
@@ -294,14 +307,14 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             const void* w3 = staged_wt(c, W);
             uint16_t* a3 = reinterpret_cast<uint16_t*>(T.S_T1);
             if (!w3) { TRY(tr_transpose16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, K, N, 3, c.st, c.err)); w3 = T.S_wt; }
-            TRY(launch_cvt_bf16(dY, a3, M * N, 3, c.st, c.err));
+            if (!staged) TRY(launch_cvt_bf16(dY, a3, M * N, 3, c.st, c.err));
             d.X = a3; d.Wt = w3;
             TRY(gemm(c, d, true));
         } else if (amp) {
             const void* w16 = staged_wt(c, W);
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
             if (!w16) { TRY(tr_transpose16(W, reinterpret_cast<uint16_t*>(T.S_wt), N, K, N, F16, c.st, c.err)); w16 = T.S_wt; }
-            TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));   // fp16: IEEE conversion, an overflow of the scaled gradient becomes inf
+            if (!staged) TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));   // fp16: IEEE conversion, an overflow of the scaled gradient becomes inf
             d.X = a16; d.Wt = w16;
             TRY(gemm16(c, d));
         } else {
@@ -319,15 +332,18 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             char* a3 = reinterpret_cast<char*>(T.S_T1);
             char* x3p = reinterpret_cast<char*>(T.S_T2);
             const size_t Mp = (M + 63) / 64 * 64;
-            if (!dX_out) TRY(launch_cvt_bf16(dY, reinterpret_cast<uint16_t*>(a3), M * N, 3, c.st, c.err));
-            TRY(launch_cvt_bf16(X, reinterpret_cast<uint16_t*>(x3p), M * K, 3, c.st, c.err));
+            if (!staged) {
+                if (!dX_out) TRY(launch_cvt_bf16(dY, reinterpret_cast<uint16_t*>(a3), M * N, 3, c.st, c.err));
+                TRY(launch_cvt_bf16(X, reinterpret_cast<uint16_t*>(x3p), M * K, 3, c.st, c.err));
+            }
             if (Mp > M) {
                 hipError_t e = hipMemsetAsync(a3 + M * N * 4, 0, (Mp - M) * N * 4, c.st);
                 if (e == hipSuccess) e = hipMemsetAsync(x3p + M * K * 4, 0, (Mp - M) * K * 4, c.st);
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
-            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            // (the bias gradient = column sums of dY rides in the same launch: one more MFMA per fragment against ones, train_wgrad_tn.hip)
+            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr));
+            if (db && !bias_in_wgrad()) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (x3) {
             const int Mp = (int)((M + 31) / 32 * 32);
@@ -342,15 +358,17 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
             uint16_t* a16 = reinterpret_cast<uint16_t*>(T.S_T1);
             uint16_t* x16 = reinterpret_cast<uint16_t*>(T.S_T2);
             const size_t Mp = (M + 63) / 64 * 64;
-            if (!dX_out) TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));
-            TRY(launch_cvt_bf16(X, x16, M * K, F16 ? 5 : 0, c.st, c.err));
+            if (!staged) {
+                if (!dX_out) TRY(launch_cvt_bf16(dY, a16, M * N, F16 ? 5 : 0, c.st, c.err));
+                TRY(launch_cvt_bf16(X, x16, M * K, F16 ? 5 : 0, c.st, c.err));
+            }
             if (Mp > M) {
                 hipError_t e = hipMemsetAsync(a16 + M * N, 0, (Mp - M) * N * 2, c.st);
                 if (e == hipSuccess) e = hipMemsetAsync(x16 + M * K, 0, (Mp - M) * K * 2, c.st);
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
-            TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err));
-            if (db) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
+            TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr));
+            if (db && !bias_in_wgrad()) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (amp) {
             const int Mp = (int)((M + 127) / 128 * 128);
@@ -432,8 +450,9 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
         }
         if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
         TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(h16), N, reinterpret_cast<uint16_t*>(xb + mrg * C * es), C, Kp, N, C, 9, rp, x3 ? 3 : F16, T.sk_part, kTrainSkPartFloats,
-                        T.S_dw, c.st, c.err));
+                        T.S_dw, c.st, c.err, bias_in_wgrad() ? db : nullptr));   // dY in halo order: its zero border adds nothing to the column sums
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+        if (bias_in_wgrad()) db = nullptr;
     } else if (dW && x3 && C % 64 == 0) {
         // x3, no im2col: like the f32 form below, but an x3 tensor is cut in 8-element units, so the views must start at multiples of 16 elements:
         // the pixel order pads every halo row to rpp = roundup(r + 2, 16) pixels (vertical taps = +- rpp) and the horizontal taps read three copies

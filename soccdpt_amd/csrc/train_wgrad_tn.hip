@@ -35,6 +35,8 @@ struct TnArgs {
     long ldA, ldB;
     int K, Nout, Ncols, C, taps, rp, splits;
     float* part;         // [splits][Nout][Ncols]
+    float* bias_part;    // nullable: [splits][Nout] partial column sums of dY (db = dY^T 1): one more MFMA per fragment against a fragment of ones in the
+                         // workgroups of the first column tile, instead of the two colsum launches per layer that re-read dY in f32 (round 5)
 };
 
 __device__ __forceinline__ int swz(int row) { return ((row & 3) << 2) | ((row >> 2) & 3); }
@@ -101,6 +103,14 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnArgs a) {
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // column sums of dY for the bias gradient: D = ones^T dY, every row of D the same sum; the wn == 0 waves of the first column tile carry it
+    const bool do_b = a.bias_part != nullptr && nt == 0 && wn == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) accb[jt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    h16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = F16 ? (short)0x3C00 : (short)0x3F80;
 
     if (kt0 < kt1) stage(kt0, 0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -121,6 +131,17 @@ __global__ __launch_bounds__(512) void wgrad_tn_kernel(TnArgs a) {
             for (int it = 0; it < 2; ++it)
 #pragma unroll
                 for (int jt = 0; jt < 4; ++jt) acc[it][jt] = mfma_16x16x32<F16>(fa[it], fb[jt], acc[it][jt]);
+            if (do_b) {
+#pragma unroll
+                for (int jt = 0; jt < 4; ++jt) accb[jt] = mfma_16x16x32<F16>(ones, fb[jt], accb[jt]);
+            }
+        }
+    }
+    if (do_b && lane < 16) {   // row i = 0 of D (lane quarter g = 0, register 0): n = lane & 15
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int n = n0 + wm * 64 + 16 * jt + lane;
+            if (n < a.Nout) a.bias_part[(size_t)split * a.Nout + n] = accb[jt][0];
         }
     }
     // ---- partial tile out: lane holds D[i = 4 g + r][j = lane & 15] -> 4 consecutive columns of one n ----
@@ -204,6 +225,13 @@ __global__ __launch_bounds__(512) void wgrad_tn_x3_kernel(TnArgs a) {
     for (int it = 0; it < 2; ++it)
 #pragma unroll
         for (int jt = 0; jt < 4; ++jt) { acc[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; accx[it][jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    const bool do_b = a.bias_part != nullptr && nt == 0 && wn == 0;   // bias gradient: ones (hi = 1, lo = 0) against the hi and the lo fragments of dY
+    f32x4 accb[4], accbx[4];
+#pragma unroll
+    for (int jt = 0; jt < 4; ++jt) { accb[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; accbx[jt] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    h16x8 ones;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ones[e] = (short)0x3C00;
 
     if (kt0 < kt1) stage(kt0, 0);
     for (int kt = kt0; kt < kt1; ++kt) {
@@ -226,6 +254,20 @@ __global__ __launch_bounds__(512) void wgrad_tn_x3_kernel(TnArgs a) {
                 accx[it][jt] = mfma_16x16x32<true>(fah[it], fbl[jt], accx[it][jt]);
                 accx[it][jt] = mfma_16x16x32<true>(fal[it], fbh[jt], accx[it][jt]);
             }
+        if (do_b) {
+#pragma unroll
+            for (int jt = 0; jt < 4; ++jt) {
+                accb[jt] = mfma_16x16x32<true>(ones, fbh[jt], accb[jt]);
+                accbx[jt] = mfma_16x16x32<true>(ones, fbl[jt], accbx[jt]);
+            }
+        }
+    }
+    if (do_b && lane < 16) {
+#pragma unroll
+        for (int jt = 0; jt < 4; ++jt) {
+            const int n = n0 + wm * 64 + 16 * jt + lane;
+            if (n < a.Nout) a.bias_part[(size_t)split * a.Nout + n] = fmaf(accbx[jt][0], 1.0f / 2048.f, accb[jt][0]);
+        }
     }
     float* mine = a.part + (size_t)split * a.Nout * a.Ncols;
 #pragma unroll
@@ -246,7 +288,8 @@ __global__ __launch_bounds__(512) void wgrad_tn_x3_kernel(TnArgs a) {
     }
 }
 
-__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, size_t n4) {
+__global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int splits, size_t n4,
+                                                        const float* __restrict__ bpart, float* __restrict__ bout, int nb) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 s = *reinterpret_cast<const float4*>(part + i * 4);
         for (int sp = 1; sp < splits; ++sp) {
@@ -255,6 +298,12 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
         }
         *reinterpret_cast<float4*>(out + i * 4) = s;
     }
+    if (bpart)   // the bias gradient's split partials, summed in split order like the weight gradient's
+        for (int n = (int)(blockIdx.x * blockDim.x + threadIdx.x); n < nb; n += (int)(gridDim.x * blockDim.x)) {
+            float s = bpart[n];
+            for (int sp = 1; sp < splits; ++sp) s += bpart[(size_t)sp * nb + n];
+            bout[n] = s;
+        }
 }
 
 }  // namespace
@@ -270,7 +319,7 @@ bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps) {
 // in halo pixel order with pitch rp and B must be readable (finite) from row -(rp + 1) to row K + rp: zero margins.  part: at least
 // splits * Nout * taps * C floats.  Returns the number of splits used through *splits_out.
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
-                float* out, hipStream_t st, std::string& err) {
+                float* out, hipStream_t st, std::string& err, float* bias_out) {
     if (!tr_wgrad_tn_ok(K, Nout, C, taps)) { err = "wgrad_tn: unsupported shape"; return 1; }
     const bool x3 = f16 == 3;   // x3 operands: 4 bytes per element, rows start at multiples of 16 elements, 32-row k-tiles
     if (x3 ? ((ldA & 15) || (ldB & 15)) : ((ldA & 7) || (ldB & 7))) { err = "wgrad_tn: row strides must be multiples of 8 (x3: 16) elements"; return 1; }
@@ -280,9 +329,11 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     long S = 512 / tiles > 0 ? 512 / tiles : 1;   // one round of two workgroups per CU
     if (S > nk / 2) S = nk / 2 > 0 ? nk / 2 : 1;
     if (S > 64) S = 64;
-    while (S > 1 && (size_t)S * Nout * a.Ncols > part_floats) --S;
-    if ((size_t)S * Nout * a.Ncols > part_floats) { err = "wgrad_tn: partial-tile scratch too small"; return 1; }
+    const size_t per_split = (size_t)Nout * a.Ncols + (bias_out ? (size_t)(Nout + 3) / 4 * 4 : 0);   // the bias partials sit behind the weight partials
+    while (S > 1 && (size_t)S * per_split > part_floats) --S;
+    if ((size_t)S * per_split > part_floats) { err = "wgrad_tn: partial-tile scratch too small"; return 1; }
     a.splits = (int)S;
+    a.bias_part = bias_out ? part + (size_t)S * Nout * a.Ncols : nullptr;
     const dim3 grid((unsigned)(tiles * S)), block(512);
     const size_t lds = 2 * 2 * 64 * 256;
     if (x3) SOCCDPT_LAUNCH(wgrad_tn_x3_kernel, grid, block, lds, st, a);
@@ -291,7 +342,7 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     const size_t n4 = (size_t)Nout * a.Ncols / 4;
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    SOCCDPT_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, out, (int)S, n4);
+    SOCCDPT_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, out, (int)S, n4, (const float*)a.bias_part, bias_out, Nout);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("wgrad_tn: ") + hipGetErrorString(e); return 1; }
     return 0;
