@@ -59,6 +59,11 @@ def test_pmc_family_names_follow_the_kernel_templates():
     sig7 = "void soccdpt::igemm_kernel<soccdpt::Cfg<128, 128, 64, 2, 4, 2, 16>, soccdpt::f16_t, false, false, false, false, %s>(soccdpt::IgemmDesc, int, int, int)"
     assert m.family(sig7 % "true") == "igemm_f16_128x128x64_s2_w8_dot3"           # the seg head's convolution with the classifier in its epilogue
     assert m.family(sig7 % "false") == "igemm_f16_128x128x64_s2_w8"
+    sig16 = "void soccdpt::igemm_kernel<soccdpt::Cfg<256, 256, 64, 4, 4, 2, 16>, soccdpt::f16_t, false, false, false, false, true>(soccdpt::IgemmDesc, int, int, int)"
+    assert m.family(sig16) == "igemm_f16_256x256x64_s2_w16_dot3"                    # round 5: the seg head on the 16-wave tile
+    assert m.family(sig % ("64, 64, 64, 2, 4, 3, 16", "soccdpt::x2w_t", "false")) == "igemm_x2w_64x64x64_s3_w8"              # round 5: one-sided split launches
+    assert m.family(sig % ("32, 64, 64, 2, 2, 4, 16", "soccdpt::x2w_t", "false")) == "igemm_x2w_32x64x64_s4"
+    assert m.family("void soccdpt::igemm_kernel<soccdpt::Cfg<64, 128, 32, 2, 2, 3, 16>, soccdpt::x2w_t, true, false, false, false, false>(soccdpt::IgemmDesc, int, int, int)") == "igemm_x2w_64x128x32_s3_ln"
     assert m.family("soccdpt::occ_expand_kernel(unsigned int const*, float*, unsigned long, int)") == "occ_expand"
     assert m.family("void soccdpt::project_rowsR_kernel<3, 256, 4, 7>(soccdpt::ProjParams, int, int)") == "project_voxelise"
 

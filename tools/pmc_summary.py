@@ -12,6 +12,9 @@ def family(kernel_name: str) -> str:
         mf32 = m.group(7) == "32"
         m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, \d+)?>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)
         t = m.group(7)
+        if "x2w_t" in t:   # one-sided split (round 5): fp16 activations, x3 weight pairs (igemm.hip kCfgNamesX2W)
+            w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("64", "64"))
+            return f"igemm_x2w_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") + ("_ln" if m.group(8) == "true" else "")
         if t == "float" or "x3_t" in t:   # 4 bytes per element: the k-tile holds BK / 2 elements (igemm.hip kCfgNamesF32 / kCfgNamesX3)
             w8 = int(m.group(4)) * int(m.group(5)) == 8 and ((m.group(1), m.group(2)) in (("128", "128"), ("64", "64")) or ((m.group(1), m.group(2)) == ("32", "64") and "x3_t" in t))
             return (f"igemm_{'f32' if t == 'float' else 'x3'}_{m.group(1)}x{m.group(2)}x{int(m.group(3)) // 2}_s{m.group(6)}" + ("_w8" if w8 else "") +
@@ -21,7 +24,8 @@ def family(kernel_name: str) -> str:
         # 8-wave forms of tiles that also exist with 4 waves carry a _w8 suffix in igemm.hip's kCfgNames
         w8 = int(m.group(4)) * int(m.group(5)) == 8 and (m.group(1), m.group(2)) in (("128", "128"), ("32", "64"), ("64", "64"))
         flags = re.findall(r"true|false", n[n.index(">,") :])   # LN, SK[, ST, GEN[, D3]]
-        return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") +
+        w16 = int(m.group(4)) * int(m.group(5)) == 16   # the 16-wave tiles of round 5
+        return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") + ("_w16" if w16 else "") +
                 ("_splitk" if m.group(9) == "true" else "") + ("_dot3" if len(flags) >= 5 and flags[4] == "true" else ""))
     for prefix, fam in (("window_attention", "window_attention"), ("mlp_ln_kernel", "mlp_ln_fused"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
                         ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
