@@ -112,3 +112,46 @@ def test_round4_bench_lines_carry_the_required_objects():
     assert main["dtype"].startswith("mixed") and main["tolerance"]["value_meets_tolerance"] is True
     assert main["tolerance"]["worst_measured"]["mixed"] <= main["tolerance"]["bar_for_value"] == 5e-4
     assert "latency_b1" in main and "f16_operands" in main and "bf16_operands" in main and main["f16_operands"]["roofline"]["frac"] > 0
+
+
+def _lines(tag):
+    out = []
+    for f in sorted(glob.glob(os.path.join(REPO, "profiles", f"{tag}*_bench*.json"))):
+        txt = open(f).read().strip()
+        if txt.startswith("{") and '"metric"' in txt:
+            out.append((os.path.basename(f), json.loads(txt.splitlines()[-1])))
+    return out
+
+
+def test_round5_bench_lines_say_what_they_are():
+    """VERDICT r4 #6 / #1d / #2: every committed forward line of round 5 prices its dominant kernel against the guide's 16-bit peak as well as against the blended
+    one (`frac_of_16bit_peak`, also per tile configuration), carries the whole-forward fraction, measured its tolerance at the benchmark's batch with the per-pixel
+    maximum, and says which precision map `value` ran; every training line has roofline and cpu_baseline."""
+    lines = _lines("r05")
+    assert lines, "no profiles/r05*_bench*.json"
+    for name, d in lines:
+        if "under_rocprof" in name:
+            continue
+        r = d["roofline"]
+        assert r and r.get("frac") is not None, name
+        if "training step" in d["metric"]:
+            assert d.get("cpu_baseline") and d["cpu_baseline"]["value"] > 0, name
+            continue
+        assert "cpu_baseline" in d, name
+        if not d["dtype"].startswith("f32"):
+            assert 0 < r["frac_of_16bit_peak"] <= r["frac"] + 1e-9, name
+            for row in r.get("by_config", []):
+                assert "frac_of_16bit_peak" in row and "frac" in row, (name, row)
+        assert 0 < r["whole_forward_frac"] < 1, name
+        if d["dtype"].startswith("mixed"):
+            assert d["config"]["precision_map_source"] in ("shipped", "calibrated"), name
+            if "measured" in d["tolerance"] and d["tolerance"]["measured"]:
+                assert "inv_per_pixel_max" in d["tolerance"]["measured"]["mixed"], name
+                assert str(d["config"]["batch_per_gpu"]) in d["tolerance"]["bar_note"], name
+    main = dict(lines).get("r05_bench.json")
+    assert main is not None and main["dtype"].startswith("mixed") and main["tolerance"]["value_meets_tolerance"] is True
+    assert main["tolerance"]["worst_measured"]["mixed"] <= main["tolerance"]["bar_for_value"] == 5e-4
+    assert main["config"]["precision_map_source"] == "shipped" and main["config"]["precision_map_x3_groups"]
+    assert abs(main["roofline"]["frac_of_16bit_peak"] - main["roofline"]["achieved"] / 2500.0) < 1e-3
+    cal = dict(lines).get("r05_bench_calibrated.json")
+    assert cal is not None and cal["config"]["precision_map_source"] == "calibrated" and cal["config"]["precision_map_calibration"]["met_budget"] == 1
