@@ -376,7 +376,9 @@ typedef struct soccdpt_igemm_args {
     int64_t grp_stride;
     /* GroupNorm statistics of the raw output (timm GroupNormAct after every StdConv2dSame of the ResNetV2 stem / stages): gn_stats
      * [M / gn_hw][N / gn_cpg][2] = {mean, 1/sqrt(var + 1e-5)} per (sample, group); gn_part: (M / 64) * (N / gn_cpg) * 2 floats of scratch,
-     * gn_count: M / gn_hw zero words (left zero).  NULL = off. */
+     * gn_count: M / gn_hw zero words (left zero).  gn_stats NULL = off.  gn_count NULL (gn_stats, gn_part set): the launch stops at the per-tile
+     * partials gn_part[(M tile * (N / gn_cpg) + group) * 2] = {sum, sum of squares} (tile rows 32 / 64 / 128 by configuration; size gn_part for 32)
+     * and writes no gn_stats -- the form the forward uses since round 5, its GroupNorm-apply kernel adds the partials up. */
     float* gn_stats;
     float* gn_part;
     uint32_t* gn_count;

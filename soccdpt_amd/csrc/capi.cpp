@@ -536,6 +536,7 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.grp_rows = a->grp_rows; d.grp_off = a->grp_off; d.grp_stride = a->grp_stride; d.seg2_k = a->seg2_k; d.seg2_off = a->seg2_off;
     d.gn_stats = a->gn_stats; d.gn_part = a->gn_part; d.gn_count = a->gn_count; d.gn_cpg = a->gn_cpg; d.gn_hw = a->gn_hw;
     d.gn_part_floats = a->gn_part_floats; d.gn_count_words = a->gn_count_words;
+    d.gn_defer = (a->gn_stats && a->gn_part && !a->gn_count) ? 1 : 0;   // no counter: the launch stops at the per-tile partials (the reader adds them up)
     d.stamps = reinterpret_cast<unsigned long long*>(a->stamps);
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);

@@ -127,58 +127,170 @@ struct Gn4x2 {
     }
 };
 
-// ---- GroupNorm apply (+ shortcut) (+ ReLU): one thread = 4 channels of one pixel ----
+// {mean, 1 / sqrt(var + eps)} from the f64 sums of a group (biased variance, torch.nn.GroupNorm).  Written without an IEEE f64 division or square root:
+// those are ~150 instructions per wave, and with every workgroup of gn_apply finishing its own statistics they were 2.6 us of a 10 us launch (round 5
+// kernel trace).  inv_cnt = 1 / (pixels * channels per group) from the host; 1 / sqrt by the f32 hardware estimate + one Newton step in f64 (1e-14).
+__device__ __forceinline__ float2 gn_mean_rstd(double a, double q, double inv_cnt, float eps) {
+    const double mean = a * inv_cnt;
+    double var = q * inv_cnt - mean * mean;
+    var = var > 0.0 ? var : 0.0;
+    const double x = var + (double)eps;
+    const double y0 = (double)rsqrtf((float)x);
+    const double y1 = y0 * (1.5 - 0.5 * x * y0 * y0);
+    return make_float2((float)mean, (float)y1);
+}
+
+// a += sum of x, q += sum of y over tiles t0, t0 + step, ... < tps of one group (base -> tile 0's float2, tiles G float2s apart), in that order, in f64.
+// U loads are issued back to back (predicated) before the first is used: the partials were written by the previous kernel on other XCDs, every dependent
+// round trip is ~2 us -- a loop of load-then-add over 9 tiles made a 13 us launch take 30 (round 5 kernel trace).  Callers size U so that one trip suffices.
+template <int U>
+__device__ __forceinline__ void gn_sum_partials(const float2* __restrict__ base, int t0, int step, int tps, int G, double& a, double& q) {
+    for (int t = t0; t < tps; t += U * step) {
+        float2 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int tt = t + u * step; v[u] = tt < tps ? base[(size_t)tt * G] : make_float2(0.f, 0.f); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) { a += (double)v[u].x; q += (double)v[u].y; }
+    }
+}
+
+// ---- GroupNorm statistics from the per-tile partials of the producing convolution (igemm ST epilogue with gn_defer) ----
+// part [tiles of the launch][G][2] = {sum, sum of squares} per M tile and group; a sample owns tps consecutive tiles.  Thread (sl = tid / gw,
+// j = tid % gw) walks tiles sl, sl + nsl, ... of group g0 + j in f64 (eight loads in flight), the slices are added in slice order: a fixed order for
+// a given (tps, gw), so the statistics are bitwise reproducible.  Result: st[j] = {mean, 1 / sqrt(var + eps)} (biased variance, torch.nn.GroupNorm)
+// for j < gw; ends with a barrier.  red: 512 doubles of LDS.  gw must divide 256.
+__device__ __forceinline__ void gn_finish_groups(const float* __restrict__ part, int tps, int G, int b, int g0, int gw, double inv_cnt, float eps, float2* st, double* red) {
+    const int tid = threadIdx.x, nsl = 256 / gw, j = tid % gw, sl = tid / gw;
+    double a = 0.0, q = 0.0;
+    gn_sum_partials<8>(reinterpret_cast<const float2*>(part) + (size_t)b * tps * G + g0 + j, sl, nsl, tps, G, a, q);
+    red[tid * 2] = a; red[tid * 2 + 1] = q;
+    __syncthreads();
+    if (tid < gw) {
+        double sa = 0.0, sq = 0.0;
+        for (int c2 = 0; c2 < nsl; ++c2) { sa += red[(c2 * gw + tid) * 2]; sq += red[(c2 * gw + tid) * 2 + 1]; }
+        st[tid] = gn_mean_rstd(sa, sq, inv_cnt, eps);
+    }
+    __syncthreads();
+}
+
+// stand-alone finish (the stem, whose reader is the max-pool kernel; tests): one workgroup per (sample, gw groups)
+__global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict__ part, float* __restrict__ stats, int tps, int G, int gw, int hw, int cpg, float eps) {
+    __shared__ float2 st[256];
+    __shared__ double red[512];
+    const int nb = G / gw, b = blockIdx.x / nb, g0 = (blockIdx.x - b * nb) * gw;
+    gn_finish_groups(part, tps, G, b, g0, gw, 1.0 / ((double)hw * cpg), eps, st, red);
+    if (threadIdx.x < gw) *reinterpret_cast<float2*>(stats + ((size_t)b * G + g0 + threadIdx.x) * 2) = st[threadIdx.x];
+}
+
+// ---- GroupNorm apply (+ shortcut) (+ ReLU): one thread = the same 4 channels of U pixels, a workgroup = 256 * U consecutive float4s of ONE sample ----
 //   y = GN(raw)                                   (+ GN2(raw2): the projection shortcut of a stage's first block)
 //                                                 (+ res:       the identity shortcut, f32 residual stream)
 //   y = relu(y) when relu != 0
 // out_f32 [M][C] (residual stream), out_op [M][C] and out_halo [B][H+2][W+2][C] (operand copies) are each optional.
-template <int OUT>
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ raw, const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ raw2, const float* __restrict__ stats2,
-                                                       const float* __restrict__ gamma2, const float* __restrict__ beta2, const float* res /* may alias out_f32 */,
-                                                       float* out_f32, void* __restrict__ out_op, void* __restrict__ out_halo, int relu,
-                                                       size_t M, int HW, int W, int C, int cpg, int halo_mode) {
-    const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int c4 = C / 4;
-    if (gid >= M * c4) return;
-    const size_t m = gid / c4;
-    const int c = (int)(gid - m * c4) * 4;
-    const int b = (int)(m / HW);
-    float4 v = *reinterpret_cast<const float4*>(raw + m * C + c);
-    if (cpg == 2) {
-        Gn4x2 n; n.load(stats, gamma, beta, b, c, C);
-        v = n.apply(v);
-        if (raw2) {
-            Gn4x2 n2; n2.load(stats2, gamma2, beta2, b, c, C);
-            const float4 s = n2.apply(*reinterpret_cast<const float4*>(raw2 + m * C + c));
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+// Statistics, by mode: 0 read from stats / stats2; 1 every thread adds the per-tile partials of its own group(s) (short lists, no barrier); 2 the workgroup
+// shares the walk through LDS (two barriers) -- from the producing convolution's partials (igemm gn_defer), while the raw loads are in flight.  Round 5: the
+// producer's own last-arriver finish cost 2-7 us on the critical path of every ResNetV2 convolution (tools/rn_stamps.py).  All U (+U) loads of a thread are
+// issued before anything else and the statistics are put together ONCE per thread: these launches are one or two rounds of workgroups long, i.e. latency --
+// tried and measured (kernel trace, us per launch, 2304 x 1024 channels + residual): one float4 per thread reading finished statistics 7.9, with
+// the per-thread walk 10.5 (nine workgroups per CU where eight fit: two rounds of a longer chain), a wave sharing the walk by shuffles 10.5, lanes of a
+// group taking different tiles 10.3 (and 30 at 4608 workgroups: four cache lines per quad of lanes), IEEE f64 division / square root in the finish +2.6.
+struct GnApplyDev {
+    const float *raw, *stats, *gamma, *beta, *raw2, *stats2, *gamma2, *beta2, *res, *part, *part2;
+    float *out_f32, *stats_w, *stats2_w;
+    void *out_op, *out_halo;
+    int relu, HW, W, C, cpg, halo_mode, tps, tps2, mode;
+    size_t M;
+    double inv_cnt;   // 1 / (HW * cpg)
+    float eps;
+};
+// statistics of ONE group from its tps partials, a thread for itself
+__device__ __forceinline__ float2 gn_finish_direct(const float* __restrict__ part, int tps, int G, int b, int g, double inv_cnt, float eps) {
+    double a = 0.0, q = 0.0;
+    gn_sum_partials<12>(reinterpret_cast<const float2*>(part) + (size_t)b * tps * G + g, 0, 1, tps, G, a, q);
+    return gn_mean_rstd(a, q, inv_cnt, eps);
+}
+template <int OUT, int U>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
+    __shared__ float2 st[2][256];
+    __shared__ double red[512];
+    const int C = a.C, cpg = a.cpg, G = C / cpg, c4 = C / 4;
+    // host: HW * c4 is a multiple of 256 * U (whole workgroups inside one sample) and c4 divides 256 (a thread keeps its channels)
+    const size_t k0 = (size_t)blockIdx.x * (256 * U) + threadIdx.x;      // float4 index of this thread's first pixel
+    const int b = (int)(k0 / ((size_t)a.HW * c4));
+    const int c = (int)(k0 % c4) * 4;
+    float4 v[U], w[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t e = (k0 + (size_t)u * 256) * 4;
+        v[u] = *reinterpret_cast<const float4*>(a.raw + e);
+        if (a.raw2) w[u] = *reinterpret_cast<const float4*>(a.raw2 + e);
+        else if (a.res) w[u] = *reinterpret_cast<const float4*>(a.res + e);
+        else w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const int g0 = c / cpg, g1 = cpg == 2 ? g0 + 1 : g0;   // cpg == 2: a float4 spans two groups
+    float2 s0, s1, t0 = make_float2(0.f, 0.f), t1 = t0;
+    if (a.mode == 2) {
+        gn_finish_groups(a.part, a.tps, G, b, 0, G, a.inv_cnt, a.eps, st[0], red);
+        if (a.raw2) gn_finish_groups(a.part2, a.tps2, G, b, 0, G, a.inv_cnt, a.eps, st[1], red);
+        s0 = st[0][g0]; s1 = st[0][g1];
+        if (a.raw2) { t0 = st[1][g0]; t1 = st[1][g1]; }
+        if (k0 - (size_t)b * a.HW * c4 < 256 && (int)threadIdx.x < G) {   // first workgroup of the sample
+            *reinterpret_cast<float2*>(a.stats_w + ((size_t)b * G + threadIdx.x) * 2) = st[0][threadIdx.x];
+            if (a.raw2) *reinterpret_cast<float2*>(a.stats2_w + ((size_t)b * G + threadIdx.x) * 2) = st[1][threadIdx.x];
+        }
+    } else if (a.mode == 1) {
+        s0 = gn_finish_direct(a.part, a.tps, G, b, g0, a.inv_cnt, a.eps);
+        s1 = cpg == 2 ? gn_finish_direct(a.part, a.tps, G, b, g1, a.inv_cnt, a.eps) : s0;
+        if (a.raw2) {
+            t0 = gn_finish_direct(a.part2, a.tps2, G, b, g0, a.inv_cnt, a.eps);
+            t1 = cpg == 2 ? gn_finish_direct(a.part2, a.tps2, G, b, g1, a.inv_cnt, a.eps) : t0;
+        }
+        if (k0 - (size_t)b * a.HW * c4 < (size_t)c4 && c % cpg == 0) {   // first pixel of the sample, first thread of every group (cpg == 2: of every pair of groups)
+            *reinterpret_cast<float2*>(a.stats_w + ((size_t)b * G + g0) * 2) = s0;
+            if (cpg == 2) *reinterpret_cast<float2*>(a.stats_w + ((size_t)b * G + g1) * 2) = s1;
+            if (a.raw2) {
+                *reinterpret_cast<float2*>(a.stats2_w + ((size_t)b * G + g0) * 2) = t0;
+                if (cpg == 2) *reinterpret_cast<float2*>(a.stats2_w + ((size_t)b * G + g1) * 2) = t1;
+            }
         }
     } else {
-        Gn4 n; n.load(stats, gamma, beta, b, c, C, cpg);
-        v = n.apply(v);
-        if (raw2) {
-            Gn4 n2; n2.load(stats2, gamma2, beta2, b, c, C, cpg);
-            const float4 s = n2.apply(*reinterpret_cast<const float4*>(raw2 + m * C + c));
-            v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
+        s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
+        s1 = cpg == 2 ? *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g1) * 2) : s0;
+        if (a.raw2) {
+            t0 = *reinterpret_cast<const float2*>(a.stats2 + ((size_t)b * G + g0) * 2);
+            t1 = cpg == 2 ? *reinterpret_cast<const float2*>(a.stats2 + ((size_t)b * G + g1) * 2) : t0;
         }
     }
-    if (res) {
-        const float4 s = *reinterpret_cast<const float4*>(res + m * C + c);
-        v.x += s.x; v.y += s.y; v.z += s.z; v.w += s.w;
-    }
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-    if (out_f32) *reinterpret_cast<float4*>(out_f32 + m * C + c) = v;
-    if (out_op) store4<OUT>(out_op, m * C + c, v.x, v.y, v.z, v.w);
-    if (out_halo) {
-        const int rem = (int)(m - (size_t)b * HW);
-        const int y = rem / W, x = rem - y * W, H = HW / W;
-        const size_t hidx = (((size_t)b * (H + 2) + y + 1) * (W + 2) + x + 1) * C + c;
-        // halo_mode: format of the halo image when it differs from out_op's (SOCCDPT_PREC_MIXED: the hooked stage output feeds the decoder's group)
-        if (halo_mode == OUT) store4<OUT>(out_halo, hidx, v.x, v.y, v.z, v.w);
-        else if (halo_mode == 3) store4<3>(out_halo, hidx, v.x, v.y, v.z, v.w);
-        else if (halo_mode == 2) store4<2>(out_halo, hidx, v.x, v.y, v.z, v.w);
-        else if (halo_mode == 1) store4<1>(out_halo, hidx, v.x, v.y, v.z, v.w);
-        else store4<0>(out_halo, hidx, v.x, v.y, v.z, v.w);
+    // ((x - mean) * rstd) * gamma + beta, the order torch.group_norm uses
+    auto norm = [](float4 x, float2 p0, float2 p1, float4 g, float4 bb) {
+        return make_float4((x.x - p0.x) * p0.y * g.x + bb.x, (x.y - p0.x) * p0.y * g.y + bb.y, (x.z - p1.x) * p1.y * g.z + bb.z, (x.w - p1.x) * p1.y * g.w + bb.w);
+    };
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c), be = *reinterpret_cast<const float4*>(a.beta + c);
+    float4 ga2 = ga, be2 = be;
+    if (a.raw2) { ga2 = *reinterpret_cast<const float4*>(a.gamma2 + c); be2 = *reinterpret_cast<const float4*>(a.beta2 + c); }
+    const int H = a.HW / a.W;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const size_t k = k0 + (size_t)u * 256;
+        const size_t m = k / c4;
+        float4 y = norm(v[u], s0, s1, ga, be);
+        if (a.raw2) { const float4 s = norm(w[u], t0, t1, ga2, be2); y.x += s.x; y.y += s.y; y.z += s.z; y.w += s.w; }
+        else if (a.res) { y.x += w[u].x; y.y += w[u].y; y.z += w[u].z; y.w += w[u].w; }
+        if (a.relu) { y.x = fmaxf(y.x, 0.f); y.y = fmaxf(y.y, 0.f); y.z = fmaxf(y.z, 0.f); y.w = fmaxf(y.w, 0.f); }
+        const size_t e = k * 4;
+        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + e) = y;
+        if (a.out_op) store4<OUT>(a.out_op, e, y.x, y.y, y.z, y.w);
+        if (a.out_halo) {
+            const int rem = (int)(m - (size_t)b * a.HW);
+            const int py = rem / a.W, px = rem - py * a.W;
+            const size_t hidx = (((size_t)b * (H + 2) + py + 1) * (a.W + 2) + px + 1) * C + c;
+            // halo_mode: format of the halo image when it differs from out_op's (SOCCDPT_PREC_MIXED: the hooked stage output feeds the decoder's group)
+            if (a.halo_mode == OUT) store4<OUT>(a.out_halo, hidx, y.x, y.y, y.z, y.w);
+            else if (a.halo_mode == 3) store4<3>(a.out_halo, hidx, y.x, y.y, y.z, y.w);
+            else if (a.halo_mode == 2) store4<2>(a.out_halo, hidx, y.x, y.y, y.z, y.w);
+            else if (a.halo_mode == 1) store4<1>(a.out_halo, hidx, y.x, y.y, y.z, y.w);
+            else store4<0>(a.out_halo, hidx, y.x, y.y, y.z, y.w);
+        }
     }
 }
 
@@ -282,6 +394,9 @@ __global__ void pos_embed_resize_kernel(const float* __restrict__ pos, float* __
 
 }  // namespace
 
+constexpr int kGnDirectTps = 12, kGnCoopTps = 64;   // see launch_gn_apply
+int launch_gn_finish(const float* part, float* stats, int B, int tps, int G, int hw, int cpg, float eps, hipStream_t st, std::string& err);
+
 #define DISPATCH_OUT(mode, ...)                                              \
     do {                                                                     \
         if ((mode) == 3) { constexpr int OUT = 3; __VA_ARGS__; }             \
@@ -309,10 +424,43 @@ int launch_stem_im2col(const float* x, void* A, int out_mode, int B, int S, hipS
 int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::string& err) {
     if (a.C % 4 || a.cpg < 2 || (a.cpg != 2 && a.cpg % 4) || a.C % a.cpg || a.HW <= 0 || a.M % (size_t)a.HW) { err = "gn_apply: bad geometry"; return 1; }
     if (a.raw2 && a.res) { err = "gn_apply: one shortcut kind at a time"; return 1; }
-    const size_t total = a.M * (size_t)(a.C / 4);
-    DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH(gn_apply_kernel<OUT>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, a.raw, a.stats, a.gamma, a.beta, a.raw2,
-                                               a.stats2, a.gamma2, a.beta2, a.res, a.out_f32, a.out_op, a.out_halo, a.relu, a.M, a.HW, a.W, a.C, a.cpg, a.halo_mode < 0 ? out_mode : a.halo_mode));
+    const int G = a.C / a.cpg, B = (int)(a.M / (size_t)a.HW), c4 = a.C / 4;
+    const size_t per_sample = (size_t)a.HW * c4;
+    if (c4 > 256 || 256 % c4 || per_sample % 256 || G > 256) { err = "gn_apply: C / 4 must divide 256 and a sample must be whole workgroups"; return 1; }
+    if (a.part && (a.tps <= 0 || (a.raw2 && (!a.part2 || a.tps2 <= 0)) || !a.stats || (a.raw2 && !a.stats2))) { err = "gn_apply: bad deferred-statistics arguments"; return 1; }
+    GnApplyDev d;
+    d.raw = a.raw; d.stats = a.stats; d.gamma = a.gamma; d.beta = a.beta; d.raw2 = a.raw2; d.stats2 = a.stats2; d.gamma2 = a.gamma2; d.beta2 = a.beta2; d.res = a.res;
+    d.part = a.part; d.part2 = a.part2; d.out_f32 = a.out_f32; d.stats_w = const_cast<float*>(a.stats); d.stats2_w = const_cast<float*>(a.stats2);
+    d.out_op = a.out_op; d.out_halo = a.out_halo; d.relu = a.relu; d.HW = a.HW; d.W = a.W; d.C = a.C; d.cpg = a.cpg; d.halo_mode = a.halo_mode < 0 ? out_mode : a.halo_mode;
+    d.tps = a.tps; d.tps2 = a.tps2; d.M = a.M; d.eps = a.eps; d.inv_cnt = 1.0 / ((double)a.HW * a.cpg);
+    // Statistics from partials: up to kGnDirectTps tiles per sample every thread adds its own group's (ResNetV2 stage 2: 9 tiles), up to kGnCoopTps the
+    // workgroup shares the walk through LDS (stage 1: 18 .. 36), longer lists (stage 0: 72 .. 144) would cost more than the pass itself -- a small launch
+    // adds them up first (gn_finish_kernel) and this one reads {mean, rstd} like any other
+    const int tmax = a.part ? (a.raw2 && a.tps2 > a.tps ? a.tps2 : a.tps) : 0;
+    d.mode = !a.part ? 0 : (tmax <= kGnDirectTps ? 1 : (tmax <= kGnCoopTps && 256 % G == 0 ? 2 : 0));
+    if (a.part && d.mode == 0) {
+        if (launch_gn_finish(a.part, d.stats_w, B, a.tps, G, a.HW, a.cpg, a.eps, st, err)) return 1;
+        if (a.raw2 && launch_gn_finish(a.part2, d.stats2_w, B, a.tps2, G, a.HW, a.cpg, a.eps, st, err)) return 1;
+    }
+    // pixels per thread: as many (4, 2, 1) as still leave about a thousand workgroups -- one round of workgroups instead of two or more
+    const size_t total = a.M * (size_t)c4;
+    int U = 1;
+    if (per_sample % 1024 == 0 && total / 1024 >= 1024) U = 4;
+    else if (per_sample % 512 == 0 && total / 512 >= 1024) U = 2;
+    const dim3 grid((unsigned)(total / (256 * (size_t)U)));
+    if (U == 4) DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH((gn_apply_kernel<OUT, 4>), grid, dim3(256), 0, st, d));
+    else if (U == 2) DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH((gn_apply_kernel<OUT, 2>), grid, dim3(256), 0, st, d));
+    else DISPATCH_OUT(out_mode, SOCCDPT_LAUNCH((gn_apply_kernel<OUT, 1>), grid, dim3(256), 0, st, d));
     return check_launch("gn_apply", err);
+}
+
+int launch_gn_finish(const float* part, float* stats, int B, int tps, int G, int hw, int cpg, float eps, hipStream_t st, std::string& err) {
+    if (!part || !stats || B <= 0 || tps <= 0 || G <= 0 || G > 256) { err = "gn_finish: bad arguments"; return 1; }
+    int gw = G;                      // few tiles: one workgroup per sample; many: split the groups so that every thread still has work
+    while (gw > 1 && gw % 2 == 0 && 256 / gw < tps / 4) gw /= 2;
+    if (256 % gw) { err = "gn_finish: the group count must divide 256"; return 1; }
+    SOCCDPT_LAUNCH(gn_finish_kernel, dim3((unsigned)(B * (G / gw))), dim3(256), 0, st, part, stats, tps, G, gw, hw, cpg, eps);
+    return check_launch("gn_finish", err);
 }
 
 int launch_gn_relu_maxpool(const float* raw, const float* stats, const float* gamma, const float* beta, void* out, int out_mode, int B, int Hi, int C, int cpg,

@@ -117,6 +117,11 @@ struct IgemmDesc {
     // floats), the LAST workgroup of a sample to arrive (gn_count[b], zero at rest) adds them in tile order in f64 -- deterministic --
     // and writes gn_stats[(b * (N / gn_cpg) + g) * 2] = {mean, 1 / sqrt(var + gn_eps)} (biased variance, torch.nn.GroupNorm).
     // gn_hw = pixels per sample (M = B * gn_hw; must be a multiple of the M tile).
+    // gn_defer: the epilogue stops at the per-tile partials (plain stores, no counter, gn_count may be null, gn_stats is only the switch);
+    // the reader of out_f32 adds them: launch_gn_apply with GnApplyArgs::part / tps, or launch_gn_finish (hybrid.hip).  Partial layout either
+    // way: gn_part[((mt * G) + g) * 2] = {sum, sum of squares} of M tile mt (tile rows: igemm_config_bm(d)), group g.
+    int gn_defer = 0;
+    int* gn_bm_out = nullptr;   // host pointer: launch_igemm stores the M-tile rows of the configuration it launched (tiles per sample = gn_hw / rows)
     float* gn_stats = nullptr;
     float* gn_part = nullptr;
     unsigned* gn_count = nullptr;

@@ -52,12 +52,13 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     const size_t lds = (size_t)C::NS * igemm_stage_bytes<C, T>();
     if constexpr (ST) {
         const int G = d.gn_cpg > 0 ? d.N / d.gn_cpg : 0;
-        if (!d.gn_part || !d.gn_count || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
-            (size_t)mtiles * G * 2 > d.gn_part_floats || (size_t)(d.M / d.gn_hw) > d.gn_count_words || G > C::THREADS ||
+        if (!d.gn_part || (!d.gn_count && !d.gn_defer) || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
+            (size_t)mtiles * G * 2 > d.gn_part_floats || (!d.gn_defer && (size_t)(d.M / d.gn_hw) > d.gn_count_words) || G > C::THREADS ||
             (size_t)(2 * C::WM * C::BN + 4) * 4 + (size_t)C::THREADS * 16 > lds) {
             err = "igemm: bad GroupNorm-statistics descriptor (pixels per sample must be a multiple of the M tile)";
             return 1;
         }
+        if (d.gn_bm_out) *d.gn_bm_out = C::BM;
     }
     static PerDeviceOnce attr_done;
     if (attr_done.need()) {
@@ -95,6 +96,8 @@ static int launch_cfg_sk(const IgemmDesc& d, hipStream_t stream, std::string& er
 template <class C>
 static int launch_cfg_st(const IgemmDesc& d, hipStream_t stream, std::string& err) {
     if (!d.gn_stats) return launch_cfg<C>(d, stream, err);
+    // plain 1x1 launches skip the generalised addressing (round 5: its address set-up is a fifth of a K = 64 .. 256 launch, tools/rn_stamps.py)
+    if (!need_gen(d)) return d.f16 ? launch_cfg_t<C, f16_t, false, false, true, false>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, true, false>(d, stream, err);
     return d.f16 ? launch_cfg_t<C, f16_t, false, false, true, true>(d, stream, err) : launch_cfg_t<C, bf16_t, false, false, true, true>(d, stream, err);
 }
 // configurations 2 and 20 also carry the generalised addressing without statistics (and 20 with split-K)
@@ -137,8 +140,8 @@ static const char* const kCfgNames[] = {"igemm_bf16_128x128x64_s4", "igemm_bf16_
 static const char* const kCfgNamesF32[] = {"igemm_f32_128x128x32_s2", "igemm_f32_64x64x32_s4", "igemm_f32_128x32x32_s4", "igemm_f32_128x128x32_s2_w8"};
 static const char* const kCfgNamesX3[] = {"igemm_x3_128x128x32_s2", "igemm_x3_64x64x32_s4", "igemm_x3_128x32x32_s4", "igemm_x3_128x128x32_s2_w8",
                                           "igemm_x3_64x64x32_s4_w8", "igemm_x3_128x128x32_s3_w8", "igemm_x3_128x128x32_s4_w8", "igemm_x3_128x64x32_s3",
-                                          "igemm_x3_128x128x64_s2_w8", "igemm_x3_64x64x64_s3", "igemm_x3_32x64x64_s3_w8", "igemm_x3_64x128x32_s3"};
-constexpr int kNumCfgX3 = 12;
+                                          "igemm_x3_128x128x64_s2_w8", "igemm_x3_64x64x64_s3", "igemm_x3_32x64x64_s3_w8", "igemm_x3_64x128x32_s3", "igemm_x3_64x64x32_s2_w8"};
+constexpr int kNumCfgX3 = 13;
 static int pick_cfg_f32(const IgemmDesc& d) {
     const bool tunable = !d.gn_stats && !need_gen(d) && !d.ln_g && d.N > 32 && d.splitk <= 1;
     if (d.x3 && d.tune >= 0 && d.tune < kNumCfgX3 && tunable) {   // in-network tuning (x3 tiles)
@@ -150,15 +153,25 @@ static int pick_cfg_f32(const IgemmDesc& d) {
         const int t = d.tune;
         const bool gen = need_gen(d);
         const int bm = (t == 0 || t == 3 || t == 7) ? 128 : 64, bn = (t == 0 || t == 3) ? 128 : 64;
-        if (d.gn_stats && (t == 0 || t == 1 || t == 3 || t == 4 || t == 7) && d.gn_hw % bm == 0 && bn % d.gn_cpg == 0 && !(gen && t != 1 && t != 4)) return t;
+        if (d.gn_stats && (t == 0 || t == 1 || t == 3 || t == 4 || t == 7 || t == 12) && d.gn_hw % bm == 0 && bn % d.gn_cpg == 0 && !(gen && t != 1 && t != 4)) return t;
         if (!d.gn_stats && gen && (t == 1 || t == 4)) return t;
     }
     if (d.x3 && d.gn_stats && d.splitk <= 1 && !need_gen(d)) {
         // in-network timings of the ResNetV2 convolutions of dpt_hybrid_384 (profiles/r03_autotune_x3_hyb_st.txt): the 8-wave 64 x 64 tile
         // wins nearly everywhere (the statistics epilogue is per-wave work, and these launches are short of workgroups)
         const long b64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+        // short K on a grid of more than one round: the two-stage ring (two workgroups per CU) -- round 5, tools/rn_stamps.py: 36864 x 256 x 64 24.9 -> 21.4 us,
+        // 36864 x 64 x 256 15.2 -> 13.1, 9216 x 512 x 128 17.6 -> 15.9, 2304 x 1024 x 256 15.1 -> 13.6
+        if (d.taps == 1 && d.Cin <= 256 && b64 > 256 && d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0 && d.tune < 0) return 12;
         if (d.gn_hw % 128 == 0 && 128 % d.gn_cpg == 0 && d.N >= 256 && d.M >= 32768) return 3;
         if (d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0 && !(d.taps == 9 && b64 >= 256 && b64 < 512)) return 4;
+    }
+    if (d.x3 && d.gn_stats && d.splitk <= 1 && d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0) {
+        // ... with generalised addressing (the 3x3 'SAME' convolutions of the ResNetV2 bottlenecks): 64 x 64 tiles only.  tools/rn_stamps.py (round 5): a
+        // 64-channel convolution on the 128 x 128 tile wastes half of it (36864 x 64 x 576: 50.6 us against 24.5 on the 8-wave 64 x 64 tile); short grids
+        // take the 8-wave form (2304 x 256 x 2304: 28.8 against 33.0), the mid grid (9216 x 128 x 1152) the 4-wave one (22.7 against 25.2)
+        const long b64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
+        return (d.N < 128 || b64 < 256) ? 4 : 1;
     }
     if (d.gn_stats) return (d.gn_hw % 128 == 0 && (long)((d.M + 127) / 128) * ((d.N + 127) / 128) >= 256) ? 0 : 1;
     if (need_gen(d)) return 1;   // the generalised addressing is instantiated for the 64 x 64 f32 tile
@@ -376,25 +389,29 @@ int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err) {
             return launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, true>(d, stream, err);
         }
         switch (pick_cfg_f32(d)) {
-            case 0: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, false, false, true, true>(d, stream, err)
+            case 0: return d.gn_stats ? (need_gen(d) ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, false, false, true, true>(d, stream, err) : launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, false, false, true, false>(d, stream, err))
                          : d.ln_g ? launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t, true>(d, stream, err)
                                   : launch_cfg_t<Cfg<128, 128, 64, 2, 2, 2>, x3_t>(d, stream, err);
-            case 1: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, true, true>(d, stream, err)
+            case 1: return d.gn_stats ? (need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, true, true>(d, stream, err) : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, true, false>(d, stream, err))
                          : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t, false, false, false, true>(d, stream, err)
                                        : launch_cfg_t<Cfg<64, 64, 64, 2, 2, 4>, x3_t>(d, stream, err);
-            case 3: return d.gn_stats ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, false, true, true>(d, stream, err)
+            case 3: return d.gn_stats ? (need_gen(d) ? launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, false, true, true>(d, stream, err) : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t, false, false, true, false>(d, stream, err))
                                       : launch_cfg_t<Cfg<128, 128, 64, 2, 4, 2>, x3_t>(d, stream, err);
-            case 4: return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, true, true>(d, stream, err)      // 8 waves, 32 x 16 per wave
+            case 4: return d.gn_stats ? (need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, true, true>(d, stream, err) : launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, true, false>(d, stream, err))      // 8 waves, 32 x 16 per wave
                          : need_gen(d) ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t, false, false, false, true>(d, stream, err)
                                        : launch_cfg_t<Cfg<64, 64, 64, 2, 4, 4>, x3_t>(d, stream, err);
             case 5: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 3>, x3_t>(d, stream, err);    // 3-stage ring (96 KB)
             case 6: return launch_cfg_t<Cfg<128, 128, 64, 2, 4, 4>, x3_t>(d, stream, err);    // 4-stage ring (128 KB)
-            case 7: return d.gn_stats ? launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t, false, false, true, true>(d, stream, err)
+            case 7: return d.gn_stats ? (need_gen(d) ? launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t, false, false, true, true>(d, stream, err) : launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t, false, false, true, false>(d, stream, err))
                                       : launch_cfg_t<Cfg<128, 64, 64, 2, 2, 3>, x3_t>(d, stream, err);     // 4 waves, 64 x 32 per wave, two workgroups per CU
             case 8: return launch_cfg_t<Cfg<128, 128, 128, 2, 4, 2>, x3_t>(d, stream, err);   // 64-deep k-tiles (256-byte rows): half the barriers
             case 9: return launch_cfg_t<Cfg<64, 64, 128, 2, 2, 3>, x3_t>(d, stream, err);
             case 10: return launch_cfg_t<Cfg<32, 64, 128, 2, 4, 3>, x3_t>(d, stream, err);    // small grids, long K
             case 11: return launch_cfg_t<Cfg<64, 128, 64, 2, 2, 3>, x3_t>(d, stream, err);
+            case 12:   // 8 waves, TWO stages (64 KB: two workgroups per CU): the short-K 1x1 convolutions (K <= 256 is 2 .. 8 k-tiles; the 4-stage ring only held the CU)
+                if (need_gen(d)) { err = "igemm: x3 configuration 12 has no generalised addressing"; return 1; }
+                return d.gn_stats ? launch_cfg_t<Cfg<64, 64, 64, 2, 4, 2>, x3_t, false, false, true, false>(d, stream, err)
+                                  : launch_cfg_t<Cfg<64, 64, 64, 2, 4, 2>, x3_t>(d, stream, err);
             default: return launch_cfg_t<Cfg<128, 32, 64, 4, 1, 4>, x3_t>(d, stream, err);
         }
     }

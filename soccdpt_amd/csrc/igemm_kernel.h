@@ -769,17 +769,28 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
 #pragma unroll
                 for (int w = 0; w < C::WM; ++w) { a += red[(w * BN + tid * cpg + c) * 2]; q += red[(w * BN + tid * cpg + c) * 2 + 1]; }
             float* pp = d.gn_part + ((size_t)mt * G + n0 / cpg + tid) * 2;
-            __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(pp + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (d.gn_defer) *reinterpret_cast<float2*>(pp) = make_float2(a, q);   // the consumer finishes (gn_apply / gn_finish, hybrid.hip): plain store, nothing to wait for
+            else {
+                __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(pp + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
         }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+        // In-kernel finish (gn_defer == 0).  The stamps (tools/rn_stamps.py, round 5) price it at 2-7 us PER WORKGROUP on top of a 1.8 us epilogue:
+        // the partial can only be published after vmcnt(0), i.e. after the whole output tile has landed, then the counter round trip, then the
+        // last workgroup's walk -- three dependent memory round trips on the critical path of a launch that is one wave of workgroups long.
+        // The eval forward therefore defers (gn_defer = 1) and lets the reader of the raw output add the partials while its own loads fly.
+        unsigned last = 0;
         const int tps = d.gn_hw / BM;                 // M tiles per sample (host: gn_hw % BM == 0)
         const int sample = mt / tps;
-        unsigned* arrival = reinterpret_cast<unsigned*>(smem) + 2 * C::WM * BN;
-        if (tid == 0) *arrival = __hip_atomic_fetch_add(d.gn_count + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __syncthreads();
-        if (*arrival == (unsigned)(tps * ntiles) - 1u) {
+        if (!d.gn_defer) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            unsigned* arrival = reinterpret_cast<unsigned*>(smem) + 2 * C::WM * BN;
+            if (tid == 0) *arrival = __hip_atomic_fetch_add(d.gn_count + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            last = *arrival == (unsigned)(tps * ntiles) - 1u;
+        }
+        if (last) {
             if (tid == 0) __hip_atomic_store(d.gn_count + sample, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             // All threads share the walk over the sample's tps tile partials: thread (chunk = tid / G, group = tid % G) adds tiles chunk,
             // chunk + nch, ... (four loads in flight at a time), then the chunks are added in chunk order: a fixed order for a given shape,

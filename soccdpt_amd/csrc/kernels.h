@@ -95,6 +95,11 @@ struct GnApplyArgs {
     const float *gamma = nullptr, *beta = nullptr;
     const float *raw2 = nullptr, *stats2 = nullptr, *gamma2 = nullptr, *beta2 = nullptr;   // projection shortcut: + GN2(raw2)
     const float* res = nullptr;      // identity shortcut: + res [M][C]
+    // deferred statistics (igemm gn_defer): per-tile partials of the producing convolution(s), tps = M tiles per sample of that launch; the kernel adds
+    // them up itself and workgroup 0 of every sample writes {mean, rstd} to stats / stats2
+    const float *part = nullptr, *part2 = nullptr;
+    int tps = 0, tps2 = 0;
+    float eps = 1e-5f;
     float* out_f32 = nullptr;        // [M][C]
     void* out_op = nullptr;          // [M][C] operand type
     void* out_halo = nullptr;        // [B][H+2][W+2][C] operand type (zero halo untouched)
@@ -104,6 +109,7 @@ struct GnApplyArgs {
     int HW = 0, W = 0, C = 0, cpg = 0;
 };
 int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::string& err);
+int launch_gn_finish(const float* part, float* stats, int B, int tps, int G, int hw, int cpg, float eps, hipStream_t st, std::string& err);   // partials -> {mean, rstd}
 int launch_gn_relu_maxpool(const float* raw, const float* stats, const float* gamma, const float* beta, void* out, int out_mode, int B, int Hi, int C, int cpg,
                            hipStream_t st, std::string& err);
 int launch_vit_tokens_ln(const float* y, const float* cls, const float* pos, float* xf, const float* g, const float* be, void* xb, int out_mode, int B, int ntok,

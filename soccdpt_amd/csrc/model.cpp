@@ -106,6 +106,7 @@ inline std::string gname(const char* a, int i) { return std::string(a) + std::to
 inline std::string gblk(int s, int j, const char* part) { return "s" + std::to_string(s) + ".b" + std::to_string(j) + "." + part; }
 inline std::string gvit(int i, const char* part) { return "vit.b" + std::to_string(i) + "." + part; }
 // ResNetV2 stage s of the hybrid: c = 1 the 1x1 reduce convolutions and the shortcut projection (both read the block input), 2 the 3x3, 3 the 1x1 expand
+inline int stem_fmt(const Handle& h) { return h.cfg.precision == SOCCDPT_PREC_F32 ? 2 : 3; }   // operand format of the hybrid's stem GEMM (see lay_out)
 inline std::string grn(int s, int c) { return "rn.s" + std::to_string(s) + ".c" + std::to_string(c); }
 
 
@@ -176,12 +177,14 @@ int lay_out(Handle& h, Arena& ar, Prepared* P, hipStream_t st, std::string& err)
     if (a.hybrid) {
         HybridW hw;
         const std::string bb = ENC + "patch_embed.backbone.";
-        {   // The stem runs in exact f32 in EVERY precision mode: weight standardisation makes each filter zero-mean, so the large DC level
+        {   // The stem runs f32-grade in EVERY precision mode: weight standardisation makes each filter zero-mean, so the large DC level
             // of the reference's un-normalised inputs (pixel values up to 509, SURVEY.md 3.4: no /255) cancels exactly in f32 and only the
             // small pixel-to-pixel variation survives -- 16-bit operand rounding of either side (absolute error ~1 on the pixels, a
             // non-zero filter sum after rounding) is as large as that signal (measured: stage-0 features 3.5e-2 off in bf16, 2.4e-3 in fp16).
+            // Exact f32 operands in SOCCDPT_PREC_F32; x3 pairs (22 bits: the DC level cancels to 1e-4 absolute) everywhere else since round 5 --
+            // the f32 MFMA ran this one GEMM at 27 TFLOP/s, 103 us of the 4.7 ms forward.
             float* p = ar.take<float>((size_t)a.stem_ch * 160);
-            if (run && launch_ws_conv_w(W(bb + "stem.conv.weight"), p, 2, a.stem_ch, 3, 7, 160, 1e-8f, st, err)) return 1;
+            if (run && launch_ws_conv_w(W(bb + "stem.conv.weight"), p, stem_fmt(h), a.stem_ch, 3, 7, 160, 1e-8f, st, err)) return 1;
             hw.stem_w = run ? static_cast<const void*>(p) : static_cast<const void*>(&kNoCopy);
         }
         if (run) { if (!hw.stem_w) return 1; hw.stem_g = W(bb + "stem.norm.weight"); hw.stem_b = W(bb + "stem.norm.bias"); }
@@ -349,8 +352,7 @@ struct Workspace {
     float* s2;
     // ViT-hybrid encoder
     void *hy_a0 = nullptr, *hy_xop = nullptr, *hy_t1[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}, *hy_t2 = nullptr;
-    float *hy_r[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_xf = nullptr, *hy_stats[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_part = nullptr;
-    unsigned* hy_count = nullptr;
+    float *hy_r[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_xf = nullptr, *hy_stats[4] = {nullptr, nullptr, nullptr, nullptr}, *hy_part[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t hy_part_floats = 0;
     float *vt_y = nullptr, *vt_xf = nullptr;
     void *vt_xb = nullptr, *vt_qkv = nullptr, *vt_attn = nullptr, *vt_h = nullptr, *vt_tok[2] = {nullptr, nullptr}, *vt_ro = nullptr, *vt_pp4 = nullptr;
@@ -380,9 +382,8 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
         const int tr[5] = {H2, H2, H2 / 2, H2 / 2, H2 / 4}, tc[5] = {64, 128, 128, 256, 256};
         for (int i = 0; i < 5; ++i) w.hy_t1[i] = op(Halo{tr[i], tr[i], tc[i]}.elems(B));
         for (int i = 0; i < 4; ++i) w.hy_stats[i] = ar.take<float>((size_t)B * 32 * 2);
-        w.hy_part_floats = (size_t)B * H1 * H1;                  // (M / 64 tiles) x 32 groups x 2 at the stem's M = B * H1^2
-        w.hy_part = ar.take<float>(w.hy_part_floats);
-        w.hy_count = ar.take<unsigned>((size_t)B + 8);
+        w.hy_part_floats = (size_t)B * H1 * H1 * 2;              // (M / 32 tiles) x 32 groups x 2 at the stem's M = B * H1^2
+        for (int i = 0; i < 4; ++i) w.hy_part[i] = ar.take<float>(w.hy_part_floats);   // per statistics slot: the reader of the slot adds the partials (gn_defer)
         w.vt_y = ar.take<float>((size_t)B * G * G * E);
         w.vt_xf = ar.take<float>((size_t)B * NT * E);
         w.vt_xb = op((size_t)B * NT * E);
@@ -739,7 +740,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
 #define RUN(call) do { if (call) return 1; ++launches; } while (0)
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d, int fmt) {   // fmt: operand format code of the launch's group
-        if (!d.f32) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 kernels for one launch (hybrid stem)
+        if (!d.f32 && !d.x3) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 / x3 kernels for one launch (hybrid stem)
         static const int dbg_skip = getenv("SOCCDPT_DBG_SKIP_OUT_OP") ? atoi(getenv("SOCCDPT_DBG_SKIP_OUT_OP")) : 0;
         d.dbg_skip_out_op = dbg_skip;
         if (MIX && fmt == 1 && !P.x2w.empty() && P.x2w.count(d.Wt)) d.x2w = 1;   // the group's weights were prepared as x3 pairs: the two-MFMA x2w tiles
@@ -780,24 +781,31 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         for (int s3 = 0; s3 < 3; ++s3) for (int c = 0; c < 3; ++c) fRn[s3][c] = GF(grn(s3, c + 1));
         const int fPe = GF("pe");
         // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
+        // ... as per-tile partials only (gn_defer): the reader of the raw output -- gn_apply, or gn_finish for the stem -- adds them up.  Round 5,
+        // tools/rn_stamps.py: the producer's own last-arriver finish put three dependent memory round trips (2-7 us) behind every one of these launches.
+        int bm_slot[4] = {0, 0, 0, 0};   // M-tile rows of the launch that last filled each slot
         auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
-            d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part; d.gn_count = w.hy_count; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
-            d.gn_part_floats = w.hy_part_floats; d.gn_count_words = (size_t)B + 8;
+            d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part[slot]; d.gn_defer = 1; d.gn_bm_out = &bm_slot[slot]; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
+            d.gn_part_floats = w.hy_part_floats;
         };
-        auto gn = [&](GnApplyArgs g, int om) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise)
+        auto gn = [&](GnApplyArgs g, int om, int slot, int slot2 = -1) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise); slot(s): whose partials
+            if (bm_slot[slot] <= 0 || (slot2 >= 0 && bm_slot[slot2] <= 0)) { err = "soccdpt: GroupNorm statistics slot read before a convolution filled it"; return 1; }
+            g.part = w.hy_part[slot]; g.tps = g.HW / bm_slot[slot];
+            if (slot2 >= 0) { g.part2 = w.hy_part[slot2]; g.tps2 = g.HW / bm_slot[slot2]; }
             const int eo = om >= 2 ? 4 : 2;
             PROF("gn_apply", 0.0, (double)g.M * g.C * (4.0 + (g.raw2 || g.res ? 4.0 : 0.0) + (g.out_f32 ? 4.0 : 0.0) + (g.out_op ? eo : 0) + (g.out_halo ? eo : 0)));
             return launch_gn_apply(g, om, st, err);
         };
         {   // stem: Conv 7x7 / 2 'SAME' (im2col + igemm) -> GroupNorm + ReLU -> MaxPool 3x3 / 2 'SAME'
             { PROF("stem_im2col", 0.0, (double)B * S * S * 12.0 + (double)B * H1 * H1 * 160.0 * 4.0);
-              RUN(launch_stem_im2col(x, w.hy_a0, 2, B, S, st, err)); }
+              RUN(launch_stem_im2col(x, w.hy_a0, stem_fmt(h), B, S, st, err)); }
             IgemmDesc d;
-            d.f32 = 1;
+            d.f32 = stem_fmt(h) == 2; d.x3 = !d.f32;
             d.X = w.hy_a0; d.Wt = Y.stem_w; d.M = B * H1 * H1; d.N = a.stem_ch; d.Cin = 160; d.ldx = 160; d.out_f32 = w.hy_r[0];
             with_stats(d, 0, a.stem_ch, H1 * H1);
-            RUN(gemm(d, 2));
+            RUN(gemm(d, stem_fmt(h)));
             { PROF("gn_relu_maxpool", 0.0, (double)B * H1 * H1 * a.stem_ch * 4.0 * 2.25 + (double)B * H2 * H2 * a.stem_ch * (fRn[0][0] >= 2 ? 4 : 2));
+              RUN(launch_gn_finish(w.hy_part[0], w.hy_stats[0], B, H1 * H1 / bm_slot[0], 32, H1 * H1, a.stem_ch / 32, 1e-5f, st, err));
               RUN(launch_gn_relu_maxpool(w.hy_r[0], w.hy_stats[0], Y.stem_g, Y.stem_b, w.hy_xop, fRn[0][0], B, H1, a.stem_ch, a.stem_ch / 32, st, err)); }
         }
         int rcur = H2;
@@ -827,7 +835,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                     GnApplyArgs g;
                     g.raw = w.hy_r[0]; g.stats = w.hy_stats[0]; g.gamma = bw.n1_g; g.beta = bw.n1_b; g.out_halo = w.hy_t1[ti];
                     g.M = (size_t)Min; g.HW = rin * rin; g.W = rin; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g, f2));   // written in the format of its reader, the 3x3
+                    RUN(gn(g, f2, 0));   // written in the format of its reader, the 3x3
                 }
                 {   // conv2 3x3 (stride on this conv; 'SAME': pad 1 at stride 1, the extra pixel right / bottom at stride 2) -> GN + ReLU
                     IgemmDesc d;
@@ -838,7 +846,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                     GnApplyArgs g;
                     g.raw = w.hy_r[1]; g.stats = w.hy_stats[1]; g.gamma = bw.n2_g; g.beta = bw.n2_b; g.out_op = w.hy_t2;
                     g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.mid; g.cpg = bw.mid / 32;
-                    RUN(gn(g, f3));
+                    RUN(gn(g, f3, 1));
                 }
                 {   // conv3 1x1 -> GN, + shortcut, ReLU: the new residual stream (f32) and its operand copy; hooked stages also as a halo image
                     IgemmDesc d;
@@ -852,7 +860,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
                     g.out_f32 = w.hy_xf; g.out_op = w.hy_xop;
                     if (j == nb - 1 && s3 < 2) { g.out_halo = w.feat[s3]; g.halo_mode = GF(gname("lrn", s3)); }   // hooks on patch_embed.backbone.stages[0], [1] (vit.py:164-167)
                     g.M = (size_t)Mout; g.HW = rout * rout; g.W = rout; g.C = bw.cout; g.cpg = bw.cout / 32;
-                    RUN(gn(g, fnext));
+                    RUN(gn(g, fnext, 2, bw.proj ? 3 : -1));
                 }
                 rcur = rout;
             }
