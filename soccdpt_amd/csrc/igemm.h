@@ -112,6 +112,7 @@ struct IgemmDesc {
     // with L2-bypassing loads (14 splits of a 128 x 128 tile: ~400 us), the deferred one is a chip-wide elementwise pass (~10 us).
     int sk_defer = 0;
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
+    int x3_among_f16 = 0;   // hint of the caller: this x3 launch sits between fp16 launches (SOCCDPT_PREC_MIXED) -- the tile heuristic differs (igemm.hip: x3 configuration 12)
     // GroupNorm statistics of the raw output (the ST instantiation): with gn_stats != nullptr the epilogue also reduces sum / sum of
     // squares of v over every (sample, group of gn_cpg consecutive channels): per-tile partials go to gn_part ((M / BM) * (N / gn_cpg) * 2
     // floats), the LAST workgroup of a sample to arrive (gn_count[b], zero at rest) adds them in tile order in f64 -- deterministic --

@@ -161,7 +161,7 @@ static int pick_cfg_f32(const IgemmDesc& d) {
         // wins nearly everywhere (the statistics epilogue is per-wave work, and these launches are short of workgroups)
         const long b64 = (long)((d.M + 63) / 64) * ((d.N + 63) / 64);
         // short K on a grid of more than one round: the two-stage ring (two workgroups per CU) -- round 5, tools/rn_stamps.py: 36864 x 256 x 64 24.9 -> 21.4 us,
-        // 36864 x 64 x 256 15.2 -> 13.1, 9216 x 512 x 128 17.6 -> 15.9, 2304 x 1024 x 256 15.1 -> 13.6
+        // 36864 x 64 x 256 15.2 -> 13.1, 9216 x 512 x 128 17.6 -> 15.9, 2304 x 1024 x 256 15.1 -> 13.6; hybrid_384 forward 892 -> 902 frames/s (alternated in one call)
         if (d.taps == 1 && d.Cin <= 256 && b64 > 256 && d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0 && d.tune < 0) return 12;
         if (d.gn_hw % 128 == 0 && 128 % d.gn_cpg == 0 && d.N >= 256 && d.M >= 32768) return 3;
         if (d.gn_hw % 64 == 0 && 64 % d.gn_cpg == 0 && !(d.taps == 9 && b64 >= 256 && b64 < 512)) return 4;
@@ -189,6 +189,14 @@ static int pick_cfg_f32(const IgemmDesc& d) {
         const long K = (long)d.taps * d.Cin, b64 = cdiv(d.M, 64) * cdiv(d.N, 64), t128x64 = cdiv(d.M, 128) * cdiv(d.N, 64);
         if (d.taps == 9 && b128 >= 2048 && k64) return 8;
         if (d.taps == 9 && b128 >= 384) return 7;
+        // (round 5: the two-stage 64 x 64 tile, configuration 12, wins 10-25 % on the wide short-K launches when every site is timed by itself
+        //  (tools/autotune_network.py ... f16x3, profiles/r05_autotune_x3_*_c12.txt) and LOSES 4 % over the forward (base_384 x3: 693 -> 667 frames/s, alternated
+        //  in one GPU call): it stays with the GroupNorm-statistics launches of the hybrid, where the forward confirmed it (892 -> 902).  Likewise 64 x 64 tiles
+        //  instead of 1.1 rounds of 128 x 128 (b128 = 288): +0.7 % on base_384 x3, -0.8 % on hybrid_384 x3: not taken.)
+        // ... but between fp16 launches (SOCCDPT_PREC_MIXED: d.x3_among_f16) it does pay over the forward: tiny_256 3979 -> 3995 frames/s, base_384 1265 -> 1275
+        // (three alternations each in one GPU call; SOCCDPT_X3_C12=0 switches it off)
+        static const int c12 = getenv("SOCCDPT_X3_C12") ? atoi(getenv("SOCCDPT_X3_C12")) : 1;
+        if (c12 && d.x3_among_f16 && d.taps == 1 && d.N >= 384 && K <= 512 && b64 >= 512) return 12;
         if (d.taps == 1 && K >= 768 && b128 >= 256 && k64) return 8;
         if (d.taps == 1 && K >= 1536 && t128x64 >= 256) return 7;
         if (b64 <= 256 && k64) return 10;

@@ -743,6 +743,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         if (!d.f32 && !d.x3) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 / x3 kernels for one launch (hybrid stem)
         static const int dbg_skip = getenv("SOCCDPT_DBG_SKIP_OUT_OP") ? atoi(getenv("SOCCDPT_DBG_SKIP_OUT_OP")) : 0;
         d.dbg_skip_out_op = dbg_skip;
+        d.x3_among_f16 = MIX && d.x3;
         if (MIX && fmt == 1 && !P.x2w.empty() && P.x2w.count(d.Wt)) d.x2w = 1;   // the group's weights were prepared as x3 pairs: the two-MFMA x2w tiles
         const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps + ((MIX && fmt == 3) ? 16 : 0) + (d.x2w ? 32 : 0));   // mixed mode: the x3 / x2w launches of a shape are their own sites
         if ((!MIX || (fmt == 1 && !d.x2w)) && !h.tune_by_shape.empty() && d.tune < 0 && !d.ln_g && !d.dot3) {   // in-network tuning override (tools/autotune_network.py; tile ids are per format: in the mixed mode the fp16 launches only)

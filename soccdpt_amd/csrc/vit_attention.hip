@@ -25,8 +25,9 @@ typedef __attribute__((ext_vector_type(16))) float f32x16;
 constexpr int D = 64;            // head dimension
 constexpr int KROW = D * 2;      // bytes per K row in LDS
 
+constexpr int KH = 2;             // key parts per query block = waves per SIMD (per launch at B = 4: 4 waves 25.8 us, 8 waves 18.5, 16 waves 20.0)
 template <bool F16>
-__global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int NPAD, int heads, int QS, int out_x3) {
+__global__ __launch_bounds__(256 * KH) void vit_attention_kernel(const uint16_t* __restrict__ qkv, uint16_t* __restrict__ out, int N, int NPAD, int heads, int QS, int out_x3) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int VT_STRIDE = NPAD * 2 + 8;
     char* Ks = smem;
@@ -43,29 +44,51 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
     const int qb_lo = part * QB0, qb_hi = (qb_lo + QB0) < NT ? (qb_lo + QB0) : NT;
     const uint16_t* base = qkv + (size_t)b * N * (3 * C) + head * D;
 
-    // ---- stage K and V^T of the whole sequence: thread = (token, 16-byte chunk of 8 d) ----
-    for (int idx = tid; idx < NPAD * 8; idx += 256) {
-        const int p = idx >> 3, c = idx & 7;
-        uint4 kv = make_uint4(0u, 0u, 0u, 0u), vv = kv;
-        if (p < N) {
-            const uint16_t* src = base + (size_t)p * (3 * C) + c * 8;
-            kv = *reinterpret_cast<const uint4*>(src + C);
-            vv = *reinterpret_cast<const uint4*>(src + 2 * C);
-        }
-        *reinterpret_cast<uint4*>(Ks + p * KROW + ((c ^ (p & 7)) * 16)) = kv;
-        const uint32_t vu[4] = {vv.x, vv.y, vv.z, vv.w};
+    // ---- stage K and V^T of the whole sequence: thread = (token, 16-byte chunk of 8 d).  SB items of a thread are loaded before the first is written to
+    // LDS: one load-then-store per trip made the 19 trips 19 dependent L2 round trips, (round 5: 25.7 -> 24.3 us per launch) ----
+    constexpr int SB = KH == 4 ? 3 : 5;
+    for (int idx0 = tid; idx0 < NPAD * 8; idx0 += 256 * KH * SB) {
+        uint4 kv[SB], vv[SB];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+        for (int u = 0; u < SB; ++u) {
+            const int idx = idx0 + u * 256 * KH, p = idx >> 3, c = idx & 7;
+            kv[u] = make_uint4(0u, 0u, 0u, 0u); vv[u] = kv[u];
+            if (idx < NPAD * 8 && p < N) {
+                const uint16_t* src = base + (size_t)p * (3 * C) + c * 8;
+                kv[u] = *reinterpret_cast<const uint4*>(src + C);
+                vv[u] = *reinterpret_cast<const uint4*>(src + 2 * C);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < SB; ++u) {
+            const int idx = idx0 + u * 256 * KH, p = idx >> 3, c = idx & 7;
+            if (idx >= NPAD * 8) break;
+            *reinterpret_cast<uint4*>(Ks + p * KROW + ((c ^ (p & 7)) * 16)) = kv[u];
+            const uint32_t vu[4] = {vv[u].x, vv[u].y, vv[u].z, vv[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
+                *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+            }
         }
     }
     __syncthreads();
 
     const int r32 = lane & 31, h = lane >> 5;
     constexpr float LOG2E = 1.4426950408889634f;
-    for (int qb = qb_lo + wave; qb < qb_hi; qb += 4) {
-        const int qrow = qb * 32 + r32;
+    // 8 waves: wave (qslot, kh) walks key half kh for the 32-query block qb_lo + qslot (host: at most 4 blocks per workgroup); the halves meet in LDS.
+    // Round 5: with 4 waves -- one per SIMD -- the softmax VALU work (~850 cycles per key tile) and the MFMAs + LDS reads (~450) of a wave ran strictly
+    // one after the other and the CU held nothing else (148 KB of LDS): two waves per SIMD overlap them.
+    const int qslot = wave & 3, kh = wave >> 2;
+    const int NTP = (NT + KH - 1) / KH, t_lo = kh * NTP, t_hi = (t_lo + NTP) < NT ? (t_lo + NTP) : NT;
+    const int qb = qb_lo + qslot;
+    const bool active = qb < qb_hi;
+    float m = -3.0e38f, l = 0.f;
+    f32x16 o0, o1;
+#pragma unroll
+    for (int rg = 0; rg < 16; ++rg) { o0[rg] = 0.f; o1[rg] = 0.f; }
+    const int qrow = qb * 32 + r32;
+    if (active) {
         const int qcl = qrow < N ? qrow : N - 1;
         // Q fragment: B operand, lane (query r32, half h) holds d = 16 ks + 8 h + j; scaled by d^-0.5 = 2^-3 (exact in bf16 / fp16)
         h16x8 qfrag[4];
@@ -81,12 +104,8 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
             }
             qfrag[ks] = f;
         }
-        float m = -3.0e38f, l = 0.f;
-        f32x16 o0, o1;
-#pragma unroll
-        for (int rg = 0; rg < 16; ++rg) { o0[rg] = 0.f; o1[rg] = 0.f; }
 #pragma unroll 1
-        for (int t = 0; t < NT; ++t) {
+        for (int t = t_lo; t < t_hi; ++t) {
             f32x16 acc;
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
@@ -115,8 +134,10 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
             for (int rg = 0; rg < 16; ++rg) {
                 acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], LOG2E, -mnl));
                 psum += acc[rg];
-                o0[rg] *= alpha;
-                o1[rg] *= alpha;
+            }
+            if (__any(alpha != 1.0f)) {   // the running maxima settle after a few tiles: most tiles skip the 32 multiplications (x 1.0 is exact, so skipping is too)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) { o0[rg] *= alpha; o1[rg] *= alpha; }
             }
             l = l * alpha + psum;
             m = mn;
@@ -144,6 +165,32 @@ __global__ __launch_bounds__(256) void vit_attention_kernel(const uint16_t* __re
             }
         }
         l += __shfl_xor(l, 32);
+    }
+    // ---- the two key halves meet: kh = 1 parks (O^T, m, l) in LDS (K / V^T are dead: one query block per wave), kh = 0 adds them in with the usual rescale ----
+    __syncthreads();
+    float* xb = reinterpret_cast<float*>(smem) + (size_t)((kh ? kh - 1 : 0) * 4 + qslot) * (34 * 64);   // [34][64]: register-major, lane-contiguous
+    if (kh >= 1 && active) {
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) { xb[rg * 64 + lane] = o0[rg]; xb[(16 + rg) * 64 + lane] = o1[rg]; }
+        xb[32 * 64 + lane] = m;
+        xb[33 * 64 + lane] = l;
+    }
+    __syncthreads();
+    if (kh == 0 && active) {
+#pragma unroll 1
+        for (int pk = 1; pk < KH; ++pk) {   // the other parts in part order (an empty part: m = -3e38, l = 0, O = 0 -> weight 0)
+            const float* xp = xb + (size_t)(pk - 1) * 4 * (34 * 64);
+            const float m1 = xp[32 * 64 + lane], l1 = xp[33 * 64 + lane];
+            const float mn = fmaxf(m, m1), mnl = mn * LOG2E;
+            const float a0 = __builtin_amdgcn_exp2f(fmaf(m, LOG2E, -mnl)), a1 = __builtin_amdgcn_exp2f(fmaf(m1, LOG2E, -mnl));
+            l = l * a0 + l1 * a1;
+            m = mn;
+#pragma unroll
+            for (int rg = 0; rg < 16; ++rg) {
+                o0[rg] = o0[rg] * a0 + xp[rg * 64 + lane] * a1;
+                o1[rg] = o1[rg] * a0 + xp[(16 + rg) * 64 + lane] * a1;
+            }
+        }
         if (qrow < N) {   // lane owns query column r32; accumulator register rg is d = (rg&3) + 8(rg>>2) + 4h (+32 for o1)
             const float inv = 1.0f / l;
             const size_t e0 = ((size_t)b * N + qrow) * C + head * D;
@@ -283,8 +330,10 @@ __global__ __launch_bounds__(256) void vit_attention_f32_kernel(const float* __r
             for (int rg = 0; rg < 16; ++rg) {
                 acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], LOG2E, -mnl));
                 psum += acc[rg];
-                o0[rg] *= alpha;
-                o1[rg] *= alpha;
+            }
+            if (__any(alpha != 1.0f)) {   // the running maxima settle after a few tiles: most tiles skip the 32 multiplications (x 1.0 is exact, so skipping is too)
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) { o0[rg] *= alpha; o1[rg] *= alpha; }
             }
             l = l * alpha + psum;
             m = mn;
@@ -336,6 +385,7 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
     if (lds > 160 * 1024) { err = "vit_attention: sequence too long for the LDS-resident K / V^T form (max 608 tokens)"; return 1; }
     // query split: enough workgroups to cover the 256 CUs, at most one 32-query block per wave and workgroup
     int QS = (256 + B * heads - 1) / (B * heads);
+    if (QS < (NT + 3) / 4) QS = (NT + 3) / 4;   // ... and at most four per workgroup (8 waves = 4 query blocks x 2 key halves, one block per wave: the halves meet in the dead K region)
     QS = QS < 1 ? 1 : (QS > NT ? NT : QS);
     const int per = (NT + QS - 1) / QS;
     QS = (NT + per - 1) / per;    // drop empty parts
@@ -348,9 +398,9 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
     }
     const unsigned blocks = (unsigned)(B * heads * QS);
     if (prec == SOCCDPT_PREC_F16)
-        SOCCDPT_LAUNCH(vit_attention_kernel<true>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
+        SOCCDPT_LAUNCH(vit_attention_kernel<true>, dim3(blocks), dim3(256 * KH), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
     else
-        SOCCDPT_LAUNCH(vit_attention_kernel<false>, dim3(blocks), dim3(256), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
+        SOCCDPT_LAUNCH(vit_attention_kernel<false>, dim3(blocks), dim3(256 * KH), lds, st, static_cast<const uint16_t*>(qkv), static_cast<uint16_t*>(out), N, NPAD, heads, QS, out_x3);
     return check_launch("vit_attention", err);
 }
 

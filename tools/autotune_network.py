@@ -52,7 +52,8 @@ for s in sites:
     Cin = s["K"] // s["taps"]
     cands = [c for c in (K64 if Cin % 64 == 0 else []) + K32 if not (c in (20, 22) and Cin % 128)]
     if pname == "f16x3":   # the x3 tile set (igemm.hip kCfgNamesX3)
-        cands = [c for c in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10, 11) if not (c in (8, 9, 10) and Cin % 64)]
+        x3c = [int(c) for c in os.environ.get('AUTOTUNE_X3_CANDS', '0,1,3,4,5,6,7,8,9,10,11,12').split(',')]
+        cands = [c for c in x3c if not (c in (8, 9, 10) and Cin % 64)]
     if s["N"] <= 32 or s["M"] < int(os.environ.get('AUTOTUNE_MIN_M', '0')):
         continue
     row = {"auto": (s["cfg"], base[s["site"]])}
