@@ -9,6 +9,7 @@
 //   * class token + position embedding + the first pre-norm LayerNorm, and the pre-norm LayerNorm (eps 1e-6) of every ViT block.
 // All of them are HBM-bound elementwise / row kernels: 16-byte accesses, NHWC, no LDS staging needed except the row reductions.
 // OUT selects the operand format written for the next GEMM: 0 = bf16, 1 = fp16, 2 = f32, 3 = x3 split fp16 (half16.h; SOCCDPT_PREC_F16X3).
+#include <stdlib.h>
 #include "half16.h"
 #include "kernels.h"
 
@@ -148,9 +149,9 @@ __device__ __forceinline__ void gn_sum_partials(const float2* __restrict__ base,
     for (int t = t0; t < tps; t += U * step) {
         float2 v[U];
 #pragma unroll
-        for (int u = 0; u < U; ++u) { const int tt = t + u * step; v[u] = tt < tps ? base[(size_t)tt * G] : make_float2(0.f, 0.f); }
-#pragma unroll
-        for (int u = 0; u < U; ++u) { a += (double)v[u].x; q += (double)v[u].y; }
+        for (int u = 0; u < U; ++u) { const int tt = t + u * step; v[u] = base[(size_t)(tt < tps ? tt : tps - 1) * G]; }   // clamped, not predicated: a load under a branch
+#pragma unroll                                                                                                          // comes with its own s_waitcnt vmcnt(0)
+        for (int u = 0; u < U; ++u) { const int tt = t + u * step; a += tt < tps ? (double)v[u].x : 0.0; q += tt < tps ? (double)v[u].y : 0.0; }
     }
 }
 
@@ -219,13 +220,12 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
     const int b = (int)(k0 / ((size_t)a.HW * c4));
     const int c = (int)(k0 % c4) * 4;
     float4 v[U], w[U];
+    const float* second = a.raw2 ? a.raw2 : (a.res ? a.res : a.raw);   // always loaded (no branch around a load: the compiler waits for each such load by itself)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
         const size_t e = (k0 + (size_t)u * 256) * 4;
         v[u] = *reinterpret_cast<const float4*>(a.raw + e);
-        if (a.raw2) w[u] = *reinterpret_cast<const float4*>(a.raw2 + e);
-        else if (a.res) w[u] = *reinterpret_cast<const float4*>(a.res + e);
-        else w[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+        w[u] = *reinterpret_cast<const float4*>(second + e);
     }
     const int g0 = c / cpg, g1 = cpg == 2 ? g0 + 1 : g0;   // cpg == 2: a float4 spans two groups
     float2 s0, s1, t0 = make_float2(0.f, 0.f), t1 = t0;
@@ -253,6 +253,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
                 if (cpg == 2) *reinterpret_cast<float2*>(a.stats2_w + ((size_t)b * G + g1) * 2) = t1;
             }
         }
+    } else if (a.mode == 3 || a.mode == 4) {   // timing-only ablations of mode 1: 3 = the partial loads + f32 sums only, 4 = the loads only (one tile)
+        s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
+        s1 = s0;
+        const float2* base = reinterpret_cast<const float2*>(a.part) + (size_t)b * a.tps * G + g0;
+        float acc = 0.f;
+        const int nt = a.mode == 3 ? a.tps : 1;
+        for (int t = 0; t < nt; ++t) acc += base[(size_t)t * G].x;
+        s0.x += 0.f * acc;
     } else {
         s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
         s1 = cpg == 2 ? *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g1) * 2) : s0;
@@ -438,7 +446,13 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     // adds them up first (gn_finish_kernel) and this one reads {mean, rstd} like any other
     const int tmax = a.part ? (a.raw2 && a.tps2 > a.tps ? a.tps2 : a.tps) : 0;
     d.mode = !a.part ? 0 : (tmax <= kGnDirectTps ? 1 : (tmax <= kGnCoopTps && 256 % G == 0 ? 2 : 0));
-    if (a.part && d.mode == 0) {
+    static const int dbg_stale = getenv("SOCCDPT_DBG_GN_STALE") ? atoi(getenv("SOCCDPT_DBG_GN_STALE")) : 0;   // timing-only ablation: 1 = no finish at all (statistics of the previous forward), 2 = also one pixel per thread
+    bool skip_finish = false;   // bit 0: the per-thread walks, bit 1: the workgroup walks, bit 2: the finish launches
+    if (a.part && d.mode == 1 && (dbg_stale & 1)) { d.mode = 0; skip_finish = true; }
+    if (a.part && d.mode == 1 && !a.raw2 && (dbg_stale == 8 || dbg_stale == 16)) { d.mode = dbg_stale == 8 ? 3 : 4; skip_finish = true; }
+    if (a.part && d.mode == 2 && (dbg_stale & 2)) { d.mode = 0; skip_finish = true; }
+    if (a.part && d.mode == 0 && !skip_finish && (dbg_stale & 4)) skip_finish = true;
+    if (a.part && d.mode == 0 && !skip_finish) {
         if (launch_gn_finish(a.part, d.stats_w, B, a.tps, G, a.HW, a.cpg, a.eps, st, err)) return 1;
         if (a.raw2 && launch_gn_finish(a.part2, d.stats2_w, B, a.tps2, G, a.HW, a.cpg, a.eps, st, err)) return 1;
     }

@@ -791,7 +791,8 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         };
         auto gn = [&](GnApplyArgs g, int om, int slot, int slot2 = -1) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise); slot(s): whose partials
             if (bm_slot[slot] <= 0 || (slot2 >= 0 && bm_slot[slot2] <= 0)) { err = "soccdpt: GroupNorm statistics slot read before a convolution filled it"; return 1; }
-            g.part = w.hy_part[slot]; g.tps = g.HW / bm_slot[slot];
+            static const int dbg_old = getenv("SOCCDPT_DBG_GN_OLDPART") ? atoi(getenv("SOCCDPT_DBG_GN_OLDPART")) : 0;   // timing-only: read another slot's (older) partials
+            g.part = w.hy_part[dbg_old ? (slot + 2) % 4 : slot]; g.tps = g.HW / bm_slot[slot];
             if (slot2 >= 0) { g.part2 = w.hy_part[slot2]; g.tps2 = g.HW / bm_slot[slot2]; }
             const int eo = om >= 2 ? 4 : 2;
             PROF("gn_apply", 0.0, (double)g.M * g.C * (4.0 + (g.raw2 || g.res ? 4.0 : 0.0) + (g.out_f32 ? 4.0 : 0.0) + (g.out_op ? eo : 0) + (g.out_halo ? eo : 0)));
