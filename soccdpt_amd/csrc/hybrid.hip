@@ -89,7 +89,10 @@ __global__ __launch_bounds__(256) void stem_im2col_kernel(const float* __restric
         const int tap = k / 3, c = k - tap * 3;
         const int ky = tap / 7, kx = tap - ky * 7;
         const int iy = oy * 2 + ky - pad_lo, ix = ox * 2 + kx - pad_lo;
-        v[j] = (k < 147 && iy >= 0 && iy < S && ix >= 0 && ix < S) ? x[(((size_t)b * 3 + c) * S + iy) * S + ix] : 0.f;
+        const bool ok = k < 147 && iy >= 0 && iy < S && ix >= 0 && ix < S;
+        const int cy = iy < 0 ? 0 : (iy < S ? iy : S - 1), cx = ix < 0 ? 0 : (ix < S ? ix : S - 1), cc = k < 147 ? c : 0;   // clamped address, select after the load
+        const float xv = x[(((size_t)b * 3 + cc) * S + cy) * S + cx];
+        v[j] = ok ? xv : 0.f;
     }
     store4<OUT>(A, m * 160 + ch * 8, v[0], v[1], v[2], v[3]);
     store4<OUT>(A, m * 160 + ch * 8 + 4, v[4], v[5], v[6], v[7]);
@@ -228,6 +231,9 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
         w[u] = *reinterpret_cast<const float4*>(second + e);
     }
     const int g0 = c / cpg, g1 = cpg == 2 ? g0 + 1 : g0;   // cpg == 2: a float4 spans two groups
+    // the affine parameters too are requested before the statistics are put together (pointer selects, no load under a condition)
+    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c), be = *reinterpret_cast<const float4*>(a.beta + c);
+    const float4 ga2 = *reinterpret_cast<const float4*>((a.raw2 ? a.gamma2 : a.gamma) + c), be2 = *reinterpret_cast<const float4*>((a.raw2 ? a.beta2 : a.beta) + c);
     float2 s0, s1, t0 = make_float2(0.f, 0.f), t1 = t0;
     if (a.mode == 2) {
         gn_finish_groups(a.part, a.tps, G, b, 0, G, a.inv_cnt, a.eps, st[0], red);
@@ -262,20 +268,16 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
         for (int t = 0; t < nt; ++t) acc += base[(size_t)t * G].x;
         s0.x += 0.f * acc;
     } else {
+        const float* sp2 = a.raw2 ? a.stats2 : a.stats;
         s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
-        s1 = cpg == 2 ? *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g1) * 2) : s0;
-        if (a.raw2) {
-            t0 = *reinterpret_cast<const float2*>(a.stats2 + ((size_t)b * G + g0) * 2);
-            t1 = cpg == 2 ? *reinterpret_cast<const float2*>(a.stats2 + ((size_t)b * G + g1) * 2) : t0;
-        }
+        s1 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g1) * 2);
+        t0 = *reinterpret_cast<const float2*>(sp2 + ((size_t)b * G + g0) * 2);
+        t1 = *reinterpret_cast<const float2*>(sp2 + ((size_t)b * G + g1) * 2);
     }
     // ((x - mean) * rstd) * gamma + beta, the order torch.group_norm uses
     auto norm = [](float4 x, float2 p0, float2 p1, float4 g, float4 bb) {
         return make_float4((x.x - p0.x) * p0.y * g.x + bb.x, (x.y - p0.x) * p0.y * g.y + bb.y, (x.z - p1.x) * p1.y * g.z + bb.z, (x.w - p1.x) * p1.y * g.w + bb.w);
     };
-    const float4 ga = *reinterpret_cast<const float4*>(a.gamma + c), be = *reinterpret_cast<const float4*>(a.beta + c);
-    float4 ga2 = ga, be2 = be;
-    if (a.raw2) { ga2 = *reinterpret_cast<const float4*>(a.gamma2 + c); be2 = *reinterpret_cast<const float4*>(a.beta2 + c); }
     const int H = a.HW / a.W;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
@@ -315,20 +317,24 @@ __global__ __launch_bounds__(256) void gn_relu_maxpool_kernel(const float* __res
     const int c = (int)(gid - m * c4) * 4;
     const int ox = (int)(m % Ho), oy = (int)((m / Ho) % Ho), b = (int)(m / ((size_t)Ho * Ho));
     float4 best = make_float4(0.f, 0.f, 0.f, 0.f);   // every candidate is >= 0 after the ReLU and the centre tap always exists
+    // the nine taps are loaded first, from clamped coordinates (a tap beyond the image repeats the last row / column: the maximum does not change), and only then
+    // normalised: loads under `if (ix < Hi)` came out as nine dependent round trips (round 5, tools/isa_scan.py)
+    float4 tap[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy * 2 + ky < Hi ? oy * 2 + ky : Hi - 1;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox * 2 + kx < Hi ? ox * 2 + kx : Hi - 1;
+            tap[ky * 3 + kx] = *reinterpret_cast<const float4*>(raw + (((size_t)b * Hi + iy) * Hi + ix) * C + c);
+        }
+    }
     Gn4 n4; Gn4x2 n2;
     if (cpg == 2) n2.load(stats, gamma, beta, b, c, C); else n4.load(stats, gamma, beta, b, c, C, cpg);
 #pragma unroll
-    for (int ky = 0; ky < 3; ++ky) {
-        const int iy = oy * 2 + ky;
-        if (iy >= Hi) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int ix = ox * 2 + kx;
-            if (ix >= Hi) continue;
-            float4 v = *reinterpret_cast<const float4*>(raw + (((size_t)b * Hi + iy) * Hi + ix) * C + c);
-            v = cpg == 2 ? n2.apply(v) : n4.apply(v);
-            best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
-        }
+    for (int k = 0; k < 9; ++k) {
+        const float4 v = cpg == 2 ? n2.apply(tap[k]) : n4.apply(tap[k]);
+        best.x = fmaxf(best.x, v.x); best.y = fmaxf(best.y, v.y); best.z = fmaxf(best.z, v.z); best.w = fmaxf(best.w, v.w);
     }
     store4<OUT>(out, m * C + c, best.x, best.y, best.z, best.w);
 }
