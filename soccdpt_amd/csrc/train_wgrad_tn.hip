@@ -14,6 +14,7 @@
 // the buffer the dgrad launch already staged.
 // Tile 128 (n) x 128 (columns) x 64 (k), 8 waves as 2 x 4, each 64 n x 32 columns; two-slot LDS ring (64 KB: two workgroups per CU); split-K with
 // the deferred reduction of igemm.h (every split stores its partial tile, sk_reduce sums them in order): deterministic.
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -326,7 +327,8 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     TnArgs a;
     a.A = A; a.B = B; a.ldA = ldA; a.ldB = ldB; a.K = (int)K; a.Nout = Nout; a.C = C; a.taps = taps; a.Ncols = taps * C; a.rp = rp; a.part = part;
     const long tiles = (long)((Nout + 127) / 128) * ((a.Ncols + 127) / 128), nk = (long)K / (x3 ? 32 : 64);
-    long S = 512 / tiles > 0 ? 512 / tiles : 1;   // one round of two workgroups per CU
+    static const long target = getenv("SOCCDPT_TN_TILES") ? atol(getenv("SOCCDPT_TN_TILES")) : 512;
+    long S = target / tiles > 0 ? target / tiles : 1;   // one round of two workgroups per CU
     if (S > nk / 2) S = nk / 2 > 0 ? nk / 2 : 1;
     if (S > 64) S = 64;
     const size_t per_split = (size_t)Nout * a.Ncols + (bias_out ? (size_t)(Nout + 3) / 4 * 4 : 0);   // the bias partials sit behind the weight partials
