@@ -104,7 +104,11 @@ size_t soccdpt_sizeof(int which);
  *             projection), "vit.b<i>.qkv" / ".proj" / ".fc1" / ".fc2", "ro<k>" (ProjectReadout + 1x1 of act_postprocess3 / 4), "pp4" (its 3x3 / 2)
  *   decoder:  "lrn<l>" (scratch.layer<l+1>_rn), "ref<l>" (the four RCU convolutions of refinenet<l+1>), "oc<l>" (its out_conv),
  *             "head" (output_conv.0 and seg_head.0: both read path_1), "head.d2" (output_conv.2 + .4), "head.s1" (format in which
- *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32)
+ *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32 -- honoured only when that
+ *             feature map exists, i.e. when "head" is F16X3 or SOCCDPT_SEG_DOT3_OFF is set: with a 16-bit "head" the classifier rides in the
+ *             convolution's epilogue on the f32 accumulators and the entry is inert)
+ * F16X2W is refused for "head", "head.d2" and "head.s1" (their weights are read by kernels without the two-MFMA form: the fused classifier, the fused
+ * depth tail; "head.s1" is a storage format): an exact name is an error, a pattern skips them (they stay F16).
  * `group` may end in '*' (prefix match) or be "*".  fmt = SOCCDPT_PREC_F16, SOCCDPT_PREC_F16X2W or SOCCDPT_PREC_F16X3.  Returns the number of groups
  * changed (>= 0) or a negative value on error.  Invalidates the prepared weights and the workspace (call soccdpt_prepare again). */
 int soccdpt_prec_map_set(void* handle, const char* group, int fmt);
@@ -392,6 +396,21 @@ typedef struct soccdpt_igemm_args {
 } soccdpt_igemm_args;
 int soccdpt_op_igemm(const soccdpt_igemm_args* args, void* stream);
 
+/* Kernel-level entries (tests): the reader side of the hybrid's GroupNorm -- timm GroupNormAct after every StdConv2dSame of the ResNetV2 stem / stages
+ * (created by _make_pretrained_vitb_rn50_384, /root/reference/SOccDPT/model/backbones/vit.py:147-201; restated in oracle/soccdpt_ref.py rn_bottleneck).
+ * soccdpt_op_gn_finish: per-tile partials [B * tps][groups][2] = {sum, sum of squares} (soccdpt_op_igemm with gn_count == NULL) -> stats [B][groups][2] =
+ *   {mean, 1 / sqrt(var + eps)} (biased variance), hw pixels per sample, cpg channels per group.
+ * soccdpt_op_gn_apply: y = GN(raw) [+ GN2(raw2) | + res], ReLU when relu != 0, for raw [M][C] f32 NHWC (M = B * hw pixels, image width w); outputs, each
+ *   optional: out_f32 [M][C], out_op [M][C] and out_halo [B][h+2][w+2][C] (zero halo left untouched) in operand format out_format (SOCCDPT_PREC_BF16 /
+ *   _F16 / _F32 / _F16X3).  Statistics: stats / stats2 as above, or -- part / part2 non-NULL, tps / tps2 tiles per sample -- added up from the partials
+ *   by the kernel itself (short lists: per thread; up to 64 tiles: per workgroup; longer: a soccdpt_op_gn_finish launch first) and ALSO written to
+ *   stats / stats2, which must then be writable.  groups = C / cpg must divide 256, C / 4 must divide 256, hw * C / 4 must be a multiple of 256. */
+int soccdpt_op_gn_finish(const float* dev_part, float* dev_stats, int B, int tps, int groups, int hw, int cpg, float eps, void* stream);
+int soccdpt_op_gn_apply(const float* dev_raw, float* dev_stats, const float* dev_part, int tps, const float* dev_gamma, const float* dev_beta,
+                        const float* dev_raw2, float* dev_stats2, const float* dev_part2, int tps2, const float* dev_gamma2, const float* dev_beta2,
+                        const float* dev_res, float* dev_out_f32, void* dev_out_op, void* dev_out_halo, int out_format, int relu, size_t M, int hw, int w,
+                        int C, int cpg, float eps, void* stream);
+
 /* Global softmax attention of one ViT block (timm vision_transformer.Attention between the qkv and proj Linear layers; created by
  * model/backbones/vit.py:248): qkv [B*N][3*heads*64] -> out [B*N][heads*64] = softmax(q k^T / 8) v per (sample, head); elements
  * bf16 / f32 / fp16 by `precision`.  N <= 608 (dpt_hybrid_384: N = 577). */
@@ -454,7 +473,9 @@ int soccdpt_train_workspace_tensor(void* handle, int B, const char* name, size_t
 
 /* Location of a named intermediate inside the workspace handed to soccdpt_network for batch B:
  * "feat0".."feat3" (hooked encoder maps, halo bf16), "path1" (halo bf16), "seg_logits" (seg head before up-sampling/activation, f32 [B,2G,2G,3]), "xf" (final stage tokens f32).
- * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC, 4 = fp16 plain, 5 = fp16 zero-halo NHWC.  Returns non-zero for unknown names. */
+ * kind: 0 = f32 plain, 1 = bf16 plain, 2 = bf16 zero-halo NHWC, 3 = f32 zero-halo NHWC, 4 = fp16 plain, 5 = fp16 zero-halo NHWC, 7 = x3 zero-halo NHWC.
+ * Returns non-zero for unknown names, and 2 for "seg_feat" (the seg head's conv + BN + ReLU map) when that map is not materialised: with 16-bit operands in
+ * the "head" group the 1x1 classifier is part of the convolution's launch (SOCCDPT_SEG_DOT3_OFF=1 restores the separate map). */
 int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind,
                              int* H, int* W, int* C);
 

@@ -582,6 +582,28 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
     return 0;
 }
 
+int soccdpt_op_gn_finish(const float* dev_part, float* dev_stats, int B, int tps, int groups, int hw, int cpg, float eps, void* stream) {
+    std::string err;
+    if (launch_gn_finish(dev_part, dev_stats, B, tps, groups, hw, cpg, eps, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_op_gn_apply(const float* dev_raw, float* dev_stats, const float* dev_part, int tps, const float* dev_gamma, const float* dev_beta,
+                        const float* dev_raw2, float* dev_stats2, const float* dev_part2, int tps2, const float* dev_gamma2, const float* dev_beta2,
+                        const float* dev_res, float* dev_out_f32, void* dev_out_op, void* dev_out_halo, int out_format, int relu, size_t M, int hw, int w,
+                        int C, int cpg, float eps, void* stream) {
+    std::string err;
+    if (!dev_raw || !dev_stats || !dev_gamma || !dev_beta || hw <= 0 || w <= 0 || hw % w) return fail(nullptr, "soccdpt_op_gn_apply: bad arguments");
+    const int om = out_format == SOCCDPT_PREC_BF16 ? 0 : (out_format == SOCCDPT_PREC_F16 ? 1 : (out_format == SOCCDPT_PREC_F32 ? 2 : (out_format == SOCCDPT_PREC_F16X3 ? 3 : -1)));
+    if (om < 0) return fail(nullptr, "soccdpt_op_gn_apply: out_format is SOCCDPT_PREC_BF16, _F16, _F32 or _F16X3");
+    GnApplyArgs g;
+    g.raw = dev_raw; g.stats = dev_stats; g.part = dev_part; g.tps = tps; g.gamma = dev_gamma; g.beta = dev_beta;
+    g.raw2 = dev_raw2; g.stats2 = dev_stats2; g.part2 = dev_part2; g.tps2 = tps2; g.gamma2 = dev_gamma2; g.beta2 = dev_beta2; g.res = dev_res;
+    g.out_f32 = dev_out_f32; g.out_op = dev_out_op; g.out_halo = dev_out_halo; g.relu = relu; g.M = M; g.HW = hw; g.W = w; g.C = C; g.cpg = cpg; g.eps = eps;
+    if (launch_gn_apply(g, om, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_workspace_tensor(void* handle, int B, const char* name, size_t* byte_offset, size_t* elems, int* kind, int* H, int* W,
                              int* C) {
     Handle* h = static_cast<Handle*>(handle);

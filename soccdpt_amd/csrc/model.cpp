@@ -620,6 +620,11 @@ std::vector<std::string> model_prec_groups(const Handle& h) {
 // "head.d2" (the fused depth tail keeps the 32 x 1152 filter in registers, depth_tail.hip), "head" (the seg head's convolution carries the classifier
 // in its epilogue, a 16-bit-operand instantiation), "head.s1" (a storage format, not a launch).
 bool model_prec_x2w_ok(const std::string& g) { return g != "head" && g != "head.d2" && g != "head.s1"; }
+// the seg head's Conv3x3 + BN + ReLU + Conv1x1 as ONE launch (igemm D3): 16-bit operands of the "head" group, 3 classes, 128-channel tiles
+static bool seg_dot3_active(const Handle& h) {
+    static const bool no_dot3 = getenv("SOCCDPT_SEG_DOT3_OFF") != nullptr;   // A/B switch: the unfused classifier of rounds 1-3
+    return group_fmt(h, "head") <= 1 && h.cfg.features % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3 && !group_x2w(h, "head");
+}
 
 int model_prec_set(Handle& h, const char* pattern, int fmt, std::string& err) {
     std::string p(pattern);
@@ -698,6 +703,9 @@ int model_workspace_tensor(Handle& h, int B, const char* name, size_t* byte_offs
     const int r1 = 2 * a.fres(0);
     if (n == "path1") return set(w.path1, Halo{r1, r1, h.cfg.features}.elems(B), halo_kind("head"), r1, r1, h.cfg.features);
     if (n == "seg_feat") {   // seg head conv3x3 + BN + ReLU output
+        // ... which does not exist when the 1x1 classifier rides in the convolution's epilogue (16-bit "head" group: the buffer then holds the partial logits
+        // [F / tile][M][4]): not a tensor anybody should read as a feature map; SOCCDPT_SEG_DOT3_OFF=1 brings it back
+        if (seg_dot3_active(h)) return 2;
         const int fs = h.cfg.precision == SOCCDPT_PREC_MIXED ? group_fmt(h, "head.s1") : group_fmt(h, "head");
         return set(w.s1, (size_t)B * r1 * r1 * h.cfg.features, fs >= 2 ? 0 : (fs == 1 ? 4 : 1), r1, r1, h.cfg.features);
     }
@@ -1089,8 +1097,7 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         const bool s1_f32 = fS1 >= 2;
         d = conv(w.path1, F, P.s0_w, F, r1);
         d.bias = P.bn_shift; d.act = ACT_RELU;
-        static const bool no_dot3 = getenv("SOCCDPT_SEG_DOT3_OFF") != nullptr;   // A/B switch: the unfused classifier of rounds 1-3
-        if (fH <= 1 && F % 128 == 0 && h.cfg.num_classes == 3 && !no_dot3 && !group_x2w(h, "head")) {
+        if (seg_dot3_active(h)) {
             // the 1x1 classifier rides in the convolution's epilogue (igemm D3): the 256-channel feature map -- 67 MB written and read back per
             // forward at B = 8, rounded to 16 bits on the way -- is never stored; the logits come from the f32 accumulators
             d.dot3 = 1; d.dot_w = P.s4_w; d.out_dot = static_cast<float*>(w.s1);   // [F / BN][M][4] partial logits in the feature map's buffer

@@ -194,6 +194,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_gt_occupancy.restype = ci
     L.soccdpt_input_transform_u8.argtypes = [vp, ci, ci, ci, ci, ci, ctypes.POINTER(cd), ctypes.POINTER(cd), vp, vp]
     L.soccdpt_input_transform_u8.restype = ci
+    L.soccdpt_op_gn_finish.argtypes = [vp, vp, ci, ci, ci, ci, ci, ctypes.c_float, vp]
+    L.soccdpt_op_gn_finish.restype = ci
+    L.soccdpt_op_gn_apply.argtypes = [vp, vp, vp, ci, vp, vp, vp, vp, vp, ci, vp, vp, vp, vp, vp, vp, ci, ci, ctypes.c_size_t, ci, ci, ci, ci, ctypes.c_float, vp]
+    L.soccdpt_op_gn_apply.restype = ci
     L.soccdpt_op_mlp_ln.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, vp]
     L.soccdpt_op_mlp_ln.restype = ci
     L.soccdpt_adam_step.argtypes = [ci, vp, vp, vp, vp, vp, cd, cd, cd, cd, cd, ci, vp]
@@ -604,6 +608,8 @@ class Engine:
         kind, H, W, C = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
         rc = self.L.soccdpt_workspace_tensor(self._h, B, name.encode(), ctypes.byref(off), ctypes.byref(n), ctypes.byref(kind),
                                              ctypes.byref(H), ctypes.byref(W), ctypes.byref(C))
+        if rc == 2:
+            raise KeyError(f"{name}: not materialised in this mode (the seg head's classifier is part of the convolution's launch; SOCCDPT_SEG_DOT3_OFF=1 restores the map)")
         if rc != 0:
             raise KeyError(name)
         raw = self._workspace[off.value:]
@@ -645,6 +651,26 @@ def op_igemm(x, wt, M, N, Cin, taps=1, ldx=0, H=0, W=0, bias=None, res1=None, re
     rc = L.soccdpt_op_igemm(ctypes.byref(a), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_igemm failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_gn_finish(part, stats, B, tps, groups, hw, cpg, eps=1e-5):
+    """Kernel-level entry (tests): per-tile GroupNorm partials -> {mean, rstd} (soccdpt_op_gn_finish) on the current stream."""
+    L = load_library()
+    rc = L.soccdpt_op_gn_finish(_ptr(part), _ptr(stats), int(B), int(tps), int(groups), int(hw), int(cpg), float(eps), _stream_ptr(part.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_gn_finish failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_gn_apply(raw, stats, gamma, beta, hw, w, cpg, part=None, tps=0, raw2=None, stats2=None, part2=None, tps2=0, gamma2=None, beta2=None, res=None,
+                out_f32=None, out_op=None, out_halo=None, out_format=PREC_F32, relu=True, eps=1e-5):
+    """Kernel-level entry (tests): GroupNorm apply (+ shortcut) (+ ReLU) of raw [M][C] (soccdpt_op_gn_apply) on the current stream."""
+    L = load_library()
+    M, C = raw.shape
+    rc = L.soccdpt_op_gn_apply(_ptr(raw), _ptr(stats), _ptr(part), int(tps), _ptr(gamma), _ptr(beta), _ptr(raw2), _ptr(stats2), _ptr(part2), int(tps2),
+                               _ptr(gamma2), _ptr(beta2), _ptr(res), _ptr(out_f32), _ptr(out_op), _ptr(out_halo), int(out_format), 1 if relu else 0, M, int(hw),
+                               int(w), int(C), int(cpg), float(eps), _stream_ptr(raw.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_gn_apply failed: " + L.soccdpt_last_error(None).decode())
 
 
 def op_vit_attention(qkv, out, B, N, heads, precision=PREC_BF16):

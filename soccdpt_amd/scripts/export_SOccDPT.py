@@ -118,6 +118,16 @@ class GraphBuilder:
                  "nearest": dict(mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")}[mode]
         return self.op("Resize", [x, "", self.f32([1.0, 1.0, sh, sw])], **attrs)
 
+    def resize_to(self, x, H: int, W: int, mode: str):
+        """F.interpolate(x, size=(H, W)): Resize with the `sizes` input ([batch, channels] taken from Shape(x), so the batch stays dynamic), as torch.onnx emits
+        for size=.  With `scales` = H / S an exported graph computes floor(S * float32(H / S)), one pixel short whenever H / S is not exact in float32
+        (width 1241 at S = 384) -- and the constant camera-size initialisers would no longer broadcast."""
+        attrs = {"bilinear_ac": dict(mode="linear", coordinate_transformation_mode="align_corners"),
+                 "bicubic": dict(mode="cubic", coordinate_transformation_mode="half_pixel", cubic_coeff_a=-0.75),
+                 "nearest": dict(mode="nearest", coordinate_transformation_mode="asymmetric", nearest_mode="floor")}[mode]
+        sizes = self.concat([self.slice(self.op("Shape", [x]), [0], [2], [0]), self.i64([int(H), int(W)])], 0)
+        return self.op("Resize", [x, "", "", sizes], **attrs)
+
     def roll2(self, x, shift: int, res: int):
         """torch.roll(x, (shift, shift), dims=(1, 2)) of [B, res, res, C] for a shift in (-res, res)."""
         s = shift % res
@@ -358,8 +368,8 @@ def build_graph(net, opset: int = 13) -> P.Model:
 
     # ---------------- get_semantic_occupancy without the voxel grid (model/SOccDPT.py:264-364) ----------------
     Hc, Wc = int(net.height), int(net.width)
-    inv_up = b.resize(inv, Hc / S, Wc / S, "bicubic")                    # F.interpolate(..., mode="bicubic", align_corners=False)
-    seg_up = b.resize(seg, Hc / S, Wc / S, "nearest")
+    inv_up = b.resize_to(inv, Hc, Wc, "bicubic")                         # F.interpolate(..., size=(height, width), mode="bicubic", align_corners=False)
+    seg_up = b.resize_to(seg, Hc, Wc, "nearest")
     inv_up = b.reshape(inv_up, [-1, Hc, Wc])
     small = b.f32(1e-8)
     inv_up = b.op("Where", [b.op("Less", [inv_up, small]), small, inv_up])                               # inv[inv < 1e-8] = 1e-8 (NaN stays NaN)
