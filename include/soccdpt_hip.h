@@ -378,11 +378,12 @@ typedef struct soccdpt_igemm_args {
     int32_t conv_general, stride, pad, in_halo, Hi, Wi, gather1;
     int32_t grp_rows, grp_off, seg2_k, seg2_off;
     int64_t grp_stride;
-    /* GroupNorm statistics of the raw output (timm GroupNormAct after every StdConv2dSame of the ResNetV2 stem / stages): gn_stats
-     * [M / gn_hw][N / gn_cpg][2] = {mean, 1/sqrt(var + 1e-5)} per (sample, group); gn_part: (M / 64) * (N / gn_cpg) * 2 floats of scratch,
-     * gn_count: M / gn_hw zero words (left zero).  gn_stats NULL = off.  gn_count NULL (gn_stats, gn_part set): the launch stops at the per-tile
-     * partials gn_part[(M tile * (N / gn_cpg) + group) * 2] = {sum, sum of squares} (tile rows 32 / 64 / 128 by configuration; size gn_part for 32)
-     * and writes no gn_stats -- the form the forward uses since round 5, its GroupNorm-apply kernel adds the partials up. */
+    /* GroupNorm statistics of the raw output (timm GroupNormAct after every StdConv2dSame of the ResNetV2 stem / stages).  gn_stats NULL = off.  The
+     * launch leaves per-tile partials gn_part[(M tile * (N / gn_cpg) + group) * 2] = {sum, sum of squares} (tile rows 32 / 64 / 128 by configuration;
+     * size gn_part for 32: (M / 32) * (N / gn_cpg) * 2 floats); no bias / residual on such a launch.  gn_count NULL: that is all -- the form the forward
+     * uses since round 5, its GroupNorm-apply kernel adds the partials up (soccdpt_op_gn_apply / soccdpt_op_gn_finish).  gn_count non-NULL (the form of
+     * rounds 2-4; the words themselves are no longer read or written): a finish launch follows and gn_stats [M / gn_hw][N / gn_cpg][2] receives
+     * {mean, 1/sqrt(var + 1e-5)} per (sample, group). */
     float* gn_stats;
     float* gn_part;
     uint32_t* gn_count;

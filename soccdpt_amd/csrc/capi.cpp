@@ -534,12 +534,16 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.sk_part_floats = a->sk_part_floats; d.sk_count_words = a->sk_count_words; d.sk_defer = a->sk_defer;
     if (a->conv_general) { d.stride = a->stride; d.pad = a->pad; d.in_halo = a->in_halo; d.Hi = a->Hi; d.Wi = a->Wi; d.gather1 = a->gather1; }
     d.grp_rows = a->grp_rows; d.grp_off = a->grp_off; d.grp_stride = a->grp_stride; d.seg2_k = a->seg2_k; d.seg2_off = a->seg2_off;
-    d.gn_stats = a->gn_stats; d.gn_part = a->gn_part; d.gn_count = a->gn_count; d.gn_cpg = a->gn_cpg; d.gn_hw = a->gn_hw;
-    d.gn_part_floats = a->gn_part_floats; d.gn_count_words = a->gn_count_words;
-    d.gn_defer = (a->gn_stats && a->gn_part && !a->gn_count) ? 1 : 0;   // no counter: the launch stops at the per-tile partials (the reader adds them up)
+    int gn_bm = 0;
+    d.gn_stats = a->gn_stats; d.gn_part = a->gn_part; d.gn_bm_out = &gn_bm; d.gn_cpg = a->gn_cpg; d.gn_hw = a->gn_hw;
+    d.gn_part_floats = a->gn_part_floats;
     d.stamps = reinterpret_cast<unsigned long long*>(a->stamps);
     std::string err;
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
+    // gn_count != NULL: the caller wants {mean, rstd} in gn_stats (the form of rounds 2-4, where the convolution's last workgroup finished them; the words of
+    // gn_count are no longer touched): a finish launch behind the convolution.  gn_count == NULL: partials only, as the forward launches it.
+    if (a->gn_stats && a->gn_count && launch_gn_finish(a->gn_part, a->gn_stats, a->M / a->gn_hw, a->gn_hw / gn_bm, a->N / a->gn_cpg, a->gn_hw, a->gn_cpg, 1e-5f, (hipStream_t)stream, err))
+        return fail(nullptr, err);
     return 0;
 }
 

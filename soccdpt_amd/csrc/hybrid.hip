@@ -158,7 +158,7 @@ __device__ __forceinline__ void gn_sum_partials(const float2* __restrict__ base,
     }
 }
 
-// ---- GroupNorm statistics from the per-tile partials of the producing convolution (igemm ST epilogue with gn_defer) ----
+// ---- GroupNorm statistics from the per-tile partials of the producing convolution (igemm ST epilogue) ----
 // part [tiles of the launch][G][2] = {sum, sum of squares} per M tile and group; a sample owns tps consecutive tiles.  Thread (sl = tid / gw,
 // j = tid % gw) walks tiles sl, sl + nsl, ... of group g0 + j in f64 (eight loads in flight), the slices are added in slice order: a fixed order for
 // a given (tps, gw), so the statistics are bitwise reproducible.  Result: st[j] = {mean, 1 / sqrt(var + eps)} (biased variance, torch.nn.GroupNorm)
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void gn_finish_kernel(const float* __restrict_
 //   y = relu(y) when relu != 0
 // out_f32 [M][C] (residual stream), out_op [M][C] and out_halo [B][H+2][W+2][C] (operand copies) are each optional.
 // Statistics, by mode: 0 read from stats / stats2; 1 every thread adds the per-tile partials of its own group(s) (short lists, no barrier); 2 the workgroup
-// shares the walk through LDS (two barriers) -- from the producing convolution's partials (igemm gn_defer), while the raw loads are in flight.  Round 5: the
+// shares the walk through LDS (two barriers) -- from the producing convolution's partials (igemm statistics epilogue), while the raw loads are in flight.  Round 5: the
 // producer's own last-arriver finish cost 2-7 us on the critical path of every ResNetV2 convolution (tools/rn_stamps.py).  All U (+U) loads of a thread are
 // issued before anything else and the statistics are put together ONCE per thread: these launches are one or two rounds of workgroups long, i.e. latency --
 // tried and measured (kernel trace, us per launch, 2304 x 1024 channels + residual): one float4 per thread reading finished statistics 7.9, with

@@ -113,22 +113,18 @@ struct IgemmDesc {
     int sk_defer = 0;
     int tune = -1;  // kernel configuration id (igemm.hip); -1 = heuristic
     int x3_among_f16 = 0;   // hint of the caller: this x3 launch sits between fp16 launches (SOCCDPT_PREC_MIXED) -- the tile heuristic differs (igemm.hip: x3 configuration 12)
-    // GroupNorm statistics of the raw output (the ST instantiation): with gn_stats != nullptr the epilogue also reduces sum / sum of
-    // squares of v over every (sample, group of gn_cpg consecutive channels): per-tile partials go to gn_part ((M / BM) * (N / gn_cpg) * 2
-    // floats), the LAST workgroup of a sample to arrive (gn_count[b], zero at rest) adds them in tile order in f64 -- deterministic --
-    // and writes gn_stats[(b * (N / gn_cpg) + g) * 2] = {mean, 1 / sqrt(var + gn_eps)} (biased variance, torch.nn.GroupNorm).
-    // gn_hw = pixels per sample (M = B * gn_hw; must be a multiple of the M tile).
-    // gn_defer: the epilogue stops at the per-tile partials (plain stores, no counter, gn_count may be null, gn_stats is only the switch);
-    // the reader of out_f32 adds them: launch_gn_apply with GnApplyArgs::part / tps, or launch_gn_finish (hybrid.hip).  Partial layout either
-    // way: gn_part[((mt * G) + g) * 2] = {sum, sum of squares} of M tile mt (tile rows: igemm_config_bm(d)), group g.
-    int gn_defer = 0;
+    // GroupNorm statistics of the raw output (the ST instantiation): with gn_stats != nullptr the epilogue also reduces sum / sum of squares of v over every
+    // (M tile, group of gn_cpg consecutive channels): gn_part[((mt * G) + g) * 2] = {sum, sum of squares} of M tile mt (tile rows: *gn_bm_out), group g,
+    // G = N / gn_cpg -- plain stores, no counter.  The reader of out_f32 adds a sample's tiles in tile order in f64 and forms {mean, 1 / sqrt(var + gn_eps)}
+    // (biased variance, torch.nn.GroupNorm): launch_gn_apply with GnApplyArgs::part / tps, or launch_gn_finish (hybrid.hip), which also write them to the
+    // [B][G][2] array gn_stats names.  gn_stats itself is only the switch here.  gn_hw = pixels per sample (M = B * gn_hw; a multiple of the M tile).
+    // Launches with statistics carry no bias / residual (v is the accumulator).
     int* gn_bm_out = nullptr;   // host pointer: launch_igemm stores the M-tile rows of the configuration it launched (tiles per sample = gn_hw / rows)
     float* gn_stats = nullptr;
     float* gn_part = nullptr;
-    unsigned* gn_count = nullptr;
     int gn_cpg = 0, gn_hw = 0;
     float gn_eps = 1e-5f;
-    size_t gn_part_floats = 0, gn_count_words = 0;   // capacities, validated by launch_igemm
+    size_t gn_part_floats = 0;   // capacity, validated by launch_igemm
     // diagnostics (tools/igemm_stamps.py): when non-null every workgroup writes 4 s_memrealtime stamps (100 MHz) -- entry, first k-tile
     // landed, main loop done, epilogue done -- to stamps[4 * blockIdx.x ..]; the values are never read by the kernel
     unsigned long long* stamps = nullptr;

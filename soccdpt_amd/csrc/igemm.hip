@@ -52,8 +52,8 @@ static int launch_cfg_t(const IgemmDesc& d, hipStream_t stream, std::string& err
     const size_t lds = (size_t)C::NS * igemm_stage_bytes<C, T>();
     if constexpr (ST) {
         const int G = d.gn_cpg > 0 ? d.N / d.gn_cpg : 0;
-        if (!d.gn_part || (!d.gn_count && !d.gn_defer) || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
-            (size_t)mtiles * G * 2 > d.gn_part_floats || (!d.gn_defer && (size_t)(d.M / d.gn_hw) > d.gn_count_words) || G > C::THREADS ||
+        if (!d.gn_part || !d.out_f32 || d.gn_cpg <= 0 || d.N % d.gn_cpg || C::BN % d.gn_cpg || d.gn_hw <= 0 || d.gn_hw % C::BM || d.M % d.gn_hw ||
+            (size_t)mtiles * G * 2 > d.gn_part_floats || G > C::THREADS ||
             (size_t)(2 * C::WM * C::BN + 4) * 4 + (size_t)C::THREADS * 16 > lds) {
             err = "igemm: bad GroupNorm-statistics descriptor (pixels per sample must be a multiple of the M tile)";
             return 1;

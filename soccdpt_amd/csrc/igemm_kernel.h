@@ -63,8 +63,8 @@ __device__ __forceinline__ int swz_of_row(int row) {
 // tile to d.sk_part[split][M][N], and the LAST workgroup to arrive at the tile (a counter in d.sk_count, left at 0 again) sums
 // the splitk partials in split order -- deterministic, no float atomics -- and runs the epilogue.  No workgroup ever waits
 // for another one.  For long-K problems whose output grid cannot fill the 256 CUs (coarse decoder levels, stage-3 fc2).
-// ST: GroupNorm statistics of the raw output (d.gn_stats): per-tile per-group partial sums, finished by the last workgroup of each
-// sample (same fence-free sc1 exchange as SK).  ResNetV2 stages of the ViT-hybrid encoder (csrc/hybrid.hip applies the normalisation).
+// ST: GroupNorm statistics of the raw output (d.gn_stats): per-tile per-group partial sums {sum, sum of squares}; the reader of the output adds them up.
+// ResNetV2 stages of the ViT-hybrid encoder (csrc/hybrid.hip applies the normalisation).
 // GEN: the generalised addressing (strided / un-haloed / gathered convolution, row groups, second A segment) and the diagnostics stamps.
 // A separate instantiation: carried by every launch they cost the Swin models 1.5 % of the forward (A/B in one GPU call, tools/ab_bench.sh).
 // One output tile `bid` (logical id: n-tile fastest, split fastest of all under SK) of the launch described by d.  `smem`: C::NS * C::STAGE bytes
@@ -737,9 +737,12 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
     if constexpr (ST) {
         // ---- GroupNorm statistics.  (1) in-wave: the 16 lanes that share (lane >> 4) hold the same 4 channels of 16 different pixels.
         // (2) per-channel sums of the WM wave rows meet in LDS (the staging ring is free after the barrier), (3) one thread per group adds
-        // its gn_cpg channels in a fixed order and publishes the tile's partial with an L2-bypassing store, (4) the last workgroup of the
-        // sample to arrive adds the tile partials in tile order in f64 and writes {mean, rstd}.  Fixed orders everywhere: bitwise
-        // reproducible; no workgroup waits for another one.
+        // its gn_cpg channels in a fixed order and stores the tile's partial.  The READER of out_f32 adds the tile partials of a sample in
+        // tile order in f64 (gn_apply / gn_finish, hybrid.hip): fixed orders everywhere, bitwise reproducible, nobody waits.
+        // (Rounds 2-4 finished here: the last workgroup of a sample to arrive -- one counter per sample -- walked the partials.  Per-workgroup
+        //  stamps priced that at 2-7 us on top of a 1.8 us epilogue for EVERY workgroup: the partial could only be published after vmcnt(0), i.e.
+        //  after the whole output tile had landed, then the counter round trip, then the walk -- three dependent memory round trips on the
+        //  critical path of launches that are one round of workgroups long.  tools/rn_stamps.py, profiles/r05_rn_stamps_before.txt.)
 #pragma unroll
         for (int i = 0; i < TNE; ++i)
 #pragma unroll
@@ -769,70 +772,7 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
 #pragma unroll
                 for (int w = 0; w < C::WM; ++w) { a += red[(w * BN + tid * cpg + c) * 2]; q += red[(w * BN + tid * cpg + c) * 2 + 1]; }
             float* pp = d.gn_part + ((size_t)mt * G + n0 / cpg + tid) * 2;
-            if (d.gn_defer) *reinterpret_cast<float2*>(pp) = make_float2(a, q);   // the consumer finishes (gn_apply / gn_finish, hybrid.hip): plain store, nothing to wait for
-            else {
-                __hip_atomic_store(pp, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(pp + 1, q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        // In-kernel finish (gn_defer == 0).  The stamps (tools/rn_stamps.py, round 5) price it at 2-7 us PER WORKGROUP on top of a 1.8 us epilogue:
-        // the partial can only be published after vmcnt(0), i.e. after the whole output tile has landed, then the counter round trip, then the
-        // last workgroup's walk -- three dependent memory round trips on the critical path of a launch that is one wave of workgroups long.
-        // The eval forward therefore defers (gn_defer = 1) and lets the reader of the raw output add the partials while its own loads fly.
-        unsigned last = 0;
-        const int tps = d.gn_hw / BM;                 // M tiles per sample (host: gn_hw % BM == 0)
-        const int sample = mt / tps;
-        if (!d.gn_defer) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            unsigned* arrival = reinterpret_cast<unsigned*>(smem) + 2 * C::WM * BN;
-            if (tid == 0) *arrival = __hip_atomic_fetch_add(d.gn_count + sample, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __syncthreads();
-            last = *arrival == (unsigned)(tps * ntiles) - 1u;
-        }
-        if (last) {
-            if (tid == 0) __hip_atomic_store(d.gn_count + sample, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            // All threads share the walk over the sample's tps tile partials: thread (chunk = tid / G, group = tid % G) adds tiles chunk,
-            // chunk + nch, ... (four loads in flight at a time), then the chunks are added in chunk order: a fixed order for a given shape,
-            // so the statistics stay bitwise reproducible.  (One thread per group walking all tps partials with dependent L2-bypassing
-            // loads kept this workgroup alive for ~50 us at 72 tiles per sample -- most of the launch: r03 autotune, ResNetV2 stage 0.)
-            double* red64 = reinterpret_cast<double*>(smem + ((2 * C::WM * BN + 2) * 4 + 7) / 8 * 8);
-            const int nch = C::THREADS / G > 0 ? C::THREADS / G : 1;
-            const int g = tid % G, ch = tid / G;
-            if (ch < nch && G <= C::THREADS) {
-                double a = 0.0, q = 0.0;
-                const float* base = d.gn_part + ((size_t)sample * tps * G + g) * 2;
-                int t = ch;
-                for (; t + 3 * nch < tps; t += 4 * nch) {
-                    float va[4], vq[4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const float* pp = base + (size_t)(t + u * nch) * G * 2;
-                        va[u] = __hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        vq[u] = __hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) { a += (double)va[u]; q += (double)vq[u]; }
-                }
-                for (; t < tps; t += nch) {
-                    const float* pp = base + (size_t)t * G * 2;
-                    a += (double)__hip_atomic_load(pp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    q += (double)__hip_atomic_load(pp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                }
-                red64[(ch * G + g) * 2] = a;
-                red64[(ch * G + g) * 2 + 1] = q;
-            }
-            __syncthreads();
-            if (tid < G) {
-                double a = 0.0, q = 0.0;
-                for (int c2 = 0; c2 < nch; ++c2) { a += red64[(c2 * G + tid) * 2]; q += red64[(c2 * G + tid) * 2 + 1]; }
-                const double cnt = (double)d.gn_hw * cpg;
-                const double mean = a / cnt;
-                double var = q / cnt - mean * mean;
-                var = var > 0.0 ? var : 0.0;
-                d.gn_stats[((size_t)sample * G + tid) * 2] = (float)mean;
-                d.gn_stats[((size_t)sample * G + tid) * 2 + 1] = (float)(1.0 / sqrt(var + (double)d.gn_eps));
-            }
+            *reinterpret_cast<float2*>(pp) = make_float2(a, q);   // plain store, nothing to wait for: the reader of out_f32 adds the partials (hybrid.hip)
         }
     }
     if (GEN && d.stamps) {

@@ -95,7 +95,7 @@ struct GnApplyArgs {
     const float *gamma = nullptr, *beta = nullptr;
     const float *raw2 = nullptr, *stats2 = nullptr, *gamma2 = nullptr, *beta2 = nullptr;   // projection shortcut: + GN2(raw2)
     const float* res = nullptr;      // identity shortcut: + res [M][C]
-    // deferred statistics (igemm gn_defer): per-tile partials of the producing convolution(s), tps = M tiles per sample of that launch; the kernel adds
+    // deferred statistics (igemm statistics epilogue): per-tile partials of the producing convolution(s), tps = M tiles per sample of that launch; the kernel adds
     // them up itself and workgroup 0 of every sample writes {mean, rstd} to stats / stats2
     const float *part = nullptr, *part2 = nullptr;
     int tps = 0, tps2 = 0;

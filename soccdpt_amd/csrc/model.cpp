@@ -383,7 +383,7 @@ void carve(const Handle& h, int B, Arena& ar, Workspace& w) {
         for (int i = 0; i < 5; ++i) w.hy_t1[i] = op(Halo{tr[i], tr[i], tc[i]}.elems(B));
         for (int i = 0; i < 4; ++i) w.hy_stats[i] = ar.take<float>((size_t)B * 32 * 2);
         w.hy_part_floats = (size_t)B * H1 * H1 * 2;              // (M / 32 tiles) x 32 groups x 2 at the stem's M = B * H1^2
-        for (int i = 0; i < 4; ++i) w.hy_part[i] = ar.take<float>(w.hy_part_floats);   // per statistics slot: the reader of the slot adds the partials (gn_defer)
+        for (int i = 0; i < 4; ++i) w.hy_part[i] = ar.take<float>(w.hy_part_floats);   // per statistics slot: the reader of the slot adds the partials
         w.vt_y = ar.take<float>((size_t)B * G * G * E);
         w.vt_xf = ar.take<float>((size_t)B * NT * E);
         w.vt_xb = op((size_t)B * NT * E);
@@ -790,11 +790,11 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         for (int s3 = 0; s3 < 3; ++s3) for (int c = 0; c < 3; ++c) fRn[s3][c] = GF(grn(s3, c + 1));
         const int fPe = GF("pe");
         // GroupNorm statistics ride on the producing convolution (igemm ST epilogue)
-        // ... as per-tile partials only (gn_defer): the reader of the raw output -- gn_apply, or gn_finish for the stem -- adds them up.  Round 5,
+        // ... as per-tile partials only: the reader of the raw output -- gn_apply, or gn_finish for the stem -- adds them up.  Round 5,
         // tools/rn_stamps.py: the producer's own last-arriver finish put three dependent memory round trips (2-7 us) behind every one of these launches.
         int bm_slot[4] = {0, 0, 0, 0};   // M-tile rows of the launch that last filled each slot
         auto with_stats = [&](IgemmDesc& d, int slot, int cout, int hw) {
-            d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part[slot]; d.gn_defer = 1; d.gn_bm_out = &bm_slot[slot]; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
+            d.gn_stats = w.hy_stats[slot]; d.gn_part = w.hy_part[slot]; d.gn_bm_out = &bm_slot[slot]; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
             d.gn_part_floats = w.hy_part_floats;
         };
         auto gn = [&](GnApplyArgs g, int om, int slot, int slot2 = -1) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise); slot(s): whose partials

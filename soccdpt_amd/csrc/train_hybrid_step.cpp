@@ -126,10 +126,17 @@ int conv_gen_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* Wtap,
     return 0;
 }
 
-void with_stats(Ctx& c, IgemmDesc& d, float* stats, int cout, int hw) {
+// GroupNorm statistics ride on the producing convolution as per-tile partials; its reader (gn_apply, gn_finish for the stem) adds them up and leaves
+// {mean, rstd} in `stats` for the backward pass (model.cpp's forward does the same: DESIGN.md 11.5)
+void with_stats(Ctx& c, IgemmDesc& d, float* stats, int cout, int hw, int slot = 0) {
     HyTape& Y = c.T.hy;
-    d.gn_stats = stats; d.gn_part = Y.gn_part; d.gn_count = Y.gn_count; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
-    d.gn_part_floats = Y.gn_part_floats; d.gn_count_words = (size_t)c.B + 8;
+    d.gn_stats = stats; d.gn_part = Y.gn_part[slot]; d.gn_bm_out = &Y.gn_bm[slot]; d.gn_cpg = cout / 32; d.gn_hw = hw; d.gn_eps = 1e-5f;
+    d.gn_part_floats = Y.gn_part_floats;
+}
+void from_partials(Ctx& c, GnApplyArgs& g, int slot, int slot2 = -1) {
+    HyTape& Y = c.T.hy;
+    g.part = Y.gn_part[slot]; g.tps = g.HW / Y.gn_bm[slot];
+    if (slot2 >= 0) { g.part2 = Y.gn_part[slot2]; g.tps2 = g.HW / Y.gn_bm[slot2]; }
 }
 
 }  // namespace
@@ -140,7 +147,6 @@ void hy_carve_halo(const Handle& h, int B, TArena& ar, Tape& T) {
     for (auto& b : Y.blk) b.t1 = ar.f((size_t)B * (b.rin + 2) * (b.rin + 2) * b.mid);
     const int G = h.arch.grid();
     Y.pp4_in = ar.f((size_t)B * (G + 2) * (G + 2) * h.arch.fdim(3));
-    Y.gn_count = reinterpret_cast<unsigned*>(ar.f((size_t)B + 8));
 }
 
 void hy_carve(const Handle& h, int B, TArena& ar, Tape& T, size_t& maxAct) {
@@ -174,8 +180,8 @@ void hy_carve(const Handle& h, int B, TArena& ar, Tape& T, size_t& maxAct) {
         maxAct = std::max(maxAct, std::max(Min * (size_t)std::max(b.cin, b.mid), Mout * (size_t)b.cout));
         maxAct = std::max(maxAct, Mout * 9 * (size_t)b.mid);   // dcol of the strided 3x3
     }
-    Y.gn_part_floats = M1s;
-    Y.gn_part = ar.f(Y.gn_part_floats);
+    Y.gn_part_floats = M1s * 2;   // (M / 32 tiles) x 32 groups x 2 at the stem's M
+    for (int i = 0; i < 2; ++i) Y.gn_part[i] = ar.f(Y.gn_part_floats);
     Y.pe_y = ar.f(Mp * E);
     Y.x0 = ar.f(Mt * E);
     Y.vb.assign(a.vit_depth, VitBlkT{});
@@ -221,6 +227,7 @@ int hy_forward(Ctx& c, const float* x) {
         d.X = Y.a0; d.Wt = Y.w_stem; d.M = B * H1 * H1; d.N = a.stem_ch; d.Cin = 160; d.ldx = 160; d.out_f32 = Y.stem_raw;
         with_stats(c, d, Y.stem_stats, a.stem_ch, H1 * H1);
         TRY(gemm(c, d));
+        TRY(launch_gn_finish(Y.gn_part[0], Y.stem_stats, B, H1 * H1 / Y.gn_bm[0], 32, H1 * H1, a.stem_ch / 32, 1e-5f, st, err));
         TRY(launch_gn_relu_maxpool(Y.stem_raw, Y.stem_stats, c.W(bb + "stem.norm.weight"), c.W(bb + "stem.norm.bias"), Y.pool, 2, B, H1, a.stem_ch, a.stem_ch / 32, st, err));
     }
     const float* xcur = Y.pool;
@@ -235,7 +242,7 @@ int hy_forward(Ctx& c, const float* x) {
             d.X = b.xin; d.Wt = b.w_ds; d.M = Mout; d.N = b.cout; d.Cin = b.cin; d.out_f32 = b.ds_raw;
             if (b.stride == 1) d.ldx = b.cin;
             else { d.gather1 = 1; d.stride = b.stride; d.pad = 0; d.in_halo = 0; d.Hi = b.rin; d.Wi = b.rin; d.H = b.rout; d.W = b.rout; }
-            with_stats(c, d, b.ds_stats, b.cout, b.rout * b.rout);
+            with_stats(c, d, b.ds_stats, b.cout, b.rout * b.rout, 1);
             TRY(gemm_fwd(c, d, (size_t)Min * b.cin, (size_t)b.cout * b.cin));   // (x3 only for the un-strided form: gemm_fwd checks)
         }
         {
@@ -247,6 +254,7 @@ int hy_forward(Ctx& c, const float* x) {
             GnApplyArgs g;
             g.raw = b.c1_raw; g.stats = b.c1_stats; g.gamma = c.W(k + "norm1.weight"); g.beta = c.W(k + "norm1.bias"); g.out_halo = b.t1;
             g.M = (size_t)Min; g.HW = b.rin * b.rin; g.W = b.rin; g.C = b.mid; g.cpg = b.mid / 32;
+            from_partials(c, g, 0);
             TRY(launch_gn_apply(g, 2, st, err));
         }
         {
@@ -259,6 +267,7 @@ int hy_forward(Ctx& c, const float* x) {
             GnApplyArgs g;
             g.raw = b.c2_raw; g.stats = b.c2_stats; g.gamma = c.W(k + "norm2.weight"); g.beta = c.W(k + "norm2.bias"); g.out_op = b.t2;
             g.M = (size_t)Mout; g.HW = b.rout * b.rout; g.W = b.rout; g.C = b.mid; g.cpg = b.mid / 32;
+            from_partials(c, g, 0);
             TRY(launch_gn_apply(g, 2, st, err));
         }
         {
@@ -275,6 +284,7 @@ int hy_forward(Ctx& c, const float* x) {
             ++cnt;
             if (stage < 2 && cnt == a.rn_layers[stage]) g.out_halo = T.feat[hook++];   // hooks on stages[0], stages[1] (vit.py:164-167)
             g.M = (size_t)Mout; g.HW = b.rout * b.rout; g.W = b.rout; g.C = b.cout; g.cpg = b.cout / 32;
+            from_partials(c, g, 0, b.proj ? 1 : -1);
             TRY(launch_gn_apply(g, 2, st, err));
             if (cnt == a.rn_layers[stage]) { ++stage; cnt = 0; }
         }

@@ -58,8 +58,8 @@ struct HyTape {
     float *pe_y, *x0;
     std::vector<VitBlkT> vb;
     float *cat[2], *ro_pre[2], *ro_act[2], *pp4_in /*halo*/, *w_pp4;
-    float* gn_part;
-    unsigned* gn_count;
+    float* gn_part[2] = {nullptr, nullptr};   // per-tile GroupNorm partials of the convolution(s) whose output is waiting for its gn_apply: [0] conv1 / conv2 / conv3, [1] the shortcut projection
+    int gn_bm[2] = {0, 0};                     // M-tile rows of the launch that last filled each buffer
     size_t gn_part_floats = 0;
     float *GT, *GR, *xg, *attn_part;           // token-stream / residual-stream gradients, strided-shortcut operand, attention segment partials
 };
