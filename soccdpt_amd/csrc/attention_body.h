@@ -183,7 +183,7 @@ __device__ __forceinline__ void window_attention_body(const bf16_t* __restrict__
             for (int st = 0; st < 2; ++st) {
                 h16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(s[t][8 * st + j]);
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h_inrange<F16>(s[t][8 * st + j]);
                 // element j of this lane half is key 32t + 16st + 8(j>>2) + 4h + (j&3): V^T must use the same k order
                 const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
                 const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
@@ -307,6 +307,9 @@ __device__ __forceinline__ void window_attention_flash_body(const bf16_t* __rest
     const int r32 = lane & 31, h = lane >> 5;
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     constexpr int HALF = WS / 2;
+    // (24 x 24 windows unsplit: 18 query blocks on 16 waves, i.e. a second round with 2 waves.  Built and removed in round 5: all 16 waves sharing the two
+    //  left-over blocks by key slices that meet in LDS, as vit_attention_kernel's halves do -- 86 -> 98 us per launch: the two waves of the second round have
+    //  a SIMD each to themselves and run their 18 tiles in a quarter of the first round's time, less than the slices' merge and the restructured loop cost.)
     for (int qb = qb_lo + wave; qb < qb_hi; qb += A::THREADS / 64) {
         const int qrow = qb * 32 + r32;
         const int qcl = qrow < A::N ? qrow : A::N - 1;
@@ -360,7 +363,12 @@ __device__ __forceinline__ void window_attention_flash_body(const bf16_t* __rest
             for (int rg = 0; rg < 16; ++rg) {
                 acc[rg] = __builtin_amdgcn_exp2f(fmaf(acc[rg], 1.4426950408889634f, -mnl));
                 psum += acc[rg];
-                o[rg] *= alpha;
+            }
+            // the key loop is VALU-bound (~180 issue slots per tile against 4 MFMAs, tools/wattn_time.py + the ISA): the running maxima settle after a few
+            // tiles, then alpha == 1 in every lane and the 16 multiplications are skipped (x 1.0 is exact: skipping them is too)
+            if (__any(alpha != 1.0f)) {
+#pragma unroll
+                for (int rg = 0; rg < 16; ++rg) o[rg] *= alpha;
             }
             l = l * alpha + psum;
             m = mn;
@@ -368,7 +376,7 @@ __device__ __forceinline__ void window_attention_flash_body(const bf16_t* __rest
             for (int st = 0; st < 2; ++st) {
                 h16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(acc[8 * st + j]);
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h_inrange<F16>(acc[8 * st + j]);   // probabilities: no clamp needed
                 const char* vrow = Vt + r32 * A::VT_STRIDE + (t * 32 + st * 16 + 4 * h) * 2;
                 const h16x4 v0 = *reinterpret_cast<const h16x4*>(vrow);
                 const h16x4 v1 = *reinterpret_cast<const h16x4*>(vrow + 16);

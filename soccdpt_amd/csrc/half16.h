@@ -29,6 +29,13 @@ __device__ __forceinline__ uint16_t f2h(float f) {
 // operands through this, so that an overflow reaches the gradients as a non-finite value and GradScaler skips the step and backs the scale off
 // -- torch.cuda.amp semantics (/root/reference/SOccDPT/scripts/train_SOccDPT.py:340,390-393).  A saturating conversion would clip silently.
 __device__ __forceinline__ uint16_t f2h_ieee(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// f32 -> 16-bit operand of a value KNOWN to lie in the format's finite range (softmax probabilities in [0, 1]): f2h without the clamp -- the same bits, one
+// v_med3_f32 per element less in the attention kernels' key loops, which are VALU-bound (round 5: 16 of ~180 issue slots per 32 x 32 key tile)
+template <bool F16>
+__device__ __forceinline__ uint16_t f2h_inrange(float f) {
+    if constexpr (F16) return __builtin_bit_cast(uint16_t, (_Float16)f);
+    else return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
 template <bool F16>
 __device__ __forceinline__ float h2f(uint16_t b) {
     if constexpr (F16) return (float)__builtin_bit_cast(_Float16, b);

@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256 * KH) void vit_attention_kernel(const uint16_t*
             for (int st = 0; st < 2; ++st) {
                 h16x8 pb;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h<F16>(acc[8 * st + j]);
+                for (int j = 0; j < 8; ++j) pb[j] = (short)f2h_inrange<F16>(acc[8 * st + j]);   // probabilities in [0, 1]: no clamp
                 // element j of this lane half is key 32t + 16st + 8(j>>2) + 4h + (j&3): V^T is read in the same k order
                 const int koff = (t * 32 + st * 16 + 4 * h) * 2;
                 {
