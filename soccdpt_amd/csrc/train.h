@@ -59,7 +59,7 @@ int tr_pad_cols(const float* in, float* out, int N, int cin, int cout, hipStream
 int tr_attention_bwd(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part, float* part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
 // MFMA form of tr_attention_bwd (train_attn.hip): no `part` scratch; rowstat holds {m + ln l, delta}; dscale_part has tr_attention_bwd_mfma_slots(ws) per (window, head)
 int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat,
-                          float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err);
+                          float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err, int op = 0);
 int tr_attention_bwd_mfma_slots(int ws);
 int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, void* out1, size_t n1, hipStream_t st, std::string& err);   // two f32 -> x3 conversions, one launch
 // Weight gradient from operands as stored (train_wgrad_tn.hip): out[Nout][taps * C] = sum_k A[k][n] B[k + shift(tap)][c], 16-bit operands

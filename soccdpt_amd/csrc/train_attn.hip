@@ -20,6 +20,7 @@
 
 #include <string>
 
+#include "half16.h"
 #include "launch.h"
 #include "train.h"
 
@@ -30,8 +31,20 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 namespace {
 
 constexpr int AST = 36;   // floats per LDS row (144 B): conflict-free for the 16-byte row reads of a half-wave and for the column reads
+template <int OP>
+__device__ __forceinline__ h16x8 frag8(const float* v) {   // OP 1: bf16 (RNE), OP 2: IEEE fp16 without a clamp (an overflow must reach GradScaler as inf: half16.h f2h_ieee)
+    h16x8 f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) f[j] = (short)(OP == 2 ? f2h_ieee(v[j]) : f2h<false>(v[j]));
+    return f;
+}
 
-template <int WS, int PASS>
+// OP: operands of the MFMA products dP, dq^ / dk^ and dv -- 0 exact f32 (v_mfma_f32_32x32x2_f32; f32 / x3 training), 1 bf16, 2 fp16 (v_mfma_f32_32x32x16: the amp modes, where
+// autocast runs these matmuls in 16 bits too, /root/reference/SOccDPT/scripts/train_SOccDPT.py:340-343).  The tiles stay f32 in LDS; fragments are rounded in
+// registers: the same k <-> (step, lane half, element) mapping on both operands of a product, so any mapping is a valid summation order.  Round 5: the f32 form
+// is 48-64 MFMAs x 64 cycles per 32 x 32 tile and wave -- with one wave per SIMD the whole kernel; in the amp modes 16 of them stay (the scores) and the other
+// 32-48 become 4-6 16-bit MFMAs x 32 cycles.
+template <int WS, int PASS, int OP = 0>
 __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ attn_out,
                                                             const float* __restrict__ table, const float* __restrict__ scale, float* __restrict__ rowstat,
                                                             float* __restrict__ dS_out, float* __restrict__ dscale_part, float* __restrict__ dqkv, int res,
@@ -41,6 +54,9 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     __shared__ __attribute__((aligned(16))) float X1[2][32 * AST];   // pass 0: k^ tile, pass 1: q^ tile (scaled)
     __shared__ __attribute__((aligned(16))) float X2[2][32 * AST];   // pass 0: v tile,  pass 1: dO tile
     __shared__ float ST[2][32][2];                                    // pass 1: {m + ln l, delta} of the walked queries
+    // the head's relative-position bias table, (2 WS - 1)^2 floats.  Round 5: read from global memory inside `cond ? x : raw + table[..]` it was sixteen loads per
+    // key tile, each under its own branch with its own s_waitcnt vmcnt(0) (tools/isa_loads.sh): sixteen dependent round trips per tile -- most of the kernel
+    __shared__ float TB[TW * TW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = heads * 32;
     const int nw = res / WS;
@@ -145,13 +161,18 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
         }
     }
 
+    h16x8 f2h_[2];   // OP != 0: the owned dO (pass 0) / v (pass 1) fragment rounded once; step ks, lane half h, element j <-> d = 16 h + 8 ks + j
+    if constexpr (OP != 0) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f2h_[ks] = frag8<OP>(&f2[8 * ks]);
+    }
     // walked index of accumulator register rg in tile t: t * 32 + (rg & 3) + 8 (rg >> 2) + 4 h
     // bias + shift mask of (query, key): table[((rq - rk + WS - 1) TW + (cq - ck + WS - 1)) heads + head]
     auto bias_of = [&](int w) -> float {
         const int wc = w < N ? w : N - 1;
         const int rw = wc / WS, cw = wc % WS;
         const int dr = PASS == 0 ? ro - rw : rw - ro, dc = PASS == 0 ? co - cw : cw - co;
-        float v = table[(size_t)((dr + WS - 1) * TW + (dc + WS - 1)) * heads + head];
+        float v = TB[(dr + WS - 1) * TW + (dc + WS - 1)];
         if ((lastrow && ((rw >= HALF) != or_hi)) || (lastcol && ((cw >= HALF) != oc_hi))) v += -100.0f;
         return v;
     };
@@ -160,6 +181,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
         for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
         const float* xrow = &X1[buf][r32 * AST + 16 * h];
+        // S = scale * cos(q, k) stays on the exact f32 MFMA in every mode: d logit_scale = sum over a row of dS * raw with sum dS = 0 -- rounding q^ / k^ to
+        // 8 bits leaves a term that does not cancel (measured: that gradient 137 % off in stage 3 with bf16 raw scores, 5e-2 is the test's bound)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float4 k4 = *reinterpret_cast<const float4*>(xrow + 4 * j);
@@ -174,9 +197,10 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
     f32x16 g1, g2;   // pass 0: g1 = dq^ (rows d, column query); pass 1: g1 = dk^, g2 = dv (rows d, column key)
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) { g1[rg] = 0.f; g2[rg] = 0.f; }
-    float m = -3.0e38f, l = 0.f, dsc = 0.f;
+    float m = -3.0e38f, l = 0.f, dsc = 0.f, dacc = 0.f;
     float* dSrow = dS_out + (wh * N + (size_t)ocl) * N;   // pass 0: the owned query's row of dS
 
+    for (int i = tid; i < TW * TW; i += 256) TB[i] = table[(size_t)i * heads + head];
     gload(0);
     lstore(0);
     __syncthreads();
@@ -193,7 +217,8 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
             for (int rg = 0; rg < 16; ++rg) {
                 const int w = t * 32 + (rg & 3) + 8 * (rg >> 2) + 4 * h;
-                s[rg] = (PASS == 0 && w >= N) ? -1.0e30f : raw[rg] + bias_of(w);
+                const float bw = bias_of(w);   // index clamped inside: read unconditionally, select after
+                s[rg] = (PASS == 0 && w >= N) ? -1.0e30f : raw[rg] + bw;
             }
             if (PASS == 0 && it < NT) {   // sweep 1: online softmax statistics of the owned query
                 float mt = s[0];
@@ -202,13 +227,44 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
                 mt = fmaxf(mt, __shfl_xor(mt, 32));
                 const float mn = fmaxf(m, mt);
                 float psum = 0.f;
+                if constexpr (OP != 0) {
+                    // 16-bit dP: delta = rowsum(P o dP) of THIS arithmetic (how softmax backward is defined, and what autograd of a 16-bit matmul gives),
+                    // accumulated online beside l.  With the exact dO . O against a rounded dP the rows of dS no longer sum to zero, and d logit_scale =
+                    // sum dS * raw picks up (row sum) * |raw|: that gradient came out 130 % off (tests/test_train_step_gpu.py bounds it at 5 %)
+                    f32x16 dp1;
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) psum += __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
-                l = l * __builtin_amdgcn_exp2f((m - mn) * LOG2E) + psum;
+                    for (int rg = 0; rg < 16; ++rg) dp1[rg] = 0.f;
+                    const float* vrow = &X2[buf][r32 * AST + 16 * h];
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float a8[8];
+                        *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(vrow + 8 * ks);
+                        *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(vrow + 8 * ks + 4);
+                        dp1 = mfma_32x32x16<OP == 2>(frag8<OP>(a8), f2h_[ks], dp1);
+                    }
+                    float dsum = 0.f;
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const float pe = __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
+                        psum += pe;
+                        dsum = fmaf(pe, dp1[rg], dsum);
+                    }
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+                    l = l * alpha + psum;
+                    dacc = dacc * alpha + dsum;
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) psum += __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
+                    l = l * __builtin_amdgcn_exp2f((m - mn) * LOG2E) + psum;
+                }
                 m = mn;
                 if (it == NT - 1) {
                     l += __shfl_xor(l, 32);
                     m_ln = m + __logf(l);
+                    if constexpr (OP != 0) {
+                        dacc += __shfl_xor(dacc, 32);
+                        delta = dacc / l;
+                    }
                 }
             } else {
                 // dP^T = X2 rows . f2
@@ -216,13 +272,23 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) dp[rg] = 0.f;
                 const float* vrow = &X2[buf][r32 * AST + 16 * h];
+                if constexpr (OP != 0) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float4 v4 = *reinterpret_cast<const float4*>(vrow + 4 * j);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.x, f2[4 * j], dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.y, f2[4 * j + 1], dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.z, f2[4 * j + 2], dp, 0, 0, 0);
-                    dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.w, f2[4 * j + 3], dp, 0, 0, 0);
+                    for (int ks = 0; ks < 2; ++ks) {
+                        float a8[8];
+                        *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(vrow + 8 * ks);
+                        *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(vrow + 8 * ks + 4);
+                        dp = mfma_32x32x16<OP == 2>(frag8<OP>(a8), f2h_[ks], dp);
+                    }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float4 v4 = *reinterpret_cast<const float4*>(vrow + 4 * j);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.x, f2[4 * j], dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.y, f2[4 * j + 1], dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.z, f2[4 * j + 2], dp, 0, 0, 0);
+                        dp = __builtin_amdgcn_mfma_f32_32x32x2f32(v4.w, f2[4 * j + 3], dp, 0, 0, 0);
+                    }
                 }
                 f32x16 p, ds;
 #pragma unroll
@@ -236,11 +302,27 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
                 // accumulate over the walked tokens: A = column reads of the tiles (token (rg & 3) + 8 (rg >> 2) + 4 h, d = r32)
                 const float* c1 = &X1[buf][(4 * h) * AST + r32];
                 const float* c2 = &X2[buf][(4 * h) * AST + r32];
+                if constexpr (OP != 0) {
+                    // step st, lane half h, element j <-> walked token 16 st + 8 (j >> 2) + 4 h + (j & 3) = the token of accumulator register 8 st + j
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int wl = (rg & 3) + 8 * (rg >> 2);
-                    g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * AST], ds[rg], g1, 0, 0, 0);
-                    if (PASS == 1) g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * AST], p[rg], g2, 0, 0, 0);
+                    for (int st = 0; st < 2; ++st) {
+                        float a8[8], b8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) { a8[j] = c1[(16 * st + 8 * (j >> 2) + (j & 3)) * AST]; b8[j] = ds[8 * st + j]; }
+                        g1 = mfma_32x32x16<OP == 2>(frag8<OP>(a8), frag8<OP>(b8), g1);
+                        if (PASS == 1) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) { a8[j] = c2[(16 * st + 8 * (j >> 2) + (j & 3)) * AST]; b8[j] = p[8 * st + j]; }
+                            g2 = mfma_32x32x16<OP == 2>(frag8<OP>(a8), frag8<OP>(b8), g2);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int wl = (rg & 3) + 8 * (rg >> 2);
+                        g1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * AST], ds[rg], g1, 0, 0, 0);
+                        if (PASS == 1) g2 = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * AST], p[rg], g2, 0, 0, 0);
+                    }
                 }
                 if (PASS == 0) {
 #pragma unroll
@@ -509,12 +591,15 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
 
 template <int WS>
 int launch_ws(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat, float* dscale_part,
-              float* dqkv, int B, int res, int shift, int heads, hipStream_t st) {
+              float* dqkv, int B, int res, int shift, int heads, hipStream_t st, int op) {
     constexpr int N = WS * WS, NT = (N + 31) / 32, NOB = (NT + 3) / 4;
     const int nw = res / WS;
     const unsigned blocks = (unsigned)(B * nw * nw * heads * NOB);
-    SOCCDPT_LAUNCH((attn_bwd_mfma_kernel<WS, 0>), dim3(blocks), dim3(256), 0, st, qkv, dO, attn_out, table, scale, rowstat, dS, dscale_part, dqkv, res, shift, heads);
-    SOCCDPT_LAUNCH((attn_bwd_mfma_kernel<WS, 1>), dim3(blocks), dim3(256), 0, st, qkv, dO, attn_out, table, scale, rowstat, dS, dscale_part, dqkv, res, shift, heads);
+#define ATTN_BWD(P, O) SOCCDPT_LAUNCH((attn_bwd_mfma_kernel<WS, P, O>), dim3(blocks), dim3(256), 0, st, qkv, dO, attn_out, table, scale, rowstat, dS, dscale_part, dqkv, res, shift, heads)
+    if (op == 1) { ATTN_BWD(0, 1); ATTN_BWD(1, 1); }
+    else if (op == 2) { ATTN_BWD(0, 2); ATTN_BWD(1, 2); }
+    else { ATTN_BWD(0, 0); ATTN_BWD(1, 0); }
+#undef ATTN_BWD
     return 0;
 }
 
@@ -530,13 +615,13 @@ int tr_attention_bwd_mfma_slots(int ws) {
 // Same contract as tr_attention_bwd (train.hip) without its `part` scratch: dqkv [B*res*res][3C] receives dq | dk | dv, dS [nwin][heads][N][N],
 // rowstat [nwin][heads][N][2] = {m + ln l, delta}, dscale_part [nwin][heads][tr_attention_bwd_mfma_slots(ws)].
 int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* dO, const float* table, const float* scale, float* dS, float* rowstat,
-                          float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err) {
+                          float* dscale_part, float* dqkv, int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err, int op) {
     if (res % ws) { err = "attention_bwd_mfma: res must be a multiple of the window size"; return 1; }
     switch (ws) {
-        case 8: launch_ws<8>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st); break;
-        case 16: launch_ws<16>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st); break;
-        case 12: launch_ws<12>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st); break;
-        case 24: launch_ws<24>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st); break;
+        case 8: launch_ws<8>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st, op); break;
+        case 16: launch_ws<16>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st, op); break;
+        case 12: launch_ws<12>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st, op); break;
+        case 24: launch_ws<24>(qkv, attn_out, dO, table, scale, dS, rowstat, dscale_part, dqkv, B, res, shift, heads, st, op); break;
         default: err = "attention_bwd_mfma: no instantiation for this window size"; return 1;
     }
     const hipError_t e = hipGetLastError();

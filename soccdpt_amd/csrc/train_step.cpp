@@ -841,8 +841,11 @@ static int encoder_backward(Ctx& c) {
             TRY(linear_bwd(c, G[0], b.attn, c.W(k + "attn.proj.weight"), M, C, C, G[2], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
             // exact-f32 MFMA form (train_attn.hip); the VALU kernels of round 2 stay selectable for A/B and as the reference form
             static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
+            // amp modes: the four products of the attention backward on 16-bit MFMAs too (autocast semantics); SOCCDPT_ATTN_BWD_F32=1 keeps them exact (A/B)
+            static const bool attn_f32 = getenv("SOCCDPT_ATTN_BWD_F32") != nullptr;
+            const int attn_op = (!attn_f32 && (c.h.train_amp == 1 || c.h.train_amp == 2)) ? c.h.train_amp : 0;
             const int dslots = attn_valu ? 0 : tr_attention_bwd_mfma_slots(wsz);
-            if (dslots) TRY(tr_attention_bwd_mfma(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
+            if (dslots) TRY(tr_attention_bwd_mfma(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, G[4], B, res, wsz, a.shift(s, j), H, st, err, attn_op));
             else TRY(tr_attention_bwd(b.qkv, b.attn, G[2], b.table, b.scale, T.dS, T.rowstat, T.dscale_part, T.attn_part, G[4], B, res, wsz, a.shift(s, j), H, st, err));
             {
                 float* dls = c.Gd(k + "attn.logit_scale");
