@@ -401,7 +401,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------------
 constexpr int VST = 68;   // floats per LDS row (272 B = 17 x 16)
 
-template <int PASS>
+template <int PASS, int OP = 0>   // OP as in attn_bwd_mfma_kernel: 16-bit operands for dP, dq / dk and dv in the amp modes; the scores stay exact f32
 __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dO, const float* __restrict__ attn_out,
                                                                 float* __restrict__ rowstat, float* __restrict__ dqkv, int N, int heads) {
     constexpr float LOG2E = 1.4426950408889634f;
@@ -492,6 +492,25 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
             delta += __shfl_xor(delta, 32);
         }
     }
+    h16x8 f2h_[4];   // OP != 0: the owned dO (pass 0) / v (pass 1) fragment rounded once; step ks, lane half h, element j <-> d = 32 h + 8 ks + j
+    if constexpr (OP != 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f2h_[ks] = frag8<OP>(&f2[8 * ks]);
+    }
+    auto rows_dot16 = [&](const float* X) -> f32x16 {   // X rows . the owned f2 fragment on 16-bit MFMAs
+        f32x16 acc;
+#pragma unroll
+        for (int rg = 0; rg < 16; ++rg) acc[rg] = 0.f;
+        const float* xrow = X + r32 * VST + 32 * h;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            float a8[8];
+            *reinterpret_cast<float4*>(a8) = *reinterpret_cast<const float4*>(xrow + 8 * ks);
+            *reinterpret_cast<float4*>(a8 + 4) = *reinterpret_cast<const float4*>(xrow + 8 * ks + 4);
+            acc = mfma_32x32x16<OP == 2>(frag8<OP == 0 ? 1 : OP>(a8), f2h_[ks], acc);
+        }
+        return acc;
+    };
     auto rows_dot = [&](const float* X, const float* f) -> f32x16 {   // rows = walked tokens of the tile, column = owned token
         f32x16 acc;
 #pragma unroll
@@ -511,7 +530,7 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
     f32x16 g1a, g1b, g2a, g2b;   // rows d (a: 0..31, b: 32..63), column owned token
 #pragma unroll
     for (int rg = 0; rg < 16; ++rg) { g1a[rg] = 0.f; g1b[rg] = 0.f; g2a[rg] = 0.f; g2b[rg] = 0.f; }
-    float m = -3.0e38f, l = 0.f;
+    float m = -3.0e38f, l = 0.f, dacc = 0.f;
 
     gload(0);
     lstore(0);
@@ -537,16 +556,36 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
                 mt = fmaxf(mt, __shfl_xor(mt, 32));
                 const float mn = fmaxf(m, mt);
                 float psum = 0.f;
+                if constexpr (OP != 0) {   // delta = rowsum(P o dP) of the 16-bit dP, accumulated online (see attn_bwd_mfma_kernel)
+                    const f32x16 dp1 = rows_dot16(X2[buf]);
+                    float dsum = 0.f;
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) psum += __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
-                l = l * __builtin_amdgcn_exp2f((m - mn) * LOG2E) + psum;
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const float pe = __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
+                        psum += pe;
+                        dsum = fmaf(pe, dp1[rg], dsum);
+                    }
+                    const float alpha = __builtin_amdgcn_exp2f((m - mn) * LOG2E);
+                    l = l * alpha + psum;
+                    dacc = dacc * alpha + dsum;
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) psum += __builtin_amdgcn_exp2f((s[rg] - mn) * LOG2E);
+                    l = l * __builtin_amdgcn_exp2f((m - mn) * LOG2E) + psum;
+                }
                 m = mn;
                 if (it == NT - 1) {
                     l += __shfl_xor(l, 32);
                     m_ln = m + __logf(l);
+                    if constexpr (OP != 0) {
+                        dacc += __shfl_xor(dacc, 32);
+                        delta = dacc / l;
+                    }
                 }
             } else {
-                const f32x16 dp = rows_dot(X2[buf], f2);
+                f32x16 dp;
+                if constexpr (OP != 0) dp = rows_dot16(X2[buf]);
+                else dp = rows_dot(X2[buf], f2);
                 f32x16 p, ds;
 #pragma unroll
                 for (int rg = 0; rg < 16; ++rg) {
@@ -558,14 +597,41 @@ __global__ __launch_bounds__(256) void vit_attn_bwd_mfma_kernel(const float* __r
                 }
                 const float* c1 = &X1[buf][(4 * h) * VST + r32];
                 const float* c2 = &X2[buf][(4 * h) * VST + r32];
+                if constexpr (OP != 0) {
 #pragma unroll
-                for (int rg = 0; rg < 16; ++rg) {
-                    const int wl = (rg & 3) + 8 * (rg >> 2);
-                    g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST], ds[rg], g1a, 0, 0, 0);
-                    g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST + 32], ds[rg], g1b, 0, 0, 0);
-                    if (PASS == 1) {
-                        g2a = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST], p[rg], g2a, 0, 0, 0);
-                        g2b = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST + 32], p[rg], g2b, 0, 0, 0);
+                    for (int st = 0; st < 2; ++st) {   // step st, lane half h, element j <-> walked token 16 st + 8 (j >> 2) + 4 h + (j & 3) = accumulator register 8 st + j
+                        float a8[8], b8[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) b8[j] = ds[8 * st + j];
+                        const h16x8 dsf = frag8<OP>(b8);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a8[j] = c1[(16 * st + 8 * (j >> 2) + (j & 3)) * VST];
+                        g1a = mfma_32x32x16<OP == 2>(frag8<OP>(a8), dsf, g1a);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a8[j] = c1[(16 * st + 8 * (j >> 2) + (j & 3)) * VST + 32];
+                        g1b = mfma_32x32x16<OP == 2>(frag8<OP>(a8), dsf, g1b);
+                        if (PASS == 1) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) b8[j] = p[8 * st + j];
+                            const h16x8 pf = frag8<OP>(b8);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a8[j] = c2[(16 * st + 8 * (j >> 2) + (j & 3)) * VST];
+                            g2a = mfma_32x32x16<OP == 2>(frag8<OP>(a8), pf, g2a);
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) a8[j] = c2[(16 * st + 8 * (j >> 2) + (j & 3)) * VST + 32];
+                            g2b = mfma_32x32x16<OP == 2>(frag8<OP>(a8), pf, g2b);
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int rg = 0; rg < 16; ++rg) {
+                        const int wl = (rg & 3) + 8 * (rg >> 2);
+                        g1a = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST], ds[rg], g1a, 0, 0, 0);
+                        g1b = __builtin_amdgcn_mfma_f32_32x32x2f32(c1[wl * VST + 32], ds[rg], g1b, 0, 0, 0);
+                        if (PASS == 1) {
+                            g2a = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST], p[rg], g2a, 0, 0, 0);
+                            g2b = __builtin_amdgcn_mfma_f32_32x32x2f32(c2[wl * VST + 32], p[rg], g2b, 0, 0, 0);
+                        }
                     }
                 }
             }
@@ -631,11 +697,14 @@ int tr_attention_bwd_mfma(const float* qkv, const float* attn_out, const float* 
 
 
 // ViT form: qkv [B*N][3E], O / dO [B*N][E], rowstat B * heads * N * 2 floats of scratch, dqkv [B*N][3E]
-int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err) {
+int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err, int op) {
     const int NT = (N + 31) / 32, NOB = (NT + 3) / 4;
     const unsigned blocks = (unsigned)(B * heads * NOB);
-    SOCCDPT_LAUNCH(vit_attn_bwd_mfma_kernel<0>, dim3(blocks), dim3(256), 0, st, qkv, dO, O, rowstat, dqkv, N, heads);
-    SOCCDPT_LAUNCH(vit_attn_bwd_mfma_kernel<1>, dim3(blocks), dim3(256), 0, st, qkv, dO, O, rowstat, dqkv, N, heads);
+#define VIT_BWD(P, OPV) SOCCDPT_LAUNCH((vit_attn_bwd_mfma_kernel<P, OPV>), dim3(blocks), dim3(256), 0, st, qkv, dO, O, rowstat, dqkv, N, heads)
+    if (op == 1) { VIT_BWD(0, 1); VIT_BWD(1, 1); }
+    else if (op == 2) { VIT_BWD(0, 2); VIT_BWD(1, 2); }
+    else { VIT_BWD(0, 0); VIT_BWD(1, 0); }
+#undef VIT_BWD
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) { err = std::string("vit_attention_bwd_mfma: ") + hipGetErrorString(e); return 1; }
     return 0;

@@ -24,7 +24,7 @@ int th_readout_cat_bwd(const float* dcat, float* dtok, int B, int NT, int E, int
 int th_tokens_to_patches(const float* dtok, float* dpatch, int B, int NT, int E, hipStream_t st, std::string& err);
 size_t th_vit_attention_part_floats(int B, int N, int heads);
 int th_vit_attention_fwd(const float* qkv, float* out, float* rowstat, float* part, int B, int N, int heads, hipStream_t st, std::string& err);
-int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err);   // train_attn.hip
+int th_vit_attention_bwd_mfma(const float* qkv, const float* O, const float* dO, float* rowstat, float* dqkv, int B, int N, int heads, hipStream_t st, std::string& err, int op);   // train_attn.hip (op: 0 exact f32, 1 bf16, 2 fp16 products)
 int th_vit_attention_bwd(const float* qkv, const float* O, const float* dO, const float* rowstat, float* part, float* dqkv, int B, int N, int heads, hipStream_t st,
                          std::string& err);
 
@@ -405,7 +405,11 @@ int hy_backward(Ctx& c) {
         TRY(linear_bwd(c, G[2], v.attn, c.W(k + "attn.proj.weight"), Mt, E, E, G[0], nullptr, c.Gd(k + "attn.proj.weight"), c.Gd(k + "attn.proj.bias")));
         static const bool attn_valu = getenv("SOCCDPT_ATTN_BWD_VALU") != nullptr;
         if (attn_valu) TRY(th_vit_attention_bwd(v.qkv, v.attn, G[0], v.rowstat, Y.attn_part, G[4], B, NT, a.vit_heads, st, err));
-        else TRY(th_vit_attention_bwd_mfma(v.qkv, v.attn, G[0], v.rowstat, G[4], B, NT, a.vit_heads, st, err));
+        else {
+            static const bool attn_f32 = getenv("SOCCDPT_ATTN_BWD_F32") != nullptr;   // A/B: keep the exact products in the amp modes too
+            const int attn_op = (!attn_f32 && (c.h.train_amp == 1 || c.h.train_amp == 2)) ? c.h.train_amp : 0;
+            TRY(th_vit_attention_bwd_mfma(v.qkv, v.attn, G[0], v.rowstat, G[4], B, NT, a.vit_heads, st, err, attn_op));
+        }
         TRY(linear_bwd(c, G[4], v.ln1, c.W(k + "attn.qkv.weight"), Mt, 3 * E, E, G[1], nullptr, c.Gd(k + "attn.qkv.weight"), c.Gd(k + "attn.qkv.bias")));
         TRY(ln_bwd(c, v.xin, c.W(k + "norm1.weight"), G[1], G[0], G[3], Mt, E, c.Gd(k + "norm1.weight"), c.Gd(k + "norm1.bias"), kLnEps));
         TRY(copy_d2d(c, Y.GT, G[2], Mt * E * 4, "hy_backward"));
