@@ -9,6 +9,7 @@
 //   * class token + position embedding + the first pre-norm LayerNorm, and the pre-norm LayerNorm (eps 1e-6) of every ViT block.
 // All of them are HBM-bound elementwise / row kernels: 16-byte accesses, NHWC, no LDS staging needed except the row reductions.
 // OUT selects the operand format written for the next GEMM: 0 = bf16, 1 = fp16, 2 = f32, 3 = x3 split fp16 (half16.h; SOCCDPT_PREC_F16X3).
+#include <stdio.h>
 #include <stdlib.h>
 #include "half16.h"
 #include "kernels.h"
@@ -453,6 +454,8 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     const int tmax = a.part ? (a.raw2 && a.tps2 > a.tps ? a.tps2 : a.tps) : 0;
     d.mode = !a.part ? 0 : (tmax <= kGnDirectTps ? 1 : (tmax <= kGnCoopTps && 256 % G == 0 ? 2 : 0));
     static const int dbg_stale = getenv("SOCCDPT_DBG_GN_STALE") ? atoi(getenv("SOCCDPT_DBG_GN_STALE")) : 0;   // timing-only ablation: 1 = no finish at all (statistics of the previous forward), 2 = also one pixel per thread
+    static const bool dbg_warned = dbg_stale ? (fprintf(stderr, "soccdpt: SOCCDPT_DBG_GN_STALE is set: TIMING-ONLY ablation -- GroupNorm statistics are those of the previous forward, results are wrong unless the input repeats\n"), true) : false;
+    (void)dbg_warned;
     bool skip_finish = false;   // bit 0: the per-thread walks, bit 1: the workgroup walks, bit 2: the finish launches
     if (a.part && d.mode == 1 && (dbg_stale & 1)) { d.mode = 0; skip_finish = true; }
     if (a.part && d.mode == 1 && !a.raw2 && (dbg_stale == 8 || dbg_stale == 16)) { d.mode = dbg_stale == 8 ? 3 : 4; skip_finish = true; }
