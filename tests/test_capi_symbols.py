@@ -85,6 +85,43 @@ def test_device_code_has_no_packed_f32_ops(tmp_path):
     assert packed == 0, f"{packed} packed-f32 instructions in the device code"
 
 
+def test_gn_apply_issues_its_partial_loads_back_to_back(tmp_path):
+    """gn_apply_kernel adds up to twelve per-tile GroupNorm partials per thread.  Written as `tt < tps ? part[tt] : 0` every one of them compiled to
+    s_cbranch_execz / global_load / s_waitcnt vmcnt(0): nine dependent L2 round trips in a launch that is one round of workgroups long (DESIGN.md 11.5,
+    4.44 -> 4.30 ms on the hybrid forward once the addresses were clamped and the select moved behind the loads).  Guard: in every gn_apply instantiation of the
+    shipped code object there is a run of at least 8 global_load_dwordx2 with no branch and no s_waitcnt vmcnt(0) between them."""
+    import shutil
+    import subprocess
+    objdump = "/opt/rocm/lib/llvm/bin/llvm-objdump"
+    so = os.path.join(REPO, "soccdpt_amd", "libsoccdpt_hip.so")
+    if not os.path.exists(objdump) or not os.path.exists(so):
+        pytest.skip("llvm-objdump or the built library is not present")
+    local = str(tmp_path / "lib.so")
+    shutil.copy(so, local)
+    subprocess.run([objdump, "--offloading", local], check=True, capture_output=True, cwd=str(tmp_path))
+    bundles = [f for f in os.listdir(tmp_path) if f.endswith("gfx950")]
+    assert bundles
+    seen = 0
+    for b in bundles:
+        asm = subprocess.run([objdump, "-d", "--no-show-raw-insn", str(tmp_path / b)], check=True, capture_output=True, text=True).stdout
+        name, run, best = None, 0, 0
+        for line in asm.splitlines() + ["0 <end>:"]:
+            m = re.match(r"^[0-9a-f]+ <(.+)>:$", line)
+            if m:
+                if name and "gn_apply_kernel" in name:
+                    seen += 1
+                    assert best >= 8, (name, best)
+                name, run, best = m.group(1), 0, 0
+                continue
+            t = line.strip()
+            if t.startswith("global_load_dwordx2"):
+                run += 1
+                best = max(best, run)
+            elif t.startswith("s_cbranch") or (t.startswith("s_waitcnt") and "vmcnt(0)" in t):
+                run = 0
+    assert seen >= 8, seen          # 4 output formats x pixels-per-thread variants
+
+
 def test_igemm_kernels_use_no_scratch(tmp_path):
     """Every igemm_kernel instantiation must keep its descriptor and address arrays in registers: a select between two per-thread arrays
     once demoted the whole IgemmDesc to private memory in 24 instantiations (472 bytes of scratch per lane, 4-5x slower launches) without
