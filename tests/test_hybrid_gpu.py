@@ -23,7 +23,7 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("B,N", [(1, 577), (3, 577), (2, 64), (1, 33)])
+@pytest.mark.parametrize("B,N", [(1, 577), (3, 577), (8, 577), (2, 64), (1, 33), (2, 20)])   # (2, 20): one key tile -- the second key half of the 8-wave form is empty
 def test_vit_attention_vs_torch(gpu_device, precision, B, N):
     """softmax(q k^T / 8) v over a prime-length sequence (ragged last key tile, padded query block) and short sequences."""
     from soccdpt_amd.lib import op_vit_attention
