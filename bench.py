@@ -173,19 +173,26 @@ def igemm_roofline(stats, prof_steps, precision, pmc=None):
     peak = flops / sum(v["flops"] / peak_of(n) for n, v in mem.items())
     ach = flops / (ms * 1e-3) / 1e12
     total_ms = sum(v["ms"] for v in stats.values())
-    roof = dict(bound="mfma", kernel="igemm_kernel (all tile configurations)", achieved=round(ach, 2), peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
+    # `peak` / `frac`: the guide's dense 16-bit MFMA peak (2500 TFLOP/s) for every 16-bit arithmetic, whatever operand splitting the launches chose -- three
+    # MFMAs per product (x3) or two (x2w) are an implementation cost, not algorithmic work; the exact-f32 mode is priced
+    # against the f32 MFMA peak.  The FLOP-weighted harmonic mean of the members' own peaks (what rounds 3-5 printed as `frac`) moves to
+    # blended_peak / frac_vs_blended_peak.
+    top = PEAK_F32_TFLOPS if precision == "f32" else PEAK_BF16_TFLOPS
+    roof = dict(bound="mfma", kernel="igemm_kernel (all tile configurations)", achieved=round(ach, 2), peak=top, unit="TFLOP/s", frac=round(ach / top, 4),
                 traffic=None, avg_launch_us=round(ms * 1e3 / launches, 2), share_of_device_time=round(ms / total_ms, 4),
                 flops_per_step=flops / prof_steps, launches_per_step=launches / prof_steps)
-    # the same achieved rate against the guide's dense 16-bit MFMA peak, whatever arithmetic the launches chose: three MFMAs per product (x3) are an
-    # implementation cost, not algorithmic work; `frac` keeps the blended denominator for continuity
-    roof["frac_of_16bit_peak"] = round(ach / PEAK_BF16_TFLOPS, 4) if not precision == "f32" else None
+    roof["frac_of_16bit_peak"] = round(ach / PEAK_BF16_TFLOPS, 4) if not precision == "f32" else None   # = frac for the 16-bit modes (kept: rounds 4-5 consumers read it)
+    roof["blended_peak"] = round(peak, 1)
+    roof["frac_vs_blended_peak"] = round(ach / peak, 4)
     if precision == "mixed":
-        roof["peak_note"] = "FLOP-weighted harmonic mean of 2500 (fp16 launches) and 833.3 (x3 launches: three MFMAs per algorithmic product); frac_of_16bit_peak = achieved / 2500"
+        roof["peak_note"] = "frac = achieved / 2500 (dense 16-bit MFMA); blended_peak = FLOP-weighted harmonic mean of 2500 (fp16 launches) and 833.3 (x3 launches: three MFMAs per algorithmic product)"
     by = []
     for name in sorted(mem, key=lambda n: -mem[n]["ms"]):
         v = mem[name]
         e = dict(config=name, launches_per_step=v["launches"] / prof_steps, avg_launch_us=round(v["ms"] * 1e3 / v["launches"], 2),
-                 achieved=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2), frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(name), 4),
+                 achieved=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                 frac=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / (PEAK_F32_TFLOPS if name.startswith("igemm_f32") else PEAK_BF16_TFLOPS), 4),
+                 frac_vs_format_peak=round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_of(name), 4),
                  frac_of_16bit_peak=(None if name.startswith("igemm_f32") else round(v["flops"] / (v["ms"] * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)))
         if pmc and name in pmc:
             e["traffic"] = round(pmc[name]["hbm_bytes_per_launch"])
@@ -252,6 +259,12 @@ def main():
     ap.add_argument("--calibrate", action="store_true",
                     help="--precision mixed: derive the precision map on the bound weights with soccdpt_prec_calibrate (sample = the first two frames of the "
                          "benchmark batch, budget = the bar of `tolerance`) before timing; config.precision_map_source says which map `value` ran")
+    ap.add_argument("--weights", default="salt0", choices=["salt0", "salt1", "salt2", "trained_like"],
+                    help="which synthetic checkpoint is bound (soccdpt_amd/utils/synth.py named_weights): salt0 = the draw the shipped precision maps were derived on "
+                         "(default); any other set is what a user's own checkpoint looks like to the library: --precision mixed then calibrates on six other frames "
+                         "(4 select + 2 verify) before timing unless --no-calibrate is given (all-x3 operands then)")
+    ap.add_argument("--no-calibrate", action="store_true", help="--weights <other>: time the uncalibrated default (every group x3) instead of calibrating")
+    ap.add_argument("--no-other-weights", action="store_true", help="skip the `other_weights` side object (salt1 and trained_like: all-x3 and calibrated frames/s)")
     ap.add_argument("--no-side-modes", action="store_true", help="skip the bf16 / fp16 side legs and the live error measurement")
     ap.add_argument("--graph", action="store_true", help="replay the network as a captured hipGraph (measured: slower than eager)")
     ap.add_argument("--prewarm", type=int, default=100, help="untimed clock/allocator pre-warm forwards before the W warm-up steps")
@@ -298,7 +311,7 @@ def main():
     import torch.distributed as dist
     from soccdpt_amd import dist as sdist
     from soccdpt_amd.model.SOccDPT import SOccDPT_V3
-    from soccdpt_amd.utils.synth import synth_input, synth_state_dict, write_synth_calib
+    from soccdpt_amd.utils.synth import named_weights, synth_input, synth_state_dict, write_synth_calib
 
     rank, local, world = sdist.init_from_env("nccl")
     if world != max(args.gpus, 1):
@@ -307,9 +320,9 @@ def main():
     dev = torch.device("cuda", local)
     torch.cuda.set_device(dev)
 
-    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     import contextlib
     import io
+    calib = write_synth_calib(os.path.join(tempfile.mkdtemp(), "calib.yaml"))
     with contextlib.redirect_stdout(io.StringIO()):
         net = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=args.streams,
                          model_type=args.model_type,
@@ -317,16 +330,20 @@ def main():
     from soccdpt_amd.model.spec import MODEL_TYPE_TO_BACKBONE, backbone_image_size
     backbone = MODEL_TYPE_TO_BACKBONE[args.model_type]
     img = backbone_image_size(backbone)
-    sd = synth_state_dict(backbone, alias_pretrained=True)
+    sd = named_weights(args.weights, backbone)
     net.load_state_dict(sd, strict=False)
     net = net.eval().to(dev)
     sdist.attach(net)
 
     B = args.batch
     x = synth_input(B, size=img, seed0=rank * B).to(dev)   # different frames per rank
+    budget = 1e-3 if args.model_type == "dpt_hybrid_384" else 5e-4
+    n_cal = 6 if img <= 256 else 3                       # calibration sample: 4 + 2 frames (2 + 1 at 384 px), none of them in the benchmark batch
+    x_cal = synth_input(n_cal, size=img, seed0=5000 + rank * n_cal).to(dev)
     calib_report = None
-    if args.calibrate and args.precision == "mixed":
-        calib_report = net.calibrate_precision(x[:2].contiguous(), budget=1e-3 if args.model_type == "dpt_hybrid_384" else 5e-4)
+    if args.precision == "mixed" and (args.calibrate or (args.weights != "salt0" and not args.no_calibrate)):
+        with contextlib.redirect_stdout(io.StringIO()):
+            calib_report = net.calibrate_precision(x_cal, budget=budget)
 
     def barrier():
         if dist.is_initialized():
@@ -455,7 +472,7 @@ def main():
                         "note": "value / ms_per_step are the median repeat (rank-0 clock; with N > 1 the maximum over ranks of each rank's median)"},
             "vs_baseline": None, "dtype": dtype_name, "data": "synthetic",
             "config": {"workload": f"SOccDPT_V3 {args.model_type} full forward, compute_occ=True, camera 1920x1080",
-                       "batch_per_gpu": B, "global_batch": B * world, "image": img, "streams_per_gpu": args.streams, "hip_graph": args.graph,
+                       "batch_per_gpu": B, "global_batch": B * world, "image": img, "weights": args.weights, "streams_per_gpu": args.streams, "hip_graph": args.graph,
                        "parallelism": f"dp{world}" if world > 1 else "single", "dist_backend": (dist.get_backend() if dist.is_initialized() else None),
                        "exchange": "RCCL all-gather of bit-packed occupancy grids (786432 B/rank)" if world > 1 else "none",
                        "precision_map_x3_groups": (sorted(g for g, f in eng.prec_map().items() if f == 3) if args.precision == "mixed" else None),
@@ -477,12 +494,24 @@ def main():
     single = rank == 0 and world == 1 and not args.graph and args.streams == 1
     side_ok = single and not args.headline_only and not args.no_side_modes
 
-    def build(prec_name, streams=1):
+    def build(prec_name, streams=1, weights=None):
         with contextlib.redirect_stdout(io.StringIO()):
             m = SOccDPT_V3(sigmoid=False, load_depth=False, camera_intrinsics_yaml=calib, compute_occ=True, streams=streams,
                            model_type=args.model_type, precision=PREC_CODE[prec_name])
-        m.load_state_dict(sd, strict=False)
-        return m.eval().to(dev)
+            m.load_state_dict(sd if weights is None else weights, strict=False)
+            m = m.eval().to(dev)
+            m.network(x[:1])   # binds and prepares (the uncalibrated-weights notice goes to the discarded stream)
+        return m
+
+    def time_steps(m, steps):
+        for _ in range(args.warmup):
+            m(x)
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(steps):
+            m(x)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t
 
     # ---- B = 1 latency: the protocol behind the paper's 47 Hz (/root/reference/SOccDPT/scripts/eval_SOccDPT.py:246-259: 50 forwards of ONE frame,
     # fps = 50 / elapsed), here WITH a device synchronisation on both sides of the 50 forwards.  x_paper_hz compares like with like.
@@ -521,7 +550,7 @@ def main():
         ref = quantities(ref_net)
         del ref_net
 
-        def errors(m):
+        def errors(m, ref=ref):
             q = quantities(m)
             e = {k: float((q[k] - ref[k]).norm() / ref[k].norm()) for k in QUANTITIES}
             pix = ((q["inv"] - ref["inv"]).abs() / ref["inv"].abs().clamp_min(1e-6)).flatten()
@@ -553,9 +582,47 @@ def main():
             measured[side] = err_side
             result[f"{side}_operands"] = {"value": round(B * args.steps / es, 2), "unit": "frames/s", "ms_per_step": round(es / args.steps * 1e3, 3),
                                           "device_ms_per_step": round(sum(v["ms"] for v in st_side.values()) / prof_steps, 3),
-                                          "roofline": {k: rs[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "avg_launch_us")} if rs else None,
+                                          "roofline": {k: rs[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "frac_vs_blended_peak", "avg_launch_us")} if rs else None,
                                           "errors_vs_f32_mode": err_side}
             del m
+    # ---- what OTHER weights get: the headline's precision map is valid for the benchmark's own synthetic draw only.  For two more
+    # checkpoints -- another draw of the generator and one with trained-like statistics -- bind them, time the uncalibrated default (the library runs every
+    # group in x3 operands), calibrate on six frames that are not in the benchmark batch (4 select the map at 0.85 x budget, 2 verify it at the budget
+    # inside the library), time the calibrated map, and measure it on the BENCHMARK batch -- frames no part of the calibration saw -- against the
+    # library's exact-f32 mode on the same weights.
+    if side_ok and args.precision == "mixed" and not args.no_other_weights:
+        ow = {}
+        for wname in [w for w in ("salt1", "trained_like") if w != args.weights]:
+            wsd = named_weights(wname, backbone)
+            rf = build("f32", weights=wsd)
+            ref_w = quantities(rf)
+            del rf
+            m = build("mixed", weights=wsd)
+            src0 = m.precision_map_source(dev)
+            err_x3 = errors(m, ref_w)
+            e_x3 = time_steps(m, args.steps)
+            with contextlib.redirect_stdout(io.StringIO()):
+                rep = m.calibrate_precision(x_cal, budget=budget)
+            err_cal = errors(m, ref_w)
+            e_cal = time_steps(m, args.steps)
+            ow[wname] = {"uncalibrated": {"precision_map_source": src0, "value": round(B * args.steps / e_x3, 2), "ms_per_step": round(e_x3 / args.steps * 1e3, 3),
+                                          "worst_vs_f32_mode": max(v for k, v in err_x3.items() if k in QUANTITIES)},
+                         "calibrated": {"precision_map_source": m.precision_map_source(dev), "value": round(B * args.steps / e_cal, 2), "ms_per_step": round(e_cal / args.steps * 1e3, 3),
+                                        "n_groups": rep["n_groups"], "n_x3": rep["n_x3"], "n_x2w": rep["n_x2w"], "forwards": rep["forwards"],
+                                        "calib_frames": rep["calib_frames"], "holdout_frames": rep["holdout_frames"], "headroom": round(rep["headroom"], 3),
+                                        "library_worst_calibration_frames": float(f"{rep['worst_calibrated']:.3e}"), "library_worst_holdout_frames": float(f"{rep['worst_holdout']:.3e}"),
+                                        "met_budget": bool(rep["met_budget"] and rep["met_holdout"] != 0),
+                                        "heldout_benchmark_batch_vs_f32_mode": err_cal,
+                                        "heldout_worst": max(v for k, v in err_cal.items() if k in QUANTITIES),
+                                        "heldout_within_budget": max(v for k, v in err_cal.items() if k in QUANTITIES) <= budget},
+                         "vs_headline": round((B * args.steps / e_cal) / result["value"], 3)}
+            del m
+        result["other_weights"] = {"budget": budget, "unit": "frames/s", "sets": ow,
+                                   "note": "value (top level) runs the shipped precision map on the synthetic draw it was derived on; these are the same forward on "
+                                           "checkpoints the map was NOT derived on: uncalibrated = the library's safe default for unknown weights (every group x3), "
+                                           "calibrated = after net.calibrate_precision(6 frames: 4 select at headroom x budget, 2 verify at budget); heldout_* = relative L2 "
+                                           "(and per-pixel p99.9 / max of the inverse depth) on the benchmark batch, which the calibration never saw"}
+
     if rank == 0 and result is not None:
         # Which arithmetic meets the north star's tolerance (1e-3 relative on depth maps / class logits), stated as top-level fields (VERDICT r1 #5e)
         # and, since round 4, MEASURED in this run: relative L2 of every hooked feature map, path_1, inverse depth and the class logits against the
@@ -574,6 +641,9 @@ def main():
         result["tolerance"] = {"north_star": "1e-3 relative (depth, logits), voxel indices bit-exact at the projection boundary",
                                "bar_for_value": bar, "bar_note": f"relative L2 of feat0-3, path_1, inverse depth, class logits vs the exact-f32 mode, measured in this run at the benchmark's batch ({B} frames)"
                                if measured else "not measured in this run (side modes off): the static table of tests/ applies",
+                               "reading": "relative L2 per quantity (||a - ref|| / ||ref||); per_pixel = the same inverse depth element-wise, |a - ref| / max(|ref|, 1e-6): its 99.9th percentile and maximum",
+                               "per_pixel": ({p: {"inv_p999": measured[p]["inv_per_pixel_p999"], "inv_max": measured[p]["inv_per_pixel_max"],
+                                                  "p999_within_1e-3": measured[p]["inv_per_pixel_p999"] <= 1e-3} for p in measured} if measured else None),
                                "dtype_of_value": args.precision, "value_meets_tolerance": bool(meets[args.precision]),
                                "worst_measured": {p: worst(p) for p in measured}, "measured": measured,
                                "meets_north_star_1e-3": {p: (worst(p) <= 1e-3) for p in measured},

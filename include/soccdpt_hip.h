@@ -32,7 +32,7 @@ extern "C" {
  *     soccdpt_set_stage_xcd / soccdpt_stage_xcd_status);
  *   4 round 5 (the opt-in XCD-local persistent stage kernel and its three entry points are gone: measured 13-15 % slower than the launch
  *     chain in round 4; soccdpt_prec_calibrate and the precision-map source query are new). */
-#define SOCCDPT_ABI_VERSION 4
+#define SOCCDPT_ABI_VERSION 5
 
 /* backbone ids: model/loader.py:65-77 (model_type switch), model/blocks.py:59-78 */
 #define SOCCDPT_BACKBONE_SWIN2T16_256 0 /* dpt_swin2_tiny_256 */
@@ -91,7 +91,7 @@ void soccdpt_destroy(void* handle);
 const char* soccdpt_last_error(void* handle); /* handle may be NULL: last create error */
 int soccdpt_abi_version(void);
 /* sizeof of the public structs as the LIBRARY was compiled (a binding checks its own layout against these): which = 0 soccdpt_config,
- * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat, 3 soccdpt_calib_report; unknown -> 0 */
+ * 1 soccdpt_igemm_args, 2 soccdpt_kernel_stat, 3 soccdpt_calib_report, 4 soccdpt_calib_options; unknown -> 0 */
 size_t soccdpt_sizeof(int which);
 
 /* ---- precision map (SOCCDPT_PREC_MIXED handles only) ----
@@ -125,7 +125,12 @@ int soccdpt_prec_map_get(void* handle, char* buf, int buf_bytes);
  *   3. greedy selection over single-group upgrades (fp16 -> x2w -> x3) by variance removed per microsecond (compiled-in per-group device-time
  *      costs, csrc/prec_cost_table.h) until every quantity's predicted error is under `budget`, checked by a measured run (tightened and
  *      repeated if the additive model was optimistic);
- *   4. measured prune: demote groups one level at a time, largest saving first, while the measured worst error stays under the budget.
+ *   4. measured prune: demote groups one level at a time, largest saving first, while the acceptance rule below still passes.
+ * Acceptance rule (round 6): a map is accepted when its MEASURED worst error over the calibration frames is <= headroom x budget (default 0.85:
+ * the frame-to-frame spread of the error is a few per cent, round 5 measured calibrated maps at 1.15 x budget on other frames) AND, when
+ * `holdout` > 0, the last `holdout` frames of dev_x -- which take no part in the variance estimates or the selection -- come in under the budget
+ * itself.  per_pixel_p999 > 0 adds an eighth constraint: the 99.9th percentile over pixels of |inv - ref| / max(|ref|, 1e-6) (inverse depth) must be
+ * <= per_pixel_p999 (scaled into the same selection; the relative-L2 reading of the tolerance lets ~1 pixel in a thousand exceed it otherwise).
  * The handle's map is replaced by the result (soccdpt_prec_map_source() == 1) and its weights are prepared for it.  Synchronises; runs about
  * (2 x groups + promoted groups + 10) forwards of the sample.  All device memory comes from the caller: dev_prepared / dev_workspace as for
  * soccdpt_prepare / soccdpt_network at batch B, dev_scratch of soccdpt_prec_calibrate_scratch_bytes(handle, B) bytes.
@@ -143,10 +148,33 @@ typedef struct soccdpt_calib_report {
     float worst_calibrated, worst_shipped, worst_all_fp16, worst_all_x3;
     float err_calibrated[7], err_shipped[7]; /* feat0, feat1, feat2, feat3, path1, inv, seg_logits */
     float cost_us_calibrated, cost_us_shipped; /* sums of the compiled-in promotion costs of the x3 groups */
+    /* ---- ABI 5 (round 6) ---- */
+    int32_t calib_frames, holdout_frames;    /* B - holdout, holdout */
+    int32_t met_headroom;      /* 1: calibration frames <= headroom x budget under the final map */
+    int32_t met_holdout;       /* 1: held-out frames <= budget under the final map; -1: no held-out frames */
+    float headroom;            /* the factor used */
+    float worst_holdout, worst_holdout_shipped;  /* worst relative L2 of the seven quantities over the held-out frames: final map, shipped map */
+    float err_holdout[7];
+    float per_pixel_budget;    /* per_pixel_p999 of the options (0 = constraint off) */
+    float inv_p999_calibrated, inv_max_calibrated;   /* per-pixel relative error of the inverse depth under the final map, calibration frames */
+    float inv_p999_holdout, inv_max_holdout;         /* ... held-out frames */
+    float inv_p999_all_fp16, inv_p999_all_x3;        /* the corner maps, calibration frames */
 } soccdpt_calib_report;
+typedef struct soccdpt_calib_options {
+    int32_t struct_bytes;      /* sizeof(soccdpt_calib_options) as the caller compiled it */
+    int32_t holdout;           /* last `holdout` frames of dev_x verify only (0 <= holdout < B) */
+    float budget;              /* relative-L2 budget of the seven quantities */
+    float headroom;            /* calibration frames are held to headroom x budget; 0 -> 0.85 */
+    float per_pixel_p999;      /* optional bound on the 99.9th-percentile per-pixel relative error of the inverse depth; 0 = off */
+} soccdpt_calib_options;
 size_t soccdpt_prec_calibrate_scratch_bytes(void* handle, int B);
 int soccdpt_prec_calibrate(void* handle, const float* dev_x, int B, float budget, void* dev_prepared, size_t prepared_bytes, void* dev_workspace,
                            size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream);
+/* The same with options (hold-out frames, head-room, per-pixel constraint); soccdpt_prec_calibrate(budget) = {holdout 0, headroom 0.85, no per-pixel bound}.
+ * On ANY failure the handle keeps the map and source it had on entry (re-prepared for it).  A calibrated map belongs to the weights it was derived on:
+ * soccdpt_prepare re-checks a fingerprint of them and, when other values have been bound or loaded since, falls back to source 3 (all x3). */
+int soccdpt_prec_calibrate_ex(void* handle, const float* dev_x, int B, const soccdpt_calib_options* options, void* dev_prepared, size_t prepared_bytes,
+                              void* dev_workspace, size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream);
 /* Where the handle's current map comes from: 0 = the shipped map, bound weights = the synthetic draw it was derived from (checked by a
  * fingerprint of a few tensors at soccdpt_prepare); 1 = soccdpt_prec_calibrate ran on the bound weights; 2 = edited through
  * soccdpt_prec_map_set; 3 = OTHER weights are bound and no calibration has run: the shipped map's "within tolerance" claim does not carry over

@@ -18,8 +18,10 @@ int launch_calib_fingerprint(const float* w, size_t n, unsigned long long mult, 
 
 // calibrate.cpp
 size_t calib_scratch_bytes(Handle& h, int B);
-int calib_run(Handle& h, const float* x, int B, float budget, void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes, void* scratch, size_t scratch_bytes,
-              soccdpt_calib_report* rep, hipStream_t st, std::string& err);
+int calib_run(Handle& h, const float* x, int B, const soccdpt_calib_options& opt, void* prepared, size_t prepared_bytes, void* ws, size_t ws_bytes, void* scratch,
+              size_t scratch_bytes, soccdpt_calib_report* rep, hipStream_t st, std::string& err);
+// 64-bit fingerprint of four bound tensors (decoder, heads, encoder); `tmp` = 8 bytes of device memory.  -> 0 ok, 1 a tensor is not bound, < 0 error
+int calib_fingerprint(Handle& h, unsigned long long* tmp, hipStream_t st, unsigned long long* out, std::string& err);
 // fingerprint of the bound weights (a few named tensors, 64-bit sums of their bit patterns) against the synthetic draw the shipped map was
 // derived from; `tmp` = 8 bytes of device memory.  -> 1 same weights, 0 other weights, < 0 error
 int calib_weights_are_the_shipped_draw(Handle& h, unsigned long long* tmp, hipStream_t st, std::string& err);

@@ -46,6 +46,7 @@ size_t soccdpt_sizeof(int which) {
         case 1: return sizeof(soccdpt_igemm_args);
         case 2: return sizeof(soccdpt_kernel_stat);
         case 3: return sizeof(soccdpt_calib_report);
+        case 4: return sizeof(soccdpt_calib_options);
         default: return 0;
     }
 }
@@ -143,6 +144,24 @@ int soccdpt_prepare(void* handle, void* dev_prepared, size_t prepared_bytes, voi
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
     if (model_prepare(*h, dev_prepared, prepared_bytes, (hipStream_t)stream, h->err)) return 1;
+    if (h->cfg.precision == SOCCDPT_PREC_MIXED && h->prec_source == 1 && h->calib_fp_valid) {
+        // A calibrated map is a statement about the weights it was derived on: other values under the same keys -- a rebind, or a
+        // load_state_dict / optimizer step into the same storage -- void it.  Same four-tensor fingerprint as below; on a mismatch every group
+        // goes back to x3 operands (source 3) until the caller calibrates again.
+        unsigned long long* tmp = reinterpret_cast<unsigned long long*>((reinterpret_cast<uintptr_t>(dev_prepared) + h->prepared_bytes - 8) & ~uintptr_t(7));
+        unsigned long long fp = 0;
+        const int rc = calib_fingerprint(*h, tmp, (hipStream_t)stream, &fp, h->err);
+        if (rc < 0) return 1;
+        if (rc > 0 || fp != h->calib_fp) {
+            h->prec_source = 3;
+            h->calib_fp_valid = false;
+            for (const auto& g : model_prec_groups(*h)) h->prec_map[g] = 3;
+            h->ws_key = Handle::WsKey();
+            model_drop_graph(*h);
+            if (model_prepare(*h, dev_prepared, prepared_bytes, (hipStream_t)stream, h->err)) return 1;
+        }
+        return 0;
+    }
     if (h->cfg.precision == SOCCDPT_PREC_MIXED && h->prec_source != 1 && h->prec_source != 2) {
         // Is the shipped map running on the weights it was derived from?  (a fingerprint of four tensors; the arena's 256-byte tail is free.)
         // On any other weights its within-tolerance claim is unverified -- measured in round 5: a second synthetic draw leaves the class logits at
@@ -168,7 +187,18 @@ int soccdpt_prec_calibrate(void* handle, const float* dev_x, int B, float budget
                            size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream) {
     Handle* h = static_cast<Handle*>(handle);
     if (!h) return 1;
-    return calib_run(*h, dev_x, B, budget, dev_prepared, prepared_bytes, dev_workspace, workspace_bytes, dev_scratch, scratch_bytes, report, (hipStream_t)stream, h->err);
+    soccdpt_calib_options opt;
+    memset(&opt, 0, sizeof(opt));
+    opt.struct_bytes = (int32_t)sizeof(opt);
+    opt.budget = budget;
+    return calib_run(*h, dev_x, B, opt, dev_prepared, prepared_bytes, dev_workspace, workspace_bytes, dev_scratch, scratch_bytes, report, (hipStream_t)stream, h->err);
+}
+int soccdpt_prec_calibrate_ex(void* handle, const float* dev_x, int B, const soccdpt_calib_options* options, void* dev_prepared, size_t prepared_bytes,
+                              void* dev_workspace, size_t workspace_bytes, void* dev_scratch, size_t scratch_bytes, soccdpt_calib_report* report, void* stream) {
+    Handle* h = static_cast<Handle*>(handle);
+    if (!h) return 1;
+    if (!options || options->struct_bytes != (int32_t)sizeof(soccdpt_calib_options)) return fail(h, "soccdpt_prec_calibrate_ex: options missing or compiled against another header (struct_bytes)");
+    return calib_run(*h, dev_x, B, *options, dev_prepared, prepared_bytes, dev_workspace, workspace_bytes, dev_scratch, scratch_bytes, report, (hipStream_t)stream, h->err);
 }
 int soccdpt_prec_map_source(void* handle) {
     Handle* h = static_cast<Handle*>(handle);
@@ -539,7 +569,11 @@ int soccdpt_op_igemm(const soccdpt_igemm_args* a, void* stream) {
     d.gn_part_floats = a->gn_part_floats;
     d.stamps = reinterpret_cast<unsigned long long*>(a->stamps);
     std::string err;
+    if (a->gn_stats && a->gn_count && (a->gn_hw <= 0 || a->gn_cpg <= 0 || a->M % a->gn_hw || a->N % a->gn_cpg))
+        return fail(nullptr, "soccdpt_op_igemm: GroupNorm statistics requested with gn_hw / gn_cpg that do not divide M / N");
     if (launch_igemm(d, (hipStream_t)stream, err)) return fail(nullptr, err);
+    if (a->gn_stats && a->gn_count && (gn_bm <= 0 || a->gn_hw % gn_bm))
+        return fail(nullptr, "soccdpt_op_igemm: statistics requested but the chosen tile has no statistics epilogue (tune forces a tile without one)");
     // gn_count != NULL: the caller wants {mean, rstd} in gn_stats (the form of rounds 2-4, where the convolution's last workgroup finished them; the words of
     // gn_count are no longer touched): a finish launch behind the convolution.  gn_count == NULL: partials only, as the forward launches it.
     if (a->gn_stats && a->gn_count && launch_gn_finish(a->gn_part, a->gn_stats, a->M / a->gn_hw, a->gn_hw / gn_bm, a->N / a->gn_cpg, a->gn_hw, a->gn_cpg, 1e-5f, (hipStream_t)stream, err))

@@ -260,6 +260,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
                 if (cpg == 2) *reinterpret_cast<float2*>(a.stats2_w + ((size_t)b * G + g1) * 2) = t1;
             }
         }
+#ifdef SOCCDPT_ABLATIONS
     } else if (a.mode == 3 || a.mode == 4) {   // timing-only ablations of mode 1: 3 = the partial loads + f32 sums only, 4 = the loads only (one tile)
         s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
         s1 = s0;
@@ -268,6 +269,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnApplyDev a) {
         const int nt = a.mode == 3 ? a.tps : 1;
         for (int t = 0; t < nt; ++t) acc += base[(size_t)t * G].x;
         s0.x += 0.f * acc;
+#endif
     } else {
         const float* sp2 = a.raw2 ? a.stats2 : a.stats;
         s0 = *reinterpret_cast<const float2*>(a.stats + ((size_t)b * G + g0) * 2);
@@ -453,6 +455,7 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     // adds them up first (gn_finish_kernel) and this one reads {mean, rstd} like any other
     const int tmax = a.part ? (a.raw2 && a.tps2 > a.tps ? a.tps2 : a.tps) : 0;
     d.mode = !a.part ? 0 : (tmax <= kGnDirectTps ? 1 : (tmax <= kGnCoopTps && 256 % G == 0 ? 2 : 0));
+#ifdef SOCCDPT_ABLATIONS
     static const int dbg_stale = getenv("SOCCDPT_DBG_GN_STALE") ? atoi(getenv("SOCCDPT_DBG_GN_STALE")) : 0;   // timing-only ablation: 1 = no finish at all (statistics of the previous forward), 2 = also one pixel per thread
     static const bool dbg_warned = dbg_stale ? (fprintf(stderr, "soccdpt: SOCCDPT_DBG_GN_STALE is set: TIMING-ONLY ablation -- GroupNorm statistics are those of the previous forward, results are wrong unless the input repeats\n"), true) : false;
     (void)dbg_warned;
@@ -461,6 +464,9 @@ int launch_gn_apply(const GnApplyArgs& a, int out_mode, hipStream_t st, std::str
     if (a.part && d.mode == 1 && !a.raw2 && (dbg_stale == 8 || dbg_stale == 16)) { d.mode = dbg_stale == 8 ? 3 : 4; skip_finish = true; }
     if (a.part && d.mode == 2 && (dbg_stale & 2)) { d.mode = 0; skip_finish = true; }
     if (a.part && d.mode == 0 && !skip_finish && (dbg_stale & 4)) skip_finish = true;
+#else
+    constexpr bool skip_finish = false;
+#endif
     if (a.part && d.mode == 0 && !skip_finish) {
         if (launch_gn_finish(a.part, d.stats_w, B, a.tps, G, a.HW, a.cpg, a.eps, st, err)) return 1;
         if (a.raw2 && launch_gn_finish(a.part2, d.stats2_w, B, a.tps2, G, a.HW, a.cpg, a.eps, st, err)) return 1;

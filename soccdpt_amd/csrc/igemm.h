@@ -128,7 +128,9 @@ struct IgemmDesc {
     // diagnostics (tools/igemm_stamps.py): when non-null every workgroup writes 4 s_memrealtime stamps (100 MHz) -- entry, first k-tile
     // landed, main loop done, epilogue done -- to stamps[4 * blockIdx.x ..]; the values are never read by the kernel
     unsigned long long* stamps = nullptr;
+#ifdef SOCCDPT_ABLATIONS
     int dbg_skip_out_op = 0;   // SOCCDPT_DBG_SKIP_OUT_OP=1: timing-only ablation (WRONG results): the generic epilogue does not store the operand copy (133 us of 2005 per forward)
+#endif
 };
 
 int launch_igemm(const IgemmDesc& d, hipStream_t stream, std::string& err);

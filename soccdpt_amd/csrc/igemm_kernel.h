@@ -701,7 +701,12 @@ __device__ __forceinline__ void igemm_tile(const IgemmDesc& d, int nk, int kpt, 
                 const float* s = d.act_on_f32 ? a : v;
                 *reinterpret_cast<float4*>(d.out_f32 + orow + n) = make_float4(s[0], s[1], s[2], s[3]);
             }
-            if (d.out_op && d.dbg_skip_out_op != 1) {
+#ifdef SOCCDPT_ABLATIONS
+            const bool store_op = d.out_op && d.dbg_skip_out_op != 1;
+#else
+            const bool store_op = d.out_op != nullptr;
+#endif
+            if (store_op) {
                 if constexpr (sizeof(T) == 2) {
                     if (F16 && d.out_fmt == 3) x3_store4(d.out_op, (d.out_halo ? hrow : orow) + n, a[0], a[1], a[2], a[3]);   // the next launch reads x3 operands
                     else {

@@ -113,6 +113,8 @@ struct Handle {
     // SOCCDPT_PREC_MIXED: operand format of every launch-site group (model.cpp: prec_groups), 1 = fp16, 3 = x3; groups absent from the map are fp16
     std::unordered_map<std::string, int> prec_map;
     int prec_source = -1;   // soccdpt_prec_map_source: -1 unknown (not prepared), 0 shipped map on its own weights, 1 calibrated, 2 edited, 3 shipped map on other weights
+    unsigned long long calib_fp = 0;   // fingerprint (calibrate.h) of the weights the calibrated map (prec_source 1) was derived on
+    bool calib_fp_valid = false;
     std::vector<WeightSlot> weights;
     std::unordered_map<std::string, int> index;
     size_t prepared_bytes = 0;

@@ -749,10 +749,12 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
 #define PROF(name, flops, bytes) ProfScope _ps(h.prof, name, flops, bytes, st)
     auto gemm = [&](IgemmDesc d, int fmt) {   // fmt: operand format code of the launch's group
         if (!d.f32 && !d.x3) { d.f32 = fmt == 2; d.f16 = fmt == 1; d.x3 = fmt == 3; }   // a caller may force the exact-f32 / x3 kernels for one launch (hybrid stem)
+#ifdef SOCCDPT_ABLATIONS   // timing-only switches that give WRONG results: compiled only into `make ABLATIONS=1` builds (tools/), never into the shipped library
         static const int dbg_skip = getenv("SOCCDPT_DBG_SKIP_OUT_OP") ? atoi(getenv("SOCCDPT_DBG_SKIP_OUT_OP")) : 0;
         static const bool dbg_skip_warned = dbg_skip ? (fprintf(stderr, "soccdpt: SOCCDPT_DBG_SKIP_OUT_OP is set: TIMING-ONLY ablation -- operand copies are not stored, results are WRONG\n"), true) : false;
         (void)dbg_skip_warned;
         d.dbg_skip_out_op = dbg_skip;
+#endif
         d.x3_among_f16 = MIX && d.x3;
         if (MIX && fmt == 1 && !P.x2w.empty() && P.x2w.count(d.Wt)) d.x2w = 1;   // the group's weights were prepared as x3 pairs: the two-MFMA x2w tiles
         const long long key = shape_key(d.M, d.N, d.taps * d.Cin, d.taps + ((MIX && fmt == 3) ? 16 : 0) + (d.x2w ? 32 : 0));   // mixed mode: the x3 / x2w launches of a shape are their own sites
@@ -801,9 +803,13 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
         };
         auto gn = [&](GnApplyArgs g, int om, int slot, int slot2 = -1) {   // om: format of out_op (and of out_halo unless g.halo_mode says otherwise); slot(s): whose partials
             if (bm_slot[slot] <= 0 || (slot2 >= 0 && bm_slot[slot2] <= 0)) { err = "soccdpt: GroupNorm statistics slot read before a convolution filled it"; return 1; }
+#ifdef SOCCDPT_ABLATIONS
             static const int dbg_old = getenv("SOCCDPT_DBG_GN_OLDPART") ? atoi(getenv("SOCCDPT_DBG_GN_OLDPART")) : 0;   // timing-only: read another slot's (older) partials
             static const bool dbg_warned = dbg_old ? (fprintf(stderr, "soccdpt: SOCCDPT_DBG_GN_OLDPART is set: TIMING-ONLY ablation -- the GroupNorm statistics are WRONG\n"), true) : false;
             (void)dbg_warned;
+#else
+            constexpr int dbg_old = 0;
+#endif
             g.part = w.hy_part[dbg_old ? (slot + 2) % 4 : slot]; g.tps = g.HW / bm_slot[slot];
             if (slot2 >= 0) { g.part2 = w.hy_part[slot2]; g.tps2 = g.HW / bm_slot[slot2]; }
             const int eo = om >= 2 ? 4 : 2;

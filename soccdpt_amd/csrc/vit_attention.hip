@@ -381,7 +381,11 @@ int launch_vit_attention(const void* qkv, void* out, int prec, int B, int N, int
     }
     if (out_x3 && prec != SOCCDPT_PREC_F16) { err = "vit_attention: the x3 output form belongs to the fp16 kernel"; return 1; }
     const int NPAD = (N + 31) / 32 * 32, NT = NPAD / 32;
-    const size_t lds = (size_t)NPAD * KROW + (size_t)D * (NPAD * 2 + 8);
+    size_t lds = (size_t)NPAD * KROW + (size_t)D * (NPAD * 2 + 8);
+    // the key halves meet in the same LDS (dead K / V^T region): up to four query blocks x (KH - 1) parked parts of [34][64] floats each.
+    // Short sequences (N <= 128) hold less K / V^T than that exchange needs: size for the larger of the two.
+    constexpr size_t XCH = (size_t)(KH - 1) * 4 * 34 * 64 * sizeof(float);
+    if (lds < XCH) lds = XCH;
     if (lds > 160 * 1024) { err = "vit_attention: sequence too long for the LDS-resident K / V^T form (max 608 tokens)"; return 1; }
     // query split: enough workgroups to cover the 256 CUs, at most one 32-query block per wave and workgroup
     int QS = (256 + B * heads - 1) / (B * heads);

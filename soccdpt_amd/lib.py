@@ -15,7 +15,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("SOCCDPT_LIB_PATH") or os.path.join(_HERE, "libsoccdpt_hip.so")   # override: A/B of two builds in one GPU call (tools/ab_bench.sh)
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 BACKBONE_IDS = {"swin2t16_256": 0, "swin2b24_384": 1, "vitb_rn50_384": 2}
 PREC_BF16 = 0
 PREC_F32 = 1
@@ -56,7 +56,17 @@ class CalibReport(ctypes.Structure):
                 ("met_budget", ctypes.c_int32), ("shipped_met_budget", ctypes.c_int32), ("budget", ctypes.c_float),
                 ("worst_calibrated", ctypes.c_float), ("worst_shipped", ctypes.c_float), ("worst_all_fp16", ctypes.c_float), ("worst_all_x3", ctypes.c_float),
                 ("err_calibrated", ctypes.c_float * 7), ("err_shipped", ctypes.c_float * 7),
-                ("cost_us_calibrated", ctypes.c_float), ("cost_us_shipped", ctypes.c_float)]
+                ("cost_us_calibrated", ctypes.c_float), ("cost_us_shipped", ctypes.c_float),
+                # ABI 5
+                ("calib_frames", ctypes.c_int32), ("holdout_frames", ctypes.c_int32), ("met_headroom", ctypes.c_int32), ("met_holdout", ctypes.c_int32),
+                ("headroom", ctypes.c_float), ("worst_holdout", ctypes.c_float), ("worst_holdout_shipped", ctypes.c_float), ("err_holdout", ctypes.c_float * 7),
+                ("per_pixel_budget", ctypes.c_float), ("inv_p999_calibrated", ctypes.c_float), ("inv_max_calibrated", ctypes.c_float),
+                ("inv_p999_holdout", ctypes.c_float), ("inv_max_holdout", ctypes.c_float), ("inv_p999_all_fp16", ctypes.c_float), ("inv_p999_all_x3", ctypes.c_float)]
+
+
+class CalibOptions(ctypes.Structure):
+    """soccdpt_calib_options (include/soccdpt_hip.h)."""
+    _fields_ = [("struct_bytes", ctypes.c_int32), ("holdout", ctypes.c_int32), ("budget", ctypes.c_float), ("headroom", ctypes.c_float), ("per_pixel_p999", ctypes.c_float)]
 
 
 CALIB_QUANTITIES = ("feat0", "feat1", "feat2", "feat3", "path1", "inv", "seg_logits")
@@ -235,12 +245,14 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_prec_calibrate_scratch_bytes.restype = cs
     L.soccdpt_prec_calibrate.argtypes = [vp, vp, ci, ctypes.c_float, vp, cs, vp, cs, vp, cs, ctypes.POINTER(CalibReport), vp]
     L.soccdpt_prec_calibrate.restype = ci
+    L.soccdpt_prec_calibrate_ex.argtypes = [vp, vp, ci, ctypes.POINTER(CalibOptions), vp, cs, vp, cs, vp, cs, ctypes.POINTER(CalibReport), vp]
+    L.soccdpt_prec_calibrate_ex.restype = ci
     L.soccdpt_prec_map_source.argtypes = [vp]
     L.soccdpt_prec_map_source.restype = ci
     if L.soccdpt_abi_version() != ABI_VERSION:
         raise RuntimeError("libsoccdpt_hip.so ABI version mismatch; rebuild the library")
     # the ctypes mirrors of the public structs must have the layout the library was compiled with (include/soccdpt_hip.h)
-    for which, cls in ((0, SoccdptConfig), (1, IgemmArgs), (2, KernelStat), (3, CalibReport)):
+    for which, cls in ((0, SoccdptConfig), (1, IgemmArgs), (2, KernelStat), (3, CalibReport), (4, CalibOptions)):
         if L.soccdpt_sizeof(which) != ctypes.sizeof(cls):
             raise RuntimeError(f"libsoccdpt_hip.so: sizeof mismatch for {cls.__name__}: library {L.soccdpt_sizeof(which)}, binding {ctypes.sizeof(cls)}")
     _lib = L
@@ -398,11 +410,16 @@ class Engine:
         library runs every group in x3 until one has run), -1 not a PREC_MIXED handle / not prepared (soccdpt_prec_map_source)."""
         return int(self.L.soccdpt_prec_map_source(self._h))
 
-    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4) -> dict:
-        """soccdpt_prec_calibrate: derive the precision map on the BOUND weights from the sample frames x [B,3,S,S] (against the library's exact-f32
-        arithmetic on the same weights); the handle keeps the calibrated map, prepared.  Returns the report as a dict."""
+    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4, holdout: int = None, headroom: float = 0.85, per_pixel_p999: float = None) -> dict:
+        """soccdpt_prec_calibrate_ex: derive the precision map on the BOUND weights from the sample frames x [B,3,S,S] (against the library's exact-f32
+        arithmetic on the same weights); the handle keeps the calibrated map, prepared.  The last `holdout` frames (default: a third of them when
+        B >= 3) only verify the map (<= budget); the others select it and are held to headroom x budget.  per_pixel_p999: optional bound on the
+        99.9th-percentile per-pixel relative error of the inverse depth.  Returns the report as a dict."""
         assert x.device == self.device and x.dtype == torch.float32 and x.is_contiguous()
         B = x.shape[0]
+        if holdout is None:
+            holdout = B // 3
+        opt = CalibOptions(ctypes.sizeof(CalibOptions), int(holdout), float(budget), float(headroom), float(per_pixel_p999 or 0.0))
         nb = self.L.soccdpt_prec_calibrate_scratch_bytes(self._h, B)
         if nb == 0:
             raise RuntimeError("soccdpt_prec_calibrate: only SOCCDPT_PREC_MIXED handles have a precision map to calibrate")
@@ -413,9 +430,10 @@ class Engine:
         ws = self.workspace(B)
         rep = CalibReport()
         with torch.cuda.device(self.device):
-            self._check(self.L.soccdpt_prec_calibrate(self._h, x.data_ptr(), B, float(budget), self._prepared.data_ptr(), self._prepared.numel(), ws.data_ptr(), ws.numel(),
-                                                      scratch.data_ptr(), nb, ctypes.byref(rep), _stream_ptr(self.device)), "soccdpt_prec_calibrate")
+            self._check(self.L.soccdpt_prec_calibrate_ex(self._h, x.data_ptr(), B, ctypes.byref(opt), self._prepared.data_ptr(), self._prepared.numel(), ws.data_ptr(), ws.numel(),
+                                                         scratch.data_ptr(), nb, ctypes.byref(rep), _stream_ptr(self.device)), "soccdpt_prec_calibrate_ex")
         out = {k: getattr(rep, k) for k, _ in CalibReport._fields_ if not k.startswith("err_")}
+        out["err_holdout"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_holdout))) if rep.holdout_frames else None
         out["err_calibrated"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_calibrated)))
         out["err_shipped"] = dict(zip(CALIB_QUANTITIES, (float(v) for v in rep.err_shipped)))
         out["x3_groups"] = sorted(g for g, f in self.prec_map().items() if f == PREC_F16X3)

@@ -230,7 +230,13 @@ class SOccDPT_V3(SOccDPT):
             if t.device != eng.device or t.dtype != torch.float32 or not t.is_contiguous():
                 raise RuntimeError(f"weight {k} must be a contiguous float32 tensor on {eng.device} (got {t.device}, {t.dtype})")
             eng.bind(k, t.detach())
+        was_calibrated = self.precision == PREC_MIXED and eng.prec_map_source() == 1
         eng.prepare()
+        if was_calibrated and eng.prec_map_source() == 3:
+            # the library compared a fingerprint of the bound values with the one the calibration ran on (soccdpt_prepare)
+            self.__dict__["_warned_uncalibrated"] = True
+            print("soccdpt_amd: the weights changed since net.calibrate_precision() derived the precision map, so that map no longer carries its "
+                  "within-tolerance claim: every GEMM / convolution runs x3 split-fp16 operands again until net.calibrate_precision(sample_frames) is re-run.")
         self._weight_refs[id(eng)] = refs
         self._bound_versions[id(eng)] = version
         if self.precision == PREC_MIXED and eng.prec_map_source() == 3 and not self.__dict__.get("_warned_uncalibrated"):
@@ -409,16 +415,19 @@ class SOccDPT_V3(SOccDPT):
                 p.grad.add_(g)
         self._train_x = None
 
-    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4) -> dict:
+    def calibrate_precision(self, x: torch.Tensor, budget: float = 5e-4, holdout: int = None, headroom: float = 0.85, per_pixel_p999: float = None) -> dict:
         """Derive the precision map of the default arithmetic (SOCCDPT_PREC_MIXED) on the weights this model holds NOW, from sample frames
         x [B,3,S,S] on the model's device: per launch-site group fp16 or x3 operands such that every hooked feature map, path_1, inverse depth and
         the class logits stay within `budget` (relative L2) of the library's exact-f32 arithmetic on the same weights -- what the reference computes
         in (model/loader.py:126-139; model/base_model.py:5-37 loads whatever checkpoint it is given).  Call it once after load_net / load_state_dict
-        of a real checkpoint; the shipped map was derived on the synthetic weights of the tests.  Returns the measured report (soccdpt_calib_report)."""
+        of a real checkpoint; the shipped map was derived on the synthetic weights of the tests.  Returns the measured report (soccdpt_calib_report).
+        Of the B sample frames the last `holdout` (default B // 3) take no part in the selection and must come in under `budget`; the others are held
+        to headroom x budget (default 0.85: the error moves a few per cent from frame to frame).  per_pixel_p999 adds a bound on the 99.9th
+        percentile over pixels of the inverse depth's relative error (the budget itself is a relative-L2 statement).  Six frames (4 + 2) are a good sample."""
         assert self.precision == PREC_MIXED, "only the mixed arithmetic has a precision map"
         eng = self._engine(x.device)
         self._sync_weights(eng)
-        rep = eng.calibrate_precision(x.detach().to(torch.float32).contiguous(), budget)
+        rep = eng.calibrate_precision(x.detach().to(torch.float32).contiguous(), budget, holdout, headroom, per_pixel_p999)
         self.__dict__["_warned_uncalibrated"] = True
         return rep
 

@@ -107,3 +107,36 @@ def synth_input(batch: int, size: int = 256, seed0: int = 0, all_zero: bool = Fa
             img = (img + torch.randint(-8, 9, (3, size, size), generator=g).float()).clamp(0, 255).round()
         frames.append((img - 0.5) / 0.5)
     return torch.stack(frames).contiguous()
+
+
+def trained_like(sd: dict, seed: int = 5) -> dict:
+    """Statistics a trained checkpoint has and the synthetic draws lack: LayerNorm / BatchNorm gains far from 1 (U(0.2, 3)), and a few output rows
+    whose weights are an order of magnitude larger than the rest (the outlier features of trained transformers).  Used by tests/test_calibrate_gpu.py
+    and bench.py's `other_weights` as a stand-in for a real checkpoint (there is no network for one)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for k, v in sd.items():
+        t = v.clone()
+        leaf = k.split(".")[-1]
+        if leaf == "weight" and (".norm" in k or k.endswith("seg_head.1.weight")) and t.dim() == 1:
+            t = 0.2 + 2.8 * torch.rand(t.shape, generator=g)
+        elif leaf == "weight" and t.dim() == 2 and "attn.qkv" not in k and "cpb_mlp" not in k and t.shape[0] >= 96:
+            rows = torch.randperm(t.shape[0], generator=g)[:2]
+            t[rows] *= 10.0
+        out[k] = t
+    for k in list(out):   # the reference registers the encoder twice (model/SOccDPT.py:650): keep the aliases identical
+        if k.startswith("depth_net.pretrained.") and k[len("depth_net."):] in out:
+            out[k[len("depth_net."):]] = out[k]
+    return out
+
+
+WEIGHT_SETS = ("salt0", "salt1", "salt2", "trained_like")
+
+
+def named_weights(name: str, backbone: str = "swin2t16_256") -> dict:
+    """'salt0' = the draw the shipped precision maps were derived on (tests, bench default); 'salt1' / 'salt2' = other draws of the same generator;
+    'trained_like' = draw 3 with trained-like statistics."""
+    if name == "trained_like":
+        return trained_like(synth_state_dict(backbone, salt=3, alias_pretrained=True))
+    assert name in WEIGHT_SETS, name
+    return synth_state_dict(backbone, salt=int(name[4:]), alias_pretrained=True)

@@ -9,7 +9,8 @@ channels) -- and check, against the fp32 CPU oracle on frames the calibration ne
   * how the SHIPPED map would have generalised is measured and reported by the calibration (round 5: on the second synthetic draw it leaves the
     class logits at 1.4e-3 -- outside the north star -- which is why the uncalibrated default is all-x3 and not the shipped map);
   * the CALIBRATED map keeps all seven quantities within the budget (5e-4) -- measured by the library against its own f32 mode on the
-    calibration frames, and re-measured here against the CPU oracle on held-out frames (10 % head-room for the change of frames)."""
+    calibration frames (held to 0.85 x budget) and on its own hold-out frames (<= budget), and re-measured here against the CPU oracle on frames
+    neither of them saw: round 6 holds these to THE BUDGET (round 5 allowed 1.1 - 1.15 x: a calibrated map outside its budget is a failed calibration)."""
 import os
 import tempfile
 
@@ -28,23 +29,8 @@ def _rel_l2(a, b):
 
 
 def _trained_like(sd, seed=5):
-    """Statistics a trained checkpoint has and the synthetic draws lack: LayerNorm / BatchNorm gains far from 1, and a few channels whose weights
-    are an order of magnitude larger than the rest (the outlier features of trained transformers)."""
-    g = torch.Generator().manual_seed(seed)
-    out = {}
-    for k, v in sd.items():
-        t = v.clone()
-        leaf = k.split(".")[-1]
-        if leaf == "weight" and (".norm" in k or k.endswith("seg_head.1.weight")) and t.dim() == 1:
-            t = 0.2 + 2.8 * torch.rand(t.shape, generator=g)
-        elif leaf == "weight" and t.dim() == 2 and "attn.qkv" not in k and "cpb_mlp" not in k and t.shape[0] >= 96:
-            rows = torch.randperm(t.shape[0], generator=g)[:2]
-            t[rows] *= 10.0
-        out[k] = t
-    for k in list(out):   # the reference registers the encoder twice (model/SOccDPT.py:650): keep the aliases identical
-        if k.startswith("depth_net.pretrained.") and k[len("depth_net."):] in out:
-            out[k[len("depth_net."):]] = out[k]
-    return out
+    from soccdpt_amd.utils.synth import trained_like
+    return trained_like(sd, seed)
 
 
 def _build(sd, model_type="dpt_swin2_tiny_256", dev="cuda:0"):
@@ -83,11 +69,12 @@ def test_shipped_weights_are_recognised_and_recalibration_keeps_the_budget(gpu_d
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict
     m = _build(synth_state_dict(alias_pretrained=True))
     assert m.precision_map_source() == "shipped"
-    rep = m.calibrate_precision(synth_input(2, seed0=4).to(gpu_device), budget=5e-4)
+    rep = m.calibrate_precision(synth_input(6, seed0=4).to(gpu_device), budget=5e-4)
     print("calibration on the shipped map's own weights:", {k: (f"{v:.3g}" if isinstance(v, float) else v) for k, v in rep.items() if not isinstance(v, (dict, list))})
     assert m.precision_map_source() == "calibrated"
-    assert rep["met_budget"] == 1 and rep["shipped_met_budget"] == 1 and rep["worst_calibrated"] <= 5e-4
-    assert rep["cost_us_calibrated"] <= rep["cost_us_shipped"] + 1e-3
+    assert rep["met_budget"] == 1 and rep["shipped_met_budget"] == 1 and rep["worst_calibrated"] <= 0.85 * 5e-4 + 1e-9
+    assert rep["calib_frames"] == 4 and rep["holdout_frames"] == 2 and rep["met_headroom"] == 1 and rep["met_holdout"] == 1 and rep["worst_holdout"] <= 5e-4
+    assert rep["inv_p999_calibrated"] > 0 and rep["inv_max_calibrated"] >= rep["inv_p999_calibrated"]
     assert rep["worst_all_x3"] < 1e-4 < rep["worst_all_fp16"]
     assert rep["forwards"] >= rep["n_groups"] + 4
 
@@ -99,7 +86,7 @@ def test_other_weights_shipped_map_reported_calibrated_map_within_budget(gpu_dev
     if case == "trained_like":
         sd = _trained_like(sd)
     m = _build(sd)
-    x_cal = synth_input(2, seed0=4)          # what the calibration sees
+    x_cal = synth_input(6, seed0=4)          # what the calibration sees: 4 frames select the map, 2 verify it inside the library
     x_test = synth_input(2, seed0=90)        # what it never saw
     ora = _oracle(sd, x_test, "swin2t16_256")
     e_safe = _errors_vs_oracle(m, x_test, gpu_device, ora)
@@ -114,9 +101,11 @@ def test_other_weights_shipped_map_reported_calibrated_map_within_budget(gpu_dev
     print(f"[{case}] calibrated map ({rep['n_x3']} of {rep['n_groups']} groups x3, shipped {rep['n_x3_shipped']}; {rep['forwards']} forwards; library-measured worst "
           f"{rep['worst_calibrated']:.2e}, shipped {rep['worst_shipped']:.2e}, all-fp16 {rep['worst_all_fp16']:.2e}): held-out worst {max(e_cal.values()):.2e}",
           {k: f"{v:.2e}" for k, v in e_cal.items()})
-    assert rep["met_budget"] == 1 and rep["worst_calibrated"] <= 5e-4
+    print(f"[{case}] library hold-out frames: worst {rep['worst_holdout']:.2e}; per-pixel inv p99.9 {rep['inv_p999_holdout']:.2e} max {rep['inv_max_holdout']:.2e}; {rep['n_x2w']} x2w groups")
+    assert rep["met_budget"] == 1 and rep["met_headroom"] == 1 and rep["met_holdout"] == 1
+    assert rep["worst_calibrated"] <= 0.85 * 5e-4 + 1e-9 and rep["worst_holdout"] <= 5e-4
     assert max(e_safe.values()) <= 2e-4          # the uncalibrated default is parity-grade
-    assert max(e_cal.values()) <= 5.5e-4
+    assert max(e_cal.values()) <= 5e-4           # THE budget, on frames no part of the calibration saw, against the fp32 CPU oracle
     assert rep["worst_all_x3"] < 2e-4 < rep["worst_all_fp16"] and rep["worst_shipped"] > 0     # reported, not bounded: the shipped map is not claimed for these weights
 
 
@@ -125,7 +114,7 @@ def test_calibrate_hybrid_384(gpu_device):
     from soccdpt_amd.utils.synth import synth_input, synth_state_dict
     sd = synth_state_dict("vitb_rn50_384", salt=1, alias_pretrained=True)
     m = _build(sd, "dpt_hybrid_384")
-    x_cal, x_test = synth_input(1, size=384, seed0=4), synth_input(1, size=384, seed0=90)
+    x_cal, x_test = synth_input(3, size=384, seed0=4), synth_input(1, size=384, seed0=90)   # 2 frames select, 1 verifies
     ora = _oracle(sd, x_test, "vitb_rn50_384")
     e_safe = _errors_vs_oracle(m, x_test, gpu_device, ora)
     print("[hybrid salt1] before calibration (all groups x3; the attention core stays fp16):", {k: f"{v:.2e}" for k, v in e_safe.items()})
@@ -134,7 +123,49 @@ def test_calibrate_hybrid_384(gpu_device):
     e_cal = _errors_vs_oracle(m, x_test, gpu_device, ora)
     print(f"[hybrid salt1] shipped map would give {rep['worst_shipped']:.2e} (library-measured); calibrated {rep['n_x3']} of {rep['n_groups']} x3: library {rep['worst_calibrated']:.2e}, held-out vs oracle {max(e_cal.values()):.2e}",
           {k: f"{v:.2e}" for k, v in e_cal.items()})
-    assert rep["met_budget"] == 1 and max(e_cal.values()) <= 1.15e-3
+    assert rep["met_budget"] == 1 and rep["met_holdout"] == 1 and max(e_cal.values()) <= 1e-3   # the north star itself (round 5: 1.15e-3)
+
+
+def test_per_pixel_constraint_and_rebinding_voids_the_calibration(gpu_device, capsys):
+    """(a) per_pixel_p999: the optional second constraint -- the 99.9th percentile over pixels of the inverse depth's relative error -- is met on the
+    calibration frames and costs promotions (more x3 / x2w groups than the L2-only map).  (b) A calibrated map belongs to the weight VALUES it was
+    derived on: loading other values into the same parameters sends the handle back to all-x3 (source 3) at the next forward, with a notice."""
+    from soccdpt_amd.utils.synth import named_weights, synth_input
+    sd = named_weights("salt1")
+    m = _build(sd)
+    x_cal = synth_input(6, seed0=4).to(gpu_device)
+    rep0 = m.calibrate_precision(x_cal, budget=5e-4)
+    rep1 = m.calibrate_precision(x_cal, budget=5e-4, per_pixel_p999=6e-4)
+    print(f"L2-only map: {rep0['n_x3']} x3 + {rep0['n_x2w']} x2w, inv per-pixel p99.9 {rep0['inv_p999_calibrated']:.2e}; with per_pixel_p999 = 6e-4: "
+          f"{rep1['n_x3']} x3 + {rep1['n_x2w']} x2w, p99.9 {rep1['inv_p999_calibrated']:.2e} (hold-out {rep1['inv_p999_holdout']:.2e}), cost {rep0['cost_us_calibrated']:.0f} -> {rep1['cost_us_calibrated']:.0f} us")
+    assert rep1["met_budget"] == 1 and rep1["per_pixel_budget"] > 0
+    assert rep1["inv_p999_calibrated"] <= 0.85 * 6e-4 * 1.001 and rep1["inv_p999_holdout"] <= 6e-4
+    assert rep1["cost_us_calibrated"] >= rep0["cost_us_calibrated"] - 1e-3
+    assert m.precision_map_source() == "calibrated"
+    capsys.readouterr()
+    m.load_state_dict(named_weights("salt2"), strict=False)     # same parameters, other values
+    m.network(x_cal[:1])
+    assert m.precision_map_source() == "uncalibrated-all-x3"
+    assert "weights changed since" in capsys.readouterr().out
+    assert all(v == 3 for v in m._engine(gpu_device).prec_map().values())
+
+
+def test_failed_calibration_leaves_the_handle_as_it_was(gpu_device):
+    """an error inside soccdpt_prec_calibrate_ex after its first measured forward used to leave a half-built map on an unprepared handle.
+    Provoked here with a workspace that is too small for the calibration batch only AFTER entry checks pass is not possible from outside, so the
+    argument checks are exercised (they must not touch the handle) and the map / source / outputs are compared before and after."""
+    from soccdpt_amd.utils.synth import named_weights, synth_input
+    m = _build(named_weights("salt1"))
+    x = synth_input(3, seed0=4).to(gpu_device)
+    inv0, _ = m.network(x)
+    eng = m._engine(gpu_device)
+    map0, src0 = dict(eng.prec_map()), eng.prec_map_source()
+    for kw in (dict(holdout=3), dict(holdout=-1), dict(headroom=1.5)):
+        with pytest.raises(RuntimeError):
+            eng.calibrate_precision(x, 5e-4, **{"holdout": 0, "headroom": 0.85, **kw})
+    assert dict(eng.prec_map()) == map0 and eng.prec_map_source() == src0
+    inv1, _ = m.network(x)
+    assert torch.equal(inv0, inv1)
 
 
 def test_calibrate_errors(gpu_device):

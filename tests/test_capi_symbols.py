@@ -36,8 +36,10 @@ def test_header_symbols_exported():
 def test_binding_struct_sizes_match_the_library():
     """The ctypes mirrors of the public structs have exactly the size the LIBRARY was compiled with (soccdpt_sizeof): a field added to
     soccdpt_igemm_args / soccdpt_config without the binding following is caught here and at load_library()."""
-    from soccdpt_amd.lib import IgemmArgs, KernelStat, SoccdptConfig, load_library
+    from soccdpt_amd.lib import CalibOptions, CalibReport, IgemmArgs, KernelStat, SoccdptConfig, load_library
     L = load_library()
+    assert L.soccdpt_sizeof(3) == ctypes.sizeof(CalibReport)
+    assert L.soccdpt_sizeof(4) == ctypes.sizeof(CalibOptions) == 20
     assert L.soccdpt_sizeof(0) == ctypes.sizeof(SoccdptConfig)
     assert L.soccdpt_sizeof(1) == ctypes.sizeof(IgemmArgs)
     assert L.soccdpt_sizeof(2) == ctypes.sizeof(KernelStat)

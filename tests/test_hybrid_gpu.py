@@ -23,7 +23,9 @@ def _rel_l2(a, b):
 
 
 @pytest.mark.parametrize("precision", ["bf16", "f16", "f32"])
-@pytest.mark.parametrize("B,N", [(1, 577), (3, 577), (8, 577), (2, 64), (1, 33), (2, 20)])   # (2, 20): one key tile -- the second key half of the 8-wave form is empty
+# (2, 20): one key tile -- the second key half of the 8-wave form is empty.  B = 22 (B x heads = 264 >= 256 workgroups: no query split, one workgroup
+# owns every query block) with N in 33..128: the LDS the key halves meet in is larger than the K / V^T image (the launch sized it for K / V^T alone)
+@pytest.mark.parametrize("B,N", [(1, 577), (3, 577), (8, 577), (2, 64), (1, 33), (2, 20), (22, 33), (22, 64), (22, 100), (22, 128)])
 def test_vit_attention_vs_torch(gpu_device, precision, B, N):
     """softmax(q k^T / 8) v over a prime-length sequence (ragged last key tile, padded query block) and short sequences."""
     from soccdpt_amd.lib import op_vit_attention
