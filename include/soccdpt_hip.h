@@ -461,6 +461,14 @@ int soccdpt_op_wgrad_tn(const void* dev_a, long lda, const void* dev_b, long ldb
 int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table, const float* dev_scale, void* dev_out,
                                 float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, void* stream);
 
+/* The same block with the qkv projection INSIDE the kernel (csrc/attention_qkv.hip, round 6): replaces `qkv = F.linear(x, Wqkv, cat(q_bias, 0, v_bias))` +
+ * WindowAttention (timm SwinTransformerV2Block._attn; call site model/backbones/swin2.py:25-27; HF modeling_swinv2.py:389-452) -- the q / k / v tensor never
+ * exists.  dev_x [B*res*res][C] 16-bit block input (C = heads*32); dev_wqkv [3C][C]: 16-bit rows (SOCCDPT_PREC_BF16 / _F16) or x3 pairs (SOCCDPT_PREC_F16X2W);
+ * dev_qkv_bias [3C] f32; the other arguments as above.  out_x3 != 0 (fp16 kernels): dev_out in the x3 operand format for an x3 proj GEMM.  16 x 16 and 8 x 8 windows.
+ * dev_stamps: NULL, or 5 x (B * windows * heads) 64-bit words that receive per-workgroup s_memrealtime stamps (diagnostics: tools/wattn_qkv_stamps.py). */
+int soccdpt_op_window_attention_qkv(const void* dev_x, const void* dev_wqkv, const float* dev_qkv_bias, const float* dev_cpb_table, const float* dev_scale,
+                                    void* dev_out, float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, int out_x3, void* dev_stamps, void* stream);
+
 /* ---- training step: replaces `masks_pred = net(images)` in train mode + `grad_scaler.scale(loss).backward()`
  * (scripts/train_SOccDPT.py:360-393) for the encoder + decoder + heads (model/SOccDPT.py:660-685, model/dpt.py:142-232).
  * SOCCDPT_PREC_F32 handles only (Swin-V2 and ViT-hybrid backbones); weights are read as bound (no soccdpt_prepare needed: they change every step).

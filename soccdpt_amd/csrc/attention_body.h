@@ -231,29 +231,16 @@ struct AttnGenCfg {
     static constexpr int LDS = 2 * NPAD * 64 + 32 * VT_STRIDE;
 };
 
-// QS: query split as in window_attention_kernel (each workgroup stages all keys / values, owns 1/QS of the 32-query blocks).
-template <int WS, bool F16, int QS>
-__device__ __forceinline__ void window_attention_flash_body(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
-                                                            const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
-                                                            int shift, int heads, int out_x3, int bid, int tid, char* smem) {
+// The key loop of the flash form on operands that are already in LDS (Q-hat / K-hat rows of 64 bytes with 16-byte chunks XOR-swizzled by (row >> 2) & 3,
+// V^T rows of VT_STRIDE bytes): query blocks qb_lo + wave, + nwaves, ... < qb_hi.  Shared by window_attention_flash_body (operands staged from a qkv tensor)
+// and the fused kernel of attention_qkv.hip (operands computed in the workgroup from the block input and the Wqkv slice: round 6).
+template <int WS, bool F16>
+__device__ __forceinline__ void window_attention_flash_core(const char* Qs, const char* Ks, const char* Vt, const float* __restrict__ bias_acc, bf16_t* __restrict__ out,
+                                                            int res, int shift, int heads, int out_x3, int head, int b, int wy, int wx, int qb_lo, int qb_hi,
+                                                            int wave, int lane, int nwaves) {
     using A = AttnGenCfg<WS>;
-    char* Qs = smem;
-    char* Ks = smem + A::KS_OFF;
-    char* Vt = smem + A::VT_OFF;
-    const int lane = tid & 63, wave = tid >> 6;
     const int C = heads * 32;
     const int nw = res / WS;
-    const int qh = QS > 1 ? bid % QS : 0;
-    bid /= QS;
-    constexpr int QB0 = (AttnGenCfg<WS>::NT + QS - 1) / QS;   // query blocks per workgroup
-    const int qb_lo = qh * QB0, qb_hi = (qb_lo + QB0) < AttnGenCfg<WS>::NT ? (qb_lo + QB0) : AttnGenCfg<WS>::NT;
-    const int head = bid % heads;
-    bid /= heads;
-    const int wx = bid % nw;
-    bid /= nw;
-    const int wy = bid % nw;
-    const int b = bid / nw;
-    const float hscale = scale[head];
     auto token_row = [&](int p) -> size_t {
         const int r = p / WS, c = p % WS;
         int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
@@ -261,56 +248,13 @@ __device__ __forceinline__ void window_attention_flash_body(const bf16_t* __rest
         sx = sx >= res ? sx - res : sx;
         return (size_t)(b * res + sy) * res + sx;
     };
-    for (int idx = tid; idx < A::NPAD * 4; idx += A::THREADS) {
-        const int p = idx >> 2, c = idx & 3;
-        uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
-        const bool own_q = QS == 1 || ((p >> 5) >= qb_lo && (p >> 5) < qb_hi);
-        if (p < A::N) {
-            const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
-            if (own_q) qv = *reinterpret_cast<const uint4*>(src);
-            kv = *reinterpret_cast<const uint4*>(src + C);
-            vv = *reinterpret_cast<const uint4*>(src + 2 * C);
-        }
-        const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
-        float qf[8], kf[8];
-        float qs = 0.f, ks = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            qf[2 * j] = h_lo<F16>(qu[j]);
-            qf[2 * j + 1] = h_hi<F16>(qu[j]);
-            kf[2 * j] = h_lo<F16>(ku[j]);
-            kf[2 * j + 1] = h_hi<F16>(ku[j]);
-            qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
-            ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
-        }
-        qs += __shfl_xor(qs, 1);
-        qs += __shfl_xor(qs, 2);
-        ks += __shfl_xor(ks, 1);
-        ks += __shfl_xor(ks, 2);
-        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
-        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
-        uint4 qo, ko;
-        qo.x = pack_h2<F16>(qf[0] * qi, qf[1] * qi); qo.y = pack_h2<F16>(qf[2] * qi, qf[3] * qi);
-        qo.z = pack_h2<F16>(qf[4] * qi, qf[5] * qi); qo.w = pack_h2<F16>(qf[6] * qi, qf[7] * qi);
-        ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
-        ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
-        const int sw = (c ^ ((p >> 2) & 3)) * 16;
-        if (own_q) *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
-        *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
-            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
-        }
-    }
-    __syncthreads();
     const int r32 = lane & 31, h = lane >> 5;
     const bool lastrow = (shift > 0) && (wy == nw - 1), lastcol = (shift > 0) && (wx == nw - 1);
     constexpr int HALF = WS / 2;
     // (24 x 24 windows unsplit: 18 query blocks on 16 waves, i.e. a second round with 2 waves.  Built and removed in round 5: all 16 waves sharing the two
     //  left-over blocks by key slices that meet in LDS, as vit_attention_kernel's halves do -- 86 -> 98 us per launch: the two waves of the second round have
     //  a SIMD each to themselves and run their 18 tiles in a quarter of the first round's time, less than the slices' merge and the restructured loop cost.)
-    for (int qb = qb_lo + wave; qb < qb_hi; qb += A::THREADS / 64) {
+    for (int qb = qb_lo + wave; qb < qb_hi; qb += nwaves) {
         const int qrow = qb * 32 + r32;
         const int qcl = qrow < A::N ? qrow : A::N - 1;
         const bool qr_hi = (qcl / WS) >= HALF, qc_hi = (qcl % WS) >= HALF;
@@ -402,6 +346,82 @@ __device__ __forceinline__ void window_attention_flash_body(const bf16_t* __rest
             }
         }
     }
+}
+
+// QS: query split as in window_attention_kernel (each workgroup stages all keys / values, owns 1/QS of the 32-query blocks).
+template <int WS, bool F16, int QS>
+__device__ __forceinline__ void window_attention_flash_body(const bf16_t* __restrict__ qkv, const float* __restrict__ bias_acc,
+                                                            const float* __restrict__ scale, bf16_t* __restrict__ out, int res,
+                                                            int shift, int heads, int out_x3, int bid, int tid, char* smem) {
+    using A = AttnGenCfg<WS>;
+    char* Qs = smem;
+    char* Ks = smem + A::KS_OFF;
+    char* Vt = smem + A::VT_OFF;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int C = heads * 32;
+    const int nw = res / WS;
+    const int qh = QS > 1 ? bid % QS : 0;
+    bid /= QS;
+    constexpr int QB0 = (AttnGenCfg<WS>::NT + QS - 1) / QS;   // query blocks per workgroup
+    const int qb_lo = qh * QB0, qb_hi = (qb_lo + QB0) < AttnGenCfg<WS>::NT ? (qb_lo + QB0) : AttnGenCfg<WS>::NT;
+    const int head = bid % heads;
+    bid /= heads;
+    const int wx = bid % nw;
+    bid /= nw;
+    const int wy = bid % nw;
+    const int b = bid / nw;
+    const float hscale = scale[head];
+    auto token_row = [&](int p) -> size_t {
+        const int r = p / WS, c = p % WS;
+        int sy = wy * WS + r + shift, sx = wx * WS + c + shift;
+        sy = sy >= res ? sy - res : sy;
+        sx = sx >= res ? sx - res : sx;
+        return (size_t)(b * res + sy) * res + sx;
+    };
+    for (int idx = tid; idx < A::NPAD * 4; idx += A::THREADS) {
+        const int p = idx >> 2, c = idx & 3;
+        uint4 qv = make_uint4(0, 0, 0, 0), kv = qv, vv = qv;
+        const bool own_q = QS == 1 || ((p >> 5) >= qb_lo && (p >> 5) < qb_hi);
+        if (p < A::N) {
+            const bf16_t* src = qkv + token_row(p) * (size_t)(3 * C) + head * 32 + c * 8;
+            if (own_q) qv = *reinterpret_cast<const uint4*>(src);
+            kv = *reinterpret_cast<const uint4*>(src + C);
+            vv = *reinterpret_cast<const uint4*>(src + 2 * C);
+        }
+        const uint32_t qu[4] = {qv.x, qv.y, qv.z, qv.w}, ku[4] = {kv.x, kv.y, kv.z, kv.w}, vu[4] = {vv.x, vv.y, vv.z, vv.w};
+        float qf[8], kf[8];
+        float qs = 0.f, ks = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qf[2 * j] = h_lo<F16>(qu[j]);
+            qf[2 * j + 1] = h_hi<F16>(qu[j]);
+            kf[2 * j] = h_lo<F16>(ku[j]);
+            kf[2 * j + 1] = h_hi<F16>(ku[j]);
+            qs += qf[2 * j] * qf[2 * j] + qf[2 * j + 1] * qf[2 * j + 1];
+            ks += kf[2 * j] * kf[2 * j] + kf[2 * j + 1] * kf[2 * j + 1];
+        }
+        qs += __shfl_xor(qs, 1);
+        qs += __shfl_xor(qs, 2);
+        ks += __shfl_xor(ks, 1);
+        ks += __shfl_xor(ks, 2);
+        const float qi = hscale / fmaxf(sqrtf(qs), 1e-12f);
+        const float ki = 1.0f / fmaxf(sqrtf(ks), 1e-12f);
+        uint4 qo, ko;
+        qo.x = pack_h2<F16>(qf[0] * qi, qf[1] * qi); qo.y = pack_h2<F16>(qf[2] * qi, qf[3] * qi);
+        qo.z = pack_h2<F16>(qf[4] * qi, qf[5] * qi); qo.w = pack_h2<F16>(qf[6] * qi, qf[7] * qi);
+        ko.x = pack_h2<F16>(kf[0] * ki, kf[1] * ki); ko.y = pack_h2<F16>(kf[2] * ki, kf[3] * ki);
+        ko.z = pack_h2<F16>(kf[4] * ki, kf[5] * ki); ko.w = pack_h2<F16>(kf[6] * ki, kf[7] * ki);
+        const int sw = (c ^ ((p >> 2) & 3)) * 16;
+        if (own_q) *reinterpret_cast<uint4*>(Qs + p * 64 + sw) = qo;
+        *reinterpret_cast<uint4*>(Ks + p * 64 + sw) = ko;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] & 0xffffu);
+            *reinterpret_cast<uint16_t*>(Vt + (c * 8 + 2 * j + 1) * A::VT_STRIDE + p * 2) = (uint16_t)(vu[j] >> 16);
+        }
+    }
+    __syncthreads();
+    window_attention_flash_core<WS, F16>(Qs, Ks, Vt, bias_acc, out, res, shift, heads, out_x3, head, b, wy, wx, qb_lo, qb_hi, wave, lane, A::THREADS / 64);
 }
 
 }  // namespace soccdpt

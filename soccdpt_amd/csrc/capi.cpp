@@ -98,6 +98,8 @@ int soccdpt_create(const soccdpt_config* cfg, void** handle) {
         return fail(nullptr, "soccdpt_create: no HIP device visible (the MI355X path has no CPU fallback)");
     Handle* h = new Handle();
     if (const char* e = getenv("SOCCDPT_MLP_FUSE_MAX")) h->mlp_fuse_max = atoi(e);   // measurement switch (0 = unfused everywhere)
+    if (const char* e = getenv("SOCCDPT_FUSE_QKV")) h->fuse_qkv = atoi(e) != 0;         // measurement switch: 0 = qkv igemm + window_attention as in rounds 1-5
+    if (const char* e = getenv("SOCCDPT_FUSE_QKV_STAGES")) h->fuse_qkv_mask = atoi(e);
     h->cfg = *cfg;
     (void)hipGetDevice(&h->device);
     std::string err;
@@ -616,6 +618,20 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
     }
     if (launch_window_attention(static_cast<const bf16_t*>(dev_qkv), dev_bias_scratch, dev_scale, static_cast<bf16_t*>(dev_out),
                                 precision == SOCCDPT_PREC_F16 ? 1 : 0, B, res, ws, shift, heads, (hipStream_t)stream, err))
+        return fail(nullptr, err);
+    return 0;
+}
+
+int soccdpt_op_window_attention_qkv(const void* dev_x, const void* dev_wqkv, const float* dev_qkv_bias, const float* dev_cpb_table, const float* dev_scale,
+                                    void* dev_out, float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, int out_x3, void* dev_stamps, void* stream) {
+    std::string err;
+    if (!dev_x || !dev_wqkv || !dev_qkv_bias || !dev_cpb_table || !dev_scale || !dev_out || !dev_bias_scratch) return fail(nullptr, "soccdpt_op_window_attention_qkv: null argument");
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16 && precision != SOCCDPT_PREC_F16X2W)
+        return fail(nullptr, "soccdpt_op_window_attention_qkv: precision is SOCCDPT_PREC_BF16, _F16 or _F16X2W (16-bit activations)");
+    if (!window_attention_qkv_supported(ws, heads * 32, precision == SOCCDPT_PREC_F16X2W)) return fail(nullptr, "soccdpt_op_window_attention_qkv: window size / width not instantiated (16 x 16 and 8 x 8 windows)");
+    if (launch_attn_bias(dev_cpb_table, dev_bias_scratch, ws, heads, (hipStream_t)stream, err)) return fail(nullptr, err);
+    if (launch_window_attention_qkv(static_cast<const bf16_t*>(dev_x), dev_wqkv, dev_qkv_bias, dev_bias_scratch, dev_scale, static_cast<bf16_t*>(dev_out),
+                                    precision != SOCCDPT_PREC_BF16 ? 1 : 0, precision == SOCCDPT_PREC_F16X2W ? 1 : 0, B, res, ws, shift, heads, (hipStream_t)stream, err, out_x3, static_cast<unsigned long long*>(dev_stamps)))
         return fail(nullptr, err);
     return 0;
 }

@@ -109,6 +109,8 @@ struct Handle {
     bool prof_sites = false;                              // profile igemm launches per shape ("site000", ...) instead of per tile family
     std::vector<SiteRec> sites;                           // shapes seen while prof_sites was on, in first-launch order
     std::unordered_map<long long, int> tune_by_shape;     // shape key -> forced tile configuration (in-network tuning)
+    bool fuse_qkv = true;                                 // Swin-V2: qkv projection inside the attention kernel where instantiated (attention_qkv.hip); SOCCDPT_FUSE_QKV=0 = the two-launch chain
+    int fuse_qkv_mask = 3;                                // ... per stage (bit s); SOCCDPT_FUSE_QKV_STAGES=<mask>: measurement switch
     int mlp_fuse_max = 128;                               // widest stage whose MLP half-block runs as one fused launch (mlp_fused.hip; wider ones lose)
     // SOCCDPT_PREC_MIXED: operand format of every launch-site group (model.cpp: prec_groups), 1 = fp16, 3 = x3; groups absent from the map are fp16
     std::unordered_map<std::string, int> prec_map;

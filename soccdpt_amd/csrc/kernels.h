@@ -130,6 +130,12 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
                             int shift, int heads, hipStream_t st, std::string& err, int out_x3 = 0);
 
+// The same with the qkv projection inside the kernel (attention_qkv.hip, round 6): x = the block input [M][C] (16-bit operand copy), wqkv = the prepared
+// [3C][C] weight (plain 16-bit, or x3 pairs when x2w != 0), qkv_bias = cat(q_bias, 0, v_bias) f32.  16 x 16 and 8 x 8 windows.
+bool window_attention_qkv_supported(int ws, int C, int x2w);
+int launch_window_attention_qkv(const bf16_t* x, const void* wqkv, const float* qkv_bias, const float* bias_acc, const float* scale, bf16_t* out, int hf, int x2w,
+                                int B, int res, int ws, int shift, int heads, hipStream_t st, std::string& err, int out_x3 = 0, unsigned long long* stamps = nullptr);
+
 // x3 != 0: `out` is written in the x3 split-fp16 operand format (half16.h) for the proj GEMM of SOCCDPT_PREC_F16X3
 int launch_window_attention_f32(const float* qkv, const float* bias_acc, const float* table, const float* scale, float* out, int B, int res,
                                 int ws, int shift, int heads, hipStream_t st, std::string& err, int x3 = 0);

@@ -969,11 +969,21 @@ static int run_chunk(Handle& h, const Workspace& w, const float* x, int B, float
             void *b_qkv = w.qkv, *b_attn = w.attn, *b_hbuf = w.hbuf, *b_xin = w.xb, *b_x1 = w.xb, *b_x2 = to_merge ? w.hbuf : w.xb;
             float *b_y1 = w.y, *b_y2 = w.y, *b_xf = w.xf;
             IgemmDesc d;
+            // round 6: qkv projection inside the attention kernel (attention_qkv.hip) where the group's activations are 16-bit (fp16 / bf16 / x2w groups) and
+            // the window form is instantiated; x3 groups and the exact-f32 mode keep the two-launch chain
+            const bool qkv_x2w = MIX && fa == 1 && group_x2w(h, gblk(s, j, "qkv"));
+            const bool fuse_qkv = h.fuse_qkv && fa <= 1 && window_attention_qkv_supported(wsz, C, qkv_x2w ? 1 : 0) && (h.fuse_qkv_mask >> s & 1);
+            if (fuse_qkv) {
+                PROF("window_attention_qkv", 6.0 * M * (double)C * C + 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 4.0);
+                RUN(launch_window_attention_qkv(static_cast<const bf16_t*>(b_xin), bw.qkv_w, bw.qkv_bias, bw.bias_acc, bw.scale, static_cast<bf16_t*>(b_attn), MIX ? 1 : fa,
+                                                qkv_x2w ? 1 : 0, B, res, wsz, a.shift(s, j), H, st, err, (MIX && fp == 3) ? 1 : 0));
+            } else {
             d.X = b_xin; d.Wt = bw.qkv_w; d.M = M; d.N = 3 * C; d.Cin = C; d.ldx = C; d.bias = bw.qkv_bias;
             if (MIX) { d.out_op = b_qkv; d.out_fmt = 1; }   // mixed mode: fp16 q, k, v for the fp16 attention kernel whatever the GEMM ran in
             else to_plain(d, b_qkv, fa);
             RUN(gemm(d, fa));
-            { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
+            }
+            if (!fuse_qkv) { PROF("window_attention", 4.0 * M * (double)(wsz * wsz) * C, (double)M * C * 8.0);
               if (!MIX && fa >= 2) RUN(launch_window_attention_f32(static_cast<const float*>(b_qkv), bw.bias_acc, bw.table, bw.scale, static_cast<float*>(b_attn), B, res, wsz,
                                                        a.shift(s, j), H, st, err, fa == 3 ? 1 : 0));
               else RUN(launch_window_attention(static_cast<const bf16_t*>(b_qkv), bw.bias_acc, bw.scale, static_cast<bf16_t*>(b_attn), MIX ? 1 : fa, B, res, wsz,

@@ -101,7 +101,7 @@ _lib = None
 # Translation units (and the headers they share) that DEFINE OR SEQUENCE the forward path's kernels.  capi.cpp / internal.h (entry points,
 # handle bookkeeping), the training step (train*), the criterion, optimiser, metrics, GT-occupancy and input-transform kernels launch
 # nothing inside soccdpt_forward, so editing them does not invalidate PMC counters collected for the forward's kernels.
-FORWARD_SOURCES = ("Makefile", "attention.hip", "attention_body.h", "conv8p.hip", "depth_tail.hip", "elementwise.hip", "gelu.h", "half16.h", "hybrid.hip", "igemm.h",
+FORWARD_SOURCES = ("Makefile", "attention.hip", "attention_body.h", "attention_qkv.hip", "conv8p.hip", "depth_tail.hip", "elementwise.hip", "gelu.h", "half16.h", "hybrid.hip", "igemm.h",
                    "igemm.hip", "igemm_kernel.h", "kernels.h", "launch.h", "ln_body.h", "mlp_fused.hip", "model.cpp", "projection.hip", "resample.h",
                    "vit_attention.hip")
 
@@ -226,6 +226,8 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_op_vit_attention.restype = ci
     L.soccdpt_op_window_attention.argtypes = [vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, vp]
     L.soccdpt_op_window_attention.restype = ci
+    L.soccdpt_op_window_attention_qkv.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
+    L.soccdpt_op_window_attention_qkv.restype = ci
     L.soccdpt_op_wgrad_tn.argtypes = [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_size_t, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp]
     L.soccdpt_op_wgrad_tn.restype = ci
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
@@ -745,3 +747,14 @@ def op_window_attention(qkv, cpb_table, scale, out, B, res, ws, shift, heads, pr
                                        heads, int(precision), _stream_ptr(qkv.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_window_attention failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_window_attention_qkv(x, wqkv, qkv_bias, cpb_table, scale, out, B, res, ws, shift, heads, precision=PREC_F16, out_x3=False, stamps=None):
+    """soccdpt_op_window_attention_qkv: one Swin-V2 block's qkv projection + window attention as ONE launch (csrc/attention_qkv.hip)."""
+    L = load_library()
+    nt = (ws * ws + 31) // 32
+    scratch = torch.empty((heads * nt * nt * 1024,), dtype=torch.float32, device=x.device)
+    rc = L.soccdpt_op_window_attention_qkv(_ptr(x), _ptr(wqkv), _ptr(qkv_bias), _ptr(cpb_table), _ptr(scale), _ptr(out), _ptr(scratch), B, res, ws, shift,
+                                           heads, int(precision), 1 if out_x3 else 0, _ptr(stamps), _stream_ptr(x.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_window_attention_qkv failed: " + L.soccdpt_last_error(None).decode())

@@ -165,6 +165,80 @@ def test_window_attention(gpu_device, B, res, ws, shift, heads):
     assert float(err.max()) < 6e-2 and float(err.mean()) < 6e-3, (float(err.max()), float(err.mean()))
 
 
+@pytest.mark.parametrize("fmt", ["f16", "x2w", "bf16"])
+@pytest.mark.parametrize("B,res,ws,shift,heads", [(2, 64, 16, 0, 3), (2, 64, 16, 8, 3), (1, 32, 16, 8, 6), (3, 16, 16, 0, 12), (2, 8, 8, 0, 24), (1, 32, 16, 0, 12), (1, 16, 8, 0, 12)])
+def test_window_attention_with_qkv_projection_inside(gpu_device, fmt, B, res, ws, shift, heads):
+    """Round 6: qkv = x Wqkv^T + cat(q_bias, 0, v_bias) and the window attention as ONE launch (csrc/attention_qkv.hip), against float64
+    of the same 16-bit operands through the reference maths, and against the two-launch chain it replaces (igemm -> fp16 qkv tensor -> window_attention):
+    the fused form skips the fp16 rounding of q, k, v in between, so it must sit at least as close to float64 as the chain does (small slack for
+    the different summation order)."""
+    from soccdpt_amd.lib import PREC_BF16, PREC_F16, PREC_F16X2W, op_igemm, op_window_attention, op_window_attention_qkv, x3_decode, x3_encode
+    g = torch.Generator().manual_seed(res * 100 + shift + heads)
+    C = heads * 32
+    M = B * res * res
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    x = (torch.randn(M, C, generator=g) * 0.8).to(dt)
+    w = torch.randn(3 * C, C, generator=g) / math.sqrt(C)
+    q_bias, v_bias = torch.randn(C, generator=g) * 0.3, torch.randn(C, generator=g) * 0.3
+    bias = torch.cat([q_bias, torch.zeros(C), v_bias])
+    table = (16 * torch.sigmoid(torch.randn((2 * ws - 1) ** 2, heads, generator=g)))
+    scale = (10.0 + 5 * torch.rand(heads, generator=g))
+    if fmt == "x2w":
+        w_dev = x3_encode(w.to(gpu_device))
+        w_eff = x3_decode(w_dev.cpu(), w.shape)        # what the pair represents (22+ bits)
+        code = PREC_F16X2W
+    else:
+        w_dev = w.to(dt).to(gpu_device)
+        w_eff = w.to(dt).float()
+        code = PREC_BF16 if fmt == "bf16" else PREC_F16
+    xd, bd, td, sd = x.to(gpu_device), bias.to(gpu_device), table.to(gpu_device), scale.to(gpu_device)
+    out = torch.empty(M, C, dtype=dt, device=gpu_device)
+    op_window_attention_qkv(xd, w_dev, bd, td, sd, out, B, res, ws, shift, heads, code)
+    torch.cuda.synchronize()
+    qkv64 = x.double() @ w_eff.double().t() + bias.double()
+    ref = _attention_ref(qkv64.float(), table, scale, B, res, ws, shift, heads)
+    err = (out.float().cpu() - ref).abs()
+    tol_max, tol_mean = (6e-2, 6e-3) if fmt == "bf16" else (1.2e-2, 8e-4)
+    assert float(err.max()) < tol_max and float(err.mean()) < tol_mean, (float(err.max()), float(err.mean()))
+    # the chain it replaces, same operands
+    qkv16 = torch.empty(M, 3 * C, dtype=dt, device=gpu_device)
+    op_igemm(xd, w_dev, M, 3 * C, C, ldx=C, bias=bd, out_bf16=qkv16, precision=code)
+    out2 = torch.empty(M, C, dtype=dt, device=gpu_device)
+    op_window_attention(qkv16, td, sd, out2, B, res, ws, shift, heads, PREC_BF16 if fmt == "bf16" else PREC_F16)
+    torch.cuda.synchronize()
+    err2 = (out2.float().cpu() - ref).abs()
+    rel = float((out.float() - out2.float()).norm() / out2.float().norm())
+    print(f"fused qkv+attention {fmt} B{B} res{res} ws{ws} shift{shift} heads{heads}: mean |err| vs float64 fused {float(err.mean()):.2e} / chain {float(err2.mean()):.2e}; fused vs chain rel L2 {rel:.2e}")
+    assert float(err.mean()) <= float(err2.mean()) * 1.05 + 1e-6
+    assert rel < (2e-2 if fmt == "bf16" else 3e-3)
+
+
+def test_window_attention_qkv_x3_output_and_errors(gpu_device):
+    """out_x3: the attention output in the x3 operand format (the proj GEMM of an x3 group reads it) decodes to the fp16-output run's values within fp16
+    rounding; unsupported window sizes / precisions are refused with an error, not launched."""
+    from soccdpt_amd.lib import PREC_F16, PREC_F32, op_window_attention_qkv, x3_decode
+    g = torch.Generator().manual_seed(5)
+    B, res, ws, heads = 1, 32, 16, 6
+    C, M = heads * 32, B * res * res
+    x = (torch.randn(M, C, generator=g) * 0.8).half().to(gpu_device)
+    w = (torch.randn(3 * C, C, generator=g) / math.sqrt(C)).half().to(gpu_device)
+    bias = (torch.randn(3 * C, generator=g) * 0.3).to(gpu_device)
+    table = (16 * torch.sigmoid(torch.randn((2 * ws - 1) ** 2, heads, generator=g))).to(gpu_device)
+    scale = (10.0 + 5 * torch.rand(heads, generator=g)).to(gpu_device)
+    o16 = torch.empty(M, C, dtype=torch.float16, device=gpu_device)
+    o3 = torch.empty(M, C, dtype=torch.float32, device=gpu_device)
+    op_window_attention_qkv(x, w, bias, table, scale, o16, B, res, ws, 8, heads, PREC_F16)
+    op_window_attention_qkv(x, w, bias, table, scale, o3, B, res, ws, 8, heads, PREC_F16, out_x3=True)
+    torch.cuda.synchronize()
+    dec = x3_decode(o3.cpu(), (M, C)).float()
+    torch.testing.assert_close(dec, o16.cpu().float(), rtol=1e-3, atol=1e-6)      # the pair carries the f32 value: within one fp16 rounding of the fp16-output run
+    assert float((dec.half() != o16.cpu()).float().mean()) < 1e-3                # (hi + lo re-rounded lands on the neighbour only at ties)
+    with pytest.raises(RuntimeError):
+        op_window_attention_qkv(x, w, bias, table, scale, o16, B, 48, 24, 0, heads, PREC_F16)     # 24 x 24 windows: the two-launch chain
+    with pytest.raises(RuntimeError):
+        op_window_attention_qkv(x, w, bias, table, scale, o16, B, res, ws, 0, heads, PREC_F32)
+
+
 # ---------------- split-K (deterministic partial-tile exchange, last arriver runs the epilogue) ----------------
 @pytest.mark.parametrize("splitk", [2, 3, 8])
 def test_igemm_splitk(gpu_device, splitk):
