@@ -274,6 +274,10 @@ def main():
                          "(what tools/collect_profiles.sh runs under rocprofv3, so profiles/*_kernel_stats.csv describe the headline launches alone)")
     ap.add_argument("--with-two-streams", action="store_true",
                     help="also time the EXPERIMENTAL two-concurrent-sub-batches mode (soccdpt_set_streams(2); opt-in, DESIGN.md section 4)")
+    ap.add_argument("--in-flight", type=int, default=2,
+                    help="side object `pipelined`: this many whole forwards in flight -- independent engines / workspaces, step i + 1 issued on another stream while "
+                         "step i drains, no synchronisation in between (the reference's timing loop never synchronises between forwards either: "
+                         "scripts/eval_SOccDPT.py:246-259); 1 = off.  `value` and the per-kernel rooflines stay single-stream")
     ap.add_argument("--cpu-sample-frames", type=int, default=2)
     ap.add_argument("--train-step", action="store_true",
                     help="BASELINE configs[4] instead of the forward: one optimisation step (train-mode forward + criterion + backward + fused Adam, exact f32) "
@@ -668,6 +672,45 @@ def main():
                                  "experimental": True,
                                  "note": "EXPERIMENTAL opt-in mode (soccdpt_set_streams(2)): same forward, batch dealt to 2 concurrent sub-batches on internal streams"}
         del net2
+
+    # ---- whole forwards in flight: N engines with their own workspaces and outputs, forward i on stream i mod N, nothing between them but
+    # the stream order of each engine's own launches.  The HBM-bound tail of one step (depth tail -> projection -> expansion: little MFMA / LDS use) and the
+    # latency-bound encoder launches of the next overlap.  Outputs are bit-compared with the sequential run first.  Not the headline: the kernels of
+    # `roofline` are timed running alone.
+    if single and args.in_flight > 1 and not args.headline_only:
+        nets = [net] + [build(args.precision) for _ in range(args.in_flight - 1)]
+        if args.precision == "mixed" and calib_report is not None:
+            for m in nets[1:]:
+                with contextlib.redirect_stdout(io.StringIO()):
+                    m.calibrate_precision(x_cal, budget=budget)
+        streams = [torch.cuda.Stream(device=dev) for _ in nets]
+        ref_out = [t.clone() for t in net(x)]
+        torch.cuda.synchronize()
+        same = True
+        outs = [None] * len(nets)
+        for r in range(2):
+            for i, (m, s) in enumerate(zip(nets, streams)):
+                with torch.cuda.stream(s):
+                    outs[i] = m(x)
+        torch.cuda.synchronize()
+        for o in outs:
+            same = same and all(torch.equal(a.view(torch.int32), b.view(torch.int32)) for a, b in zip(o, ref_out))
+        def run(n):
+            for k in range(n):
+                i = k % len(nets)
+                with torch.cuda.stream(streams[i]):
+                    outs[i] = nets[i](x)
+        run(args.warmup)
+        torch.cuda.synchronize()
+        t6 = time.perf_counter()
+        run(args.steps)
+        torch.cuda.synchronize()
+        e6 = time.perf_counter() - t6
+        result["pipelined"] = {"in_flight": len(nets), "value": round(B * args.steps / e6, 2), "unit": "frames/s", "ms_per_step": round(e6 / args.steps * 1e3, 3),
+                               "vs_value": round(B * args.steps / e6 / result["value"], 4), "bit_identical_to_sequential": bool(same),
+                               "note": f"{len(nets)} independent engines (own workspace, own outputs), forward i on stream i mod {len(nets)}, no synchronisation between forwards; "
+                                       "throughput of the same step when the caller keeps more than one frame batch in flight -- a side field, `value` stays one forward at a time"}
+        del nets, outs
 
     # ---- CPU baseline: the oracle on this host's cores, bounded sample, rank 0 at N = 1 only ----
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

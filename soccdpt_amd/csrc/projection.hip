@@ -349,10 +349,10 @@ __global__ __launch_bounds__(256) void project_rows_kernel(ProjParams P, int nse
 // in-order), forcing 5 waves per SIMD (spills: 184 us), and multiply-and-correct division by the five run-time constants (verified bit-equal to
 // IEEE division for all 2^23 significands per constant, but no faster: 111 us -- the kernel is not VALU-bound any more).
 // Per-pixel arithmetic, its order and therefore every output bit are those of project_rows_kernel / oracle/projection_ref.c.
-template <int C, int SW, int R, int NR>
+template <int C, int SW, int R, int NR, int NS>
 __global__ __launch_bounds__(256) void project_rowsR_kernel(ProjParams P, int nseg, int rot_bc_identity) {
     __shared__ float s_inv[NR][SW];
-    __shared__ float s_seg[C][2][SW];
+    __shared__ float s_seg[C][NS][SW];   // NS nearest-neighbour class rows cover the group (2 for R = 4, 3 for R = 8 at 256 -> 1080)
     __shared__ float4 s_pts[4][3 * 64];   // per wave: 64 threads x 3 float4
     __shared__ int s_lk[R][4];
     __shared__ uint32_t s_lc[R][4];
@@ -387,7 +387,7 @@ __global__ __launch_bounds__(256) void project_rowsR_kernel(ProjParams P, int ns
 #pragma unroll
             for (int c = 0; c < C; ++c)
 #pragma unroll
-                for (int k = 0; k < 2; ++k) {
+                for (int k = 0; k < NS; ++k) {
                     int rr = su0 + k;
                     rr = rr > P.h - 1 ? P.h - 1 : rr;
                     s_seg[c][k][threadIdx.x] = P.seg[(((size_t)b * C + c) * P.h + rr) * P.w + col];
@@ -654,11 +654,19 @@ int launch_project(const soccdpt_config& cfg, const float* inv, const float* seg
         // the R rows of a group need source rows idx0(u0) .. idx3(u0 + R - 1): at most 4 + ceil((R - 1) h / Hc) + 1
         const float sy_h = (float)P.h / (float)P.Hc;
         static const int force_rows1 = getenv("SOCCDPT_PROJECT_ROWS1") ? atoi(getenv("SOCCDPT_PROJECT_ROWS1")) : 0;   // A/B against the one-row kernel
+        static const int rows8 = getenv("SOCCDPT_PROJECT_ROWS8") ? atoi(getenv("SOCCDPT_PROJECT_ROWS8")) : 0;         // A/B: 8 camera rows per workgroup
+        bool ident = true;   // Rb and Rc exactly the identity? (rotate_points with b = c = 0)
+        for (int i = 0; i < 9; ++i) ident = ident && P.rot[9 + i] == ((i % 4 == 0) ? 1.0f : 0.0f) && P.rot[18 + i] == ((i % 4 == 0) ? 1.0f : 0.0f);
+        if (rows8 && !force_rows1 && 5 + (int)ceilf(7 * sy_h) <= 7 && 1.0f + 7 * sy_h < 3.0f) {
+            const int ngrp = (P.Hc + 7) / 8;
+            SOCCDPT_LAUNCH((project_rowsR_kernel<3, SW, 8, 7, 3>), dim3((unsigned)(B * ngrp * nseg)), dim3(256), 0, stream, P, nseg, ident ? 1 : 0);
+            hipError_t e3 = hipGetLastError();
+            if (e3 != hipSuccess) { err = hipGetErrorString(e3); return 1; }
+            return 0;
+        }
         if (!force_rows1 && 5 + (int)ceilf((R - 1) * sy_h) <= NR && 1.0f + (R - 1) * sy_h < 2.0f) {
-            bool ident = true;   // Rb and Rc exactly the identity? (rotate_points with b = c = 0)
-            for (int i = 0; i < 9; ++i) ident = ident && P.rot[9 + i] == ((i % 4 == 0) ? 1.0f : 0.0f) && P.rot[18 + i] == ((i % 4 == 0) ? 1.0f : 0.0f);
             const int ngrp = (P.Hc + R - 1) / R;
-            SOCCDPT_LAUNCH((project_rowsR_kernel<3, SW, R, NR>), dim3((unsigned)(B * ngrp * nseg)), dim3(256), 0, stream, P, nseg, ident ? 1 : 0);
+            SOCCDPT_LAUNCH((project_rowsR_kernel<3, SW, R, NR, 2>), dim3((unsigned)(B * ngrp * nseg)), dim3(256), 0, stream, P, nseg, ident ? 1 : 0);
             hipError_t e3 = hipGetLastError();
             if (e3 != hipSuccess) { err = hipGetErrorString(e3); return 1; }
             return 0;

@@ -64,6 +64,8 @@ def test_pmc_family_names_follow_the_kernel_templates():
     assert m.family(sig % ("64, 64, 64, 2, 4, 3, 16", "soccdpt::x2w_t", "false")) == "igemm_x2w_64x64x64_s3_w8"              # round 5: one-sided split launches
     assert m.family(sig % ("32, 64, 64, 2, 2, 4, 16", "soccdpt::x2w_t", "false")) == "igemm_x2w_32x64x64_s4"
     assert m.family("void soccdpt::igemm_kernel<soccdpt::Cfg<64, 128, 32, 2, 2, 3, 16>, soccdpt::x2w_t, true, false, false, false, false>(soccdpt::IgemmDesc, int, int, int)") == "igemm_x2w_64x128x32_s3_ln"
+    assert m.family("void soccdpt::(anonymous namespace)::window_attention_qkv_kernel<16, true, 96, true, false>(unsigned short const*, void const*, float const*, float const*, float const*, unsigned short*, int, int, int, int, unsigned long long*)") == "window_attention_qkv"   # round 6
+    assert m.family("void soccdpt::window_attention_flash_kernel<16, true, 1>(unsigned short const*, float const*, float const*, unsigned short*, int, int, int, int)") == "window_attention"
     assert m.family("soccdpt::occ_expand_kernel(unsigned int const*, float*, unsigned long, int)") == "occ_expand"
     assert m.family("void soccdpt::project_rowsR_kernel<3, 256, 4, 7>(soccdpt::ProjParams, int, int)") == "project_voxelise"
 

@@ -22,6 +22,8 @@ if [ "$PART" = "all" ] || [ "$PART" = "2" ]; then
 bash tools/collect_profiles.sh ${TAG}_hybrid384 --config 2 > $OUT/collect_hybrid.log 2>&1
 echo "hybrid done"
 for p in f16 f16x3 f32; do python3 bench.py --precision $p --no-cpu-baseline > $OUT/bench_$p.json 2>> $OUT/bench.err; done
+for w in salt1 salt2 trained_like; do python3 bench.py --weights $w --no-cpu-baseline --no-other-weights > $OUT/bench_weights_$w.json 2>> $OUT/bench.err; done
+python3 bench.py --no-cpu-baseline --no-side-modes --in-flight 3 > $OUT/bench_in_flight3.json 2>> $OUT/bench.err
 python3 bench.py --config 2 --precision f16x3 --no-cpu-baseline > $OUT/bench_hybrid384_f16x3.json 2>> $OUT/bench.err
 python3 bench.py --config 2 --precision f32 --no-cpu-baseline > $OUT/bench_hybrid384_f32.json 2>> $OUT/bench.err
 python3 bench.py --config 3 --precision f16x3 --no-cpu-baseline > $OUT/bench_base384_f16x3.json 2>> $OUT/bench.err
@@ -33,6 +35,7 @@ python3 bench.py --train-step --amp x3 > $OUT/bench_train_step_x3.json 2>> $OUT/
 python3 bench.py --train-step --amp bf16 > $OUT/bench_train_step_amp.json 2>> $OUT/bench.err
 python3 bench.py --train-step --amp f16 > $OUT/bench_train_step_amp_f16.json 2>> $OUT/bench.err
 python3 bench.py --train-step --batch 3 --encoder-percentage 0.5 --patchwise-percentage 0.5 > $OUT/bench_train_step_B3_enc50_patch50.json 2>> $OUT/bench.err
+python3 bench.py --train-step --amp bf16 --batch 3 --encoder-percentage 0.5 --patchwise-percentage 0.5 > $OUT/bench_train_step_amp_B3_enc50_patch50.json 2>> $OUT/bench.err
 python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 > $OUT/bench_train_step_base384.json 2>> $OUT/bench.err
 python3 bench.py --train-step --model-type dpt_swin2_base_384 --batch 8 --amp bf16 > $OUT/bench_train_step_amp_base384.json 2>> $OUT/bench.err
 python3 bench.py --train-step --model-type dpt_hybrid_384 --batch 4 > $OUT/bench_train_step_hybrid384.json 2>> $OUT/bench.err

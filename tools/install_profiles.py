@@ -19,6 +19,8 @@ for name, f in (("fetch_size", "pmc_fetch/f"), ("write_size", "pmc_write/w"), ("
         w.writerow(["Kernel_Name", "Counter_Name", "Dispatches", "Counter_Value_Sum"])
         for (k, c), (n, v) in agg.items():
             w.writerow([k, c, n, v])
+if os.path.exists(f"{src}/pmc_stall.json"):   # round 6: SQ stall-reason shares per kernel family (tools/pmc_stall_summary.py on the box)
+    shutil.copy(f"{src}/pmc_stall.json", f"{dst}/{tag}_pmc_stall.json")
 subprocess.check_call([sys.executable, "tools/pmc_summary.py", f"{dst}/{tag}_pmc_fetch_size_counter_collection.csv",
                        f"{dst}/{tag}_pmc_write_size_counter_collection.csv", f"{dst}/{tag}_pmc_traffic.json",
                        f"{dst}/{tag}_pmc_mfma_counter_collection.csv"])

@@ -6,7 +6,7 @@ import collections, csv, json, re, sys
 
 def family(kernel_name: str) -> str:
     """Kernel symbol -> the family name bench.py's HIP-event profiler reports (model.cpp PROF scopes)."""
-    n = kernel_name.split("(")[0].replace("void ", "").replace("soccdpt::", "")
+    n = kernel_name.replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").replace("soccdpt::", "")
     m = re.match(r"igemm_kernel<Cfg<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)(?:, (\d+))?>, ([\w: ]+), (true|false), (true|false)(?:, (?:true|false))*>", n)   # Cfg<BM, BN, BK, WM, WN, NS[, MF]>, T, LN, SK[, ST, GEN]
     if m:
         mf32 = m.group(7) == "32"
@@ -27,7 +27,7 @@ def family(kernel_name: str) -> str:
         w16 = int(m.group(4)) * int(m.group(5)) == 16   # the 16-wave tiles of round 5
         return (f"igemm_{'f16' if 'f16' in t else 'bf16'}_{m.group(1)}x{m.group(2)}x{m.group(3)}_s{m.group(6)}" + ("_w8" if w8 else "") + ("_w16" if w16 else "") +
                 ("_splitk" if m.group(9) == "true" else "") + ("_dot3" if len(flags) >= 5 and flags[4] == "true" else ""))
-    for prefix, fam in (("window_attention", "window_attention"), ("mlp_ln_kernel", "mlp_ln_fused"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
+    for prefix, fam in (("window_attention_qkv", "window_attention_qkv"), ("window_attention", "window_attention"), ("mlp_ln_kernel", "mlp_ln_fused"), ("project_", "project_voxelise"), ("occ_expand", "occ_expand"),
                         ("ln_residual", "ln_residual"), ("depth_tail", "depth_tail_fused"), ("patch_embed", "patch_embed_ln"),
                         ("bilinear", "bilinear_resize"), ("merge_gather", "merge_gather"), ("conv1x1_c3", "seg_tail"), ("seg_up_act", "seg_tail"), ("seg_logits_finish", "seg_tail")):
         if n.startswith(prefix):
