@@ -469,6 +469,15 @@ int soccdpt_op_window_attention(const void* dev_qkv, const float* dev_cpb_table,
 int soccdpt_op_window_attention_qkv(const void* dev_x, const void* dev_wqkv, const float* dev_qkv_bias, const float* dev_cpb_table, const float* dev_scale,
                                     void* dev_out, float* dev_bias_scratch, int B, int res, int ws, int shift, int heads, int precision, int out_x3, void* dev_stamps, void* stream);
 
+/* Winograd F(2x2, 3x3) form of nn.Conv2d(C, N, 3, padding=1) over a 16-bit zero-halo NHWC image (csrc/wino.hip, round 6; the RCU convolutions of
+ * model/blocks.py:391-414).  soccdpt_op_wino_weights: dev_w [N][C][3][3] f32 (x dev_scale[n] when given) -> dev_u, 16 * N * C 16-bit elements laid out [C/32][16][N][32]
+ * (U = G g G^T computed in f32, rounded once).  soccdpt_op_wino_conv: dev_x_halo [B][H+2][W+2][C]; H, W multiples of 16, C of 32, N of 64; epilogue in igemm's order:
+ * + bias, + res1 [M][N] f32, + res2 [B][res2_h][res2_w][N] f32 sampled bilinearly (align_corners), ReLU on the operand copy (and on the f32 output when act_on_f32),
+ * dev_out_f32 [M][N] and / or dev_out_op (16-bit, or x3 when out_x3; plain [M][N] or zero-halo [B][H+2][W+2][N]).  precision = SOCCDPT_PREC_F16 or _BF16. */
+int soccdpt_op_wino_weights(const float* dev_w, const float* dev_scale, void* dev_u, int N, int C, int precision, void* stream);
+int soccdpt_op_wino_conv(const void* dev_x_halo, const void* dev_u, int B, int H, int W, int C, int N, const float* dev_bias, const float* dev_res1, const float* dev_res2,
+                         int res2_h, int res2_w, int relu, int act_on_f32, float* dev_out_f32, void* dev_out_op, int out_halo, int out_x3, int precision, void* dev_stamps /* NULL, or 8 words per workgroup: diagnostics */, void* stream);
+
 /* ---- training step: replaces `masks_pred = net(images)` in train mode + `grad_scaler.scale(loss).backward()`
  * (scripts/train_SOccDPT.py:360-393) for the encoder + decoder + heads (model/SOccDPT.py:660-685, model/dpt.py:142-232).
  * SOCCDPT_PREC_F32 handles only (Swin-V2 and ViT-hybrid backbones); weights are read as bound (no soccdpt_prepare needed: they change every step).

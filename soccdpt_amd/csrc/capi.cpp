@@ -636,6 +636,25 @@ int soccdpt_op_window_attention_qkv(const void* dev_x, const void* dev_wqkv, con
     return 0;
 }
 
+int soccdpt_op_wino_weights(const float* dev_w, const float* dev_scale, void* dev_u, int N, int C, int precision, void* stream) {
+    std::string err;
+    if (!dev_w || !dev_u || (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16)) return fail(nullptr, "soccdpt_op_wino_weights: null argument or precision not BF16 / F16");
+    if (launch_wino_weights(dev_w, dev_scale, dev_u, precision == SOCCDPT_PREC_F16 ? 1 : 0, N, C, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+int soccdpt_op_wino_conv(const void* dev_x_halo, const void* dev_u, int B, int H, int W, int C, int N, const float* dev_bias, const float* dev_res1, const float* dev_res2,
+                         int res2_h, int res2_w, int relu, int act_on_f32, float* dev_out_f32, void* dev_out_op, int out_halo, int out_x3, int precision, void* dev_stamps, void* stream) {
+    std::string err;
+    if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16) return fail(nullptr, "soccdpt_op_wino_conv: precision is SOCCDPT_PREC_BF16 or _F16");
+    WinoArgs a;
+    a.X = dev_x_halo; a.U = dev_u; a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.bias = dev_bias; a.res1 = dev_res1; a.res2 = dev_res2; a.res2_h = res2_h; a.res2_w = res2_w;
+    a.act = relu ? ACT_RELU : ACT_NONE; a.act_on_f32 = act_on_f32; a.out_f32 = dev_out_f32; a.out_op = dev_out_op; a.out_halo = out_halo; a.out_x3 = out_x3;
+    a.hf = precision == SOCCDPT_PREC_F16 ? 1 : 0;
+    a.stamps = static_cast<unsigned long long*>(dev_stamps);
+    if (launch_wino_conv(a, (hipStream_t)stream, err)) return fail(nullptr, err);
+    return 0;
+}
+
 int soccdpt_op_gn_finish(const float* dev_part, float* dev_stats, int B, int tps, int groups, int hw, int cpg, float eps, void* stream) {
     std::string err;
     if (launch_gn_finish(dev_part, dev_stats, B, tps, groups, hw, cpg, eps, (hipStream_t)stream, err)) return fail(nullptr, err);

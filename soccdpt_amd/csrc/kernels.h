@@ -130,6 +130,27 @@ int launch_attn_bias(const float* table, float* bias_acc, int ws, int heads, hip
 int launch_window_attention(const bf16_t* qkv, const float* bias_acc, const float* scale, bf16_t* out, int hf, int B, int res, int ws,
                             int shift, int heads, hipStream_t st, std::string& err, int out_x3 = 0);
 
+// Winograd F(2x2, 3x3) form of a 3x3 stride-1 convolution over a 16-bit zero-halo NHWC image (wino.hip, round 6).  U = launch_wino_weights' output.
+struct WinoArgs {
+    const void* X = nullptr;       // [B][H + 2][W + 2][C] 16-bit
+    const void* U = nullptr;       // [C / 32][16][N][32] 16-bit
+    int B = 0, H = 0, W = 0, C = 0, N = 0;
+    const float* bias = nullptr;
+    const float* res1 = nullptr;   // [M][N] f32
+    const float* res2 = nullptr;   // [B][res2_h][res2_w][N] f32, bilinearly sampled
+    int res2_h = 0, res2_w = 0;
+    int act = 0, act_on_f32 = 0;
+    float* out_f32 = nullptr;
+    void* out_op = nullptr;
+    int out_halo = 0, out_x3 = 0;
+    int hf = 1;                    // 1 = fp16 operands, 0 = bf16
+    unsigned long long* stamps = nullptr;   // diagnostics
+};
+bool wino_supported(int H, int W, int C, int N);
+size_t wino_weight_elems(int N, int C);
+int launch_wino_weights(const float* w /*[N][C][3][3]*/, const float* scale /*[N] or null*/, void* U, int hf, int N, int C, hipStream_t st, std::string& err);
+int launch_wino_conv(const WinoArgs& a, hipStream_t st, std::string& err);
+
 // The same with the qkv projection inside the kernel (attention_qkv.hip, round 6): x = the block input [M][C] (16-bit operand copy), wqkv = the prepared
 // [3C][C] weight (plain 16-bit, or x3 pairs when x2w != 0), qkv_bias = cat(q_bias, 0, v_bias) f32.  16 x 16 and 8 x 8 windows.
 bool window_attention_qkv_supported(int ws, int C, int x2w);

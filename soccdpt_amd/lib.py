@@ -103,7 +103,7 @@ _lib = None
 # nothing inside soccdpt_forward, so editing them does not invalidate PMC counters collected for the forward's kernels.
 FORWARD_SOURCES = ("Makefile", "attention.hip", "attention_body.h", "attention_qkv.hip", "conv8p.hip", "depth_tail.hip", "elementwise.hip", "gelu.h", "half16.h", "hybrid.hip", "igemm.h",
                    "igemm.hip", "igemm_kernel.h", "kernels.h", "launch.h", "ln_body.h", "mlp_fused.hip", "model.cpp", "projection.hip", "resample.h",
-                   "vit_attention.hip")
+                   "vit_attention.hip", "wino.hip")
 
 
 def csrc_sha() -> str:
@@ -228,6 +228,10 @@ def load_library() -> ctypes.CDLL:
     L.soccdpt_op_window_attention.restype = ci
     L.soccdpt_op_window_attention_qkv.argtypes = [vp, vp, vp, vp, vp, vp, vp, ci, ci, ci, ci, ci, ci, ci, vp, vp]
     L.soccdpt_op_window_attention_qkv.restype = ci
+    L.soccdpt_op_wino_weights.argtypes = [vp, vp, vp, ci, ci, ci, vp]
+    L.soccdpt_op_wino_weights.restype = ci
+    L.soccdpt_op_wino_conv.argtypes = [vp, vp, ci, ci, ci, ci, ci, vp, vp, vp, ci, ci, ci, ci, vp, vp, ci, ci, ci, vp, vp]
+    L.soccdpt_op_wino_conv.restype = ci
     L.soccdpt_op_wgrad_tn.argtypes = [vp, ctypes.c_long, vp, ctypes.c_long, ctypes.c_size_t, ci, ci, ci, ci, ci, vp, ctypes.c_size_t, vp, vp]
     L.soccdpt_op_wgrad_tn.restype = ci
     L.soccdpt_workspace_tensor.argtypes = [vp, ci, ctypes.c_char_p, ctypes.POINTER(cs), ctypes.POINTER(cs),
@@ -758,3 +762,24 @@ def op_window_attention_qkv(x, wqkv, qkv_bias, cpb_table, scale, out, B, res, ws
                                            heads, int(precision), 1 if out_x3 else 0, _ptr(stamps), _stream_ptr(x.device))
     if rc != 0:
         raise RuntimeError("soccdpt_op_window_attention_qkv failed: " + L.soccdpt_last_error(None).decode())
+
+
+def op_wino_weights(w, scale=None, precision=PREC_F16):
+    """soccdpt_op_wino_weights: [N][C][3][3] f32 -> the Winograd-domain weights U = G g G^T, 16-bit [C/32][16][N][32] (csrc/wino.hip)."""
+    L = load_library()
+    N, C = w.shape[0], w.shape[1]
+    u = torch.empty((16 * N * C,), dtype=torch.float16 if precision == PREC_F16 else torch.bfloat16, device=w.device)
+    rc = L.soccdpt_op_wino_weights(_ptr(w), _ptr(scale), _ptr(u), N, C, int(precision), _stream_ptr(w.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_wino_weights failed: " + L.soccdpt_last_error(None).decode())
+    return u
+
+
+def op_wino_conv(x_halo, u, B, H, W, C, N, bias=None, res1=None, res2=None, res2_hw=(0, 0), relu=False, act_on_f32=False, out_f32=None, out_op=None, out_halo=False,
+                 out_x3=False, precision=PREC_F16, stamps=None):
+    """soccdpt_op_wino_conv: 3x3 stride-1 convolution over a zero-halo NHWC image in the Winograd F(2x2, 3x3) form, igemm's epilogue options."""
+    L = load_library()
+    rc = L.soccdpt_op_wino_conv(_ptr(x_halo), _ptr(u), B, H, W, C, N, _ptr(bias), _ptr(res1), _ptr(res2), int(res2_hw[0]), int(res2_hw[1]), 1 if relu else 0,
+                                1 if act_on_f32 else 0, _ptr(out_f32), _ptr(out_op), 1 if out_halo else 0, 1 if out_x3 else 0, int(precision), _ptr(stamps), _stream_ptr(x_halo.device))
+    if rc != 0:
+        raise RuntimeError("soccdpt_op_wino_conv failed: " + L.soccdpt_last_error(None).decode())
