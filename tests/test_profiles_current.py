@@ -157,3 +157,41 @@ def test_round5_bench_lines_say_what_they_are():
     assert abs(main["roofline"]["frac_of_16bit_peak"] - main["roofline"]["achieved"] / 2500.0) < 1e-3
     cal = dict(lines).get("r05_bench_calibrated.json")
     assert cal is not None and cal["config"]["precision_map_source"] == "calibrated" and cal["config"]["precision_map_calibration"]["met_budget"] == 1
+
+
+def test_round6_bench_lines_say_what_other_weights_get():
+    """the committed round-6 forward lines price the dominant kernel against the guide's 16-bit peak in `frac` itself (the blended figure under its
+    own key), carry what checkpoints the shipped map was NOT derived on get (uncalibrated, calibrated, held-out error inside the budget), the forwards-in-flight side field with a
+    bit-identical check, the per-pixel reading of the tolerance, and an SQ stall-counter summary from the same tree sits beside each model's PMC traffic file."""
+    lines = dict(_lines("r06"))
+    assert lines, "no profiles/r06*_bench*.json"
+    main = lines.get("r06_bench.json")
+    assert main is not None and main["dtype"].startswith("mixed") and main["tolerance"]["value_meets_tolerance"] is True
+    r = main["roofline"]
+    assert r["peak"] == 2500.0 and abs(r["frac"] - r["achieved"] / 2500.0) < 1e-3 and r["frac_vs_blended_peak"] >= r["frac"] and r["blended_peak"] <= 2500.0
+    for row in r["by_config"]:
+        assert "frac" in row and "frac_vs_format_peak" in row
+    ow = main["other_weights"]
+    assert set(ow["sets"]) >= {"salt1", "trained_like"} and ow["budget"] == 5e-4
+    for name, v in ow["sets"].items():
+        assert v["uncalibrated"]["precision_map_source"] == "uncalibrated-all-x3" and v["uncalibrated"]["worst_vs_f32_mode"] < 2e-4, name
+        c = v["calibrated"]
+        assert c["precision_map_source"] == "calibrated" and c["met_budget"] and c["heldout_within_budget"] and c["heldout_worst"] <= 5e-4, name
+        assert c["holdout_frames"] >= 1 and c["library_worst_calibration_frames"] <= 0.85 * 5e-4 * 1.001 and c["library_worst_holdout_frames"] <= 5e-4, name
+        assert v["uncalibrated"]["value"] < c["value"] <= main["value"] * 1.02, name
+    p = main["pipelined"]
+    assert p["in_flight"] == 2 and p["bit_identical_to_sequential"] is True and p["value"] > main["value"]
+    assert main["tolerance"]["reading"].startswith("relative L2") and "inv_p999" in main["tolerance"]["per_pixel"]["mixed"]
+    assert main["config"]["weights"] == "salt0" and main["config"]["precision_map_source"] == "shipped"
+    for w in ("salt1", "trained_like"):
+        d = lines.get(f"r06_bench_weights_{w}.json")
+        assert d is not None and d["config"]["weights"] == w and d["config"]["precision_map_source"] == "calibrated", w
+        assert d["tolerance"]["worst_measured"]["mixed"] <= 5e-4, w
+    from soccdpt_amd.lib import csrc_sha
+    for sfx in ("", "_base384", "_hybrid384"):
+        st = json.load(open(os.path.join(REPO, "profiles", f"r06{sfx}_pmc_stall.json")))
+        assert st["csrc_sha"] == csrc_sha() and st["kernels"], sfx
+        k = next(iter(st["kernels"].values()))
+        assert 0.9 < k["wait_any"] + k["wait_inst_any"] + k["active_inst_any"] < 1.1
+    amp = lines.get("r06_bench_train_step_amp_B3_enc50_patch50.json")
+    assert amp is not None and amp["config"]["batch_per_gpu"] == 3 and amp["config"]["encoder_percentage"] == 0.5 and "bf16" in amp["dtype"] and amp["roofline"] and amp["cpu_baseline"]
