@@ -107,8 +107,8 @@ size_t soccdpt_sizeof(int which);
  *             the seg head's conv + BN + ReLU output is kept for the 1x1 classifier: F16 = fp16, F16X3 = plain f32 -- honoured only when that
  *             feature map exists, i.e. when "head" is F16X3 or SOCCDPT_SEG_DOT3_OFF is set: with a 16-bit "head" the classifier rides in the
  *             convolution's epilogue on the f32 accumulators and the entry is inert)
- * F16X2W is refused for "head", "head.d2" and "head.s1" (their weights are read by kernels without the two-MFMA form: the fused classifier, the fused
- * depth tail; "head.s1" is a storage format): an exact name is an error, a pattern skips them (they stay F16).
+ * F16X2W is refused for "head.d2" and "head.s1" (the fused depth tail reads its filter as plain 16-bit; "head.s1" is a storage format): an exact name is an
+ * error, a pattern skips them (they stay F16).  "head" takes it since round 6 (the seg head then runs convolution -> feature map -> classifier, as under F16X3).
  * `group` may end in '*' (prefix match) or be "*".  fmt = SOCCDPT_PREC_F16, SOCCDPT_PREC_F16X2W or SOCCDPT_PREC_F16X3.  Returns the number of groups
  * changed (>= 0) or a negative value on error.  Invalidates the prepared weights and the workspace (call soccdpt_prepare again). */
 int soccdpt_prec_map_set(void* handle, const char* group, int fmt);
