@@ -591,8 +591,19 @@ __global__ void logit_scale_kernel(const float* ls, float* out, int H) {
     if (i < H) out[i] = expf(fminf(ls[i], 4.605170185988092f));
 }
 // continuous position bias table: 16*sigmoid(cpb_mlp(coords))  [(2ws-1)^2][heads]
-__global__ void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, const float* __restrict__ b0, const float* __restrict__ w2 /*[H][512]*/,
-                                 float* __restrict__ table, int ws, int pws, int H) {
+// One thread per (entry, head), 512 hidden units in order (the addition order every earlier round used: same bits).  Round 6: the MLP's weights -- w0 [512][2], b0 [512] and
+// w2 [H][512], read by every thread -- are staged in LDS first: the serial loop's loads were L2 round trips (29 us per launch; the training step rebuilds the table of all 12
+// blocks every forward: 0.35 ms of a 16 ms step).
+__global__ __launch_bounds__(256) void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, const float* __restrict__ b0, const float* __restrict__ w2 /*[H][512]*/,
+                                                        float* __restrict__ table, int ws, int pws, int H) {
+    extern __shared__ float cpb_s[];
+    float* s_w0 = cpb_s;            // 1024
+    float* s_b0 = cpb_s + 1024;     // 512
+    float* s_w2 = cpb_s + 1536;     // H * 512
+    for (int i = threadIdx.x; i < 1024; i += blockDim.x) s_w0[i] = w0[i];
+    for (int i = threadIdx.x; i < 512; i += blockDim.x) s_b0[i] = b0[i];
+    for (int i = threadIdx.x; i < H * 512; i += blockDim.x) s_w2[i] = w2[i];
+    __syncthreads();
     const int T = 2 * ws - 1;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= T * T * H) return;
@@ -602,10 +613,11 @@ __global__ void cpb_table_kernel(const float* __restrict__ w0 /*[512][2]*/, cons
     cy = (cy > 0.f ? 1.f : (cy < 0.f ? -1.f : 0.f)) * log2f(fabsf(cy) + 1.f) / 3.f;
     cx = (cx > 0.f ? 1.f : (cx < 0.f ? -1.f : 0.f)) * log2f(fabsf(cx) + 1.f) / 3.f;
     float s = 0.f;
-#pragma unroll 8   // same addition order; eight w2 loads in flight (the training step rebuilds the table every forward: 29 -> see DESIGN us)
+    const float* w2h = s_w2 + hd * 512;
+#pragma unroll 8
     for (int k = 0; k < 512; ++k) {
-        const float hdn = fmaxf(w0[2 * k] * cy + w0[2 * k + 1] * cx + b0[k], 0.f);
-        s += hdn * w2[hd * 512 + k];
+        const float hdn = fmaxf(s_w0[2 * k] * cy + s_w0[2 * k + 1] * cx + s_b0[k], 0.f);
+        s += hdn * w2h[k];
     }
     table[i] = 16.f / (1.f + expf(-s));
 }
@@ -649,7 +661,14 @@ int launch_logit_scale(const float* ls, float* out, int H, hipStream_t st, std::
 int launch_cpb_table(const float* w0, const float* b0, const float* w2, float* table, int ws, int pws, int H, hipStream_t st,
                      std::string& err) {
     const int n = (2 * ws - 1) * (2 * ws - 1) * H;
-    SOCCDPT_LAUNCH(cpb_table_kernel, dim3((n + 127) / 128), dim3(128), 0, st, w0, b0, w2, table, ws, pws, H);
+    const size_t lds = (size_t)(1536 + H * 512) * sizeof(float);   // 8 - 54 KB for 1 - 24 heads... (32 heads: 70 KB)
+    static PerDeviceOnce attr;
+    if (attr.need()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cpb_table_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) { err = "cpb_table: hipFuncSetAttribute failed"; return 1; }
+        attr.done();
+    }
+    if (lds > 160 * 1024) { err = "cpb_table: too many heads for the LDS-resident MLP"; return 1; }
+    SOCCDPT_LAUNCH(cpb_table_kernel, dim3((n + 255) / 256), dim3(256), lds, st, w0, b0, w2, table, ws, pws, H);
     return check_launch("cpb_table", err);
 }
 

@@ -1,5 +1,6 @@
 // Launchers of train.hip (backward / train-mode forward kernels, exact f32) and the training entry points of train_step.cpp.
 #pragma once
+#include <vector>
 #include "internal.h"
 #include "kernels.h"
 
@@ -64,8 +65,19 @@ int tr_attention_bwd_mfma_slots(int ws);
 int tr_cvt_x3_pair(const float* in0, void* out0, size_t n0, const float* in1, void* out1, size_t n1, hipStream_t st, std::string& err);   // two f32 -> x3 conversions, one launch
 // Weight gradient from operands as stored (train_wgrad_tn.hip): out[Nout][taps * C] = sum_k A[k][n] B[k + shift(tap)][c], 16-bit operands
 bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps);
+// Deferred reduction of the weight-gradient partials (round 6): every tr_wgrad_tn call used to be followed by its own tn_reduce launch -- 74 launches of ~14 us per
+// bf16-amp step whose work is a few hundred KB each.  With a TnDefer the partials of successive calls stay in an arena (bump allocation, flushed when full) and ONE
+// batched launch per <= 48 gradients sums them -- in split order, like tn_reduce_kernel: the same bits -- at the end of the backward pass (tn_flush).  perm_C > 0: the
+// batched launch also writes the 3x3 gradient from the kernel's tap-major [N][9][C] into the parameter layout [N][C][3][3] (tr_wgrad_permute's job).
+struct TnPending { const float* part; float* out; const float* bpart; float* bout; unsigned long long n4; int splits, nb, perm_N, perm_C; };
+struct TnDefer {
+    float* arena = nullptr;
+    size_t cap = 0, used = 0;
+    std::vector<TnPending> pend;
+};
+int tn_flush(TnDefer& d, hipStream_t st, std::string& err);
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
-                float* out, hipStream_t st, std::string& err, float* bias_out = nullptr);
+                float* out, hipStream_t st, std::string& err, float* bias_out = nullptr, TnDefer* defer = nullptr, int perm_C = 0);
 int tr_attn_param_grads(float* dS, const float* dscale_part, const float* table, const float* ls, const float* w0, const float* b0, const float* w2, float* dtable, float* dt, float* hid, float* dls, float* dw0, float* db0, float* dw2, int nwin, int ws, int pws, int heads, hipStream_t st, std::string& err, int dscale_slots = 0);
 int tr_drop_path_fill(float* out, int B, float p, unsigned seed, unsigned stream_id, hipStream_t st, std::string& err);
 int tr_scale_rows(const float* in, float* out, const float* scale, size_t M, int C, int rows_per_scale, hipStream_t st, std::string& err);

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <string>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "train.h"
@@ -30,6 +31,7 @@ inline std::string blk_key(int s, int j) { return ENC + "layers." + std::to_stri
 
 constexpr size_t kTrainSkPartFloats = (size_t)8 << 20;   // 32 MB of f32 split-K partials
 constexpr size_t kTrainSkCountWords = 4096;
+constexpr size_t kTrainTnArenaFloats = (size_t)160 << 20;   // 640 MB: the weight-gradient partials of one backward pass wait here for the batched sum (train.h TnDefer); flushed when full
 
 struct BlkT {
     float *qkv_bias, *scale, *table, *bias_acc;
@@ -86,6 +88,8 @@ struct Tape {
     float *S_T1, *S_T2, *S_halo, *S_wt, *S_dw, *S_col, *S_vec;
     float *dS, *rowstat, *dscale_part, *dtable, *dt, *S_cpb, *attn_part;
     float* sk_part;
+    float* tn_arena;
+    size_t S_dw_n = 0;   // floats of S_dw (a weight gradient written THERE is post-processed at once by its caller: never deferred)
     unsigned* sk_count;
     // dgrad weight operands of the whole backward pass, staged by stage_weights() in a few batched launches (4 bytes per element reserved per weight)
     float* WT = nullptr;
@@ -101,6 +105,10 @@ struct Ctx {
     int B;
     hipStream_t st;
     std::string& err;
+    TnDefer tn;   // deferred weight-gradient sums of this pass (flushed by train_backward / train_backward_encoder before they return)
+    std::unordered_set<const void*> grad_ptrs;   // the bound parameter-gradient buffers: only sums that land THERE may wait (a gradient written into scratch is read by its caller's next launch)
+    bool may_defer(const float* dW, const float* db) const { return tn.arena && grad_ptrs.count(dW) && (!db || grad_ptrs.count(db)); }
+    void arm_defer(float* arena, size_t cap) { tn.arena = arena; tn.cap = cap; for (const auto& w : h.weights) if (w.grad) grad_ptrs.insert(w.grad); }
     const float* W(const std::string& key) const { return h.weights[h.index.at(key)].ptr; }
     float* Gd(const std::string& key) const { return h.weights[h.index.at(key)].grad; }
 };

@@ -128,6 +128,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
     const size_t wmax = std::max(std::max((size_t)9 * F * F, 4 * Cmax * Cmax), a.hybrid ? (size_t)9 * 768 * 768 : 0);
     T.S_wt = ar.f(wmax);
     T.S_dw = ar.f(wmax);
+    T.S_dw_n = wmax;
     T.S_col = ar.f((size_t)1 << 20);
     {   // slots of the staged dgrad weight operands (stage_weights): Linear [N][K] and 1x1 conv weights with N, K multiples of 32 and K > 32, 3x3 conv weights with N, C multiples of 32
         T.wt_off.assign(h.weights.size(), -1);
@@ -143,6 +144,7 @@ void carve(const Handle& h, int B, TArena& ar, Tape& T) {
         T.WT = ar.f(tot);
     }
     T.sk_part = ar.f(kTrainSkPartFloats);
+    T.tn_arena = ar.f(kTrainTnArenaFloats);
     T.S_vec = ar.f(std::max((size_t)4 * Cmax, (size_t)4 * F) * 2);
     T.dS = ar.f(maxDS);
     T.rowstat = ar.f(maxStat);
@@ -298,6 +300,8 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
     const bool tn16 = amp && dW && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1) && (M * N) % 4 == 0 && (M * K) % 4 == 0;
     const bool tn3 = x3 && dW && wgrad_tn_on() && tr_wgrad_tn_ok((M + 63) / 64 * 64, N, K, 1);
     bool staged = false;   // S_T1 holds dY and S_T2 holds X in the launch format
+    // a gradient written into scratch (standardised ResNetV2 kernels, the padded patch embedding) is read by its caller's next launch: summed at once; parameter gradients wait for the batched sum
+    TnDefer* const df = c.may_defer(dW, bias_in_wgrad() ? db : nullptr) ? &c.tn : nullptr;   // (the qkv bias gradient, e.g., goes through scratch into q_bias / v_bias)
     if (tn16) { TRY(tr_cvt16_pair(dY, reinterpret_cast<uint16_t*>(T.S_T1), M * N, X, reinterpret_cast<uint16_t*>(T.S_T2), M * K, F16, c.st, c.err)); staged = true; }
     else if (tn3) { TRY(tr_cvt_x3_pair(dY, T.S_T1, M * N, X, T.S_T2, M * K, c.st, c.err)); staged = true; }
     if (dX_out) {
@@ -342,7 +346,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
             // (the bias gradient = column sums of dY rides in the same launch: one more MFMA per fragment against ones, train_wgrad_tn.hip)
-            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr));
+            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(a3), N, reinterpret_cast<uint16_t*>(x3p), K, Mp, N, K, 1, 0, 3, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr, df));
             if (db && !bias_in_wgrad()) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (x3) {
@@ -367,7 +371,7 @@ int linear_bwd(Ctx& c, const float* dY, const float* X, const float* W, size_t M
                 if (e == hipSuccess) e = hipMemsetAsync(x16 + M * K, 0, (Mp - M) * K * 2, c.st);
                 if (e != hipSuccess) { c.err = std::string("linear_bwd memset: ") + hipGetErrorString(e); return 1; }
             }
-            TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr));
+            TRY(tr_wgrad_tn(a16, N, x16, K, Mp, N, K, 1, 0, F16, T.sk_part, kTrainSkPartFloats, dW, c.st, c.err, bias_in_wgrad() ? db : nullptr, df));
             if (db && !bias_in_wgrad()) TRY(tr_colsum(dY, nullptr, db, T.S_col, M, N, 0, c.st, c.err));
             return 0;
         } else if (amp) {
@@ -449,9 +453,14 @@ int conv3_bwd(Ctx& c, const float* dY, const float* Xhalo, const float* W, int r
             if (e == hipSuccess) TRY(launch_cvt_bf16(Xhalo, reinterpret_cast<uint16_t*>(xb + mrg * C * es), Kh * C, cvt, c.st, c.err));
         }
         if (e != hipSuccess) { c.err = std::string("conv3_bwd memset: ") + hipGetErrorString(e); return 1; }
+        if (C % 4 == 0 && c.may_defer(dW, bias_in_wgrad() ? db : nullptr)) {   // deferred: the batched sum writes the parameter layout itself
+            TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(h16), N, reinterpret_cast<uint16_t*>(xb + mrg * C * es), C, Kp, N, C, 9, rp, x3 ? 3 : F16, T.sk_part, kTrainSkPartFloats,
+                            dW, c.st, c.err, bias_in_wgrad() ? db : nullptr, &c.tn, C));
+        } else {
         TRY(tr_wgrad_tn(reinterpret_cast<uint16_t*>(h16), N, reinterpret_cast<uint16_t*>(xb + mrg * C * es), C, Kp, N, C, 9, rp, x3 ? 3 : F16, T.sk_part, kTrainSkPartFloats,
                         T.S_dw, c.st, c.err, bias_in_wgrad() ? db : nullptr));   // dY in halo order: its zero border adds nothing to the column sums
         TRY(tr_wgrad_permute(T.S_dw, dW, N, C, c.st, c.err));
+        }
         if (bias_in_wgrad()) db = nullptr;
     } else if (dW && x3 && C % 64 == 0) {
         // x3, no im2col: like the f32 form below, but an x3 tensor is cut in 8-element units, so the views must start at multiples of 16 elements:
@@ -896,13 +905,15 @@ int train_backward_encoder(Handle& h, int B, const float* const* d_feat, void* w
     Tape T;
     carve(h, B, ar, T);
     Ctx c{h, T, B, st, err};
+    c.arm_defer(T.tn_arena, kTrainTnArenaFloats);
     for (int l = 0; l < 4; ++l) {
         if (!d_feat || !d_feat[l]) { err = "soccdpt_train_backward_encoder: null feature gradient"; return 1; }
         const size_t n = (size_t)B * h.arch.fres(l) * h.arch.fres(l) * h.arch.fdim(l);
         TRY(copy_d2d(c, T.DF[l], d_feat[l], n * 4, "train_backward_encoder"));
     }
     TRY(stage_weights(c));
-    return encoder_backward(c);
+    TRY(encoder_backward(c));
+    return tn_flush(c.tn, st, err);   // the deferred weight-gradient sums of this pass
 }
 
 int train_backward(Handle& h, const float* x, int B, const float* d_inv, const float* d_seg, void* ws, size_t ws_bytes, hipStream_t st, std::string& err) {
@@ -914,7 +925,9 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     carve(h, B, ar, T);
     T.dropout_p = h.train_key.dropout_p;
     Ctx c{h, T, B, st, err};
+    c.arm_defer(T.tn_arena, kTrainTnArenaFloats);   // weight-gradient partials wait for ONE batched sum at the end of the pass (train.h TnDefer)
     TRY(stage_weights(c));
+    auto pass = [&]() -> int {
     const int F = h.cfg.features;
     float** G = T.G;
     const int r1 = 2 * a.fres(0), r0 = 4 * a.fres(0);
@@ -1005,6 +1018,9 @@ int train_backward(Handle& h, const float* x, int B, const float* d_inv, const f
     }
     if (!enc_train) return 0;
     return encoder_backward(c);
+    };
+    TRY(pass());
+    return tn_flush(c.tn, st, err);
 }
 
 }  // namespace soccdpt

@@ -307,7 +307,50 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
         }
 }
 
+// the deferred form of tn_reduce_kernel (train.h TnDefer): blockIdx.y = gradient, grid-stride over its float4s; the same split-order sums
+struct TnBatch { TnPending e[48]; };
+__global__ __launch_bounds__(256) void tn_reduce_batch_kernel(TnBatch b) {
+    const TnPending& e = b.e[blockIdx.y];
+    const size_t n4 = (size_t)e.n4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 s = *reinterpret_cast<const float4*>(e.part + i * 4);
+        for (int sp = 1; sp < e.splits; ++sp) {
+            const float4 v = *reinterpret_cast<const float4*>(e.part + ((size_t)sp * n4 + i) * 4);
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        if (e.perm_C) {   // tap-major [N][9][C] element 4 i .. 4 i + 3 (one tap, four consecutive channels) -> [N][C][3][3]
+            const size_t el = i * 4, per_n = (size_t)9 * e.perm_C;
+            const size_t nn = el / per_n, r = el - nn * per_n;
+            const int tap = (int)(r / e.perm_C), c = (int)(r - (size_t)tap * e.perm_C);
+            float* o = e.out + (nn * e.perm_C + c) * 9 + tap;
+            o[0] = s.x; o[9] = s.y; o[18] = s.z; o[27] = s.w;
+        } else {
+            *reinterpret_cast<float4*>(e.out + i * 4) = s;
+        }
+    }
+    if (e.bpart)
+        for (int n = (int)(blockIdx.x * blockDim.x + threadIdx.x); n < e.nb; n += (int)(gridDim.x * blockDim.x)) {
+            float s = e.bpart[n];
+            for (int sp = 1; sp < e.splits; ++sp) s += e.bpart[(size_t)sp * e.nb + n];
+            e.bout[n] = s;
+        }
+}
+
 }  // namespace
+
+int tn_flush(TnDefer& d, hipStream_t st, std::string& err) {
+    for (size_t i = 0; i < d.pend.size(); i += 48) {
+        TnBatch b;
+        const size_t n = std::min<size_t>(48, d.pend.size() - i);
+        for (size_t k = 0; k < n; ++k) b.e[k] = d.pend[i + k];
+        SOCCDPT_LAUNCH(tn_reduce_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, b);
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { err = std::string("tn_flush: ") + hipGetErrorString(e); return 1; }
+    }
+    d.pend.clear();
+    d.used = 0;
+    return 0;
+}
 
 // Shapes the kernel takes (the caller falls back to the transposing path otherwise)
 bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps) {
@@ -320,7 +363,7 @@ bool tr_wgrad_tn_ok(size_t K, int Nout, int C, int taps) {
 // in halo pixel order with pitch rp and B must be readable (finite) from row -(rp + 1) to row K + rp: zero margins.  part: at least
 // splits * Nout * taps * C floats.  Returns the number of splits used through *splits_out.
 int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t K, int Nout, int C, int taps, int rp, int f16, float* part, size_t part_floats,
-                float* out, hipStream_t st, std::string& err, float* bias_out) {
+                float* out, hipStream_t st, std::string& err, float* bias_out, TnDefer* defer, int perm_C) {
     if (!tr_wgrad_tn_ok(K, Nout, C, taps)) { err = "wgrad_tn: unsupported shape"; return 1; }
     const bool x3 = f16 == 3;   // x3 operands: 4 bytes per element, rows start at multiples of 16 elements, 32-row k-tiles
     if (x3 ? ((ldA & 15) || (ldB & 15)) : ((ldA & 7) || (ldB & 7))) { err = "wgrad_tn: row strides must be multiples of 8 (x3: 16) elements"; return 1; }
@@ -332,8 +375,19 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     if (S > nk / 2) S = nk / 2 > 0 ? nk / 2 : 1;
     if (S > 64) S = 64;
     const size_t per_split = (size_t)Nout * a.Ncols + (bias_out ? (size_t)(Nout + 3) / 4 * 4 : 0);   // the bias partials sit behind the weight partials
-    while (S > 1 && (size_t)S * per_split > part_floats) --S;
+    while (S > 1 && (size_t)S * per_split > part_floats) --S;   // (part_floats bounds the split count in the deferred form too: the same splits, the same bits)
     if ((size_t)S * per_split > part_floats) { err = "wgrad_tn: partial-tile scratch too small"; return 1; }
+    if (defer && defer->arena) {   // the partials stay in the arena until tn_flush; a full arena is flushed first (stream order: the sums run before the region is rewritten)
+        const size_t need = ((size_t)S * per_split + 63) & ~size_t(63);
+        if (need > defer->cap) defer = nullptr;
+        else {
+            if (defer->used + need > defer->cap && tn_flush(*defer, st, err)) return 1;
+            part = defer->arena + defer->used;
+            defer->used += need;
+            a.part = part;
+        }
+    } else defer = nullptr;
+    if (perm_C && !defer) { err = "wgrad_tn: the permuted output exists in the deferred form only"; return 1; }
     a.splits = (int)S;
     a.bias_part = bias_out ? part + (size_t)S * Nout * a.Ncols : nullptr;
     const dim3 grid((unsigned)(tiles * S)), block(512);
@@ -342,6 +396,12 @@ int tr_wgrad_tn(const uint16_t* A, long ldA, const uint16_t* B, long ldB, size_t
     else if (f16) SOCCDPT_LAUNCH(wgrad_tn_kernel<true>, grid, block, lds, st, a);
     else SOCCDPT_LAUNCH(wgrad_tn_kernel<false>, grid, block, lds, st, a);
     const size_t n4 = (size_t)Nout * a.Ncols / 4;
+    if (defer) {
+        defer->pend.push_back(TnPending{part, out, (const float*)a.bias_part, bias_out, (unsigned long long)n4, (int)S, Nout, perm_C ? Nout : 0, perm_C});
+        const hipError_t e0 = hipGetLastError();
+        if (e0 != hipSuccess) { err = std::string("wgrad_tn: ") + hipGetErrorString(e0); return 1; }
+        return 0;
+    }
     size_t blocks = (n4 + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     SOCCDPT_LAUNCH(tn_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, st, part, out, (int)S, n4, (const float*)a.bias_part, bias_out, Nout);
