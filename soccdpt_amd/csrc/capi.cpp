@@ -646,6 +646,8 @@ int soccdpt_op_wino_conv(const void* dev_x_halo, const void* dev_u, int B, int H
                          int res2_h, int res2_w, int relu, int act_on_f32, float* dev_out_f32, void* dev_out_op, int out_halo, int out_x3, int precision, void* dev_stamps, void* stream) {
     std::string err;
     if (precision != SOCCDPT_PREC_BF16 && precision != SOCCDPT_PREC_F16) return fail(nullptr, "soccdpt_op_wino_conv: precision is SOCCDPT_PREC_BF16 or _F16");
+    if (dev_res2 && (res2_h <= 0 || res2_w <= 0)) return fail(nullptr, "soccdpt_op_wino_conv: dev_res2 needs its source size (res2_h, res2_w > 0)");
+    if (B <= 0) return fail(nullptr, "soccdpt_op_wino_conv: B must be positive");
     WinoArgs a;
     a.X = dev_x_halo; a.U = dev_u; a.B = B; a.H = H; a.W = W; a.C = C; a.N = N; a.bias = dev_bias; a.res1 = dev_res1; a.res2 = dev_res2; a.res2_h = res2_h; a.res2_w = res2_w;
     a.act = relu ? ACT_RELU : ACT_NONE; a.act_on_f32 = act_on_f32; a.out_f32 = dev_out_f32; a.out_op = dev_out_op; a.out_halo = out_halo; a.out_x3 = out_x3;
